@@ -1,0 +1,170 @@
+"""Pins the oracle (oracle/) against the reference's recorded outputs and the
+closed-form expectations of the reference's own unit tests.  CPU only."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from graphmat_amd import generators as gen
+from graphmat_amd.mtx import read_mtx_bin
+from oracle import binding as ob
+
+MAXD = np.uint32(0xFFFFFFFF)
+
+
+@pytest.fixture(scope="module")
+def ref(golden_dir):
+    with open(os.path.join(golden_dir, "reference_outputs.json")) as f:
+        return json.load(f)
+
+
+def _graph(golden_dir, name, threads=1):
+    nv, s, d, v = read_mtx_bin(os.path.join(golden_dir, name))
+    return ob.OracleGraph(nv, s, d, v, ref_threads=threads)
+
+
+def test_fixture_headers(golden_dir):
+    # test/ data quirk: header nnz governs, one trailing duplicate record is ignored
+    for name, (nv, nnz) in {"test.bin.mtx": (8, 13), "ratings7.bin.mtx": (7, 7),
+                            "2_10_upper_triangle.bin.mtx": (1024, 15069)}.items():
+        n, s, d, v = read_mtx_bin(os.path.join(golden_dir, name))
+        assert (n, s.size) == (nv, nnz)
+        assert s.min() >= 1 and d.max() <= nv
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_G1_pagerank(golden_dir, ref, threads):
+    g1 = ref["G1_pagerank_test_bin_mtx"]
+    g = _graph(golden_dir, g1["file"], threads)
+    deg = g.degree()
+    assert deg.tolist() == g1["out_degree"]
+    pr, it, hist = g.pagerank(-1)
+    assert it == g1["pagerank_iterations"]
+    assert hist.tolist() == g1["changed_per_iteration"]
+    assert ["%.6f" % x for x in pr] == g1["pagerank_6dp"]
+
+
+def test_G2_bfs_small(golden_dir, ref):
+    g2 = ref["G2_bfs_test_bin_mtx"]
+    g = _graph(golden_dir, g2["file"])
+    depth, parent, it, _ = g.bfs(g2["source"])
+    assert it == g2["iterations"]
+    assert depth.tolist() == g2["depth"]
+    assert parent.astype(np.int64).tolist() == g2["parent"]
+    assert int((depth != MAXD).sum()) == g2["reachable"]
+
+
+def test_G2_bfs_upper_triangle_parents(golden_dir, ref):
+    # V=1024 IS permuted at 1 thread (P=16, h=64): pins vertexToNative and the
+    # "largest native index wins" consequence of the a=b reduce.
+    g2 = ref["G2_bfs_2_10_upper_triangle"]
+    g = _graph(golden_dir, g2["file"])
+    depth, parent, it, _ = g.bfs(g2["source"])
+    assert it == g2["iterations"]
+    assert int((depth != MAXD).sum()) == g2["reachable"]
+    assert depth[:10].tolist() == g2["first10_depth"]
+    assert parent[:10].astype(np.int64).tolist() == g2["first10_parent"]
+
+
+def rand_r_latent(nv, K, dtype=np.float64):
+    """src/SGD.cpp:176-184: glibc rand_r seeded with the 1-based vertex id."""
+    libc = ctypes.CDLL("libc.so.6")
+    libc.rand_r.argtypes = [ctypes.POINTER(ctypes.c_uint)]
+    lv = np.zeros((nv, K), dtype)
+    for i in range(1, nv + 1):
+        r = ctypes.c_uint(i)
+        for j in range(K):
+            lv[i - 1, j] = libc.rand_r(ctypes.byref(r)) / 2147483647.0
+    return lv
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_G3_sgd(golden_dir, ref, threads):
+    g3 = ref["G3_sgd_ratings7"]
+    g = _graph(golden_dir, g3["file"], threads)
+    lv = rand_r_latent(g.nv, g3["K"])
+    e0, _ = g.rmse_sum(lv)
+    assert "%.6f" % np.sqrt(e0 / g.nnz) == g3["rmse_before_6dp"]
+    lv2, it = g.sgd(lv, g3["lambda"], g3["step"], g3["iterations"])
+    assert it == g3["iterations"]
+    e1, _ = g.rmse_sum(lv2)
+    assert "%.6f" % np.sqrt(e1 / g.nnz) == g3["rmse_after_6dp"]
+
+
+# ---- closed forms from the reference's unit tests ---------------------------------
+@pytest.mark.parametrize("n", [100, 500])
+@pytest.mark.parametrize("threads", [1, 2])
+def test_bfs_depths_closed_form(n, threads):
+    """test/test_bfs.cpp:97-236 (upper triangular, dense, circular chain; source 1 and n/2)."""
+    h = n // 2
+    i = np.arange(1, n + 1)
+    nv, s, d, v = gen.upper_triangular_edges(n)
+    g = ob.OracleGraph(nv, s, d, v, threads)
+    depth = g.bfs(1)[0]
+    assert depth[0] == 0 and (depth[1:] == 1).all()
+    depth = g.bfs(h)[0]
+    assert (depth[: h - 1] == MAXD).all() and depth[h - 1] == 0 and (depth[h:] == 1).all()
+    nv, s, d, v = gen.dense_edges(n)
+    g = ob.OracleGraph(nv, s, d, v, threads)
+    for src in (1, h):
+        depth = g.bfs(src)[0]
+        exp = np.ones(n, np.uint32)
+        exp[src - 1] = 0
+        assert (depth == exp).all()
+    nv, s, d, v = gen.chain_edges(n)
+    g = ob.OracleGraph(nv, s, d, v, threads)
+    assert (g.bfs(1)[0] == (i - 1)).all()
+    depth = g.bfs(h)[0]
+    exp = np.where(i < h, h + i, i - h)  # test_bfs.cpp:222-233
+    assert (depth == exp).all()
+
+
+@pytest.mark.parametrize("n", [10, 5000])
+def test_identity_spmv(n):
+    """test/test_spmv.cpp:38-81: y = I*x over (mul, add) equals x."""
+    nv, s, d, v = gen.identity_edges(n)
+    g = ob.OracleGraph(nv, s, d, v, 1)
+    x = np.arange(1, n + 1, dtype=np.float64) * 0.5
+    for tr in (0, 1):
+        y, ym = g.spmv_f64(x, np.ones(n, np.uint8), tr)
+        assert ym.all() and (y == x).all()
+    xm = (np.arange(n) % 3 == 0).astype(np.uint8)
+    y, ym = g.spmv_f64(x, xm, 0)
+    assert (ym == xm).all() and (y[xm == 1] == x[xm == 1]).all()
+
+
+@pytest.mark.parametrize("n,nparts", [(1024, 16), (1000, 16), (8, 16), (5000, 64), (4099, 128)])
+def test_permutation_roundtrip(n, nparts):
+    """test/test_graph_basics.cpp:56-81 (get/set through the permutation): the map
+    include/Graph.h:111-150 is a bijection with nativeToVertex as its inverse."""
+    nat = np.array([ob.vertex_to_native(v, nparts, n) for v in range(1, n + 1)])
+    assert sorted(nat.tolist()) == list(range(1, n + 1))
+    back = np.array([ob.native_to_vertex(int(x), nparts, n) for x in nat])
+    assert (back == np.arange(1, n + 1)).all()
+    if n < nparts:
+        assert (nat == np.arange(1, n + 1)).all()  # identity when V < P
+
+
+def test_sssp_upper_triangle(golden_dir):
+    """Weighted fixture: distances equal a plain Dijkstra on the same edges."""
+    import heapq
+    nv, s, d, v = read_mtx_bin(os.path.join(golden_dir, "2_10_upper_triangle.bin.mtx"))
+    g = ob.OracleGraph(nv, s, d, v, 1)
+    dist, _ = g.sssp(1)
+    adj = [[] for _ in range(nv + 1)]
+    for a, b, w in zip(s.tolist(), d.tolist(), v.tolist()):
+        adj[a].append((b, w))
+    best = {1: 0}
+    pq = [(0, 1)]
+    while pq:
+        du, u = heapq.heappop(pq)
+        if du > best.get(u, 1 << 62):
+            continue
+        for b, w in adj[u]:
+            if du + w < best.get(b, 1 << 62):
+                best[b] = du + w
+                heapq.heappush(pq, (du + w, b))
+    exp = np.array([best.get(i, 0xFFFFFFFF) for i in range(1, nv + 1)], np.uint32)
+    assert (dist == exp).all()
