@@ -1,0 +1,99 @@
+"""ctypes loader of libgraphmat_hip.so.  Fails loudly when the HIP library is missing:
+there is no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libgraphmat_hip.so")
+
+GM_DIR_OUT = 1
+GM_DIR_IN = 2
+GM_XCHG_MESSAGES = 0
+GM_XCHG_CONVERGED = 1
+
+
+class GraphDesc(C.Structure):
+    _fields_ = [("nvertices", C.c_int32), ("nparts", C.c_int32), ("row_lo", C.c_int32), ("row_hi", C.c_int32),
+                ("directions", C.c_int32), ("val_bytes", C.c_int32), ("ids_on_device", C.c_int32),
+                ("ids_are_native", C.c_int32)]
+
+
+class Csr(C.Structure):
+    _fields_ = [("nnz", C.c_int64), ("nrows", C.c_int32), ("row_base", C.c_int32), ("ncols", C.c_int32),
+                ("val_bytes", C.c_int32), ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("vals", C.c_void_p),
+                ("blk_row", C.c_void_p), ("nblk", C.c_int32), ("long_row", C.c_void_p), ("nlong", C.c_int32)]
+
+
+class RunStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("send_ms", C.c_float), ("spmv_ms", C.c_float), ("apply_ms", C.c_float),
+                ("total_ms", C.c_float), ("spmv_launches", C.c_int32)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int))
+
+# name -> (restype, argtypes); every symbol include/graphmat_hip.h declares
+_P = C.c_void_p
+SIGNATURES = {
+    "gm_last_error": (C.c_char_p, []),
+    "gm_version": (C.c_int, []),
+    "gm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "gm_set_device": (C.c_int, [C.c_int]),
+    "gm_vertex_to_native": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "gm_native_to_vertex": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "gm_mtx_read": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(_P),
+                              C.POINTER(_P), C.POINTER(_P)]),
+    "gm_host_free": (None, [_P]),
+    "gm_graph_create": (C.c_int, [C.POINTER(_P), C.POINTER(GraphDesc), C.c_int64, _P, _P, _P, _P]),
+    "gm_graph_destroy": (C.c_int, [_P]),
+    "gm_graph_desc": (C.c_int, [_P, C.POINTER(GraphDesc)]),
+    "gm_graph_csr": (C.c_int, [_P, C.c_int, C.POINTER(Csr)]),
+    "gm_graph_csr_to_host": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "gm_graph_set_vals": (C.c_int, [_P, C.c_int, _P]),
+    "gm_rmat_generate": (C.c_int, [C.c_int, C.c_uint64, C.c_int64, C.c_int64, _P, _P, _P, C.c_int, _P]),
+    "gm_graph_set_exchange": (C.c_int, [_P, EXCHANGE_FN, _P]),
+    "gm_run_degree": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int), _P]),
+    "gm_run_pagerank": (C.c_int, [_P, _P, C.c_float, C.c_int, C.POINTER(C.c_int), _P]),
+    "gm_run_bfs": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_int), _P]),
+    "gm_run_sssp": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_int), _P]),
+    "gm_run_sgd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), _P]),
+    "gm_run_rmse": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "gm_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "gm_graph_enable_timing": (C.c_int, [_P, C.c_int]),
+    "gm_graph_last_stats": (C.c_int, [_P, C.POINTER(RunStats)]),
+    "gm_graph_workspace": (C.c_int, [_P, C.c_int, C.c_size_t, C.POINTER(_P)]),
+    "gm_graph_exchange": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.POINTER(C.c_int)]),
+    "gm_graph_has_exchange": (C.c_int, [_P]),
+    "gm_graph_timing_enabled": (C.c_int, [_P]),
+    "gm_graph_record_stats": (C.c_int, [_P, C.POINTER(RunStats)]),
+    "gm_reduce_sum_f64": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_double), _P]),
+    "gm_reduce_sum_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_double), _P]),
+    "gm_count_less_u32": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint32, C.POINTER(C.c_int64), _P]),
+    "gm_popcount_bits": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the C-ABI library.  Raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise RuntimeError("libgraphmat_hip.so is missing: build it with `python -m graphmat_amd.build` "
+                               "(hipcc, gfx950).  graphmat_amd has no CPU fallback.")
+        L = C.CDLL(SO)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class GMError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise GMError("libgraphmat_hip error %d: %s" % (rc, lib().gm_last_error().decode()))

@@ -1,0 +1,221 @@
+"""Host-side mirror of the GraphMat application surface over the C-ABI.
+
+`Graph` plays the role of GraphMat::Graph<V,E> + the run_* drivers of the
+reference's example applications (src/PageRank.cpp:115-161, src/BFS.cpp:110-156,
+src/SSSP.cpp:99-125, src/SGD.cpp:163-224): it owns the device adjacency, keeps
+vertex state in HBM (torch tensors are used purely as device buffers) and calls
+the fixed-menu programs of libgraphmat_hip.so.  Per-vertex results are returned
+in ORIGINAL vertex order (index v-1 for vertex id v), like getVertexproperty(v).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GM_DIR_IN, GM_DIR_OUT, check
+
+MAX_DIST = 0xFFFFFFFF
+
+
+def native_index(nv, nparts):
+    """native0[v-1] for v = 1..nv: the permutation of include/Graph.h:111-130 (vectorised)."""
+    v = np.arange(nv, dtype=np.int64)
+    h = nv // nparts
+    vmax = h * nparts
+    nat = np.where(v >= vmax, v, (v // nparts) + (v % nparts) * h)
+    return nat
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Graph:
+    def __init__(self, nv, src, dst, val=None, ref_threads=1, directions=GM_DIR_OUT | GM_DIR_IN, device=0,
+                 row_range=None, keep_values=True, nranks_layout=1):
+        """src/dst: 1-based ids, numpy (host) or torch.cuda int32 tensors (device)."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("graphmat_amd needs a GPU (no CPU fallback)")
+        self.L = _lib.lib()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        check(self.L.gm_set_device(device))
+        self.nv = int(nv)
+        self.nparts = int(ref_threads) * 16 * int(nranks_layout)
+        lo, hi = (0, self.nv) if row_range is None else row_range
+        self.row_lo, self.row_hi = int(lo), int(hi)
+        self.rows = self.row_hi - self.row_lo
+        on_dev = isinstance(src, torch.Tensor)
+        if on_dev:
+            assert src.is_cuda and src.dtype == torch.int32 and dst.dtype == torch.int32
+            src = src.contiguous()
+            dst = dst.contiguous()
+            sp, dp = src.data_ptr(), dst.data_ptr()
+            vp = val.contiguous().data_ptr() if (val is not None and keep_values) else None
+            nnz = src.numel()
+        else:
+            src = np.ascontiguousarray(src, np.int32)
+            dst = np.ascontiguousarray(dst, np.int32)
+            sp, dp = src.ctypes.data, dst.ctypes.data
+            if val is not None and keep_values:
+                val = np.ascontiguousarray(val, np.int32)
+                vp = val.ctypes.data
+            else:
+                vp = None
+            nnz = src.size
+        self.nnz_input = int(nnz)
+        d = _lib.GraphDesc(self.nv, self.nparts, self.row_lo, self.row_hi, directions, 4 if vp else 0,
+                           1 if on_dev else 0, 0)
+        h = C.c_void_p()
+        check(self.L.gm_graph_create(C.byref(h), C.byref(d), nnz, sp, dp, vp, _stream()))
+        self.h = h
+        self._nat = None
+        self._cb = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gm_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- id spaces ---------------------------------------------------------------------
+    @property
+    def native_of_vertex(self):
+        if self._nat is None:
+            self._nat = torch.from_numpy(native_index(self.nv, self.nparts)).to(self.device)
+        return self._nat
+
+    def to_native_order(self, arr_vertex_order):
+        """array indexed by vertex-1 -> device tensor indexed by native id (full graph only)."""
+        t = torch.as_tensor(arr_vertex_order).to(self.device)
+        out = torch.empty_like(t)
+        out[self.native_of_vertex] = t
+        return out
+
+    def to_vertex_order(self, t_native):
+        return t_native[self.native_of_vertex]
+
+    def csr(self, direction):
+        c = _lib.Csr()
+        check(self.L.gm_graph_csr(self.h, direction, C.byref(c)))
+        return c
+
+    def csr_to_host(self, direction):
+        c = self.csr(direction)
+        rp = np.zeros(c.nrows + 1, np.int64)
+        ci = np.zeros(max(c.nnz, 1), np.int32)
+        vv = np.zeros(max(c.nnz, 1), np.int32)
+        check(self.L.gm_graph_csr_to_host(self.h, direction, rp.ctypes.data, ci.ctypes.data,
+                                          vv.ctypes.data if c.vals else None))
+        return rp, ci[: c.nnz], (vv[: c.nnz] if c.vals else None)
+
+    def enable_timing(self, on=True):
+        check(self.L.gm_graph_enable_timing(self.h, 1 if on else 0))
+
+    def last_stats(self):
+        s = _lib.RunStats()
+        check(self.L.gm_graph_last_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    # ---- PageRank ------------------------------------------------------------------------
+    def new_pr_state(self):
+        """PR{pagerank=0.3f, degree=0} for every row of this shard; [rows,2] int32 view of gm_pr_t."""
+        st = torch.zeros((self.rows, 2), dtype=torch.int32, device=self.device)
+        st[:, 0] = int(np.float32(0.3).view(np.int32))
+        return st
+
+    def run_degree(self, state):
+        it = C.c_int(0)
+        check(self.L.gm_run_degree(self.h, state.data_ptr(), 1, C.byref(it), _stream()))
+        return it.value
+
+    def run_pagerank(self, state, iterations, alpha=0.3):
+        it = C.c_int(0)
+        check(self.L.gm_run_pagerank(self.h, state.data_ptr(), alpha, iterations, C.byref(it), _stream()))
+        return it.value
+
+    def pagerank(self, iterations, alpha=0.3):
+        """Degree pass then PageRank, like run_pagerank() of the reference app.
+        Returns (pagerank float32[nv], out_degree int32[nv], iterations_done), vertex order."""
+        st = self.new_pr_state()
+        self.run_degree(st)
+        it = self.run_pagerank(st, iterations, alpha)
+        pr = self.to_vertex_order(st[:, 0].contiguous().view(torch.float32)).cpu().numpy()
+        deg = self.to_vertex_order(st[:, 1].contiguous()).cpu().numpy()
+        return pr, deg, it
+
+    # ---- BFS -----------------------------------------------------------------------------
+    def bfs(self, source):
+        """Returns (depth uint32[nv], parent uint64[nv], iterations) in vertex order."""
+        n = self.rows
+        st = torch.zeros((n, 3), dtype=torch.int64, device=self.device)  # gm_bfs_t = 24 bytes
+        st[:, 0] = MAX_DIST          # depth (low 32 bits), pad = 0
+        st[:, 1] = -1                # parent
+        ids = torch.arange(1, self.nv + 1, dtype=torch.int64, device=self.device)
+        st[:, 2] = self.to_native_order(ids)  # id of the vertex living at each native slot
+        act = torch.zeros((n + 31) // 32 + 2, dtype=torch.int32, device=self.device)
+        s_nat = int(native_index(self.nv, self.nparts)[source - 1])
+        st[s_nat, 0] = 0
+        act[s_nat >> 5] = int(np.uint32(1 << (s_nat & 31)).view(np.int32))
+        it = C.c_int(0)
+        check(self.L.gm_run_bfs(self.h, st.data_ptr(), act.data_ptr(), -1, C.byref(it), _stream()))
+        depth = self.to_vertex_order(st[:, 0] & 0xFFFFFFFF).cpu().numpy().astype(np.uint32)
+        parent = self.to_vertex_order(st[:, 1].contiguous()).cpu().numpy().view(np.uint64)
+        return depth, parent, it.value
+
+    # ---- SSSP ----------------------------------------------------------------------------
+    def sssp(self, source):
+        n = self.rows
+        dist = torch.full((n,), -1, dtype=torch.int32, device=self.device)  # 0xFFFFFFFF
+        act = torch.zeros((n + 31) // 32 + 2, dtype=torch.int32, device=self.device)
+        s_nat = int(native_index(self.nv, self.nparts)[source - 1])
+        dist[s_nat] = 0
+        act[s_nat >> 5] = int(np.uint32(1 << (s_nat & 31)).view(np.int32))
+        it = C.c_int(0)
+        check(self.L.gm_run_sssp(self.h, dist.data_ptr(), act.data_ptr(), -1, C.byref(it), _stream()))
+        return self.to_vertex_order(dist).cpu().numpy().view(np.uint32), it.value
+
+    # ---- SGD / RMSE ------------------------------------------------------------------------
+    def _latent_to_device(self, lv):
+        lv = np.ascontiguousarray(lv)
+        K = lv.shape[1]
+        full = np.zeros((self.nv, K + 1), lv.dtype)
+        full[:, :K] = lv
+        return self.to_native_order(full).contiguous(), K
+
+    def sgd(self, lv, lam, step, iterations):
+        st, K = self._latent_to_device(lv)
+        it = C.c_int(0)
+        check(self.L.gm_run_sgd(self.h, st.data_ptr(), K, st.element_size(), lam, step, iterations, C.byref(it),
+                                _stream()))
+        return self.to_vertex_order(st)[:, :K].cpu().numpy(), it.value
+
+    def rmse_sum(self, lv):
+        """sum over vertices of sqerr after one RMSE pass (caller: sqrt(sum/nnz))."""
+        st, K = self._latent_to_device(lv)
+        check(self.L.gm_run_rmse(self.h, st.data_ptr(), K, st.element_size(), _stream()))
+        out = C.c_double(0)
+        fn = self.L.gm_reduce_sum_f64 if st.dtype == torch.float64 else self.L.gm_reduce_sum_f32
+        check(fn(st.data_ptr() + K * st.element_size(), self.nv, K + 1, C.byref(out), _stream()))
+        sq = self.to_vertex_order(st)[:, K].cpu().numpy()
+        return out.value, sq
+
+
+def rmat_on_device(scale, edge_factor=16, seed=1, weights=False, device=0):
+    """RMAT edges generated in HBM (bit-identical to generators.rmat_edges)."""
+    L = _lib.lib()
+    dev = torch.device("cuda", device)
+    nv = 1 << scale
+    ne = edge_factor * nv
+    src = torch.empty(ne, dtype=torch.int32, device=dev)
+    dst = torch.empty(ne, dtype=torch.int32, device=dev)
+    val = torch.empty(ne, dtype=torch.int32, device=dev) if weights else None
+    check(L.gm_rmat_generate(scale, seed, 0, ne, src.data_ptr(), dst.data_ptr(),
+                             val.data_ptr() if weights else None, 1 if weights else 0, _stream()))
+    return nv, src, dst, val

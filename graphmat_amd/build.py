@@ -1,0 +1,55 @@
+"""Builds libgraphmat_hip.so (gfx950) in-tree with hipcc.  No GPU needed to build."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libgraphmat_hip.so")
+SOURCES = ["gm_core.hip", "gm_graph.hip", "gm_programs.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-DGRAPHMAT_NO_MPI"]
+
+
+def _deps():
+    out = []
+    for d in (CSRC, os.path.join(ROOT, "include"), os.path.join(ROOT, "include", "graphmat")):
+        for f in os.listdir(d):
+            if f.endswith((".hip", ".hpp", ".h")):
+                out.append(os.path.join(d, f))
+    out.append(os.path.abspath(__file__))
+    return out
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    deps_mtime = max(os.path.getmtime(p) for p in _deps())
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if (not force) and os.path.exists(obj) and os.path.getmtime(obj) >= deps_mtime:
+            continue
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError("hipcc failed on %s" % src)
+        elif verbose and out:
+            sys.stderr.write(out.decode())
+    if procs or not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(o) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,61 @@
+// gm_internal.hpp -- shared by the translation units of libgraphmat_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "graphmat_hip.h"
+
+namespace gm {
+
+void set_error(const char* fmt, ...);
+
+#define GM_TRY_HIP(expr)                                                                  \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      gm::set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return GM_ERR_HIP;                                                                  \
+    }                                                                                     \
+  } while (0)
+
+// 0-based native id of 1-based vertex id; include/Graph.h:111-130 of the reference
+__host__ __device__ inline int to_native0(int vertex1, int nparts, int len) {
+  int v = vertex1 - 1;
+  int height = len / nparts;
+  int vmax = height * nparts;
+  if (v >= vmax) return v;
+  return (v / nparts) + (v % nparts) * height;
+}
+// 1-based vertex id of 0-based native id; include/Graph.h:132-150
+__host__ __device__ inline int to_vertex1(int native0, int nparts, int len) {
+  int v = native0;
+  int height = len / nparts;
+  int vmax = height * nparts;
+  if (v >= vmax) return v + 1;
+  return (v / height) + (v % height) * nparts + 1;
+}
+
+struct CsrOwned {
+  gm_csr_t view;
+  int64_t* rowptr = nullptr;
+  int32_t* colidx = nullptr;
+  void* vals = nullptr;
+  int32_t* blk_row = nullptr;
+  int32_t* long_row = nullptr;
+  bool present = false;
+};
+
+}  // namespace gm
+
+struct gm_graph {
+  gm_graph_desc_t desc;
+  gm::CsrOwned out, in;
+  void* ws[GM_WS_SLOTS];
+  size_t ws_bytes[GM_WS_SLOTS];
+  gm_exchange_fn xfn;
+  void* xctx;
+  int timing;
+  gm_run_stats_t stats;
+};

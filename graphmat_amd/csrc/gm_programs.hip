@@ -1,0 +1,259 @@
+// gm_programs.hip -- the fixed-menu vertex programs behind the C-ABI.
+//
+// Each program is an ordinary GraphMat::GraphProgram subclass (this project's own
+// restatement of the programs in the reference's src/PageRank.cpp, src/BFS.cpp,
+// src/SSSP.cpp, src/SGD.cpp) run by the same engine (include/graphmat/engine.hpp)
+// that user programs compiled against include/GraphMatRuntime.h use.  The only
+// difference to a user program is that the methods are annotated __host__
+// __device__ here, so this file builds without --hipstdpar.
+// Built with -ffp-contract=off: floating-point expressions are evaluated as
+// written (no fused multiply-add), like the oracle.
+#include <limits.h>
+#include <math.h>
+
+#include "GraphMatRuntime.h"
+#include "gm_internal.hpp"
+
+#define HD __host__ __device__
+
+namespace gm {
+
+static int g_force_ordered = 0;
+
+// ---------------- PageRank (reference: src/PageRank.cpp:34-112) ----------------------------
+struct PRv : gm_pr_t {
+  HD PRv() { pagerank = 0.3; degree = 0; }
+  // tolerance test of the reference's PR::operator!= (:44-46)
+  HD int operator!=(const PRv& p) { return ((double)fabsf(p.pagerank - pagerank) > 1e-5); }
+};
+
+struct DegreeP : GraphMat::GraphProgram<int, int, PRv, int> {
+  DegreeP() {
+    this->order = GraphMat::IN_EDGES;
+    this->process_message_requires_vertexprop = false;
+  }
+  HD bool send_message(const PRv&, int& message) const { message = 1; return true; }
+  HD void process_message(const int& message, const int, const PRv&, int& result) const { result = message; }
+  HD void reduce_function(int& a, const int& b) const { a += b; }
+  HD void apply(const int& message_out, PRv& vertexprop) { vertexprop.degree = message_out; }
+};
+
+template <int ORDERED>
+struct PageRankP : GraphMat::GraphProgram<float, float, PRv, int> {
+  float alpha;
+  explicit PageRankP(float a) : alpha(a) {
+    this->activity = GraphMat::ALL_VERTICES;
+    this->process_message_requires_vertexprop = false;
+  }
+  HD void reduce_function(float& a, const float& b) const { a += b; }
+  HD void process_message(const float& message, const int, const PRv&, float& res) const { res = message; }
+  HD bool send_message(const PRv& vertexprop, float& message) const {
+    if (vertexprop.degree == 0) message = 0.0f;
+    else message = vertexprop.pagerank / (float)vertexprop.degree;
+    return true;
+  }
+  // double arithmetic on float operands, narrowed on store (:108-110)
+  HD void apply(const float& message_out, PRv& vertexprop) { vertexprop.pagerank = alpha + (1.0 - alpha) * message_out; }
+};
+
+// ---------------- BFS (reference: src/BFS.cpp:36-99) -----------------------------------------
+struct BFSv : gm_bfs_t {
+  HD BFSv() { depth = UINT_MAX; pad_ = 0; parent = (uint64_t)-1; id = (uint64_t)-1; }
+  HD bool operator!=(const BFSv& p) { return this->depth != p.depth; }
+};
+struct BfsP : GraphMat::GraphProgram<unsigned long long, unsigned long long, BFSv, int> {
+  unsigned int current_depth;
+  BfsP() : current_depth(1) {
+    this->order = GraphMat::OUT_EDGES;
+    this->process_message_requires_vertexprop = false;
+  }
+  HD void reduce_function(unsigned long long& a, const unsigned long long& b) const { a = b; }
+  HD void process_message(const unsigned long long& m, const int, const BFSv&, unsigned long long& res) const { res = m; }
+  HD bool send_message(const BFSv& vp, unsigned long long& m) const { m = vp.id; return vp.depth == current_depth - 1; }
+  HD void apply(const unsigned long long& y, BFSv& vp) {
+    if (vp.depth == UINT_MAX) { vp.depth = current_depth; vp.parent = y; }
+  }
+  void do_every_iteration(int) { current_depth++; }
+};
+
+// ---------------- SSSP (reference: src/SSSP.cpp:36-90) -----------------------------------------
+struct SSSPv {
+  unsigned int distance;
+  HD SSSPv() : distance(UINT_MAX) {}
+  HD bool operator!=(const SSSPv& p) { return this->distance != p.distance; }
+};
+struct SsspP : GraphMat::GraphProgram<unsigned int, unsigned int, SSSPv, int> {
+  SsspP() {
+    this->order = GraphMat::OUT_EDGES;
+    this->process_message_requires_vertexprop = false;
+  }
+  HD void reduce_function(unsigned int& a, const unsigned int& b) const { a = (a <= b) ? a : b; }
+  HD void process_message(const unsigned int& m, const int e, const SSSPv&, unsigned int& res) const { res = m + e; }
+  HD bool send_message(const SSSPv& vp, unsigned int& m) const { m = vp.distance; return true; }
+  HD void apply(const unsigned int& y, SSSPv& vp) { vp.distance = vp.distance < y ? vp.distance : y; }
+};
+
+// ---------------- SGD / RMSE (reference: src/SGD.cpp:36-156) --------------------------------------
+template <class R, int K>
+struct Latent {
+  R lv[K];
+  R sqerr;
+  HD Latent() {}
+  HD bool operator!=(const Latent& p) {
+    bool result = false;
+    for (int i = 0; i < K; i++)
+      if (fabs(p.lv[i] - lv[i]) > 1e-7) result = true;
+    return result;
+  }
+};
+template <class R, int K>
+struct SgdP : GraphMat::GraphProgram<Latent<R, K>, Latent<R, K>, Latent<R, K>, int> {
+  typedef Latent<R, K> L;
+  R lambda, step;
+  SgdP(R l, R s) : lambda(l), step(s) {
+    this->order = GraphMat::ALL_EDGES;
+    this->activity = GraphMat::ALL_VERTICES;
+  }
+  HD void reduce_function(L& v, const L& w) const { for (int i = 0; i < K; i++) v.lv[i] += w.lv[i]; }
+  HD void process_message(const L& m, const int e, const L& vp, L& res) const {
+    R estimate = 0;
+    for (int i = 0; i < K; i++) estimate += m.lv[i] * vp.lv[i];
+    R error = e - estimate;
+    for (int i = 0; i < K; i++) res.lv[i] = m.lv[i] * error;
+    res.sqerr = 0;
+  }
+  HD bool send_message(const L& vp, L& m) const { m = vp; return true; }
+  HD void apply(const L& y, L& vp) { for (int i = 0; i < K; i++) vp.lv[i] += step * (-lambda * vp.lv[i] + y.lv[i]); }
+};
+template <class R, int K>
+struct RmseP : GraphMat::GraphProgram<Latent<R, K>, R, Latent<R, K>, int> {
+  typedef Latent<R, K> L;
+  RmseP() { this->order = GraphMat::IN_EDGES; }
+  HD void reduce_function(R& v, const R& w) const { v += w; }
+  HD void process_message(const L& m, const int e, const L& vp, R& res) const {
+    R est = 0;
+    for (int i = 0; i < K; i++) est += m.lv[i] * vp.lv[i];
+    R error = e - est;
+    res = error * error;
+  }
+  HD bool send_message(const L& vp, L& m) const { m = vp; return true; }
+  HD void apply(const R& y, L& vp) { vp.sqerr = y; }
+};
+
+}  // namespace gm
+
+// what the runtime may assume about each program's reduce_function
+namespace GraphMat {
+template <> struct program_traits<gm::DegreeP> { static constexpr reduce_kind reduce = REDUCE_COMMUTATIVE; };
+template <> struct program_traits<gm::PageRankP<0> > { static constexpr reduce_kind reduce = REDUCE_F32_ADD; };
+template <> struct program_traits<gm::PageRankP<1> > { static constexpr reduce_kind reduce = REDUCE_ORDERED; };
+template <> struct program_traits<gm::BfsP> { static constexpr reduce_kind reduce = REDUCE_LAST; };
+template <> struct program_traits<gm::SsspP> { static constexpr reduce_kind reduce = REDUCE_COMMUTATIVE; };
+}  // namespace GraphMat
+
+namespace gm {
+
+// run a program on caller-provided device state through the common engine
+template <class P, class V>
+int run_fixed(P& prog, gm_graph_t* g, V* d_vp, uint32_t* d_active, int iterations, int* iters_done, hipStream_t s) {
+  typedef typename GraphMat::detail::types_of<P>::type PT;
+  typedef typename PT::msg T;
+  typedef typename PT::red U;
+  if (!g || !d_vp) { set_error("gm_run_*: null graph or vertex state"); return GM_ERR_INVALID; }
+  const gm_graph_desc_t& d = g->desc;
+  const int rows = d.row_hi - d.row_lo;
+  const auto order = prog.getOrder();
+  if ((order != GraphMat::IN_EDGES && !g->out.present) || (order != GraphMat::OUT_EDGES && !g->in.present)) {
+    set_error("gm_run_*: graph was built without the adjacency direction this program needs");
+    return GM_ERR_INVALID;
+  }
+  void *p0, *p1, *p2, *p3, *p5;
+  int rc;
+  if ((rc = gm_graph_workspace(g, 1, (size_t)d.nvertices * sizeof(T) + 16, &p0))) return rc;
+  if ((rc = gm_graph_workspace(g, 2, ((size_t)(d.nvertices + 31) / 32 + 2) * 4, &p1))) return rc;
+  if ((rc = gm_graph_workspace(g, 3, (size_t)rows * sizeof(U) + 16, &p2))) return rc;
+  if ((rc = gm_graph_workspace(g, 4, ((size_t)(rows + 31) / 32 + 2) * 4, &p3))) return rc;
+  if (!d_active) {
+    const size_t nw = (size_t)(rows + 31) / 32;
+    if ((rc = gm_graph_workspace(g, 5, (nw + 2) * 4, &p5))) return rc;
+    d_active = (uint32_t*)p5;
+    hipLaunchKernelGGL(GraphMat::dev::k_fill_u32, dim3(GraphMat::detail::grid_for((int64_t)nw)),
+                       dim3(GraphMat::dev::kBlock), 0, s, d_active, (int64_t)nw, 0xffffffffu);
+    if (rows & 31) {
+      uint32_t tail = (1u << (rows & 31)) - 1u;
+      GM_TRY_HIP(hipMemcpyAsync(d_active + nw - 1, &tail, 4, hipMemcpyHostToDevice, s));
+      GM_TRY_HIP(hipStreamSynchronize(s));
+    }
+  }
+  int it = GraphMat::detail::run_on_device<P, T, U, V, int>(&prog, g, order, prog.getActivity(),
+                                                             prog.getProcessMessageRequiresVertexprop(), d_vp, d_active,
+                                                             (T*)p0, (uint32_t*)p1, (U*)p2, (uint32_t*)p3, iterations, s);
+  if (iters_done) *iters_done = it;
+  return GM_OK;
+}
+
+}  // namespace gm
+
+extern "C" {
+
+int gm_set_option(const char* key, int value) {
+  if (key && !strcmp(key, "force_ordered")) { gm::g_force_ordered = value; return GM_OK; }
+  gm::set_error("gm_set_option: unknown option");
+  return GM_ERR_INVALID;
+}
+
+int gm_run_degree(gm_graph_t* g, gm_pr_t* d_vp, int iterations, int* iters_done, gm_stream_t stream) {
+  gm::DegreeP p;
+  return gm::run_fixed(p, g, (gm::PRv*)d_vp, (uint32_t*)nullptr, iterations, iters_done, (hipStream_t)stream);
+}
+
+int gm_run_pagerank(gm_graph_t* g, gm_pr_t* d_vp, float alpha, int iterations, int* iters_done, gm_stream_t stream) {
+  if (gm::g_force_ordered) {
+    gm::PageRankP<1> p(alpha);
+    return gm::run_fixed(p, g, (gm::PRv*)d_vp, (uint32_t*)nullptr, iterations, iters_done, (hipStream_t)stream);
+  }
+  gm::PageRankP<0> p(alpha);
+  return gm::run_fixed(p, g, (gm::PRv*)d_vp, (uint32_t*)nullptr, iterations, iters_done, (hipStream_t)stream);
+}
+
+int gm_run_bfs(gm_graph_t* g, gm_bfs_t* d_vp, uint32_t* d_active, int iterations, int* iters_done, gm_stream_t stream) {
+  gm::BfsP p;
+  return gm::run_fixed(p, g, (gm::BFSv*)d_vp, d_active, iterations, iters_done, (hipStream_t)stream);
+}
+
+int gm_run_sssp(gm_graph_t* g, uint32_t* d_dist, uint32_t* d_active, int iterations, int* iters_done,
+                gm_stream_t stream) {
+  gm::SsspP p;
+  return gm::run_fixed(p, g, (gm::SSSPv*)d_dist, d_active, iterations, iters_done, (hipStream_t)stream);
+}
+
+int gm_run_sgd(gm_graph_t* g, void* d_latent, int K, int real_bytes, double lambda, double step, int iterations,
+               int* iters_done, gm_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (K == 20 && real_bytes == 8) {
+    gm::SgdP<double, 20> p(lambda, step);
+    return gm::run_fixed(p, g, (gm::Latent<double, 20>*)d_latent, (uint32_t*)nullptr, iterations, iters_done, s);
+  }
+  if (K == 20 && real_bytes == 4) {
+    gm::SgdP<float, 20> p((float)lambda, (float)step);
+    return gm::run_fixed(p, g, (gm::Latent<float, 20>*)d_latent, (uint32_t*)nullptr, iterations, iters_done, s);
+  }
+  gm::set_error("gm_run_sgd: (K=%d, real_bytes=%d) is not in the fixed menu", K, real_bytes);
+  return GM_ERR_UNSUPPORTED;
+}
+
+int gm_run_rmse(gm_graph_t* g, void* d_latent, int K, int real_bytes, gm_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (K == 20 && real_bytes == 8) {
+    gm::RmseP<double, 20> p;
+    return gm::run_fixed(p, g, (gm::Latent<double, 20>*)d_latent, (uint32_t*)nullptr, 1, nullptr, s);
+  }
+  if (K == 20 && real_bytes == 4) {
+    gm::RmseP<float, 20> p;
+    return gm::run_fixed(p, g, (gm::Latent<float, 20>*)d_latent, (uint32_t*)nullptr, 1, nullptr, s);
+  }
+  gm::set_error("gm_run_rmse: (K=%d, real_bytes=%d) is not in the fixed menu", K, real_bytes);
+  return GM_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

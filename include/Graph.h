@@ -1,0 +1,463 @@
+// Graph.h -- Graph<V,E> of the MI355X GraphMat engine.
+//
+// Same public surface as the reference's include/Graph.h:58-107 (fields
+// nvertices/nnz/..., ReadMTX, ReadEdgelist, set/get vertex properties, activity,
+// applyTo*), with different internals:
+//   * adjacency: one gm_graph_t (C-ABI, include/graphmat_hip.h) holding CSR by
+//     destination and CSR by source in HBM -- the roles of the reference's AT and A
+//     (SpMat<DCSCTile<E>>), built on the device;
+//   * vertex properties and the active set are device arrays in native order with a
+//     lazily synchronised host mirror, because applications touch single vertices
+//     from host loops before/after a run (src/BFS.cpp:114-119, src/SGD.cpp:176-184
+//     of the reference) while the iteration loop itself is device resident.
+// Vertex ids at this API are 1-based, as in the reference.
+#ifndef GRAPHMAT_HIP_GRAPH_H_
+#define GRAPHMAT_HIP_GRAPH_H_
+
+#include <sys/time.h>
+
+#include <algorithm>
+#include <cassert>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#if !defined(GRAPHMAT_NO_MPI) && defined(__has_include)
+#if __has_include(<mpi.h>)
+#include <mpi.h>
+#define GRAPHMAT_HAVE_REAL_MPI 1
+#endif
+#endif
+#ifndef GRAPHMAT_HAVE_REAL_MPI
+#include "graphmat/mpi_single.h"
+#endif
+
+#include "graphmat/edgelist.h"
+#include "graphmat/engine.hpp"
+
+namespace GraphMat {
+
+inline int get_global_nrank() {
+  int n = 1;
+  MPI_Comm_size(MPI_COMM_WORLD, &n);
+  return n;
+}
+inline int get_global_myrank() {
+  int r = 0;
+  MPI_Comm_rank(MPI_COMM_WORLD, &r);
+  return r;
+}
+inline double get_compression_threshold() { return 0.5; }
+
+class Serializable {};  // tag of the reference (gmdp.h:80); such message types are host-only there and unsupported here
+
+inline double sec(struct timeval start, struct timeval end) {
+  return ((double)(((end.tv_sec * 1000000 + end.tv_usec) - (start.tv_sec * 1000000 + start.tv_usec)))) / 1.0e6;
+}
+
+template <class T>
+void AddFn(const T& a, const T& b, T* c, void* vsp) {
+  *c = a + b;
+}
+
+// ---- device vector with the reference's "dense segment" semantics ---------------------
+// value[capacity] + presence bits (bit i&31 of word i>>5), cf. the reference's
+// include/GMDP/vectors/DenseSegment.h:423-640; here both live in HBM, with an
+// optional host mirror.
+template <class T>
+class DenseSegment {
+ public:
+  typedef typename std::conditional<std::is_same<T, bool>::value, unsigned char, T>::type store_t;
+  int capacity;
+  int num_ints;
+  store_t* value;        // device; nullptr for bits-only vectors (the active set)
+  uint32_t* bit_vector;  // device
+  bool owns_device;
+  bool mirrored;
+  std::vector<store_t> hvalue;
+  std::vector<uint32_t> hbits;
+  bool host_valid, dev_valid;
+
+  DenseSegment(int n, bool with_values)
+      : capacity(n), num_ints((n + 31) / 32), value(nullptr), bit_vector(nullptr), owns_device(true), mirrored(true),
+        host_valid(true), dev_valid(false) {
+    // one spare word so 64-wide kernels may write a full pair of words at the tail
+    GM_HIP_OK(hipMalloc((void**)&bit_vector, (size_t)(num_ints + 2) * 4));
+    GM_HIP_OK(hipMemset(bit_vector, 0, (size_t)(num_ints + 2) * 4));
+    if (with_values) {
+      GM_HIP_OK(hipMalloc((void**)&value, std::max<size_t>((size_t)n * sizeof(store_t), 16)));
+      hvalue.resize(n);
+    }
+    hbits.assign(num_ints, 0u);
+  }
+  // borrow existing device arrays (C-ABI fixed-menu entry points): no host mirror
+  DenseSegment(int n, store_t* d_value, uint32_t* d_bits)
+      : capacity(n), num_ints((n + 31) / 32), value(d_value), bit_vector(d_bits), owns_device(false), mirrored(false),
+        host_valid(false), dev_valid(true) {}
+  ~DenseSegment() {
+    if (owns_device) {
+      if (value) (void)hipFree(value);
+      if (bit_vector) (void)hipFree(bit_vector);
+    }
+  }
+  DenseSegment(const DenseSegment&) = delete;
+  DenseSegment& operator=(const DenseSegment&) = delete;
+
+  void need_host() {
+    if (!mirrored) { printf("GraphMat(HIP): host access to a device-only vector\n"); exit(1); }
+    if (host_valid) return;
+    if (value) GM_HIP_OK(hipMemcpy(hvalue.data(), value, (size_t)capacity * sizeof(store_t), hipMemcpyDeviceToHost));
+    GM_HIP_OK(hipMemcpy(hbits.data(), bit_vector, (size_t)num_ints * 4, hipMemcpyDeviceToHost));
+    host_valid = true;
+  }
+  void need_device() {
+    if (dev_valid) return;
+    if (value && capacity) GM_HIP_OK(hipMemcpy(value, hvalue.data(), (size_t)capacity * sizeof(store_t), hipMemcpyHostToDevice));
+    if (num_ints) GM_HIP_OK(hipMemcpy(bit_vector, hbits.data(), (size_t)num_ints * 4, hipMemcpyHostToDevice));
+    dev_valid = true;
+  }
+  void host_modified() { need_host(); dev_valid = false; }
+  void device_modified() { host_valid = false; dev_valid = true; }
+
+  void setAllBits(bool on) {  // exactly `capacity` bits (DenseSegment.h:617-633)
+    host_modified();
+    std::fill(hbits.begin(), hbits.end(), on ? 0xffffffffu : 0u);
+    if (on && (capacity & 31)) hbits[num_ints - 1] = (1u << (capacity & 31)) - 1u;
+  }
+};
+
+template <class Segment>
+class SpVec;
+
+template <class T>
+class SpVec<DenseSegment<T> > {
+ public:
+  int n;
+  int nsegments;
+  DenseSegment<T>* segment;
+  SpVec(int _n, bool with_values = true) : n(_n), nsegments(1), segment(new DenseSegment<T>(_n, with_values)) {}
+  SpVec(int _n, typename DenseSegment<T>::store_t* d_value, uint32_t* d_bits)
+      : n(_n), nsegments(1), segment(new DenseSegment<T>(_n, d_value, d_bits)) {}
+  ~SpVec() { delete segment; }
+  void setAll(const T& v) {
+    segment->setAllBits(true);
+    for (auto& e : segment->hvalue) e = v;
+  }
+  void set(int idx, const T& v) {  // 1-based native index
+    segment->host_modified();
+    if (segment->value) segment->hvalue[idx - 1] = v;
+    segment->hbits[(idx - 1) >> 5] |= (1u << ((idx - 1) & 31));
+  }
+  void unset(int idx) {
+    segment->host_modified();
+    segment->hbits[(idx - 1) >> 5] &= ~(1u << ((idx - 1) & 31));
+  }
+  void get(int idx, T* out) const {
+    segment->need_host();
+    *out = segment->hvalue[idx - 1];
+  }
+  int getNNZ() const {
+    segment->need_host();
+    int c = 0;
+    for (uint32_t w : segment->hbits) c += __builtin_popcount(w);
+    return c;
+  }
+  bool node_owner(int) const { return true; }
+};
+
+// ---- the graph ---------------------------------------------------------------------------
+template <class V, class E = int>
+class Graph {
+ public:
+  int nvertices;
+  long long int nnz;
+  bool vertexpropertyowner;
+  int tiles_per_dim;
+  int num_threads;  // layout parameter only: enters the id permutation like the reference's OpenMP thread count
+
+  gm_graph_t* A;   // both directions live in one handle; A and AT name the same object
+  gm_graph_t* AT;
+  bool adjacencyowner;
+  SpVec<DenseSegment<V> >* vertexproperty;
+  SpVec<DenseSegment<bool> >* active;
+
+ public:
+  Graph()
+      : nvertices(0), nnz(0), vertexpropertyowner(true), tiles_per_dim(get_global_nrank()),
+        num_threads(default_num_threads()), A(nullptr), AT(nullptr), adjacencyowner(true), vertexproperty(nullptr),
+        active(nullptr) {}
+  // Wrap an existing adjacency and device state (used by the C-ABI fixed-menu programs).
+  Graph(gm_graph_t* handle, V* d_vp, uint32_t* d_active)
+      : vertexpropertyowner(true), tiles_per_dim(1), num_threads(1), A(handle), AT(handle), adjacencyowner(false) {
+    gm_graph_desc_t d;
+    gm_graph_desc(handle, &d);
+    nvertices = d.nvertices;
+    gm_csr_t c;
+    nnz = 0;
+    if (gm_graph_csr(handle, GM_DIR_OUT, &c) == GM_OK) nnz = c.nnz;
+    else if (gm_graph_csr(handle, GM_DIR_IN, &c) == GM_OK) nnz = c.nnz;
+    int rows = d.row_hi - d.row_lo;
+    vertexproperty = new SpVec<DenseSegment<V> >(rows, (typename DenseSegment<V>::store_t*)d_vp, nullptr);
+    active = new SpVec<DenseSegment<bool> >(rows, nullptr, d_active);
+  }
+
+  void ReadEdgelist(GraphMat::edgelist_t<E> A_edges);
+  void getVertexEdgelist(GraphMat::edgelist_t<V>& myedges);
+  void getEdgelist(GraphMat::edgelist_t<E>& myedges);
+  void ReadMTX(const char* filename);
+  void ReadGraphMatBin(const char* filename);
+  void WriteGraphMatBin(const char* filename);
+
+  void setAllActive();
+  void setAllInactive();
+  void setActive(int v);
+  void setInactive(int v);
+
+  void setAllVertexproperty(const V& val);
+  void setVertexproperty(int v, const V& val);
+  V getVertexproperty(int v) const;
+  bool vertexNodeOwner(const int v) const;
+  void saveVertexproperty(std::string fname, bool includeHeader = true) const;
+  void reset();
+  void shareVertexProperty(Graph<V, E>& g);
+  int getNumberOfVertices() const;
+  void applyToAllVertices(void (*ApplyFn)(const V&, V*, void*), void* param = nullptr);
+  template <class T>
+  void applyReduceAllVertices(T* val, void (*ApplyFn)(V*, T*, void*),
+                              void (*ReduceFn)(const T&, const T&, T*, void*) = AddFn<T>, void* param = nullptr);
+  void applyToAllEdges(void (*ApplyFn)(E*, const V&, const V&, void*), void* param = nullptr);
+  ~Graph();
+
+  int vertexToNative(int vertex, int nsegments, int len) const {
+    return gm_vertex_to_native(vertex, num_threads * 16 * nsegments, len);
+  }
+  int nativeToVertex(int vertex, int nsegments, int len) const {
+    return gm_native_to_vertex(vertex, num_threads * 16 * nsegments, len);
+  }
+
+ private:
+  static int default_num_threads() {
+    const char* e = getenv("GRAPHMAT_NUM_THREADS");
+    if (!e) e = getenv("OMP_NUM_THREADS");
+    int t = e ? atoi(e) : 1;
+    return t > 0 ? t : 1;
+  }
+};
+
+template <class V, class E>
+void Graph<V, E>::ReadEdgelist(GraphMat::edgelist_t<E> A_edges) {
+  struct timeval start, end;
+  gettimeofday(&start, 0);
+  tiles_per_dim = GraphMat::get_global_nrank();
+  const size_t ne = (size_t)A_edges.nnz;
+  std::vector<int32_t> src(ne), dst(ne);
+  std::vector<E> val(ne);
+  for (size_t i = 0; i < ne; i++) {
+    src[i] = A_edges.edges[i].src;
+    dst[i] = A_edges.edges[i].dst;
+    val[i] = A_edges.edges[i].val;
+  }
+  gm_graph_desc_t d;
+  memset(&d, 0, sizeof(d));
+  d.nvertices = A_edges.m;
+  d.nparts = num_threads * 16 * tiles_per_dim;  // Graph.h:117 of the reference
+  d.row_lo = 0;
+  d.row_hi = A_edges.m;
+  d.directions = GM_DIR_OUT | GM_DIR_IN;
+  d.val_bytes = (int)sizeof(E);
+  if (A && adjacencyowner) gm_graph_destroy(A);
+  A = AT = nullptr;
+  if (gm_graph_create(&A, &d, (int64_t)ne, src.data(), dst.data(), val.data(), nullptr) != GM_OK) {
+    printf("GraphMat(HIP): graph construction failed: %s\n", gm_last_error());
+    exit(1);
+  }
+  AT = A;
+  adjacencyowner = true;
+  nvertices = A_edges.m;
+  nnz = (long long)ne;
+  if (vertexproperty && vertexpropertyowner) delete vertexproperty;
+  if (active) delete active;
+  vertexproperty = new SpVec<DenseSegment<V> >(nvertices, true);
+  V* __v = new V;
+  vertexproperty->setAll(*__v);
+  delete __v;
+  active = new SpVec<DenseSegment<bool> >(nvertices, false);
+  vertexpropertyowner = true;
+  gettimeofday(&end, 0);
+  std::cout << "Finished GraphMat read + construction, time: " << sec(start, end) << std::endl;
+}
+
+template <class V, class E>
+void Graph<V, E>::ReadMTX(const char* filename) {
+  GraphMat::edgelist_t<E> A_edges;
+  GraphMat::load_edgelist(filename, &A_edges, true, true, true);  // binary format with header and edge weights
+  if (A_edges.m != A_edges.n) {
+    int maxn = std::max(A_edges.m, A_edges.n);
+    A_edges.m = maxn;
+    A_edges.n = maxn;
+  }
+  ReadEdgelist(A_edges);
+  A_edges.clear();
+}
+
+template <class V, class E>
+void Graph<V, E>::ReadGraphMatBin(const char*) {
+  std::cout << "GraphMat(HIP): GraphMat-bin archives (boost::serialization) are not supported" << std::endl;
+  exit(1);
+}
+template <class V, class E>
+void Graph<V, E>::WriteGraphMatBin(const char*) {
+  std::cout << "GraphMat(HIP): GraphMat-bin archives (boost::serialization) are not supported" << std::endl;
+  exit(1);
+}
+
+template <class V, class E>
+void Graph<V, E>::setAllActive() { active->segment->setAllBits(true); }
+template <class V, class E>
+void Graph<V, E>::setAllInactive() { active->segment->setAllBits(false); }
+template <class V, class E>
+void Graph<V, E>::setActive(int v) { active->set(vertexToNative(v, tiles_per_dim, nvertices), true); }
+template <class V, class E>
+void Graph<V, E>::setInactive(int v) { active->unset(vertexToNative(v, tiles_per_dim, nvertices)); }
+
+template <class V, class E>
+void Graph<V, E>::reset() {
+  setAllInactive();
+  V v;
+  vertexproperty->setAll(v);
+}
+
+template <class V, class E>
+void Graph<V, E>::shareVertexProperty(Graph<V, E>& g) {
+  if (vertexproperty != nullptr && vertexpropertyowner) delete vertexproperty;
+  vertexproperty = g.vertexproperty;
+  vertexpropertyowner = false;
+}
+
+template <class V, class E>
+void Graph<V, E>::setAllVertexproperty(const V& val) { vertexproperty->setAll(val); }
+template <class V, class E>
+void Graph<V, E>::setVertexproperty(int v, const V& val) {
+  vertexproperty->set(vertexToNative(v, tiles_per_dim, nvertices), val);
+}
+template <class V, class E>
+V Graph<V, E>::getVertexproperty(const int v) const {
+  V vp;
+  vertexproperty->get(vertexToNative(v, tiles_per_dim, nvertices), &vp);
+  return vp;
+}
+template <class V, class E>
+bool Graph<V, E>::vertexNodeOwner(const int v) const { return v >= 1 && v <= nvertices; }
+template <class V, class E>
+int Graph<V, E>::getNumberOfVertices() const { return nvertices; }
+
+template <class V, class E>
+void Graph<V, E>::getVertexEdgelist(GraphMat::edgelist_t<V>& myedges) {
+  vertexproperty->segment->need_host();
+  myedges = edgelist_t<V>(nvertices, 1, nvertices);
+  for (int i = 0; i < nvertices; i++) {
+    myedges.edges[i].src = nativeToVertex(i + 1, tiles_per_dim, nvertices);
+    myedges.edges[i].dst = 1;
+    myedges.edges[i].val = vertexproperty->segment->hvalue[i];
+  }
+}
+
+template <class V, class E>
+void Graph<V, E>::getEdgelist(GraphMat::edgelist_t<E>& myedges) {
+  gm_csr_t c;
+  if (gm_graph_csr(A, GM_DIR_IN, &c) != GM_OK) { printf("%s\n", gm_last_error()); exit(1); }
+  std::vector<int64_t> rp(c.nrows + 1);
+  std::vector<int32_t> ci((size_t)c.nnz);
+  std::vector<E> vv((size_t)c.nnz);
+  gm_graph_csr_to_host(A, GM_DIR_IN, rp.data(), ci.data(), vv.data());
+  myedges = edgelist_t<E>(nvertices, nvertices, (int)c.nnz);
+  size_t k = 0;
+  for (int r = 0; r < c.nrows; r++)
+    for (int64_t e = rp[r]; e < rp[r + 1]; e++, k++) {
+      myedges.edges[k].src = nativeToVertex(r + 1, tiles_per_dim, nvertices);
+      myedges.edges[k].dst = nativeToVertex(ci[e] + 1, tiles_per_dim, nvertices);
+      myedges.edges[k].val = vv[e];
+    }
+}
+
+// text dump "vertex value" per line, vertices in id order (reference: Graph.h:337-350 writes one
+// file per rank via DenseSegment::save; single rank here, file name gets the rank suffix 0)
+template <class V, class E>
+void Graph<V, E>::saveVertexproperty(std::string fname, bool includeHeader) const {
+  vertexproperty->segment->need_host();
+  std::ofstream f((fname + std::to_string(get_global_myrank())).c_str());
+  if (includeHeader) f << nvertices << " " << 1 << " " << nvertices << std::endl;
+  for (int v = 1; v <= nvertices; v++)
+    f << v << " " << vertexproperty->segment->hvalue[vertexToNative(v, tiles_per_dim, nvertices) - 1] << std::endl;
+}
+
+// Host-side element-wise helpers.  The callbacks are host function pointers, so they run
+// on the host mirror (the reference runs them under OpenMP: include/GMDP/singlenode/apply.h,
+// reduce.h:51-99).
+template <class V, class E>
+void Graph<V, E>::applyToAllVertices(void (*ApplyFn)(const V&, V*, void*), void* param) {
+  vertexproperty->segment->host_modified();
+  for (auto& v : vertexproperty->segment->hvalue) ApplyFn(v, &v, param);
+}
+
+template <class V, class E>
+template <class T>
+void Graph<V, E>::applyReduceAllVertices(T* val, void (*ApplyFn)(V*, T*, void*),
+                                         void (*ReduceFn)(const T&, const T&, T*, void*), void* param) {
+  vertexproperty->segment->need_host();
+  std::vector<V>& h = vertexproperty->segment->hvalue;
+  const int n = (int)h.size();
+  const int nthreads = num_threads;  // chunking of reduce.h:57-66
+  const int per = (n + nthreads - 1) / nthreads;
+  for (int p = 0; p < nthreads; p++) {
+    int s = std::min(per * p, n), e = std::min(per * (p + 1), n);
+    bool first = false;
+    T local;
+    for (int i = s; i < e; i++) {
+      T t2;
+      ApplyFn(&h[i], &t2, param);
+      if (first) { T t = local; ReduceFn(t, t2, &local, param); }
+      else { local = t2; first = true; }
+    }
+    if (first) { T t = *val; ReduceFn(t, local, val, param); }
+  }
+}
+
+template <class V, class E>
+void Graph<V, E>::applyToAllEdges(void (*ApplyFn)(E*, const V&, const V&, void*), void* param) {
+  vertexproperty->segment->need_host();
+  const std::vector<V>& h = vertexproperty->segment->hvalue;
+  for (int dir : {GM_DIR_OUT, GM_DIR_IN}) {
+    gm_csr_t c;
+    if (gm_graph_csr(A, dir, &c) != GM_OK) continue;
+    std::vector<int64_t> rp(c.nrows + 1);
+    std::vector<int32_t> ci((size_t)c.nnz);
+    std::vector<E> vv((size_t)c.nnz);
+    gm_graph_csr_to_host(A, dir, rp.data(), ci.data(), vv.data());
+    for (int r = 0; r < c.nrows; r++)
+      for (int64_t e = rp[r]; e < rp[r + 1]; e++) {
+        // OUT: row = destination, col = source;  IN: row = source, col = destination
+        if (dir == GM_DIR_OUT) ApplyFn(&vv[e], h[ci[e]], h[r], param);
+        else ApplyFn(&vv[e], h[r], h[ci[e]], param);
+      }
+    gm_graph_set_vals(A, dir, vv.data());
+  }
+}
+
+template <class V, class E>
+Graph<V, E>::~Graph() {
+  if (A != nullptr && adjacencyowner) gm_graph_destroy(A);
+  A = AT = nullptr;
+  if (vertexpropertyowner && vertexproperty != nullptr) delete vertexproperty;
+  vertexproperty = nullptr;
+  if (active != nullptr) delete active;
+  active = nullptr;
+}
+
+}  // namespace GraphMat
+#endif

@@ -1,0 +1,105 @@
+// graphmat/edgelist.h -- host edge lists with the reference's public names
+// (edge_t / edgelist_t: include/GMDP/utils/edgelist.h:38-78 of the reference) and
+// the binary .mtx loader (ibid. :242-334) on top of the C-ABI reader.
+#ifndef GRAPHMAT_HIP_EDGELIST_H_
+#define GRAPHMAT_HIP_EDGELIST_H_
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <string>
+
+#include "../graphmat_hip.h"
+
+namespace GraphMat {
+
+inline int get_global_nrank();
+inline int get_global_myrank();
+
+template <typename T>
+struct edge_t {
+  edge_t() {}
+  edge_t(int _src, int _dst, T _val) : src(_src), dst(_dst), val(_val) {}
+  int src;
+  int dst;
+  T val;
+};
+
+template <typename T>
+struct edgelist_t {
+  edge_t<T>* edges;
+  int m;
+  int n;
+  int nnz;
+  edgelist_t() : edges(nullptr), m(0), n(0), nnz(0) {}
+  edgelist_t(int _m, int _n, int _nnz) : edges(nullptr), m(_m), n(_n), nnz(_nnz) {
+    if (nnz > 0) edges = static_cast<edge_t<T>*>(malloc((size_t)nnz * sizeof(edge_t<T>)));
+  }
+  edgelist_t(edge_t<T>* e, int _m, int _n, int _nnz) : edges(e), m(_m), n(_n), nnz(_nnz) {}
+  void clear() {
+    if (nnz > 0) free(edges);
+    edges = nullptr;
+    nnz = 0;
+    m = 0;
+    n = 0;
+  }
+};
+
+// Binary .mtx with header and weights.  File naming follows the reference: rank r
+// reads <prefix><r>, <prefix><r+nranks>, ... until one is missing.  As a
+// convenience a plain <prefix> (no suffix) is read when <prefix>0 does not exist.
+template <typename T>
+void load_edgelist(const char* dir, edgelist_t<T>* edgelist, bool binaryformat = true, bool header = true,
+                   bool edgeweights = true) {
+  if (!binaryformat || !header || !edgeweights) {
+    printf("GraphMat(HIP): only binary .mtx with header and weights is supported by this loader\n");
+    exit(1);
+  }
+  edgelist->m = edgelist->n = edgelist->nnz = 0;
+  edgelist->edges = nullptr;
+  const int nrank = get_global_nrank(), myrank = get_global_myrank();
+  for (int i = myrank;; i += nrank) {
+    std::stringstream fname_ss;
+    fname_ss << dir << i;
+    std::string fname = fname_ss.str();
+    FILE* probe = fopen(fname.c_str(), "rb");
+    if (!probe) {
+      if (i == 0 && nrank == 1 && (probe = fopen(dir, "rb")) != nullptr) {
+        fname = dir;
+      } else {
+        if (i == myrank) printf("Could not open file: %s\n", fname.c_str());
+        break;
+      }
+    }
+    fclose(probe);
+    printf("Reading file: %s\n", fname.c_str());
+    int nv = 0;
+    int64_t nnz = 0;
+    int32_t *s = nullptr, *d = nullptr;
+    void* v = nullptr;
+    if (gm_mtx_read(fname.c_str(), (int)sizeof(T), &nv, &nnz, &s, &d, &v) != GM_OK) {
+      printf("%s\n", gm_last_error());
+      exit(1);
+    }
+    size_t old = (size_t)edgelist->nnz;
+    edgelist->edges = static_cast<edge_t<T>*>(realloc(edgelist->edges, (old + (size_t)nnz + 1) * sizeof(edge_t<T>)));
+    for (int64_t k = 0; k < nnz; k++) {
+      edge_t<T>& e = edgelist->edges[old + k];
+      e.src = s[k];
+      e.dst = d[k];
+      memcpy(&e.val, (const char*)v + (size_t)k * sizeof(T), sizeof(T));
+    }
+    gm_host_free(s);
+    gm_host_free(d);
+    gm_host_free(v);
+    edgelist->nnz += (int)nnz;
+    if (nv > edgelist->m) edgelist->m = nv;
+    if (nv > edgelist->n) edgelist->n = nv;
+    if (fname == dir) break;
+  }
+  printf("Got: %d by %d  vertices\n", edgelist->m, edgelist->n);
+  printf("Got: %d edges\n", edgelist->nnz);
+}
+
+}  // namespace GraphMat
+#endif

@@ -1,0 +1,185 @@
+// graphmat/engine.hpp -- host driver of the device iteration loop.
+//
+// Restates the control flow of the reference's run_graph_program
+// (include/GraphMatRuntime.h:93-279) around the kernels of kernels.hpp: the whole
+// loop is device resident; per iteration only the 1-int "changed" flag (and only
+// when running until convergence) and the host hook do_every_iteration cross back.
+#pragma once
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace GraphMat {
+
+enum edge_direction { OUT_EDGES, IN_EDGES, ALL_EDGES };  // GraphProgram.h:34
+enum activity_type { ACTIVE_ONLY, ALL_VERTICES };        // GraphProgram.h:36
+
+namespace detail {
+
+#define GM_HIP_OK(expr)                                                                         \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      printf("GraphMat(HIP): %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, \
+             __LINE__);                                                                         \
+      exit(1); /* the reference's error convention: message + exit(1) */                        \
+    }                                                                                           \
+  } while (0)
+
+inline int grid_for(int64_t n) { return (int)((n + dev::kBlock - 1) / dev::kBlock); }
+
+struct PhaseTimer {
+  bool on;
+  hipStream_t s;
+  std::vector<hipEvent_t> ev;  // 4 per iteration: t0 send t1 spmv t2 apply t3
+  explicit PhaseTimer(bool on_, hipStream_t s_) : on(on_), s(s_) {}
+  void mark() {
+    if (!on) return;
+    hipEvent_t e;
+    GM_HIP_OK(hipEventCreate(&e));
+    GM_HIP_OK(hipEventRecord(e, s));
+    ev.push_back(e);
+  }
+  void finish(gm_run_stats_t* st) {
+    if (!on || ev.empty()) return;
+    GM_HIP_OK(hipEventSynchronize(ev.back()));
+    for (size_t i = 0; i + 3 < ev.size(); i += 4) {
+      float a = 0, b = 0, c = 0;
+      GM_HIP_OK(hipEventElapsedTime(&a, ev[i], ev[i + 1]));
+      GM_HIP_OK(hipEventElapsedTime(&b, ev[i + 1], ev[i + 2]));
+      GM_HIP_OK(hipEventElapsedTime(&c, ev[i + 2], ev[i + 3]));
+      st->send_ms += a;
+      st->spmv_ms += b;
+      st->apply_ms += c;
+    }
+    float t = 0;
+    GM_HIP_OK(hipEventElapsedTime(&t, ev.front(), ev.back()));
+    st->total_ms = t;
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    ev.clear();
+  }
+};
+
+// one multiply+reduce pass over one direction of the adjacency
+template <class P, class T, class U, class V, class E, bool USE_VP>
+void launch_spmv(const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits, const V* vp, U* y,
+                 uint32_t* ybits, int accumulate, hipStream_t s, int* launches) {
+  constexpr int RK = (int)program_traits<P>::reduce;
+  if (A.nnz == 0) return;
+  if (A.nblk > 0) {
+    hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A, x,
+                       xbits, vp, y, ybits, accumulate);
+    (*launches)++;
+  }
+  if (A.nlong > 0) {
+    hipLaunchKernelGGL((dev::k_spmv_longrow<P, T, U, V, E, USE_VP, RK>), dim3(A.nlong), dim3(dev::kBlock), 0, s, pa, A,
+                       x, xbits, vp, y, ybits, accumulate);
+    (*launches)++;
+  }
+}
+
+// The iteration loop.  d_vp / d_active cover the shard's rows in native order.
+// x/xbits are global-size scratch, y/ybits shard-size scratch.  Returns iterations done.
+template <class P, class T, class U, class V, class E>
+int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act, bool use_vp, V* d_vp,
+                  uint32_t* d_active, T* x, uint32_t* xbits, U* y, uint32_t* ybits, int iterations, hipStream_t s) {
+  gm_graph_desc_t desc;
+  gm_graph_desc(g, &desc);
+  gm_csr_t Aout, Ain;
+  memset(&Aout, 0, sizeof(Aout));
+  memset(&Ain, 0, sizeof(Ain));
+  if (order != IN_EDGES && gm_graph_csr(g, GM_DIR_OUT, &Aout) != GM_OK) {
+    printf("GraphMat(HIP): program needs OUT_EDGES adjacency (GM_DIR_OUT) which this graph was built without\n");
+    exit(1);
+  }
+  if (order != OUT_EDGES && gm_graph_csr(g, GM_DIR_IN, &Ain) != GM_OK) {
+    printf("GraphMat(HIP): program needs IN_EDGES adjacency (GM_DIR_IN) which this graph was built without\n");
+    exit(1);
+  }
+  const int n = desc.row_hi - desc.row_lo;
+  const int nwords = (n + 31) / 32;
+  const bool multi = gm_graph_has_exchange(g) != 0;
+
+  void* flag_v = nullptr;
+  gm_graph_workspace(g, 0, 256, &flag_v);
+  int* d_changed = (int*)flag_v;
+  int* h_changed = nullptr;
+  GM_HIP_OK(hipHostMalloc((void**)&h_changed, sizeof(int), hipHostMallocDefault));
+
+  if (act == ALL_VERTICES) {  // GraphMatRuntime.h:121-123 g.setAllActive()
+    hipLaunchKernelGGL(dev::k_fill_u32, dim3(grid_for(nwords)), dim3(dev::kBlock), 0, s, d_active, (int64_t)nwords,
+                       0xffffffffu);
+  }
+  gm_run_stats_t st;
+  memset(&st, 0, sizeof(st));
+  PhaseTimer timer(gm_graph_timing_enabled(g) != 0, s);
+
+  int it = 0;
+  while (true) {
+    dev::ProgArg<P> pa = dev::make_prog_arg(gp);  // re-captured every iteration (do_every_iteration may change it)
+    // Clear(&x) / Clear(&y) (:139-140): x presence words are fully rewritten by send
+    GM_HIP_OK(hipMemsetAsync(ybits, 0, (size_t)nwords * 4, s));
+    GM_HIP_OK(hipMemsetAsync(d_changed, 0, sizeof(int), s));
+    timer.mark();
+    // send (:145)
+    const bool dense_x = (act == ALL_VERTICES);
+    hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
+                       dense_x ? (const uint32_t*)nullptr : (const uint32_t*)d_active, x, xbits, n, desc.row_lo);
+    if (multi) {
+      if (gm_graph_exchange(g, GM_XCHG_MESSAGES, x, (int64_t)sizeof(T), xbits, nullptr) != 0) {
+        printf("GraphMat(HIP): message exchange callback failed\n");
+        exit(1);
+      }
+    }
+    timer.mark();
+    // multiply + reduce (:160-176)
+    const uint32_t* xb = dense_x ? nullptr : xbits;
+    if (order == OUT_EDGES || order == ALL_EDGES) {
+      if (use_vp) launch_spmv<P, T, U, V, E, true>(pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches);
+      else launch_spmv<P, T, U, V, E, false>(pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches);
+    }
+    if (order == IN_EDGES || order == ALL_EDGES) {
+      int acc = (order == ALL_EDGES) ? 1 : 0;
+      if (use_vp) launch_spmv<P, T, U, V, E, true>(pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches);
+      else launch_spmv<P, T, U, V, E, false>(pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches);
+    }
+    timer.mark();
+    // setAllInactive (:184) + apply (:195-225): the active vector is rewritten by k_apply
+    hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, (const U*)y,
+                       (const uint32_t*)ybits, d_vp, d_active, n, d_changed);
+    timer.mark();
+    int converged = 0;
+    if (iterations <= 0) {  // the flag only matters when running until convergence (:257-259)
+      GM_HIP_OK(hipMemcpyAsync(h_changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, s));
+      GM_HIP_OK(hipStreamSynchronize(s));
+      converged = (*h_changed == 0) ? 1 : 0;
+      if (multi) gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &converged);  // :226 Allreduce(LAND)
+    }
+    gp->do_every_iteration(it);  // :236
+    if (act == ALL_VERTICES && iterations > 0 && it + 1 == iterations) {
+      // last iteration of a fixed-count run: leave the graph all-active (:250-252)
+      hipLaunchKernelGGL(dev::k_fill_u32, dim3(grid_for(nwords)), dim3(dev::kBlock), 0, s, d_active, (int64_t)nwords,
+                         0xffffffffu);
+    }
+    it++;
+    if (it == iterations) break;
+    if (iterations <= 0 && converged == 1) {
+      if (act == ALL_VERTICES)
+        hipLaunchKernelGGL(dev::k_fill_u32, dim3(grid_for(nwords)), dim3(dev::kBlock), 0, s, d_active,
+                           (int64_t)nwords, 0xffffffffu);
+      break;
+    }
+  }
+  GM_HIP_OK(hipStreamSynchronize(s));
+  st.iterations = it;
+  timer.finish(&st);
+  gm_graph_record_stats(g, &st);
+  (void)hipHostFree(h_changed);
+  return it;
+}
+
+}  // namespace detail
+}  // namespace GraphMat

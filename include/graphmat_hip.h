@@ -1,0 +1,215 @@
+/* graphmat_hip.h -- C-ABI of libgraphmat_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for GraphMat's generalized-SpMV hot path.  The
+ * reference has no FFI layer (it is a header-only C++ template library), so the
+ * seam is cut where the reference's host code meets its compute loops:
+ *
+ *   reference                                            this library
+ *   ---------------------------------------------------  ---------------------------
+ *   Graph::vertexToNative / nativeToVertex               gm_vertex_to_native / gm_native_to_vertex
+ *     (include/Graph.h:111-150)
+ *   load_edgelist, binary .mtx                           gm_mtx_read
+ *     (include/GMDP/utils/edgelist.h:242-334)
+ *   Graph::ReadEdgelist -> SpMat/DCSCTile ctor,          gm_graph_create (device-side CSR build)
+ *     Transpose (include/Graph.h:210-246,
+ *     include/GMDP/matrices/DCSCTile.h:241-381)
+ *   run_graph_program for the example programs            gm_run_pagerank / gm_run_degree /
+ *     (include/GraphMatRuntime.h:93-279 driving           gm_run_bfs / gm_run_sssp / gm_run_sgd /
+ *      include/SPMV.h:41-95 ->                            gm_run_rmse  ("fixed menu": the programs
+ *      include/GMDP/singlenode/spmspv.h:39-86,            of src/PageRank.cpp, src/BFS.cpp,
+ *      spmspv3.h:38-90, intersectreduce.h:39-66)          src/SSSP.cpp, src/SGD.cpp)
+ *   MapReduce (include/GMDP/singlenode/reduce.h:51-99)   gm_reduce_*
+ *
+ * Arbitrary user vertex programs cannot cross a C ABI (their functors must be
+ * compiled for the device); for them the C++ headers include/GraphMatRuntime.h,
+ * Graph.h, GraphProgram.h instantiate the same kernel templates in the
+ * application's translation unit (hipcc --hipstdpar) and use this C-ABI for the
+ * graph, memory and utility kernels.
+ *
+ * Conventions: every function returns 0 on success and a GM_ERR_* code
+ * otherwise (gm_last_error() gives text); nothing throws; plain pointers and
+ * sizes only.  Pointers named d_* are DEVICE pointers, h_* HOST pointers.  The
+ * caller owns every buffer it passes; the library owns what it allocates inside
+ * a gm_graph_t.  `stream` is a hipStream_t (NULL = default stream).  One host
+ * thread per process drives a given graph.
+ *
+ * Vertex ids: the API speaks GraphMat's two id spaces: "vertex" ids are the
+ * 1-based ids of the .mtx file, "native" ids are the 0-based permuted ids in
+ * which all device arrays are laid out (native = gm_vertex_to_native(v)-1).
+ */
+#ifndef GRAPHMAT_HIP_H_
+#define GRAPHMAT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GM_OK 0
+#define GM_ERR_INVALID 1
+#define GM_ERR_HIP 2
+#define GM_ERR_NOMEM 3
+#define GM_ERR_UNSUPPORTED 4
+#define GM_ERR_IO 5
+
+typedef void* gm_stream_t; /* hipStream_t */
+typedef struct gm_graph gm_graph_t;
+
+const char* gm_last_error(void);
+int gm_version(void);
+int gm_device_count(int* count);
+int gm_set_device(int device);
+
+/* ---- id permutation: include/Graph.h:111-150 ------------------------------------
+ * nparts = num_threads * 16 * nranks of the GraphMat layout being reproduced.
+ * 1-based in, 1-based out. */
+int gm_vertex_to_native(int vertex, int nparts, int len);
+int gm_native_to_vertex(int native, int nparts, int len);
+
+/* ---- binary .mtx reader: include/GMDP/utils/edgelist.h:242-334 --------------------
+ * header (int32 m,n,nnz) + nnz x (int32 src, int32 dst, val[val_bytes]); the header
+ * count governs.  *nv = max(m,n) (Graph::ReadMTX squares the matrix).  Arrays are
+ * malloc'ed; release each with gm_host_free. */
+int gm_mtx_read(const char* path, int val_bytes, int* nv, int64_t* nnz, int32_t** h_src, int32_t** h_dst,
+                void** h_val);
+void gm_host_free(void* p);
+
+/* ---- graph ---------------------------------------------------------------------- */
+#define GM_DIR_OUT 1 /* rows = destinations, cols = sources: GraphMat's AT, used by OUT_EDGES programs */
+#define GM_DIR_IN 2  /* rows = sources, cols = destinations: GraphMat's A, used by IN_EDGES programs  */
+
+typedef struct {
+  int32_t nvertices;     /* global vertex count */
+  int32_t nparts;        /* layout parameter of the id permutation (see above)            */
+  int32_t row_lo;        /* this shard owns native rows [row_lo,row_hi); multiples of 64   */
+  int32_t row_hi;        /*   (0,nvertices for a single GPU)                               */
+  int32_t directions;    /* GM_DIR_OUT | GM_DIR_IN                                         */
+  int32_t val_bytes;     /* sizeof(edge value), 0 = drop edge values                       */
+  int32_t ids_on_device; /* 1: src/dst/val are device pointers, 0: host pointers           */
+  int32_t ids_are_native;/* 1: src/dst are already 0-based native ids (skip permutation)   */
+} gm_graph_desc_t;
+
+/* One direction of the adjacency as laid out in HBM (see DESIGN.md "data layout"). */
+typedef struct {
+  int64_t nnz;            /* edges in this shard and direction                            */
+  int32_t nrows;          /* row_hi - row_lo                                              */
+  int32_t row_base;       /* row_lo                                                       */
+  int32_t ncols;          /* global vertex count                                          */
+  int32_t val_bytes;
+  const int64_t* rowptr;  /* [nrows+1]                                                    */
+  const int32_t* colidx;  /* [nnz] native column ids, ascending inside a row, duplicates
+                             in input order: the reference's reduction order               */
+  const void* vals;       /* [nnz] edge values or NULL                                    */
+  const int32_t* blk_row; /* [nblk+1] row-block boundaries (local row ids)                */
+  int32_t nblk;
+  const int32_t* long_row;/* [nlong] local rows with more than GM_LONG_ROW edges          */
+  int32_t nlong;
+} gm_csr_t;
+
+#define GM_BLOCK_NNZ 1024 /* a row-block holds < 2*GM_BLOCK_NNZ edges and <= 256 rows  */
+#define GM_LONG_ROW 1024  /* rows above this get a workgroup of their own               */
+
+/* src/dst: 1-based vertex ids as in the .mtx (or native ids, see desc).  Edges whose
+ * row falls outside [row_lo,row_hi) are dropped per direction, so every rank may pass
+ * the full edge list.  The input arrays are not modified. */
+int gm_graph_create(gm_graph_t** g, const gm_graph_desc_t* desc, int64_t nnz, const int32_t* src,
+                    const int32_t* dst, const void* val, gm_stream_t stream);
+int gm_graph_destroy(gm_graph_t* g);
+int gm_graph_desc(const gm_graph_t* g, gm_graph_desc_t* out);
+int gm_graph_csr(const gm_graph_t* g, int direction, gm_csr_t* out);
+/* copy a direction's CSR back to the host in native ids (tests, Graph::getEdgelist) */
+int gm_graph_csr_to_host(const gm_graph_t* g, int direction, int64_t* h_rowptr, int32_t* h_colidx, void* h_vals);
+
+/* overwrite a direction's edge values from a host array laid out like gm_graph_csr_to_host's
+ * (Graph::applyToAllEdges) */
+int gm_graph_set_vals(gm_graph_t* g, int direction, const void* h_vals);
+
+/* ---- synthetic RMAT edges generated on the device ---------------------------------
+ * Same integer-only definition as graphmat_amd/generators.py:rmat_edges (bit-identical).
+ * Writes edges [first_edge, first_edge+count) of the scale/edge-factor/seed stream as
+ * 1-based ids; d_val may be NULL.  weights_mode 0: 1, 1: 1 + hash%127. */
+int gm_rmat_generate(int scale, uint64_t seed, int64_t first_edge, int64_t count, int32_t* d_src, int32_t* d_dst,
+                     int32_t* d_val, int weights_mode, gm_stream_t stream);
+
+/* ---- multi-GPU hook ---------------------------------------------------------------
+ * With row-sharded graphs the message vector must be made globally visible between
+ * send and multiply, and the convergence flag combined.  The library calls back;
+ * the caller implements it with its collective library (bench.py: torch.distributed
+ * over RCCL).  kind GM_XCHG_MESSAGES: d_ptr = x values (elt_bytes each, nvertices
+ * entries, own slice [row_lo,row_hi) valid), d_bits = presence bit vector
+ * (nvertices/32 words, own words valid).  kind GM_XCHG_CONVERGED: h_flag points to a
+ * host int (1 = locally converged) to be AND-reduced in place.  Return 0 on success. */
+#define GM_XCHG_MESSAGES 0
+#define GM_XCHG_CONVERGED 1
+typedef int (*gm_exchange_fn)(void* ctx, int kind, void* d_ptr, int64_t elt_bytes, uint32_t* d_bits, int* h_flag);
+int gm_graph_set_exchange(gm_graph_t* g, gm_exchange_fn fn, void* ctx);
+
+/* ---- fixed-menu vertex programs ------------------------------------------------------
+ * Vertex state arrays are DEVICE arrays over the shard's rows in native order
+ * (entry i = native vertex row_lo+i).  iterations <= 0 runs until convergence
+ * (GraphMatRuntime.h:254-260); *iters_done (may be NULL) receives the count.
+ * d_active: presence bit vector over the shard's rows (bit i&31 of word i>>5),
+ * in/out, as Graph::active; NULL = all vertices active on entry. */
+
+/* layout of class PR, src/PageRank.cpp:34-38 */
+typedef struct { float pagerank; int32_t degree; } gm_pr_t;
+/* Degree program (src/PageRank.cpp:53-79): IN_EDGES, sum of 1s -> vp.degree (out-degree). */
+int gm_run_degree(gm_graph_t* g, gm_pr_t* d_vp, int iterations, int* iters_done, gm_stream_t stream);
+/* PageRank program (src/PageRank.cpp:81-112): ALL_VERTICES, OUT_EDGES. */
+int gm_run_pagerank(gm_graph_t* g, gm_pr_t* d_vp, float alpha, int iterations, int* iters_done, gm_stream_t stream);
+
+/* layout of class BFSD2, src/BFS.cpp:40-45 (natural alignment: 4 bytes padding after depth) */
+typedef struct { uint32_t depth; uint32_t pad_; uint64_t parent; uint64_t id; } gm_bfs_t;
+/* BFS2 program (src/BFS.cpp:62-99): messages carry vp.id, reduce "a=b" (last writer in
+ * native column order wins), do_every_iteration bumps current_depth starting at 1. */
+int gm_run_bfs(gm_graph_t* g, gm_bfs_t* d_vp, uint32_t* d_active, int iterations, int* iters_done, gm_stream_t stream);
+
+/* SSSP program (src/SSSP.cpp:64-90): uint32 distances, msg + int edge value, min. */
+int gm_run_sssp(gm_graph_t* g, uint32_t* d_dist, uint32_t* d_active, int iterations, int* iters_done,
+                gm_stream_t stream);
+
+/* SGD / RMSE programs (src/SGD.cpp:77-156): vertex state is LatentVector<K> =
+ * K reals then sqerr, i.e. (K+1) reals per vertex.  real_bytes 8 (reference) or 4. */
+int gm_run_sgd(gm_graph_t* g, void* d_latent, int K, int real_bytes, double lambda, double step, int iterations,
+               int* iters_done, gm_stream_t stream);
+int gm_run_rmse(gm_graph_t* g, void* d_latent, int K, int real_bytes, gm_stream_t stream);
+
+/* runtime options.  "force_ordered" (0/1): run PageRank with the plain serial long-row fold
+ * instead of the exact parallel replay (A/B check; results are bit-identical). */
+int gm_set_option(const char* key, int value);
+
+/* ---- timing of the last gm_run_* call on this graph -------------------------------------
+ * HIP-event times (ms) summed over iterations; kernel launches counted. */
+typedef struct {
+  int32_t iterations;
+  float send_ms, spmv_ms, apply_ms, total_ms;
+  int32_t spmv_launches;
+} gm_run_stats_t;
+int gm_graph_enable_timing(gm_graph_t* g, int on);
+int gm_graph_last_stats(const gm_graph_t* g, gm_run_stats_t* out);
+
+/* ---- services for the C++ header layer (include/graphmat/engine.hpp) -------------------------
+ * Device scratch owned by the graph, grown on demand and reused across runs (the
+ * reference allocates x/y per run_graph_program call, GraphMatRuntime.h:110-120).
+ * slot in [0, GM_WS_SLOTS). */
+#define GM_WS_SLOTS 8
+int gm_graph_workspace(gm_graph_t* g, int slot, size_t bytes, void** d_ptr);
+/* invoke the exchange callback if one is set (no-op returning 0 otherwise) */
+int gm_graph_exchange(gm_graph_t* g, int kind, void* d_ptr, int64_t elt_bytes, uint32_t* d_bits, int* h_flag);
+int gm_graph_has_exchange(const gm_graph_t* g);
+int gm_graph_timing_enabled(const gm_graph_t* g);
+int gm_graph_record_stats(gm_graph_t* g, const gm_run_stats_t* st);
+
+/* ---- reductions over device arrays (MapReduce, include/GMDP/singlenode/reduce.h:51-99) --- */
+int gm_reduce_sum_f64(const double* d_x, int64_t n, int64_t stride_elems, double* h_out, gm_stream_t stream);
+int gm_reduce_sum_f32(const float* d_x, int64_t n, int64_t stride_elems, double* h_out, gm_stream_t stream);
+int gm_count_less_u32(const uint32_t* d_x, int64_t n, int64_t stride_elems, uint32_t bound, int64_t* h_out,
+                      gm_stream_t stream);
+int gm_popcount_bits(const uint32_t* d_bits, int64_t nbits, int64_t* h_out, gm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHMAT_HIP_H_ */

@@ -1,0 +1,239 @@
+"""Parity of the HIP path (through the C-ABI) against the oracle.  Needs an MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from graphmat_amd import generators as gen
+from graphmat_amd.mtx import read_mtx_bin
+
+MAXD = np.uint32(0xFFFFFFFF)
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from graphmat_amd import build
+    build.build()
+    from graphmat_amd import api
+    from oracle import binding as ob
+    return api, ob
+
+
+def f32bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+# ---------------- golden fixtures -------------------------------------------------------------
+def test_G1_pagerank_fixture(env, golden_dir):
+    api, ob = env
+    ref = json.load(open(os.path.join(golden_dir, "reference_outputs.json")))["G1_pagerank_test_bin_mtx"]
+    nv, s, d, v = read_mtx_bin(os.path.join(golden_dir, ref["file"]))
+    g = api.Graph(nv, s, d, v)
+    pr, deg, it = g.pagerank(-1)
+    assert deg.tolist() == ref["out_degree"]
+    assert it == ref["pagerank_iterations"]
+    assert ["%.6f" % x for x in pr] == ref["pagerank_6dp"]
+    opr, oit, _ = ob.OracleGraph(nv, s, d, v, 1).pagerank(-1)
+    assert oit == it and (f32bits(pr) == f32bits(opr)).all()
+
+
+def test_G2_bfs_fixtures(env, golden_dir):
+    api, ob = env
+    ref = json.load(open(os.path.join(golden_dir, "reference_outputs.json")))
+    r = ref["G2_bfs_test_bin_mtx"]
+    nv, s, d, v = read_mtx_bin(os.path.join(golden_dir, r["file"]))
+    depth, parent, it = api.Graph(nv, s, d, v).bfs(r["source"])
+    assert it == r["iterations"] and depth.tolist() == r["depth"]
+    assert parent.astype(np.int64).tolist() == r["parent"]
+    r = ref["G2_bfs_2_10_upper_triangle"]
+    nv, s, d, v = read_mtx_bin(os.path.join(golden_dir, r["file"]))
+    depth, parent, it = api.Graph(nv, s, d, v).bfs(r["source"])
+    assert it == r["iterations"] and int((depth != MAXD).sum()) == r["reachable"]
+    assert depth[:10].tolist() == r["first10_depth"]
+    assert parent[:10].astype(np.int64).tolist() == r["first10_parent"]
+    od, op, oit, _ = ob.OracleGraph(nv, s, d, v, 1).bfs(r["source"])
+    assert (depth == od).all() and (parent == op).all() and it == oit
+
+
+def test_G3_sgd_fixture(env, golden_dir):
+    api, ob = env
+    from tests.test_oracle_golden import rand_r_latent
+    r = json.load(open(os.path.join(golden_dir, "reference_outputs.json")))["G3_sgd_ratings7"]
+    nv, s, d, v = read_mtx_bin(os.path.join(golden_dir, r["file"]))
+    g = api.Graph(nv, s, d, v)
+    lv = rand_r_latent(nv, r["K"])
+    e0, _ = g.rmse_sum(lv)
+    assert "%.6f" % np.sqrt(e0 / len(s)) == r["rmse_before_6dp"]
+    lv2, it = g.sgd(lv, r["lambda"], r["step"], r["iterations"])
+    e1, _ = g.rmse_sum(lv2)
+    assert it == r["iterations"] and "%.6f" % np.sqrt(e1 / len(s)) == r["rmse_after_6dp"]
+    olv, _ = ob.OracleGraph(nv, s, d, v, 1).sgd(lv, r["lambda"], r["step"], r["iterations"])
+    np.testing.assert_allclose(lv2, olv, rtol=1e-6, atol=0)  # tolerance stated by north_star; observed: exact
+
+
+# ---------------- structure ---------------------------------------------------------------------
+def test_rmat_device_generator_matches_numpy(env):
+    api, _ = env
+    for scale, ef, seed in ((8, 16, 1), (13, 8, 7)):
+        nv, s, d, v = gen.rmat_edges(scale, ef, seed, weights="hash")
+        dnv, ds, dd, dv = api.rmat_on_device(scale, ef, seed, weights=True)
+        assert dnv == nv
+        assert (ds.cpu().numpy() == s).all() and (dd.cpu().numpy() == d).all() and (dv.cpu().numpy() == v).all()
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_csr_build_order(env, threads):
+    """columns ascending inside a row, duplicates kept in input order, both directions."""
+    api, _ = env
+    nv, s, d, v = gen.rmat_edges(10, 16, 3, weights="hash")
+    v = np.arange(len(s), dtype=np.int32)  # unique values expose the duplicate order
+    g = api.Graph(nv, s, d, v, ref_threads=threads)
+    nat = api.native_index(nv, threads * 16)
+    sn, dn = nat[s - 1], nat[d - 1]
+    for direction, rows, cols in ((api.GM_DIR_OUT, dn, sn), (api.GM_DIR_IN, sn, dn)):
+        rp, ci, vv = g.csr_to_host(direction)
+        order = np.lexsort((np.arange(len(s)), cols, rows))  # stable: row, col, input position
+        assert (ci == cols[order]).all() and (vv == v[order]).all()
+        assert (rp == np.searchsorted(rows[order], np.arange(nv + 1))).all()
+
+
+# ---------------- programs on synthetic graphs -----------------------------------------------------
+@pytest.mark.parametrize("scale,threads", [(10, 1), (12, 4), (14, 1), (16, 2)])
+def test_pagerank_bit_exact_rmat(env, scale, threads):
+    api, ob = env
+    nv, s, d, v = gen.rmat_edges(scale, 16, seed=scale)
+    og = ob.OracleGraph(nv, s, d, v, threads)
+    g = api.Graph(nv, s, d, v, ref_threads=threads)
+    for force in (0, 1):
+        api._lib.lib().gm_set_option(b"force_ordered", force)
+        pr, deg, it = g.pagerank(10)
+        opr, oit, _ = og.pagerank(10)
+        assert (deg == og.degree()).all()
+        assert it == oit == 10
+        assert (f32bits(pr) == f32bits(opr)).all(), "pagerank bits differ (force_ordered=%d)" % force
+    api._lib.lib().gm_set_option(b"force_ordered", 0)
+
+
+def test_pagerank_until_convergence(env):
+    api, ob = env
+    nv, s, d, v = gen.rmat_edges(12, 16, seed=5)
+    pr, deg, it = api.Graph(nv, s, d, v).pagerank(-1)
+    opr, oit, _ = ob.OracleGraph(nv, s, d, v, 1).pagerank(-1)
+    assert it == oit and (f32bits(pr) == f32bits(opr)).all()
+
+
+@pytest.mark.parametrize("scale,threads", [(10, 1), (13, 4), (16, 1)])
+def test_bfs_bit_exact_rmat(env, scale, threads):
+    api, ob = env
+    nv, s, d, v = gen.rmat_edges(scale, 16, seed=100 + scale)
+    og = ob.OracleGraph(nv, s, d, v, threads)
+    g = api.Graph(nv, s, d, v, ref_threads=threads)
+    for source in (1, 2, int(s[len(s) // 2])):
+        depth, parent, it = g.bfs(source)
+        od, op, oit, _ = og.bfs(source)
+        assert it == oit and (depth == od).all()
+        assert (parent == op).all(), "BFS parents differ"
+
+
+def test_sssp_bit_exact(env, golden_dir):
+    api, ob = env
+    nv, s, d, v = read_mtx_bin(os.path.join(golden_dir, "2_10_upper_triangle.bin.mtx"))
+    dist, it = api.Graph(nv, s, d, v).sssp(1)
+    odist, oit = ob.OracleGraph(nv, s, d, v, 1).sssp(1)
+    assert it == oit and (dist == odist).all()
+    nv, s, d, v = gen.rmat_edges(13, 16, seed=11, weights="hash")
+    dist, it = api.Graph(nv, s, d, v, ref_threads=2).sssp(1)
+    odist, oit = ob.OracleGraph(nv, s, d, v, 2).sssp(1)
+    assert it == oit and (dist == odist).all()
+
+
+@pytest.mark.parametrize("n", [100, 500])
+def test_bfs_depths_closed_form(env, n):
+    """The reference's own BFS tests (test/test_bfs.cpp:97-236) against the HIP path."""
+    api, _ = env
+    h = n // 2
+    i = np.arange(1, n + 1)
+    g = api.Graph(*gen.upper_triangular_edges(n))
+    depth = g.bfs(1)[0]
+    assert depth[0] == 0 and (depth[1:] == 1).all()
+    depth = g.bfs(h)[0]
+    assert (depth[: h - 1] == MAXD).all() and depth[h - 1] == 0 and (depth[h:] == 1).all()
+    g = api.Graph(*gen.dense_edges(n))
+    for src in (1, h):
+        exp = np.ones(n, np.uint32)
+        exp[src - 1] = 0
+        assert (g.bfs(src)[0] == exp).all()
+    g = api.Graph(*gen.chain_edges(n))
+    assert (g.bfs(1)[0] == (i - 1)).all()
+    assert (g.bfs(h)[0] == np.where(i < h, h + i, i - h)).all()
+
+
+# ---------------- the exact fp32 replay on long rows ---------------------------------------------
+def _pagerank_custom(api, ob, nv, s, d, pr0, deg, alpha, iters, threads=1):
+    import torch
+    g = api.Graph(nv, s, d, np.ones(len(s), np.int32), ref_threads=threads)
+    st = torch.zeros((nv, 2), dtype=torch.int32, device=g.device)
+    st[:, 0] = g.to_native_order(f32bits(pr0).view(np.int32))
+    st[:, 1] = g.to_native_order(np.asarray(deg, np.int32))
+    out = []
+    for force in (0, 1):
+        api._lib.lib().gm_set_option(b"force_ordered", force)
+        s2 = st.clone()
+        g.run_pagerank(s2, iters, alpha)
+        out.append(g.to_vertex_order(s2[:, 0].contiguous().view(torch.float32)).cpu().numpy())
+    api._lib.lib().gm_set_option(b"force_ordered", 0)
+    opr, _, _ = ob.OracleGraph(nv, s, d, None, threads).pagerank(iters, alpha, pr0, deg)
+    return out[0], out[1], opr
+
+
+@pytest.mark.parametrize("kind", ["ties", "wide", "mixed_sign", "tiny"])
+def test_long_row_float_sum_is_bit_exact(env, kind):
+    """Star graphs: every vertex points at a few hubs, so hub rows (thousands of terms) take
+    the long-row kernel.  alpha=0 makes pagerank := the fp32 row sum, exposing every bit."""
+    api, ob = env
+    rng = np.random.default_rng(42)
+    nv = 40000
+    hubs = np.array([1, 2, 3, 777, 40000])
+    src = np.repeat(np.arange(1, nv + 1), len(hubs)).astype(np.int32)
+    dst = np.tile(hubs, nv).astype(np.int32)
+    keep = rng.random(len(src)) < 0.7
+    src, dst = src[keep], dst[keep]
+    if kind == "ties":      # few mantissa bits: round-to-even ties everywhere
+        pr0 = (rng.integers(1, 64, nv) * np.float32(2.0) ** rng.integers(-12, 3, nv)).astype(np.float32)
+    elif kind == "wide":    # 30 binades of magnitudes, full mantissas
+        pr0 = (rng.random(nv).astype(np.float32) * np.float32(2.0) ** rng.integers(-20, 10, nv)).astype(np.float32)
+    elif kind == "mixed_sign":  # must fall back to the serial fold
+        pr0 = rng.standard_normal(nv).astype(np.float32)
+    else:                   # subnormal-scale terms
+        pr0 = (rng.random(nv) * 1e-38).astype(np.float32)
+        pr0[::7] = 0
+    deg = np.ones(nv, np.int32)
+    a, b, o = _pagerank_custom(api, ob, nv, src, dst, pr0, deg, 0.0, 1)
+    assert (f32bits(a) == f32bits(o)).all(), "exact replay differs from the oracle"
+    assert (f32bits(b) == f32bits(o)).all(), "serial long-row fold differs from the oracle"
+
+
+def test_edge_cases(env):
+    api, ob = env
+    # vertices without edges, nv not a multiple of 32, self loops and duplicates
+    nv = 77
+    s = np.array([1, 1, 1, 5, 5, 77, 77, 3], np.int32)
+    d = np.array([2, 2, 2, 5, 6, 1, 1, 77], np.int32)
+    v = np.ones(len(s), np.int32)
+    g = api.Graph(nv, s, d, v)
+    og = ob.OracleGraph(nv, s, d, v, 1)
+    pr, deg, it = g.pagerank(5)
+    opr, _, _ = og.pagerank(5)
+    assert (deg == og.degree()).all() and (f32bits(pr) == f32bits(opr)).all()
+    depth, parent, it = g.bfs(1)
+    od, op, oit, _ = og.bfs(1)
+    assert (depth == od).all() and (parent == op).all() and it == oit
+    # graph with no edges at all: nothing is applied, one iteration
+    g0 = api.Graph(64, np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    pr, deg, it = g0.pagerank(-1)
+    assert it == 1 and (pr == np.float32(0.3)).all() and (deg == 0).all()
