@@ -81,6 +81,9 @@ def lib():
         if not os.path.exists(SO):
             raise RuntimeError("libgraphmat_hip.so is missing: build it with `python -m graphmat_amd.build` "
                                "(hipcc, gfx950).  graphmat_amd has no CPU fallback.")
+        # torch ships its own HIP runtime; import it first so this library binds to the same
+        # libamdhip64 instead of bringing a second runtime into the process.
+        import torch  # noqa: F401
         L = C.CDLL(SO)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it

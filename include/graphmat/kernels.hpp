@@ -99,12 +99,12 @@ k_send(ProgArg<P> pa, const V* __restrict__ vp, const uint32_t* __restrict__ act
 
 // ------------------------------------------------------------------------------------
 // apply on rows whose y bit is set; a changed vertex (V::operator!=) becomes active and
-// clears the converged flag.  The active vector is fully rewritten (the reference clears
+// raises the changed flag (zeroed by the host before the launch).  The active vector is fully rewritten (the reference clears
 // it right before, GraphMatRuntime.h:184).
 template <class P, class U, class V>
 __global__ void __launch_bounds__(kBlock)
 k_apply(ProgArg<P> pa, const U* __restrict__ y, const uint32_t* __restrict__ ybits, V* __restrict__ vp,
-        uint32_t* __restrict__ active, int n, int* __restrict__ converged) {
+        uint32_t* __restrict__ active, int n, int* __restrict__ changed_flag) {
   int i = blockIdx.x * kBlock + threadIdx.x;
   bool changed = false;
   if (i < n && bit_get(ybits, i)) {
@@ -120,7 +120,7 @@ k_apply(ProgArg<P> pa, const U* __restrict__ y, const uint32_t* __restrict__ ybi
   if ((threadIdx.x & 63) == 0 && i < n) {
     active[i >> 5] = (uint32_t)m;
     if (i + 32 < n) active[(i >> 5) + 1] = (uint32_t)(m >> 32);
-    if (m) *converged = 0;
+    if (m) *changed_flag = 1;
   }
 }
 
