@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- PageRank on a synthetic RMAT graph, GTEPS per iteration + achieved HBM GB/s.
+
+One "step" = one PageRank iteration (send -> multiply+reduce -> apply) over the whole
+graph through libgraphmat_hip.so.  N>1: one process per GPU (torch.distributed, backend
+nccl = RCCL), rows sharded 1-D by edge-balanced native ranges, x all-gathered per step.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3            # RMAT-26, the metric's config
+  python bench.py --scale 22                                # BASELINE.json configs[1]
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def log(rank, *a):
+    if rank == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(scale, iters, rank):
+    """The oracle (CPU restatement of the reference algorithm, OpenMP over row partitions like
+    the reference) timed on this box's host cores on a bounded sample: RMAT-<scale>."""
+    from graphmat_amd import generators
+    from oracle import binding as ob
+    cores = os.cpu_count() or 1
+    ob.lib().gmo_set_num_threads(cores)
+    nv, s, d, v = generators.rmat_edges(scale, 16, seed=1)
+    t0 = time.time()
+    og = ob.OracleGraph(nv, s, d, None, ref_threads=1)
+    deg = og.degree()
+    build_s = time.time() - t0
+    og.pagerank(1, degree=deg)  # warm
+    t0 = time.time()
+    og.pagerank(iters, degree=deg)
+    dt = time.time() - t0
+    log(rank, "cpu_baseline: RMAT-%d build %.1fs, %d iterations %.2fs on %d threads" % (scale, build_s, iters, dt, cores))
+    return {"value": round(len(s) * iters / dt / 1e9, 4), "unit": "GTEPS", "cores": cores, "kind": "port",
+            "sample": "oracle (oracle/gm_oracle.hpp, OpenMP) PageRank, %d iterations on RMAT-%d (V=%d, E=%d), "
+                      "graph build excluded" % (iters, scale, nv, len(s))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scale", type=int, default=26, help="RMAT scale (26 = the metric's configuration, 22 = configs[1])")
+    ap.add_argument("--edge-factor", type=int, default=16)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--ref-threads", type=int, default=1, help="layout parameter of the id permutation (oracle config)")
+    ap.add_argument("--cpu-scale", type=int, default=20, help="RMAT scale of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--no-timing", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--native-layout", action="store_true", help="device order = native order (single GPU; for A/B)")
+    ap.add_argument("--debug-flags", type=int, default=0, help="ablation only (results become invalid): 1 skip fold, 2 skip gathers")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus %d needs torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world), file=sys.stderr)
+            sys.exit(2)
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    from graphmat_amd import _lib, api
+    from graphmat_amd.dist import MessageExchange
+    L = _lib.lib()
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    # ---- synthetic input, generated in HBM ------------------------------------------------
+    t0 = time.time()
+    nv, src, dst, _ = api.rmat_on_device(args.scale, args.edge_factor, args.seed, weights=False, device=local_rank)
+    E = src.numel()
+    nparts = args.ref_threads * 16
+    # device order chosen by the library: degree-ranked, dealt over the `world` shards
+    g = api.Graph(nv, src, dst, None, ref_threads=args.ref_threads, device=local_rank, keep_values=False,
+                  layout=(_lib.GM_LAYOUT_NATIVE if args.native_layout else _lib.GM_LAYOUT_DEGREE), nshards=world, shard=rank)
+    S = g.row_hi - g.row_lo
+    ranges = [(r * S, (r + 1) * S) for r in range(world)] if world > 1 else [(0, g.ndevice)]
+    del src, dst
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    c_out = g.csr(api.GM_DIR_OUT)
+    log(rank, "RMAT-%d V=%d E=%d built in %.1fs; rank0 rows [%d,%d) nnz=%d blocks=%d wave_rows=%d giant_rows=%d" % (
+        args.scale, nv, E, build_s, ranges[rank][0], ranges[rank][1], c_out.nnz, c_out.nblk, c_out.nmid, c_out.ngiant))
+
+    ex = None
+    if world > 1:
+        x_bytes = torch.zeros(g.ndevice * 4 + 64, dtype=torch.uint8, device=dev)
+        x_bits = torch.zeros((g.ndevice + 31) // 32 + 2, dtype=torch.int32, device=dev)
+        _lib.check(L.gm_graph_adopt_workspace(g.h, 1, x_bytes.data_ptr(), x_bytes.numel()))
+        _lib.check(L.gm_graph_adopt_workspace(g.h, 2, x_bits.data_ptr(), x_bits.numel() * 4))
+        ex = MessageExchange(ranges, rank, x_bytes, x_bits)
+        cb = ex.callback()
+        g._cb = cb
+        _lib.check(L.gm_graph_set_exchange(g.h, cb, None))
+
+    # edges handled by the long-row kernel (for per-kernel algorithmic bytes):
+    # pull rowptr to the host once (8 bytes/row) and compute degrees
+    rowptr = np.zeros(c_out.nrows + 1, np.int64)
+    _lib.check(L.gm_graph_csr_to_host(g.h, api.GM_DIR_OUT, rowptr.ctypes.data, None, None))
+    degs = np.diff(rowptr)
+    e_giant = int(degs[degs > 16384].sum())
+    e_mid = int(degs[degs > 64].sum()) - e_giant
+    e_long = e_mid + e_giant
+    max_deg = int(degs.max()) if degs.size else 0
+    del rowptr, degs
+
+    # ---- state, Degree pass, warm-up ---------------------------------------------------------
+    st = g.new_pr_state()
+    g.run_degree(st)
+    if args.warmup > 0:
+        g.run_pagerank(st, args.warmup)
+    cnt64 = (C.c_int64 * 4)()
+    L.gm_debug_counters(cnt64)  # reset
+    if args.debug_flags:
+        L.gm_set_option(b"debug_flags", args.debug_flags)
+
+    # ---- timed region: exactly K steps -------------------------------------------------------
+    g.enable_timing(not args.no_timing)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.run_pagerank(st, args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    stats = g.last_stats()
+    L.gm_debug_counters(cnt64)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    ms_per_step = dt * 1e3 / args.steps
+    gteps = E * args.steps / dt / 1e9
+    # algorithmic bytes: whole iteration 4E + 48V; multiply+reduce kernels:
+    #   row-block kernel: 4 B column id per edge it owns + per row (8 rowptr + 4 x + 4 y)
+    #   wave / giant kernels: 4 B per edge they own
+    rows0 = ranges[rank][1] - ranges[rank][0]
+    e_short = int(c_out.nnz) - e_long
+    bytes_rowblock = 4 * e_short + 16 * rows0
+    roof = None
+    if stats["rowblock_launches"] > 0 and stats["rowblock_ms"] > 0:
+        avg_ms = stats["rowblock_ms"] / stats["rowblock_launches"]
+        ach = bytes_rowblock / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get("scale%d" % args.scale, {}).get("k_spmv_rowblock_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": "k_spmv_rowblock<PageRank>", "achieved": round(ach, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": bytes_rowblock,
+                "wave_avg_ms": round(stats["wave_ms"] / max(stats["wave_launches"], 1), 4),
+                "giant_avg_ms": round(stats["giant_ms"] / max(stats["giant_launches"], 1), 4),
+                "edges_rowblock_wave_giant": [e_short, e_mid, e_giant],
+                "send_avg_ms": round(stats["send_ms"] / args.steps, 4),
+                "apply_avg_ms": round(stats["apply_ms"] / args.steps, 4)}
+    iter_bytes = 4 * E + 48 * nv
+    out = {
+        "metric": "GTEPS (edges/s) per iter + achieved HBM GB/s, PageRank RMAT-%d" % args.scale,
+        "value": round(gteps, 3), "unit": "GTEPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "PageRank (alpha=0.3, fp32, fixed iteration count) on RMAT scale-%d, a/b/c=.57/.19/.19, "
+                               "edge factor %d, seed %d, duplicates and self loops kept" % (args.scale, args.edge_factor, args.seed),
+                   "V": nv, "E": E, "parallelism": "1d-rows x%d" % world, "id_layout_nparts": nparts,
+                   "device_order": "native" if args.native_layout else "degree-ranked, dealt over shards",
+                   "max_in_degree_rank0": max_deg,
+                   "replay_chunks": int(cnt64[0]), "serial_chunks": int(cnt64[1])},
+        "iter_hbm_gbps": round(iter_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+        "iter_hbm_frac": round(iter_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4),
+        "roofline": roof,
+    }
+    if args.debug_flags:
+        out["INVALID_ablation_debug_flags"] = args.debug_flags
+    if rank == 0 and world == 1 and args.cpu_scale > 0:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_scale, args.cpu_iters, rank)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        r = roof or {}
+        log(rank, "summary scale=%d gpus=%d dbg=%d ms/step=%.3f GTEPS=%.1f rowblock=%.3fms wave=%.3fms giant=%.3fms send=%.3f "
+                  "apply=%.3f replayed=%d serial=%d" % (args.scale, world, args.debug_flags, ms_per_step, gteps,
+                                                        r.get("avg_launch_ms", 0), r.get("wave_avg_ms", 0), r.get("giant_avg_ms", 0),
+                                                        r.get("send_avg_ms", 0), r.get("apply_avg_ms", 0), int(cnt64[0]), int(cnt64[1])))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

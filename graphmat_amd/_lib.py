@@ -10,23 +10,29 @@ GM_DIR_OUT = 1
 GM_DIR_IN = 2
 GM_XCHG_MESSAGES = 0
 GM_XCHG_CONVERGED = 1
+GM_LAYOUT_NATIVE = 0
+GM_LAYOUT_DEGREE = 1
 
 
 class GraphDesc(C.Structure):
     _fields_ = [("nvertices", C.c_int32), ("nparts", C.c_int32), ("row_lo", C.c_int32), ("row_hi", C.c_int32),
                 ("directions", C.c_int32), ("val_bytes", C.c_int32), ("ids_on_device", C.c_int32),
-                ("ids_are_native", C.c_int32)]
+                ("ids_are_native", C.c_int32), ("layout", C.c_int32), ("nshards", C.c_int32), ("shard", C.c_int32),
+                ("ndevice", C.c_int32)]
 
 
 class Csr(C.Structure):
     _fields_ = [("nnz", C.c_int64), ("nrows", C.c_int32), ("row_base", C.c_int32), ("ncols", C.c_int32),
                 ("val_bytes", C.c_int32), ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("vals", C.c_void_p),
-                ("blk_row", C.c_void_p), ("nblk", C.c_int32), ("long_row", C.c_void_p), ("nlong", C.c_int32)]
+                ("seg_row", C.c_void_p), ("nseg", C.c_int32), ("blk_seg", C.c_void_p), ("nblk", C.c_int32),
+                ("mid_row", C.c_void_p), ("nmid", C.c_int32), ("giant_row", C.c_void_p), ("ngiant", C.c_int32)]
 
 
 class RunStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("send_ms", C.c_float), ("spmv_ms", C.c_float), ("apply_ms", C.c_float),
-                ("total_ms", C.c_float), ("spmv_launches", C.c_int32)]
+                ("total_ms", C.c_float), ("spmv_launches", C.c_int32), ("rowblock_ms", C.c_float),
+                ("wave_ms", C.c_float), ("giant_ms", C.c_float), ("rowblock_launches", C.c_int32),
+                ("wave_launches", C.c_int32), ("giant_launches", C.c_int32)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int))
@@ -48,6 +54,8 @@ SIGNATURES = {
     "gm_graph_desc": (C.c_int, [_P, C.POINTER(GraphDesc)]),
     "gm_graph_csr": (C.c_int, [_P, C.c_int, C.POINTER(Csr)]),
     "gm_graph_csr_to_host": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "gm_graph_maps": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
+    "gm_graph_maps_to_host": (C.c_int, [_P, _P, _P]),
     "gm_graph_set_vals": (C.c_int, [_P, C.c_int, _P]),
     "gm_rmat_generate": (C.c_int, [C.c_int, C.c_uint64, C.c_int64, C.c_int64, _P, _P, _P, C.c_int, _P]),
     "gm_graph_set_exchange": (C.c_int, [_P, EXCHANGE_FN, _P]),
@@ -61,6 +69,8 @@ SIGNATURES = {
     "gm_graph_enable_timing": (C.c_int, [_P, C.c_int]),
     "gm_graph_last_stats": (C.c_int, [_P, C.POINTER(RunStats)]),
     "gm_graph_workspace": (C.c_int, [_P, C.c_int, C.c_size_t, C.POINTER(_P)]),
+    "gm_graph_adopt_workspace": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
+    "gm_debug_counters": (C.c_int, [C.POINTER(C.c_int64)]),
     "gm_graph_exchange": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.POINTER(C.c_int)]),
     "gm_graph_has_exchange": (C.c_int, [_P]),
     "gm_graph_timing_enabled": (C.c_int, [_P]),

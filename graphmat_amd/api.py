@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import GM_DIR_IN, GM_DIR_OUT, check
+from ._lib import GM_DIR_IN, GM_DIR_OUT, GM_LAYOUT_DEGREE, GM_LAYOUT_NATIVE, check
 
 MAX_DIST = 0xFFFFFFFF
 
@@ -33,8 +33,12 @@ def _stream():
 
 class Graph:
     def __init__(self, nv, src, dst, val=None, ref_threads=1, directions=GM_DIR_OUT | GM_DIR_IN, device=0,
-                 row_range=None, keep_values=True, nranks_layout=1):
-        """src/dst: 1-based ids, numpy (host) or torch.cuda int32 tensors (device)."""
+                 row_range=None, keep_values=True, nranks_layout=1, layout=GM_LAYOUT_DEGREE, nshards=1, shard=0):
+        """src/dst: 1-based ids, numpy (host) or torch.cuda int32 tensors (device).
+
+        layout GM_LAYOUT_DEGREE (default): the library picks the device order (degree-ranked,
+        dealt over `nshards`); GM_LAYOUT_NATIVE: device order = native order, optional
+        row_range=(lo,hi) shard.  Results are identical in both."""
         if not torch.cuda.is_available():
             raise RuntimeError("graphmat_amd needs a GPU (no CPU fallback)")
         self.L = _lib.lib()
@@ -44,8 +48,6 @@ class Graph:
         self.nv = int(nv)
         self.nparts = int(ref_threads) * 16 * int(nranks_layout)
         lo, hi = (0, self.nv) if row_range is None else row_range
-        self.row_lo, self.row_hi = int(lo), int(hi)
-        self.rows = self.row_hi - self.row_lo
         on_dev = isinstance(src, torch.Tensor)
         if on_dev:
             assert src.is_cuda and src.dtype == torch.int32 and dst.dtype == torch.int32
@@ -65,12 +67,16 @@ class Graph:
                 vp = None
             nnz = src.size
         self.nnz_input = int(nnz)
-        d = _lib.GraphDesc(self.nv, self.nparts, self.row_lo, self.row_hi, directions, 4 if vp else 0,
-                           1 if on_dev else 0, 0)
+        d = _lib.GraphDesc(self.nv, self.nparts, int(lo), int(hi), directions, 4 if vp else 0,
+                           1 if on_dev else 0, 0, layout, nshards, shard, 0)
         h = C.c_void_p()
         check(self.L.gm_graph_create(C.byref(h), C.byref(d), nnz, sp, dp, vp, _stream()))
         self.h = h
-        self._nat = None
+        check(self.L.gm_graph_desc(self.h, C.byref(d)))
+        self.row_lo, self.row_hi, self.ndevice = d.row_lo, d.row_hi, d.ndevice
+        self.rows = self.row_hi - self.row_lo
+        self.layout, self.nshards, self.shard = layout, nshards, shard
+        self._dov = None
         self._cb = None
 
     def close(self):
@@ -85,21 +91,31 @@ class Graph:
             pass
 
     # ---- id spaces ---------------------------------------------------------------------
-    @property
-    def native_of_vertex(self):
-        if self._nat is None:
-            self._nat = torch.from_numpy(native_index(self.nv, self.nparts)).to(self.device)
-        return self._nat
+    def maps_to_host(self):
+        """(dev_of_native[nv], native_of_dev[ndevice]) as numpy int32."""
+        don = np.zeros(self.nv, np.int32)
+        nod = np.zeros(self.ndevice, np.int32)
+        check(self.L.gm_graph_maps_to_host(self.h, don.ctypes.data, nod.ctypes.data))
+        return don, nod
 
-    def to_native_order(self, arr_vertex_order):
-        """array indexed by vertex-1 -> device tensor indexed by native id (full graph only)."""
+    @property
+    def dev_of_vertex(self):
+        """device slot of vertex v (index v-1): vertex id -> native id -> device id."""
+        if self._dov is None:
+            don, _ = self.maps_to_host()
+            self._dov = torch.from_numpy(don.astype(np.int64)[native_index(self.nv, self.nparts)]).to(self.device)
+        return self._dov
+
+    def to_device_order(self, arr_vertex_order, fill=0):
+        """array indexed by vertex-1 -> device tensor indexed by device id (single-shard graphs)."""
+        assert self.rows == self.ndevice, "vertex-order conversion needs the whole graph on one device"
         t = torch.as_tensor(arr_vertex_order).to(self.device)
-        out = torch.empty_like(t)
-        out[self.native_of_vertex] = t
+        out = torch.full((self.ndevice,) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=self.device)
+        out[self.dev_of_vertex] = t
         return out
 
-    def to_vertex_order(self, t_native):
-        return t_native[self.native_of_vertex]
+    def to_vertex_order(self, t_dev):
+        return t_dev[self.dev_of_vertex]
 
     def csr(self, direction):
         c = _lib.Csr()
@@ -158,9 +174,9 @@ class Graph:
         st[:, 0] = MAX_DIST          # depth (low 32 bits), pad = 0
         st[:, 1] = -1                # parent
         ids = torch.arange(1, self.nv + 1, dtype=torch.int64, device=self.device)
-        st[:, 2] = self.to_native_order(ids)  # id of the vertex living at each native slot
+        st[:, 2] = self.to_device_order(ids)  # id of the vertex living in each device slot
         act = torch.zeros((n + 31) // 32 + 2, dtype=torch.int32, device=self.device)
-        s_nat = int(native_index(self.nv, self.nparts)[source - 1])
+        s_nat = int(self.dev_of_vertex[source - 1])
         st[s_nat, 0] = 0
         act[s_nat >> 5] = int(np.uint32(1 << (s_nat & 31)).view(np.int32))
         it = C.c_int(0)
@@ -174,7 +190,7 @@ class Graph:
         n = self.rows
         dist = torch.full((n,), -1, dtype=torch.int32, device=self.device)  # 0xFFFFFFFF
         act = torch.zeros((n + 31) // 32 + 2, dtype=torch.int32, device=self.device)
-        s_nat = int(native_index(self.nv, self.nparts)[source - 1])
+        s_nat = int(self.dev_of_vertex[source - 1])
         dist[s_nat] = 0
         act[s_nat >> 5] = int(np.uint32(1 << (s_nat & 31)).view(np.int32))
         it = C.c_int(0)
@@ -187,7 +203,7 @@ class Graph:
         K = lv.shape[1]
         full = np.zeros((self.nv, K + 1), lv.dtype)
         full[:, :K] = lv
-        return self.to_native_order(full).contiguous(), K
+        return self.to_device_order(full).contiguous(), K
 
     def sgd(self, lv, lam, step, iterations):
         st, K = self._latent_to_device(lv)
@@ -202,7 +218,7 @@ class Graph:
         check(self.L.gm_run_rmse(self.h, st.data_ptr(), K, st.element_size(), _stream()))
         out = C.c_double(0)
         fn = self.L.gm_reduce_sum_f64 if st.dtype == torch.float64 else self.L.gm_reduce_sum_f32
-        check(fn(st.data_ptr() + K * st.element_size(), self.nv, K + 1, C.byref(out), _stream()))
+        check(fn(st.data_ptr() + K * st.element_size(), self.rows, K + 1, C.byref(out), _stream()))
         sq = self.to_vertex_order(st)[:, K].cpu().numpy()
         return out.value, sq
 

@@ -26,36 +26,71 @@ namespace gm {
 constexpr int kT = 256;
 inline int grid_for(int64_t n) { return (int)((n + kT - 1) / kT); }
 
-// key = (local row + dropped-flag) << 32 | col.  Edges whose row is outside the shard
-// get row field = nrows (sorts last).
+// total degree (in + out) per native vertex, for the GM_LAYOUT_DEGREE ranking
 __global__ void __launch_bounds__(kT)
-k_make_keys(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t nnz, int by_dst, int nparts,
-            int nv, int row_lo, int row_hi, int ids_are_native, uint64_t* __restrict__ keys,
-            uint32_t* __restrict__ idx, unsigned long long* __restrict__ kept) {
+k_degree(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t nnz, int nparts, int nv,
+         int ids_are_native, uint32_t* __restrict__ deg) {
   int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x;
   if (e >= nnz) return;
   int s = src[e], d = dst[e];
   int sn = ids_are_native ? s : to_native0(s, nparts, nv);
   int dn = ids_are_native ? d : to_native0(d, nparts, nv);
-  int r = by_dst ? dn : sn;
-  int c = by_dst ? sn : dn;
-  uint32_t rf;
-  if (r >= row_lo && r < row_hi) {
-    rf = (uint32_t)(r - row_lo);
-    atomicAdd(kept, 1ull);
-  } else {
-    rf = (uint32_t)(row_hi - row_lo);
+  atomicAdd(&deg[sn], 1u);
+  atomicAdd(&deg[dn], 1u);
+}
+
+__global__ void __launch_bounds__(kT)
+k_rank_keys(const uint32_t* __restrict__ deg, int nv, uint32_t* __restrict__ keys, int32_t* __restrict__ ids) {
+  int v = blockIdx.x * kT + threadIdx.x;
+  if (v >= nv) return;
+  keys[v] = 0xffffffffu - deg[v];  // ascending sort => descending degree; stable => ties by native id
+  ids[v] = v;
+}
+
+// rank k -> device id (k % nshards) * S + k / nshards
+__global__ void __launch_bounds__(kT)
+k_deal(const int32_t* __restrict__ order, int nv, int nshards, int S, int32_t* __restrict__ dev_of_native,
+       int32_t* __restrict__ native_of_dev) {
+  int k = blockIdx.x * kT + threadIdx.x;
+  if (k >= nv) return;
+  int v = order[k];
+  int d = (k % nshards) * S + k / nshards;
+  dev_of_native[v] = d;
+  native_of_dev[d] = v;
+}
+
+// key = (local device row, or nrows when the row is not in this shard) << 32 | NATIVE col:
+// sorting by it stores a row's edges in the reference's reduction order.
+__global__ void __launch_bounds__(kT)
+k_make_keys(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t nnz, int by_dst, int nparts,
+            int nv, int row_lo, int row_hi, int ids_are_native, const int32_t* __restrict__ dev_of_native,
+            uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, unsigned long long* __restrict__ kept) {
+  int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x;
+  bool mine = false;
+  if (e < nnz) {
+    int s = src[e], d = dst[e];
+    int sn = ids_are_native ? s : to_native0(s, nparts, nv);
+    int dn = ids_are_native ? d : to_native0(d, nparts, nv);
+    int rn = by_dst ? dn : sn;
+    int c = by_dst ? sn : dn;
+    int r = dev_of_native ? dev_of_native[rn] : rn;
+    mine = (r >= row_lo && r < row_hi);
+    uint32_t rf = mine ? (uint32_t)(r - row_lo) : (uint32_t)(row_hi - row_lo);
+    keys[e] = ((uint64_t)rf << 32) | (uint32_t)c;
+    idx[e] = (uint32_t)e;
   }
-  keys[e] = ((uint64_t)rf << 32) | (uint32_t)c;
-  idx[e] = (uint32_t)e;
+  unsigned long long m = __ballot(mine);  // one atomic per wave
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(kept, (unsigned long long)__popcll(m));
 }
 
 __global__ void __launch_bounds__(kT)
 k_unpack(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, int64_t n, const void* __restrict__ val,
-         int val_bytes, int32_t* __restrict__ colidx, void* __restrict__ vals) {
+         int val_bytes, const int32_t* __restrict__ dev_of_native, int32_t* __restrict__ colidx,
+         void* __restrict__ vals) {
   int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x;
   if (k >= n) return;
-  colidx[k] = (int32_t)(uint32_t)keys[k];
+  int32_t cn = (int32_t)(uint32_t)keys[k];
+  colidx[k] = dev_of_native ? dev_of_native[cn] : cn;
   if (vals) {
     uint32_t e = idx[k];
     if (val_bytes == 4) {
@@ -84,22 +119,35 @@ k_rowptr(const uint64_t* __restrict__ keys, int64_t n, int nrows, int64_t* __res
   rowptr[r] = lo;
 }
 
-// row-block starts and long-row flags (see include/graphmat/kernels.hpp for the scheme)
+// segment starts (runs of rows, see gm_csr_t) and row classes
 __global__ void __launch_bounds__(kT)
-k_block_flags(const int64_t* __restrict__ rowptr, int nrows, unsigned char* __restrict__ start,
-              unsigned char* __restrict__ islong) {
+k_row_flags(const int64_t* __restrict__ rowptr, int nrows, unsigned char* __restrict__ start,
+            unsigned char* __restrict__ ismid, unsigned char* __restrict__ isgiant) {
   int r = blockIdx.x * kT + threadIdx.x;
   if (r >= nrows) return;
   int64_t a = rowptr[r], b = rowptr[r + 1];
-  bool lng = (b - a) > GM_LONG_ROW;
+  bool lng = (b - a) > GM_SHORT_ROW;
   bool st = (r == 0) || ((r & 255) == 0) || lng;
   if (!st) {
     int64_t pa = rowptr[r - 1];
-    bool prev_long = (a - pa) > GM_LONG_ROW;
+    bool prev_long = (a - pa) > GM_SHORT_ROW;
     st = prev_long || (a / GM_BLOCK_NNZ != pa / GM_BLOCK_NNZ);
   }
   start[r] = st ? 1 : 0;
-  islong[r] = lng ? 1 : 0;
+  ismid[r] = (lng && (b - a) <= GM_GIANT_ROW) ? 1 : 0;
+  isgiant[r] = ((b - a) > GM_GIANT_ROW) ? 1 : 0;
+}
+
+// a segment is a row-block iff its first row is short and it holds at least one edge
+__global__ void __launch_bounds__(kT)
+k_seg_flags(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ seg_row, int nseg,
+            unsigned char* __restrict__ isblk) {
+  int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= nseg) return;
+  int r0 = seg_row[i], r1 = seg_row[i + 1];
+  int64_t n = rowptr[r1] - rowptr[r0];
+  bool longrow = (r1 - r0 == 1) && n > GM_SHORT_ROW;
+  isblk[i] = (!longrow && n > 0) ? 1 : 0;
 }
 
 struct DevBuf {
@@ -136,8 +184,8 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   GM_TRY_HIP(hipMemsetAsync(kept_d.p, 0, 8, s));
   if (nnz > 0) {
     hipLaunchKernelGGL(k_make_keys, dim3(grid_for(nnz)), dim3(kT), 0, s, d_src, d_dst, nnz, by_dst, D.nparts,
-                       D.nvertices, D.row_lo, D.row_hi, D.ids_are_native, keys_in.as<uint64_t>(),
-                       idx_in.as<uint32_t>(), kept_d.as<unsigned long long>());
+                       D.nvertices, D.row_lo, D.row_hi, D.ids_are_native, (const int32_t*)g->dev_of_native,
+                       keys_in.as<uint64_t>(), idx_in.as<uint32_t>(), kept_d.as<unsigned long long>());
     GM_TRY_HIP(hipGetLastError());
     size_t tmp_bytes = 0;
     const unsigned end_bit = 32 + (unsigned)bits_for((uint32_t)nrows);
@@ -154,71 +202,129 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   idx_in.alloc(0);
   tmp.alloc(0);
 
-  DevBuf rowptr, colidx, vals, start, islong, blk, lng, cnt;
+  DevBuf rowptr, colidx, vals, cnt;
   if ((rc = rowptr.alloc((size_t)(nrows + 1) * 8))) return rc;
   if ((rc = colidx.alloc((size_t)kept * 4))) return rc;
   const bool keep_vals = D.val_bytes > 0 && d_val != nullptr;
   if (keep_vals && (rc = vals.alloc((size_t)kept * D.val_bytes))) return rc;
   if (kept > 0) {
     hipLaunchKernelGGL(k_unpack, dim3(grid_for((int64_t)kept)), dim3(kT), 0, s, keys_out.as<uint64_t>(),
-                       idx_out.as<uint32_t>(), (int64_t)kept, d_val, D.val_bytes, colidx.as<int32_t>(),
-                       keep_vals ? vals.p : nullptr);
+                       idx_out.as<uint32_t>(), (int64_t)kept, d_val, D.val_bytes, (const int32_t*)g->dev_of_native,
+                       colidx.as<int32_t>(), keep_vals ? vals.p : nullptr);
   }
   hipLaunchKernelGGL(k_rowptr, dim3(grid_for(nrows + 1)), dim3(kT), 0, s, keys_out.as<uint64_t>(), (int64_t)kept,
                      nrows, rowptr.as<int64_t>());
   GM_TRY_HIP(hipGetLastError());
 
-  // row-blocks and long rows
-  if ((rc = start.alloc((size_t)nrows + 1))) return rc;
-  if ((rc = islong.alloc((size_t)nrows + 1))) return rc;
-  if ((rc = blk.alloc((size_t)(nrows + 2) * 4))) return rc;
-  if ((rc = lng.alloc((size_t)(nrows + 1) * 4))) return rc;
-  if ((rc = cnt.alloc(16))) return rc;
-  unsigned int nblk = 0, nlong = 0;
+  // work decomposition: segments, row-blocks, wave rows, giant rows
+  DevBuf f0, f1, f2, seg, blkl, mid, giant;
+  if ((rc = f0.alloc((size_t)nrows + 1))) return rc;
+  if ((rc = f1.alloc((size_t)nrows + 1))) return rc;
+  if ((rc = f2.alloc((size_t)nrows + 1))) return rc;
+  if ((rc = seg.alloc((size_t)(nrows + 2) * 4))) return rc;
+  if ((rc = mid.alloc((size_t)(nrows + 1) * 4))) return rc;
+  if ((rc = giant.alloc((size_t)(nrows + 1) * 4))) return rc;
+  if ((rc = cnt.alloc(32))) return rc;
+  unsigned int nseg = 0, nblk = 0, nmid = 0, ngiant = 0;
   if (nrows > 0) {
-    hipLaunchKernelGGL(k_block_flags, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr.as<int64_t>(), nrows,
-                       start.as<unsigned char>(), islong.as<unsigned char>());
+    hipLaunchKernelGGL(k_row_flags, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr.as<int64_t>(), nrows,
+                       f0.as<unsigned char>(), f1.as<unsigned char>(), f2.as<unsigned char>());
     GM_TRY_HIP(hipGetLastError());
-    rocprim::counting_iterator<int32_t> rows(0);
-    size_t tb = 0, tb2 = 0;
-    GM_TRY_HIP(rocprim::select(nullptr, tb, rows, start.as<unsigned char>(), blk.as<int32_t>(), cnt.as<unsigned int>(),
+    rocprim::counting_iterator<int32_t> ids(0);
+    size_t tb = 0;
+    GM_TRY_HIP(rocprim::select(nullptr, tb, ids, f0.as<unsigned char>(), seg.as<int32_t>(), cnt.as<unsigned int>(),
                                (size_t)nrows, s));
-    GM_TRY_HIP(rocprim::select(nullptr, tb2, rows, islong.as<unsigned char>(), lng.as<int32_t>(),
-                               cnt.as<unsigned int>() + 1, (size_t)nrows, s));
-    if ((rc = tmp.alloc(std::max(tb, tb2)))) return rc;
-    GM_TRY_HIP(rocprim::select(tmp.p, tb, rows, start.as<unsigned char>(), blk.as<int32_t>(), cnt.as<unsigned int>(),
+    if ((rc = tmp.alloc(tb + 256))) return rc;
+    GM_TRY_HIP(rocprim::select(tmp.p, tb, ids, f0.as<unsigned char>(), seg.as<int32_t>(), cnt.as<unsigned int>(),
                                (size_t)nrows, s));
-    GM_TRY_HIP(rocprim::select(tmp.p, tb2, rows, islong.as<unsigned char>(), lng.as<int32_t>(),
-                               cnt.as<unsigned int>() + 1, (size_t)nrows, s));
-    unsigned int h[2] = {0, 0};
-    GM_TRY_HIP(hipMemcpyAsync(h, cnt.p, 8, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(rocprim::select(tmp.p, tb, ids, f1.as<unsigned char>(), mid.as<int32_t>(), cnt.as<unsigned int>() + 1,
+                               (size_t)nrows, s));
+    GM_TRY_HIP(rocprim::select(tmp.p, tb, ids, f2.as<unsigned char>(), giant.as<int32_t>(),
+                               cnt.as<unsigned int>() + 2, (size_t)nrows, s));
+    unsigned int h[3] = {0, 0, 0};
+    GM_TRY_HIP(hipMemcpyAsync(h, cnt.p, 12, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    nseg = h[0];
+    nmid = h[1];
+    ngiant = h[2];
+    int32_t last = nrows;
+    GM_TRY_HIP(hipMemcpyAsync(seg.as<int32_t>() + nseg, &last, 4, hipMemcpyHostToDevice, s));
+    // row-blocks = the segments that hold short rows with at least one edge
+    if ((rc = blkl.alloc((size_t)(nseg + 1) * 4))) return rc;
+    hipLaunchKernelGGL(k_seg_flags, dim3(grid_for(nseg)), dim3(kT), 0, s, rowptr.as<int64_t>(), seg.as<int32_t>(),
+                       (int)nseg, f0.as<unsigned char>());
+    GM_TRY_HIP(rocprim::select(tmp.p, tb, ids, f0.as<unsigned char>(), blkl.as<int32_t>(), cnt.as<unsigned int>() + 3,
+                               (size_t)nseg, s));
+    GM_TRY_HIP(hipMemcpyAsync(h, cnt.as<unsigned int>() + 3, 4, hipMemcpyDeviceToHost, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
     nblk = h[0];
-    nlong = h[1];
-    int32_t last = nrows;
-    GM_TRY_HIP(hipMemcpyAsync(blk.as<int32_t>() + nblk, &last, 4, hipMemcpyHostToDevice, s));
-    GM_TRY_HIP(hipStreamSynchronize(s));
+  } else {
+    if ((rc = blkl.alloc(16))) return rc;
   }
 
   out->rowptr = (int64_t*)rowptr.release();
   out->colidx = (int32_t*)colidx.release();
   out->vals = keep_vals ? vals.release() : nullptr;
-  out->blk_row = (int32_t*)blk.release();
-  out->long_row = (int32_t*)lng.release();
+  out->seg_row = (int32_t*)seg.release();
+  out->blk_seg = (int32_t*)blkl.release();
+  out->mid_row = (int32_t*)mid.release();
+  out->giant_row = (int32_t*)giant.release();
   out->present = true;
   gm_csr_t& v = out->view;
   v.nnz = (int64_t)kept;
   v.nrows = nrows;
   v.row_base = D.row_lo;
-  v.ncols = D.nvertices;
+  v.ncols = D.ndevice;
   v.val_bytes = keep_vals ? D.val_bytes : 0;
   v.rowptr = out->rowptr;
   v.colidx = out->colidx;
   v.vals = out->vals;
-  v.blk_row = out->blk_row;
+  v.seg_row = out->seg_row;
+  v.nseg = (int32_t)nseg;
+  v.blk_seg = out->blk_seg;
   v.nblk = (int32_t)nblk;
-  v.long_row = out->long_row;
-  v.nlong = (int32_t)nlong;
+  v.mid_row = out->mid_row;
+  v.nmid = (int32_t)nmid;
+  v.giant_row = out->giant_row;
+  v.ngiant = (int32_t)ngiant;
+  return GM_OK;
+}
+
+// GM_LAYOUT_DEGREE: rank vertices by total degree, deal the ranks round-robin over the shards
+static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, const int32_t* d_dst, hipStream_t s) {
+  gm_graph_desc_t& D = g->desc;
+  const int nv = D.nvertices, G = D.nshards;
+  int S = (nv + G - 1) / G;
+  if (G > 1) S = (S + 63) / 64 * 64;
+  const int vd = (G > 1) ? G * S : nv;
+  DevBuf deg, keys_in, keys_out, ids_in, order, tmp, don, nod;
+  int rc;
+  if ((rc = deg.alloc((size_t)nv * 4)) || (rc = keys_in.alloc((size_t)nv * 4)) || (rc = keys_out.alloc((size_t)nv * 4)) ||
+      (rc = ids_in.alloc((size_t)nv * 4)) || (rc = order.alloc((size_t)nv * 4)) || (rc = don.alloc((size_t)nv * 4)) ||
+      (rc = nod.alloc((size_t)vd * 4)))
+    return rc;
+  GM_TRY_HIP(hipMemsetAsync(deg.p, 0, (size_t)nv * 4, s));
+  GM_TRY_HIP(hipMemsetAsync(nod.p, 0xff, (size_t)vd * 4, s));  // -1 = unused slot
+  if (nnz > 0)
+    hipLaunchKernelGGL(k_degree, dim3(grid_for(nnz)), dim3(kT), 0, s, d_src, d_dst, nnz, D.nparts, nv, D.ids_are_native,
+                       deg.as<uint32_t>());
+  hipLaunchKernelGGL(k_rank_keys, dim3(grid_for(nv)), dim3(kT), 0, s, deg.as<uint32_t>(), nv, keys_in.as<uint32_t>(),
+                     ids_in.as<int32_t>());
+  size_t tb = 0;
+  GM_TRY_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in.as<uint32_t>(), keys_out.as<uint32_t>(), ids_in.as<int32_t>(),
+                                       order.as<int32_t>(), (size_t)nv, 0u, 32u, s));
+  if ((rc = tmp.alloc(tb))) return rc;
+  GM_TRY_HIP(rocprim::radix_sort_pairs(tmp.p, tb, keys_in.as<uint32_t>(), keys_out.as<uint32_t>(), ids_in.as<int32_t>(),
+                                       order.as<int32_t>(), (size_t)nv, 0u, 32u, s));
+  hipLaunchKernelGGL(k_deal, dim3(grid_for(nv)), dim3(kT), 0, s, order.as<int32_t>(), nv, G, S, don.as<int32_t>(),
+                     nod.as<int32_t>());
+  GM_TRY_HIP(hipGetLastError());
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  g->dev_of_native = (int32_t*)don.release();
+  g->native_of_dev = (int32_t*)nod.release();
+  D.ndevice = vd;
+  D.row_lo = (G > 1) ? D.shard * S : 0;
+  D.row_hi = (G > 1) ? D.row_lo + S : nv;
   return GM_OK;
 }
 
@@ -226,8 +332,10 @@ static void free_csr(CsrOwned* c) {
   if (c->rowptr) (void)hipFree(c->rowptr);
   if (c->colidx) (void)hipFree(c->colidx);
   if (c->vals) (void)hipFree(c->vals);
-  if (c->blk_row) (void)hipFree(c->blk_row);
-  if (c->long_row) (void)hipFree(c->long_row);
+  if (c->seg_row) (void)hipFree(c->seg_row);
+  if (c->blk_seg) (void)hipFree(c->blk_seg);
+  if (c->mid_row) (void)hipFree(c->mid_row);
+  if (c->giant_row) (void)hipFree(c->giant_row);
   *c = CsrOwned();
 }
 
@@ -246,8 +354,17 @@ int gm_graph_create(gm_graph_t** gout, const gm_graph_desc_t* desc, int64_t nnz,
                   (long long)nnz, desc->nparts, desc->row_lo, desc->row_hi, desc->directions);
     return GM_ERR_INVALID;
   }
-  if ((desc->row_lo & 63) != 0 || ((desc->row_hi & 63) != 0 && desc->row_hi != desc->nvertices)) {
+  if (desc->layout == GM_LAYOUT_NATIVE &&
+      ((desc->row_lo & 63) != 0 || ((desc->row_hi & 63) != 0 && desc->row_hi != desc->nvertices))) {
     gm::set_error("gm_graph_create: shard boundaries must be multiples of 64 (got [%d,%d))", desc->row_lo, desc->row_hi);
+    return GM_ERR_INVALID;
+  }
+  if (desc->layout != GM_LAYOUT_NATIVE && desc->layout != GM_LAYOUT_DEGREE) {
+    gm::set_error("gm_graph_create: unknown layout %d", desc->layout);
+    return GM_ERR_INVALID;
+  }
+  if (desc->layout == GM_LAYOUT_DEGREE && (desc->nshards < 1 || desc->shard < 0 || desc->shard >= desc->nshards)) {
+    gm::set_error("gm_graph_create: invalid shard %d of %d", desc->shard, desc->nshards);
     return GM_ERR_INVALID;
   }
   if (nnz >= (1ll << 32)) { gm::set_error("gm_graph_create: more than 2^32-1 edges per call is unsupported"); return GM_ERR_UNSUPPORTED; }
@@ -278,6 +395,9 @@ int gm_graph_create(gm_graph_t** gout, const gm_graph_desc_t* desc, int64_t nnz,
       d_val = uval.p;
     }
   }
+  g->desc.ndevice = desc->nvertices;
+  if (desc->layout == GM_LAYOUT_DEGREE) rc = gm::build_degree_layout(g, nnz, d_src, d_dst, s);
+  if (rc != GM_OK) { gm_graph_destroy(g); return rc; }
   if (desc->directions & GM_DIR_OUT) rc = gm::build_direction(g, 1, nnz, d_src, d_dst, d_val, s, &g->out);
   if (rc == GM_OK && (desc->directions & GM_DIR_IN)) rc = gm::build_direction(g, 0, nnz, d_src, d_dst, d_val, s, &g->in);
   if (rc != GM_OK) { gm_graph_destroy(g); return rc; }
@@ -290,8 +410,10 @@ int gm_graph_destroy(gm_graph_t* g) {
   if (!g) return GM_OK;
   gm::free_csr(&g->out);
   gm::free_csr(&g->in);
+  if (g->dev_of_native) (void)hipFree(g->dev_of_native);
+  if (g->native_of_dev) (void)hipFree(g->native_of_dev);
   for (int i = 0; i < GM_WS_SLOTS; i++)
-    if (g->ws[i]) (void)hipFree(g->ws[i]);
+    if (g->ws[i] && !g->ws_external[i]) (void)hipFree(g->ws[i]);
   delete g;
   return GM_OK;
 }
@@ -307,6 +429,27 @@ int gm_graph_csr(const gm_graph_t* g, int direction, gm_csr_t* out) {
   const gm::CsrOwned* c = direction == GM_DIR_OUT ? &g->out : direction == GM_DIR_IN ? &g->in : nullptr;
   if (!c || !c->present) { gm::set_error("gm_graph_csr: direction %d not built", direction); return GM_ERR_INVALID; }
   *out = c->view;
+  return GM_OK;
+}
+
+int gm_graph_maps(const gm_graph_t* g, const int32_t** d_dev_of_native, const int32_t** d_native_of_dev) {
+  if (!g) { gm::set_error("gm_graph_maps: null graph"); return GM_ERR_INVALID; }
+  if (d_dev_of_native) *d_dev_of_native = g->dev_of_native;
+  if (d_native_of_dev) *d_native_of_dev = g->native_of_dev;
+  return GM_OK;
+}
+
+int gm_graph_maps_to_host(const gm_graph_t* g, int32_t* h_dev_of_native, int32_t* h_native_of_dev) {
+  if (!g) { gm::set_error("gm_graph_maps_to_host: null graph"); return GM_ERR_INVALID; }
+  const int nv = g->desc.nvertices, vd = g->desc.ndevice;
+  if (h_dev_of_native) {
+    if (g->dev_of_native) GM_TRY_HIP(hipMemcpy(h_dev_of_native, g->dev_of_native, (size_t)nv * 4, hipMemcpyDeviceToHost));
+    else for (int i = 0; i < nv; i++) h_dev_of_native[i] = i;
+  }
+  if (h_native_of_dev) {
+    if (g->native_of_dev) GM_TRY_HIP(hipMemcpy(h_native_of_dev, g->native_of_dev, (size_t)vd * 4, hipMemcpyDeviceToHost));
+    else for (int i = 0; i < vd; i++) h_native_of_dev[i] = i;
+  }
   return GM_OK;
 }
 
@@ -331,6 +474,10 @@ int gm_graph_set_vals(gm_graph_t* g, int direction, const void* h_vals) {
 int gm_graph_workspace(gm_graph_t* g, int slot, size_t bytes, void** d_ptr) {
   if (!g || slot < 0 || slot >= GM_WS_SLOTS || !d_ptr) { gm::set_error("gm_graph_workspace: invalid argument"); return GM_ERR_INVALID; }
   if (g->ws_bytes[slot] < bytes) {
+    if (g->ws_external[slot]) {
+      gm::set_error("adopted workspace slot %d is too small (%zu < %zu bytes)", slot, g->ws_bytes[slot], bytes);
+      return GM_ERR_INVALID;
+    }
     if (g->ws[slot]) (void)hipFree(g->ws[slot]);
     g->ws[slot] = nullptr;
     g->ws_bytes[slot] = 0;
@@ -339,6 +486,15 @@ int gm_graph_workspace(gm_graph_t* g, int slot, size_t bytes, void** d_ptr) {
     g->ws_bytes[slot] = bytes;
   }
   *d_ptr = g->ws[slot];
+  return GM_OK;
+}
+
+int gm_graph_adopt_workspace(gm_graph_t* g, int slot, void* d_ptr, size_t bytes) {
+  if (!g || slot < 0 || slot >= GM_WS_SLOTS) { gm::set_error("gm_graph_adopt_workspace: invalid argument"); return GM_ERR_INVALID; }
+  if (g->ws[slot] && !g->ws_external[slot]) (void)hipFree(g->ws[slot]);
+  g->ws[slot] = d_ptr;
+  g->ws_bytes[slot] = d_ptr ? bytes : 0;
+  g->ws_external[slot] = d_ptr ? 1 : 0;
   return GM_OK;
 }
 

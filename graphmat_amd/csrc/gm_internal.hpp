@@ -42,8 +42,10 @@ struct CsrOwned {
   int64_t* rowptr = nullptr;
   int32_t* colidx = nullptr;
   void* vals = nullptr;
-  int32_t* blk_row = nullptr;
-  int32_t* long_row = nullptr;
+  int32_t* seg_row = nullptr;
+  int32_t* blk_seg = nullptr;
+  int32_t* mid_row = nullptr;
+  int32_t* giant_row = nullptr;
   bool present = false;
 };
 
@@ -52,8 +54,11 @@ struct CsrOwned {
 struct gm_graph {
   gm_graph_desc_t desc;
   gm::CsrOwned out, in;
+  int32_t* dev_of_native;  // nullptr = identity
+  int32_t* native_of_dev;
   void* ws[GM_WS_SLOTS];
   size_t ws_bytes[GM_WS_SLOTS];
+  int ws_external[GM_WS_SLOTS];
   gm_exchange_fn xfn;
   void* xctx;
   int timing;

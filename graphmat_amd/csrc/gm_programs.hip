@@ -169,8 +169,8 @@ int run_fixed(P& prog, gm_graph_t* g, V* d_vp, uint32_t* d_active, int iteration
   }
   void *p0, *p1, *p2, *p3, *p5;
   int rc;
-  if ((rc = gm_graph_workspace(g, 1, (size_t)d.nvertices * sizeof(T) + 16, &p0))) return rc;
-  if ((rc = gm_graph_workspace(g, 2, ((size_t)(d.nvertices + 31) / 32 + 2) * 4, &p1))) return rc;
+  if ((rc = gm_graph_workspace(g, 1, (size_t)d.ndevice * sizeof(T) + 16, &p0))) return rc;
+  if ((rc = gm_graph_workspace(g, 2, ((size_t)(d.ndevice + 31) / 32 + 2) * 4, &p1))) return rc;
   if ((rc = gm_graph_workspace(g, 3, (size_t)rows * sizeof(U) + 16, &p2))) return rc;
   if ((rc = gm_graph_workspace(g, 4, ((size_t)(rows + 31) / 32 + 2) * 4, &p3))) return rc;
   if (!d_active) {
@@ -198,8 +198,18 @@ extern "C" {
 
 int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "force_ordered")) { gm::g_force_ordered = value; return GM_OK; }
+  if (key && !strcmp(key, "debug_flags")) { GraphMat::detail::debug_flags() = value; return GM_OK; }
   gm::set_error("gm_set_option: unknown option");
   return GM_ERR_INVALID;
+}
+
+int gm_debug_counters(int64_t out[4]) {
+  unsigned long long h[4] = {0, 0, 0, 0};
+  GM_TRY_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(GraphMat::dev::g_longrow_counters), sizeof(h)));
+  for (int i = 0; i < 4; i++) out[i] = (int64_t)h[i];
+  unsigned long long z[4] = {0, 0, 0, 0};
+  GM_TRY_HIP(hipMemcpyToSymbol(HIP_SYMBOL(GraphMat::dev::g_longrow_counters), z, sizeof(z)));
+  return GM_OK;
 }
 
 int gm_run_degree(gm_graph_t* g, gm_pr_t* d_vp, int iterations, int* iters_done, gm_stream_t stream) {

@@ -1,0 +1,106 @@
+"""Multi-GPU glue: 1-D vertex-range sharding over one process per GPU.
+
+The reference distributes a 2-D tile grid over MPI ranks and exchanges x/y segments
+with point-to-point messages (include/GMDP/multinode/spmspv.h:41-206).  Here each
+GPU owns a contiguous range of native rows (complete rows, so there is no y
+reduction) and the only per-iteration exchange is making the message vector x
+globally visible: every rank contributes its slice (values + presence words), i.e.
+an all-gather, done with torch.distributed (backend "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in the CPU tests).  Convergence is a 1-int MIN all-reduce
+(include/GraphMatRuntime.h:226 analogue).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+ALIGN = 64  # shard boundaries are multiples of 64 rows (whole presence words)
+
+
+def edge_balanced_ranges(row_counts_cumsum, nv, nranks, align=ALIGN):
+    """Split native rows [0,nv) into nranks contiguous ranges with ~equal edge counts.
+
+    row_counts_cumsum[i] = number of edges in rows < i (length nv+1, numpy or torch on cpu).
+    Boundaries are rounded to multiples of `align`; every range is non-empty where possible.
+    """
+    cs = np.asarray(row_counts_cumsum)
+    total = int(cs[-1])
+    bounds = [0]
+    for r in range(1, nranks):
+        target = total * r // nranks
+        b = int(np.searchsorted(cs, target, side="left"))
+        b = (b + align // 2) // align * align
+        b = max(b, bounds[-1] + align) if bounds[-1] + align <= nv else nv
+        b = min(b, nv)
+        bounds.append(b)
+    bounds.append(nv)
+    for i in range(1, len(bounds)):  # keep monotone
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return [(bounds[i], bounds[i + 1]) for i in range(nranks)]
+
+
+class MessageExchange:
+    """Implements the library's exchange callback with torch.distributed.
+
+    x_bytes: uint8 tensor of nv*elt_bytes (+pad) that the library uses as its x values
+    buffer; x_bits: int32 tensor of (nv+31)//32 (+2) presence words.  Both are adopted by
+    the graph (gm_graph_adopt_workspace), so the pointers the callback receives are these.
+    """
+
+    def __init__(self, ranges, rank, x_bytes, x_bits, group=None):
+        self.ranges = [(int(a), int(b)) for a, b in ranges]
+        self.rank = rank
+        self.x_bytes = x_bytes
+        self.x_bits = x_bits
+        self.group = group
+        self.flag = torch.zeros(1, dtype=torch.int32, device=x_bytes.device)
+        self.calls = 0
+
+    def _equal_slices(self):
+        n = len(self.ranges)
+        S = self.ranges[0][1] - self.ranges[0][0]
+        return S > 0 and all(lo == r * S and hi == (r + 1) * S for r, (lo, hi) in enumerate(self.ranges)) and n > 1
+
+    def all_gather_slices(self, elt_bytes):
+        if self._equal_slices() and dist.get_backend(self.group) == "nccl":
+            # equal slices (GM_LAYOUT_DEGREE): one in-place all-gather per array
+            n = len(self.ranges)
+            S = self.ranges[0][1]
+            lo = self.rank * S
+            dist.all_gather_into_tensor(self.x_bytes[: n * S * elt_bytes], self.x_bytes[lo * elt_bytes: (lo + S) * elt_bytes],
+                                        group=self.group)
+            W = S // 32
+            dist.all_gather_into_tensor(self.x_bits[: n * W], self.x_bits[self.rank * W: (self.rank + 1) * W],
+                                        group=self.group)
+            return
+        hs = []
+        for r, (lo, hi) in enumerate(self.ranges):
+            if hi <= lo:
+                continue
+            hs.append(dist.broadcast(self.x_bytes[lo * elt_bytes: hi * elt_bytes], src=r, group=self.group,
+                                     async_op=True))
+            hs.append(dist.broadcast(self.x_bits[lo // 32: (hi + 31) // 32], src=r, group=self.group, async_op=True))
+        for h in hs:
+            h.wait()
+
+    def all_reduce_converged(self, value):
+        self.flag[0] = int(value)
+        dist.all_reduce(self.flag, op=dist.ReduceOp.MIN, group=self.group)
+        return int(self.flag.item())
+
+    def callback(self):
+        def fn(ctx, kind, d_ptr, elt_bytes, d_bits, h_flag):
+            try:
+                self.calls += 1
+                if kind == _lib.GM_XCHG_MESSAGES:
+                    if d_ptr != self.x_bytes.data_ptr() or d_bits != self.x_bits.data_ptr():
+                        return 2
+                    self.all_gather_slices(int(elt_bytes))
+                else:
+                    h_flag[0] = self.all_reduce_converged(h_flag[0])
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                print("graphmat_amd.dist: exchange failed:", repr(e), flush=True)
+                return 1
+        return _lib.EXCHANGE_FN(fn)

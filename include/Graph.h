@@ -183,6 +183,7 @@ class Graph {
   gm_graph_t* A;   // both directions live in one handle; A and AT name the same object
   gm_graph_t* AT;
   bool adjacencyowner;
+  std::vector<int32_t> dev_of_native;  // device slot of each native id (host copy; identity if empty)
   SpVec<DenseSegment<V> >* vertexproperty;
   SpVec<DenseSegment<bool> >* active;
 
@@ -239,6 +240,11 @@ class Graph {
   int nativeToVertex(int vertex, int nsegments, int len) const {
     return gm_native_to_vertex(vertex, num_threads * 16 * nsegments, len);
   }
+  // 1-based slot in the device-ordered vectors of the vertex with 1-based id `vertex`
+  int vertexToSlot(int vertex) const {
+    int nat = vertexToNative(vertex, tiles_per_dim, nvertices);
+    return dev_of_native.empty() ? nat : dev_of_native[nat - 1] + 1;
+  }
 
  private:
   static int default_num_threads() {
@@ -270,6 +276,10 @@ void Graph<V, E>::ReadEdgelist(GraphMat::edgelist_t<E> A_edges) {
   d.row_hi = A_edges.m;
   d.directions = GM_DIR_OUT | GM_DIR_IN;
   d.val_bytes = (int)sizeof(E);
+  const char* lay = getenv("GRAPHMAT_LAYOUT");
+  d.layout = (lay && !strcmp(lay, "native")) ? GM_LAYOUT_NATIVE : GM_LAYOUT_DEGREE;
+  d.nshards = 1;
+  d.shard = 0;
   if (A && adjacencyowner) gm_graph_destroy(A);
   A = AT = nullptr;
   if (gm_graph_create(&A, &d, (int64_t)ne, src.data(), dst.data(), val.data(), nullptr) != GM_OK) {
@@ -278,6 +288,8 @@ void Graph<V, E>::ReadEdgelist(GraphMat::edgelist_t<E> A_edges) {
   }
   AT = A;
   adjacencyowner = true;
+  dev_of_native.assign((size_t)A_edges.m, 0);
+  gm_graph_maps_to_host(A, dev_of_native.data(), nullptr);
   nvertices = A_edges.m;
   nnz = (long long)ne;
   if (vertexproperty && vertexpropertyowner) delete vertexproperty;
@@ -321,9 +333,9 @@ void Graph<V, E>::setAllActive() { active->segment->setAllBits(true); }
 template <class V, class E>
 void Graph<V, E>::setAllInactive() { active->segment->setAllBits(false); }
 template <class V, class E>
-void Graph<V, E>::setActive(int v) { active->set(vertexToNative(v, tiles_per_dim, nvertices), true); }
+void Graph<V, E>::setActive(int v) { active->set(vertexToSlot(v), true); }
 template <class V, class E>
-void Graph<V, E>::setInactive(int v) { active->unset(vertexToNative(v, tiles_per_dim, nvertices)); }
+void Graph<V, E>::setInactive(int v) { active->unset(vertexToSlot(v)); }
 
 template <class V, class E>
 void Graph<V, E>::reset() {
@@ -343,12 +355,12 @@ template <class V, class E>
 void Graph<V, E>::setAllVertexproperty(const V& val) { vertexproperty->setAll(val); }
 template <class V, class E>
 void Graph<V, E>::setVertexproperty(int v, const V& val) {
-  vertexproperty->set(vertexToNative(v, tiles_per_dim, nvertices), val);
+  vertexproperty->set(vertexToSlot(v), val);
 }
 template <class V, class E>
 V Graph<V, E>::getVertexproperty(const int v) const {
   V vp;
-  vertexproperty->get(vertexToNative(v, tiles_per_dim, nvertices), &vp);
+  vertexproperty->get(vertexToSlot(v), &vp);
   return vp;
 }
 template <class V, class E>
@@ -360,10 +372,10 @@ template <class V, class E>
 void Graph<V, E>::getVertexEdgelist(GraphMat::edgelist_t<V>& myedges) {
   vertexproperty->segment->need_host();
   myedges = edgelist_t<V>(nvertices, 1, nvertices);
-  for (int i = 0; i < nvertices; i++) {
-    myedges.edges[i].src = nativeToVertex(i + 1, tiles_per_dim, nvertices);
-    myedges.edges[i].dst = 1;
-    myedges.edges[i].val = vertexproperty->segment->hvalue[i];
+  for (int v = 1; v <= nvertices; v++) {
+    myedges.edges[v - 1].src = v;
+    myedges.edges[v - 1].dst = 1;
+    myedges.edges[v - 1].val = vertexproperty->segment->hvalue[vertexToSlot(v) - 1];
   }
 }
 
@@ -376,11 +388,13 @@ void Graph<V, E>::getEdgelist(GraphMat::edgelist_t<E>& myedges) {
   std::vector<E> vv((size_t)c.nnz);
   gm_graph_csr_to_host(A, GM_DIR_IN, rp.data(), ci.data(), vv.data());
   myedges = edgelist_t<E>(nvertices, nvertices, (int)c.nnz);
+  std::vector<int32_t> nod((size_t)c.ncols);
+  gm_graph_maps_to_host(A, nullptr, nod.data());
   size_t k = 0;
   for (int r = 0; r < c.nrows; r++)
     for (int64_t e = rp[r]; e < rp[r + 1]; e++, k++) {
-      myedges.edges[k].src = nativeToVertex(r + 1, tiles_per_dim, nvertices);
-      myedges.edges[k].dst = nativeToVertex(ci[e] + 1, tiles_per_dim, nvertices);
+      myedges.edges[k].src = nativeToVertex(nod[r] + 1, tiles_per_dim, nvertices);
+      myedges.edges[k].dst = nativeToVertex(nod[ci[e]] + 1, tiles_per_dim, nvertices);
       myedges.edges[k].val = vv[e];
     }
 }
@@ -393,7 +407,7 @@ void Graph<V, E>::saveVertexproperty(std::string fname, bool includeHeader) cons
   std::ofstream f((fname + std::to_string(get_global_myrank())).c_str());
   if (includeHeader) f << nvertices << " " << 1 << " " << nvertices << std::endl;
   for (int v = 1; v <= nvertices; v++)
-    f << v << " " << vertexproperty->segment->hvalue[vertexToNative(v, tiles_per_dim, nvertices) - 1] << std::endl;
+    f << v << " " << vertexproperty->segment->hvalue[vertexToSlot(v) - 1] << std::endl;
 }
 
 // Host-side element-wise helpers.  The callbacks are host function pointers, so they run
@@ -418,9 +432,9 @@ void Graph<V, E>::applyReduceAllVertices(T* val, void (*ApplyFn)(V*, T*, void*),
     int s = std::min(per * p, n), e = std::min(per * (p + 1), n);
     bool first = false;
     T local;
-    for (int i = s; i < e; i++) {
+    for (int i = s; i < e; i++) {  // native order, like the reference's segment walk
       T t2;
-      ApplyFn(&h[i], &t2, param);
+      ApplyFn(&h[dev_of_native.empty() ? i : dev_of_native[i]], &t2, param);
       if (first) { T t = local; ReduceFn(t, t2, &local, param); }
       else { local = t2; first = true; }
     }

@@ -73,8 +73,8 @@ void run_graph_program(
   uint32_t* ybits;
   if (rgpts == NULL) {
     void *p0, *p1, *p2, *p3;
-    gm_graph_workspace(g.A, 1, (size_t)d.nvertices * sizeof(T) + 16, &p0);
-    gm_graph_workspace(g.A, 2, ((size_t)(d.nvertices + 31) / 32 + 2) * 4, &p1);
+    gm_graph_workspace(g.A, 1, (size_t)d.ndevice * sizeof(T) + 16, &p0);
+    gm_graph_workspace(g.A, 2, ((size_t)(d.ndevice + 31) / 32 + 2) * 4, &p1);
     gm_graph_workspace(g.A, 3, (size_t)rows * sizeof(U) + 16, &p2);
     gm_graph_workspace(g.A, 4, ((size_t)(rows + 31) / 32 + 2) * 4, &p3);
     x = (T*)p0; xbits = (uint32_t*)p1; y = (U*)p2; ybits = (uint32_t*)p3;

@@ -31,53 +31,85 @@ namespace detail {
 
 inline int grid_for(int64_t n) { return (int)((n + dev::kBlock - 1) / dev::kBlock); }
 
+// ablation switches for the multiply+reduce kernels (dev::DBG_*); 0 in production
+inline int& debug_flags() {
+  static int f = 0;
+  return f;
+}
+
+// HIP-event phase timer: every mark closes an interval that is charged to `tag`.
+enum { TAG_START = 0, TAG_SEND = 1, TAG_ROWBLOCK = 2, TAG_WAVE = 3, TAG_GIANT = 4, TAG_APPLY = 5 };
 struct PhaseTimer {
   bool on;
   hipStream_t s;
-  std::vector<hipEvent_t> ev;  // 4 per iteration: t0 send t1 spmv t2 apply t3
+  std::vector<hipEvent_t> ev;
+  std::vector<int> tags;
   explicit PhaseTimer(bool on_, hipStream_t s_) : on(on_), s(s_) {}
-  void mark() {
+  void mark(int tag) {
     if (!on) return;
     hipEvent_t e;
     GM_HIP_OK(hipEventCreate(&e));
     GM_HIP_OK(hipEventRecord(e, s));
     ev.push_back(e);
+    tags.push_back(tag);
   }
   void finish(gm_run_stats_t* st) {
     if (!on || ev.empty()) return;
     GM_HIP_OK(hipEventSynchronize(ev.back()));
-    for (size_t i = 0; i + 3 < ev.size(); i += 4) {
-      float a = 0, b = 0, c = 0;
-      GM_HIP_OK(hipEventElapsedTime(&a, ev[i], ev[i + 1]));
-      GM_HIP_OK(hipEventElapsedTime(&b, ev[i + 1], ev[i + 2]));
-      GM_HIP_OK(hipEventElapsedTime(&c, ev[i + 2], ev[i + 3]));
-      st->send_ms += a;
-      st->spmv_ms += b;
-      st->apply_ms += c;
+    for (size_t i = 1; i < ev.size(); i++) {
+      if (tags[i] == TAG_START) continue;
+      float ms = 0;
+      GM_HIP_OK(hipEventElapsedTime(&ms, ev[i - 1], ev[i]));
+      if (tags[i] == TAG_SEND) st->send_ms += ms;
+      else if (tags[i] == TAG_ROWBLOCK) { st->rowblock_ms += ms; st->rowblock_launches++; }
+      else if (tags[i] == TAG_WAVE) { st->wave_ms += ms; st->wave_launches++; }
+      else if (tags[i] == TAG_GIANT) { st->giant_ms += ms; st->giant_launches++; }
+      else if (tags[i] == TAG_APPLY) st->apply_ms += ms;
     }
+    st->spmv_ms = st->rowblock_ms + st->wave_ms + st->giant_ms;
     float t = 0;
     GM_HIP_OK(hipEventElapsedTime(&t, ev.front(), ev.back()));
     st->total_ms = t;
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     ev.clear();
+    tags.clear();
   }
 };
 
 // one multiply+reduce pass over one direction of the adjacency
 template <class P, class T, class U, class V, class E, bool USE_VP>
 void launch_spmv(const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits, const V* vp, U* y,
-                 uint32_t* ybits, int accumulate, hipStream_t s, int* launches) {
+                 uint32_t* ybits, int accumulate, hipStream_t s, int* launches, PhaseTimer* timer = nullptr) {
   constexpr int RK = (int)program_traits<P>::reduce;
   if (A.nnz == 0) return;
   if (A.nblk > 0) {
     hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A, x,
-                       xbits, vp, y, ybits, accumulate);
+                       xbits, vp, y, ybits, accumulate, debug_flags());
     (*launches)++;
+    if (timer) timer->mark(TAG_ROWBLOCK);
   }
-  if (A.nlong > 0) {
-    hipLaunchKernelGGL((dev::k_spmv_longrow<P, T, U, V, E, USE_VP, RK>), dim3(A.nlong), dim3(dev::kBlock), 0, s, pa, A,
-                       x, xbits, vp, y, ybits, accumulate);
+  constexpr int WPB = dev::kBlock / 64;  // rows (waves) per workgroup of k_spmv_wave
+  if (A.nmid > 0) {
+    hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, RK>), dim3((A.nmid + WPB - 1) / WPB),
+                       dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
+                       debug_flags());
     (*launches)++;
+    if (timer) timer->mark(TAG_WAVE);
+  }
+  if (A.ngiant > 0) {
+    // giant rows: a workgroup each when the reduction kind has a block-wide strategy,
+    // otherwise the ordered wave fold (always correct)
+    if constexpr ((RK == REDUCE_F32_ADD && sizeof(U) == 4) ||
+                  ((RK == REDUCE_COMMUTATIVE || RK == REDUCE_LAST) && sizeof(U) <= 8)) {
+      hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kBlock), 0, s, pa,
+                         A, x, xbits, vp, y, ybits, accumulate, debug_flags());
+    } else {
+      hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, REDUCE_ORDERED>),
+                         dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, s, pa, A, A.giant_row, A.ngiant, x,
+                         xbits, vp, y, ybits, accumulate, debug_flags());
+    }
+    (*launches)++;
+    if (timer) timer->mark(TAG_GIANT);
   }
 }
 
@@ -123,7 +155,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     // Clear(&x) / Clear(&y) (:139-140): x presence words are fully rewritten by send
     GM_HIP_OK(hipMemsetAsync(ybits, 0, (size_t)nwords * 4, s));
     GM_HIP_OK(hipMemsetAsync(d_changed, 0, sizeof(int), s));
-    timer.mark();
+    timer.mark(TAG_START);
     // send (:145)
     const bool dense_x = (act == ALL_VERTICES);
     hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
@@ -134,23 +166,22 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         exit(1);
       }
     }
-    timer.mark();
+    timer.mark(TAG_SEND);
     // multiply + reduce (:160-176)
     const uint32_t* xb = dense_x ? nullptr : xbits;
     if (order == OUT_EDGES || order == ALL_EDGES) {
-      if (use_vp) launch_spmv<P, T, U, V, E, true>(pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches);
-      else launch_spmv<P, T, U, V, E, false>(pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches);
+      if (use_vp) launch_spmv<P, T, U, V, E, true>(pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches, &timer);
+      else launch_spmv<P, T, U, V, E, false>(pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches, &timer);
     }
     if (order == IN_EDGES || order == ALL_EDGES) {
       int acc = (order == ALL_EDGES) ? 1 : 0;
-      if (use_vp) launch_spmv<P, T, U, V, E, true>(pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches);
-      else launch_spmv<P, T, U, V, E, false>(pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches);
+      if (use_vp) launch_spmv<P, T, U, V, E, true>(pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer);
+      else launch_spmv<P, T, U, V, E, false>(pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer);
     }
-    timer.mark();
     // setAllInactive (:184) + apply (:195-225): the active vector is rewritten by k_apply
     hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, (const U*)y,
                        (const uint32_t*)ybits, d_vp, d_active, n, d_changed);
-    timer.mark();
+    timer.mark(TAG_APPLY);
     int converged = 0;
     if (iterations <= 0) {  // the flag only matters when running until convergence (:257-259)
       GM_HIP_OK(hipMemcpyAsync(h_changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, s));

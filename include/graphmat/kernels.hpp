@@ -14,7 +14,9 @@
 //  * rows are grouped into row-blocks of < 2*GM_BLOCK_NNZ edges: a 256-thread
 //    workgroup streams the block's column ids coalesced, gathers the messages
 //    in parallel into LDS, then one lane per row folds its segment from LDS.
-//  * rows longer than GM_LONG_ROW get a workgroup each (k_spmv_longrow) with a
+//  * rows of GM_SHORT_ROW+1..GM_GIANT_ROW edges get one wave each (k_spmv_wave): the
+//    products of 64 edges are folded in order straight out of the lanes' registers.
+//  * rows longer than GM_GIANT_ROW get a workgroup each (k_spmv_giant) with a
 //    reduction strategy chosen by program_traits<P>::reduce.
 //  * presence bit vectors keep the reference layout (bit i&31 of word i>>5).
 //  * the vertex program is passed by value as raw bytes and its methods are
@@ -44,6 +46,9 @@ struct program_traits {
 };
 
 namespace dev {
+
+// [0] chunks accepted by the exact fp32 replay, [1] chunks folded serially (long rows)
+static __device__ unsigned long long g_longrow_counters[4];
 
 constexpr int kBlock = 256;               // threads per workgroup (4 wave64)
 constexpr int kStage = 2 * GM_BLOCK_NNZ;  // LDS slots of a row-block
@@ -144,62 +149,243 @@ __device__ __forceinline__ E edge_at(const void* __restrict__ vals, int64_t k) {
 }
 
 // ------------------------------------------------------------------------------------
-// multiply+reduce over row-blocks (rows of at most GM_LONG_ROW edges).
+// debug/ablation switches (gm_set_option("debug_flags", ...)); 0 in production
+enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8 };
+
+// ------------------------------------------------------------------------------------
+// multiply+reduce over row-blocks (rows of at most GM_SHORT_ROW edges).
 //   USE_VP : 3-operand form, process_message sees vp[row] (spmspv3.h:70)
 //   xbits == nullptr : every x entry present (ALL_VERTICES programs)
 //   accumulate : y may already hold partial results (second pass of ALL_EDGES)
+// Phase 1 keeps many independent loads in flight per lane: all column ids of the lane's
+// slots first, then all gathers, then the LDS stores.
 template <class P, class T, class U, class V, class E, bool USE_VP>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
-                const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate) {
+                const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg) {
   constexpr bool STAGE = stageable<T>::value;
+  constexpr int PER = kStage / kBlock;  // 8 slots per lane
   typedef typename raw_of<STAGE ? (int)sizeof(T) : 1>::type raw_t;
   __shared__ int s_col[kStage];
   __shared__ raw_t s_msg[STAGE ? kStage : 1];
 
   const P& p = *reinterpret_cast<const P*>(pa.b);
-  const int b = blockIdx.x;
-  const int r0 = A.blk_row[b], r1 = A.blk_row[b + 1];
+  const int sg = A.blk_seg[blockIdx.x];
+  const int r0 = A.seg_row[sg], r1 = A.seg_row[sg + 1];
+  const int row = r0 + threadIdx.x;
+  int64_t rp0 = 0, rp1 = 0;
+  if (row < r1) { rp0 = A.rowptr[row]; rp1 = A.rowptr[row + 1]; }
   const int64_t e0 = A.rowptr[r0], e1 = A.rowptr[r1];
   const int n = (int)(e1 - e0);
-  if (n == 0) return;
-  if (r1 - r0 == 1 && n > GM_LONG_ROW) return;  // handled by k_spmv_longrow
+  if (n == 0 || n > kStage) return;  // cannot happen for a row-block (see gm_csr_t)
+  const bool dense = (xbits == nullptr);
 
-  // phase 1: coalesced column ids, parallel gathers, into LDS in edge order
-  for (int k = threadIdx.x; k < n; k += kBlock) {
-    int c = A.colidx[e0 + k];
-    bool present = (xbits == nullptr) || bit_get(xbits, c);
-    s_col[k] = present ? c : -1;
-    if (STAGE && present) s_msg[k] = reinterpret_cast<const raw_t*>(x)[c];
+  int c[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    int k = threadIdx.x + j * kBlock;
+    c[j] = (k < n) ? A.colidx[e0 + k] : -1;
+  }
+  if (!dense) {
+#pragma unroll
+    for (int j = 0; j < PER; j++)
+      if (c[j] >= 0 && !bit_get(xbits, c[j])) c[j] = -1;
+  }
+  if constexpr (STAGE) {
+    raw_t m[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      m[j] = raw_t();
+      if (c[j] >= 0 && !(dbg & DBG_SKIP_GATHER)) m[j] = reinterpret_cast<const raw_t*>(x)[c[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      int k = threadIdx.x + j * kBlock;
+      if (k < n) { s_msg[k] = m[j]; if (!dense) s_col[k] = c[j]; }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      int k = threadIdx.x + j * kBlock;
+      if (k < n) s_col[k] = c[j];
+    }
   }
   __syncthreads();
+  if (dbg & DBG_SKIP_FOLD) return;
 
   // phase 2: one lane per row folds its segment in ascending column order
-  const int row = r0 + threadIdx.x;
-  if (row < r1) {
-    const int kb = (int)(A.rowptr[row] - e0), ke = (int)(A.rowptr[row + 1] - e0);
-    if (ke > kb) {
-      bool has = accumulate && bit_get(ybits, row);
-      U acc;
-      if (has) acc = y[row];
-      V vprow;
-      if (USE_VP) vprow = vp[row];
-      for (int k = kb; k < ke; k++) {
-        int c = s_col[k];
-        if (c < 0) continue;
-        T m;
-        if (STAGE) {
-          raw_t r = s_msg[k];
-          memcpy(&m, &r, sizeof(T));
-        } else {
-          m = x[c];
+  if (row < r1 && rp1 > rp0) {
+    const int kb = (int)(rp0 - e0), ke = (int)(rp1 - e0);
+    bool has = accumulate && bit_get(ybits, row);
+    U acc;
+    if (has) acc = y[row];
+    V vprow;
+    if constexpr (USE_VP) vprow = vp[row];
+    for (int k = kb; k < ke; k++) {
+      T m;
+      if constexpr (STAGE) {
+        if (!dense && s_col[k] < 0) continue;
+        raw_t r = s_msg[k];
+        memcpy(&m, &r, sizeof(T));
+      } else {
+        int cc = s_col[k];
+        if (cc < 0) continue;
+        m = x[cc];
+      }
+      fold_one<P, T, U, V, E>(p, m, edge_at<E>(A.vals, e0 + k), vprow, acc, has);
+    }
+    if (has) {
+      y[row] = acc;
+      atomicOr(&ybits[row >> 5], 1u << (row & 31));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// wave-level helpers for values of any small trivially-copyable type
+template <class U>
+__device__ __forceinline__ U wave_bcast(const U& v, int srclane) {  // srclane is wave-uniform
+  constexpr int NW = (int)((sizeof(U) + 3) / 4);
+  uint32_t w[NW] = {};
+  memcpy(w, &v, sizeof(U));
+#pragma unroll
+  for (int i = 0; i < NW; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)w[i], srclane);
+  U r;
+  memcpy(&r, w, sizeof(U));
+  return r;
+}
+template <class U>
+__device__ __forceinline__ U wave_shfl_down(const U& v, int delta) {
+  constexpr int NW = (int)((sizeof(U) + 3) / 4);
+  uint32_t w[NW] = {};
+  memcpy(w, &v, sizeof(U));
+#pragma unroll
+  for (int i = 0; i < NW; i++) w[i] = (uint32_t)__shfl_down((int)w[i], delta, 64);
+  U r;
+  memcpy(&r, w, sizeof(U));
+  return r;
+}
+
+// ------------------------------------------------------------------------------------
+// multiply+reduce, one wave per row (rows of GM_SHORT_ROW+1 .. GM_GIANT_ROW edges; also
+// giant rows of programs without a faster strategy).  64 edges at a time: coalesced
+// column ids, parallel gathers and products, then -- for ordered reductions -- the 64
+// products are folded in order by broadcasting them one by one out of the lanes'
+// registers (v_readlane), every lane carrying the same running value: no LDS, no
+// barriers, a few cycles per edge.  Loads run two chunks ahead of the fold.
+template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_wave(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nlist, const T* __restrict__ x,
+            const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
+            uint32_t* __restrict__ ybits, int accumulate, int dbg) {
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (w >= nlist) return;
+  const int lane = threadIdx.x & 63;
+  const int row = rows[w];
+  const int64_t e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
+  const bool dense = (xbits == nullptr);
+  V vprow;
+  if constexpr (USE_VP) vprow = vp[row];
+
+  if constexpr (RK == REDUCE_LAST) {
+    // reduce is a=b: the last present edge of the row wins; scan backwards
+    for (int64_t hi = e1; hi > e0; hi -= 64) {
+      const int64_t k = hi - 64 + lane;
+      int c = -1;
+      bool pres = false;
+      if (k >= e0) { c = A.colidx[k]; pres = dense || bit_get(xbits, c); }
+      const unsigned long long mask = __ballot(pres);
+      if (mask) {
+        if (lane == 63 - __clzll(mask)) {
+          T m = x[c];
+          U res;
+          p.P::process_message(m, edge_at<E>(A.vals, k), vprow, res);
+          y[row] = res;
+          atomicOr(&ybits[row >> 5], 1u << (row & 31));
         }
-        fold_one<P, T, U, V, E>(p, m, edge_at<E>(A.vals, e0 + k), vprow, acc, has);
+        return;
+      }
+    }
+    return;  // nothing present: with accumulate an earlier pass's value simply stays
+  } else if constexpr (RK == REDUCE_COMMUTATIVE) {
+    // any order: private strided folds, then a shuffle tree with the user's reduce_function
+    bool has = false;
+    U acc;
+    for (int64_t k = e0 + lane; k < e1; k += 64) {
+      int c = A.colidx[k];
+      if (!dense && !bit_get(xbits, c)) continue;
+      T m = x[c];
+      fold_one<P, T, U, V, E>(p, m, edge_at<E>(A.vals, k), vprow, acc, has);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      U o = wave_shfl_down(acc, off);
+      int oh = __shfl_down((int)has, off, 64);
+      if (oh) { if (has) p.P::reduce_function(acc, o); else { acc = o; has = true; } }
+    }
+    if (lane == 0) {
+      if (accumulate && bit_get(ybits, row)) {
+        U prev = y[row];
+        if (has) { U t = acc; acc = prev; p.P::reduce_function(acc, t); } else { acc = prev; has = true; }
       }
       if (has) {
         y[row] = acc;
         atomicOr(&ybits[row >> 5], 1u << (row & 31));
       }
+    }
+    return;
+  } else {
+    // ordered: every lane carries the same running value
+    bool has = false;
+    U acc;
+    if (accumulate && bit_get(ybits, row)) { acc = y[row]; has = true; }
+    // software pipeline: column ids two chunks ahead, gathers one chunk ahead
+    int64_t base = e0;
+    int c_cur = (base + lane < e1) ? A.colidx[base + lane] : -1;
+    if (c_cur >= 0 && !dense && !bit_get(xbits, c_cur)) c_cur = -1;
+    T m_cur;
+    if (c_cur >= 0 && !(dbg & DBG_SKIP_GATHER)) m_cur = x[c_cur];
+    int c_nxt = (base + 64 + lane < e1) ? A.colidx[base + 64 + lane] : -1;
+    while (base < e1) {
+      // issue the next chunk's gathers and the column ids after that
+      if (c_nxt >= 0 && !dense && !bit_get(xbits, c_nxt)) c_nxt = -1;
+      T m_nxt;
+      if (c_nxt >= 0 && !(dbg & DBG_SKIP_GATHER)) m_nxt = x[c_nxt];
+      const int64_t b2 = base + 128;
+      int c_nn = (b2 + lane < e1) ? A.colidx[b2 + lane] : -1;
+      // products of the current chunk
+      const bool pres = c_cur >= 0;
+      U term;
+      if (pres) p.P::process_message(m_cur, edge_at<E>(A.vals, base + lane), vprow, term);
+      unsigned long long mask = __ballot(pres);
+      if (!(dbg & DBG_SKIP_FOLD)) {
+        if (!has && mask) {  // first message of the row assigns
+          const int i = __ffsll((long long)mask) - 1;
+          acc = wave_bcast(term, i);
+          has = true;
+          mask &= mask - 1;
+        }
+        if (mask == ~0ull) {
+#pragma unroll
+          for (int i = 0; i < 64; i++) { U t = wave_bcast(term, i); p.P::reduce_function(acc, t); }
+        } else {
+          while (mask) {
+            const int i = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            U t = wave_bcast(term, i);
+            p.P::reduce_function(acc, t);
+          }
+        }
+      }
+      c_cur = c_nxt;
+      m_cur = m_nxt;
+      c_nxt = c_nn;
+      base += 64;
+    }
+    if (lane == 0 && has) {
+      y[row] = acc;
+      atomicOr(&ybits[row >> 5], 1u << (row & 31));
     }
   }
 }
@@ -213,15 +399,17 @@ k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32
 // with integer q and fraction f, and round-to-nearest-even adds q, plus 1 when f > 1/2,
 // plus (parity of S+q) when f == 1/2.  So each term is a map on (integer S), depending on
 // S only through its parity in the tie case; such maps compose associatively as a pair
-// (delta if S even, delta if S odd).  A chunk is folded with an ordered tree of these
-// pairs; it is accepted iff all terms are finite, non-negative and smaller than 2^e and
-// the chunk total keeps S below 2^24 (no binade crossing, S is monotone).  Otherwise the
-// chunk is replayed serially.  Results are bit-identical to the serial loop.
+// (delta if S even, delta if S odd).  Each lane composes the maps of its consecutive
+// terms, an ordered block-wide scan composes the lanes, and the longest prefix whose
+// terms are all finite, non-negative and below 2^e and which keeps S below 2^24 (no
+// binade crossing; S is monotone) is accepted in one step.  The lane group where the
+// prefix stops is folded serially (this is where S changes binade), then the replay
+// resumes in the new binade.  Results are bit-identical to the serial loop.
 struct ulp_map {
   uint32_t de, dod;  // ulps added when the incoming S is even / odd
 };
-// Deltas are non-negative and a chunk is only accepted when its total stays below 2^23,
-// so partial results saturate at 2^24 (no 32-bit wrap; a saturated value forces a reject).
+// Deltas are non-negative and a prefix is only accepted while S stays below 2^24, so
+// partial results saturate at 2^24 (no 32-bit wrap; a saturated value forces a stop).
 constexpr uint32_t kUlpSat = 0x1000000u;
 __device__ __forceinline__ ulp_map ulp_compose(ulp_map a, ulp_map b) {  // a first, then b
   ulp_map r;
@@ -235,7 +423,7 @@ __device__ __forceinline__ ulp_map ulp_compose(ulp_map a, ulp_map b) {  // a fir
 // returns false when the term cannot be handled in this binade (a >= 2^e, negative, nan/inf).
 __device__ __forceinline__ bool ulp_term(uint32_t abits, int eS, ulp_map& out) {
   if (abits == 0u) { out.de = 0; out.dod = 0; return true; }
-  if (abits >> 31) return false;  // negative (or -0: replay serially)
+  if (abits >> 31) return false;  // negative (or -0: fold serially)
   int ea = (int)(abits >> 23);
   if (ea == 255) return false;
   uint32_t ma = abits & 0x7fffffu;
@@ -255,20 +443,27 @@ __device__ __forceinline__ bool ulp_term(uint32_t abits, int eS, ulp_map& out) {
 }
 
 // ------------------------------------------------------------------------------------
-// multiply+reduce for one long row per workgroup.
+// multiply+reduce for one giant row per workgroup (REDUCE_COMMUTATIVE, REDUCE_LAST and
+// REDUCE_F32_ADD; giant rows of plain REDUCE_ORDERED programs go to k_spmv_wave).
+constexpr int kLongPer = 16;                    // consecutive edges per lane and chunk
+constexpr int kLongChunk = kLongPer * kBlock;   // 4096 edges per chunk
+
 template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
 __global__ void __launch_bounds__(kBlock)
-k_spmv_longrow(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
-               const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate) {
-  constexpr int CH = kStage;  // edges per chunk
-  __shared__ int s_col[CH];
-  __shared__ __attribute__((aligned(16))) unsigned char s_res_raw[(RK == REDUCE_COMMUTATIVE || RK == REDUCE_F32_ADD) ? kBlock * sizeof(U) : 16];
+k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
+               const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg) {
+  constexpr bool SMALL_U = sizeof(U) <= 8;
+  constexpr int CH = kLongChunk, PER = kLongPer;
+  // ordered kinds stage the per-edge products (U) of a chunk in LDS for the serial fold
+  __shared__ __attribute__((aligned(16))) unsigned char s_term_raw[(SMALL_U && RK != REDUCE_LAST) ? CH * sizeof(U) : 16];
+  __shared__ uint32_t s_pres[CH / 32];
   __shared__ int s_has[kBlock];
-  __shared__ ulp_map s_map[kBlock / 64];
-  __shared__ int s_flag;
+  __shared__ ulp_map s_wave[kBlock / 64];
+  __shared__ int s_flag, s_next, s_fail;
+  __shared__ uint32_t s_Sbits;
 
   const P& p = *reinterpret_cast<const P*>(pa.b);
-  const int row = A.long_row[blockIdx.x];
+  const int row = A.giant_row[blockIdx.x];
   const int64_t e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
   const int tid = threadIdx.x;
   V vprow;
@@ -276,7 +471,8 @@ k_spmv_longrow(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_
 
   if constexpr (RK == REDUCE_COMMUTATIVE) {
     // any order: strided private folds, then an LDS tree with the user's reduce_function
-    U* s_res = reinterpret_cast<U*>(s_res_raw);
+    static_assert(SMALL_U, "REDUCE_COMMUTATIVE is for small reduction types");
+    U* s_res = reinterpret_cast<U*>(s_term_raw);
     bool has = false;
     U acc;
     for (int64_t k = e0 + tid; k < e1; k += kBlock) {
@@ -304,9 +500,7 @@ k_spmv_longrow(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_
       atomicOr(&ybits[row >> 5], 1u << (row & 31));
     }
     return;
-  }
-
-  if constexpr (RK == REDUCE_LAST) {
+  } else if constexpr (RK == REDUCE_LAST) {
     // reduce is a=b: the answer is the last present edge of the row; scan backwards
     if (tid == 0) s_flag = -1;
     __syncthreads();
@@ -333,111 +527,162 @@ k_spmv_longrow(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_
       }
     }
     return;  // no present message: with accumulate an earlier pass's value simply stays
-  }
-
-  // ordered kinds: chunked; thread 0 carries the running value
-  bool has = false;
-  U acc;
-  if (tid == 0 && accumulate && bit_get(ybits, row)) { acc = y[row]; has = true; }
-  for (int64_t base = e0; base < e1; base += CH) {
-    const int n = (int)((e1 - base) < CH ? (e1 - base) : CH);
-    __syncthreads();  // previous chunk fully consumed
-    for (int k = tid; k < n; k += kBlock) {
-      int c = A.colidx[base + k];
-      bool present = (xbits == nullptr) || bit_get(xbits, c);
-      s_col[k] = present ? c : -1;
+  } else {
+    // ---- REDUCE_F32_ADD: chunked exact replay; lane t owns PER consecutive edges ------------
+    static_assert(RK == REDUCE_F32_ADD && sizeof(U) == 4 && SMALL_U, "k_spmv_giant: unsupported reduction kind");
+    float* s_term = reinterpret_cast<float*>(s_term_raw);
+    const int lane = tid & 63;
+    if (tid == 0) {
+      uint32_t sb = 0;
+      bool h = accumulate && bit_get(ybits, row);
+      if (h) { U prev = y[row]; memcpy(&sb, &prev, 4); }
+      s_Sbits = sb;
+      s_has[0] = h;
     }
-    __syncthreads();
-    bool done = false;
-    if constexpr (RK == REDUCE_F32_ADD) {
-      static_assert(sizeof(U) == 4 && sizeof(T) >= 1, "REDUCE_F32_ADD needs a float reduction type");
-      // requires U = float and process_message(m, e, vp) independent of order (it is per edge)
-      float* s_res = reinterpret_cast<float*>(s_res_raw);
-      // each thread owns CH/kBlock consecutive edges of the chunk: products first
-      constexpr int PER = CH / kBlock;
+    for (int64_t base = e0; base < e1; base += CH) {
+      const int n = (int)((e1 - base) < CH ? (e1 - base) : CH);
+      const int ngroups = (n + PER - 1) / PER;
+      __syncthreads();  // previous chunk fully consumed
+      int c[PER];
+      const int k0 = tid * PER;
+#pragma unroll
+      for (int j = 0; j < PER; j++) c[j] = (k0 + j < n) ? A.colidx[base + k0 + j] : -1;
+      if (xbits != nullptr) {
+#pragma unroll
+        for (int j = 0; j < PER; j++)
+          if (c[j] >= 0 && !bit_get(xbits, c[j])) c[j] = -1;
+      }
+      uint32_t presmask = 0;
+#pragma unroll
+      for (int j = 0; j < PER; j++) presmask |= (c[j] >= 0 ? 1u : 0u) << j;
+      T m[PER];
+#pragma unroll
+      for (int j = 0; j < PER; j++)
+        if (c[j] >= 0) { if (dbg & DBG_SKIP_GATHER) memset(&m[j], 0, sizeof(T)); else m[j] = x[c[j]]; }
       float term[PER];
-      bool pres[PER];
 #pragma unroll
       for (int j = 0; j < PER; j++) {
-        int k = tid * PER + j;
-        pres[j] = false;
         term[j] = 0.f;
-        if (k < n) {
-          int c = s_col[k];
-          if (c >= 0) {
-            T m = x[c];
-            U res;
-            p.P::process_message(m, edge_at<E>(A.vals, base + k), vprow, res);
-            memcpy(&term[j], &res, sizeof(float));
-            pres[j] = true;
-          }
+        if (c[j] >= 0) {
+          U t;
+          p.P::process_message(m[j], edge_at<E>(A.vals, base + k0 + j), vprow, t);
+          memcpy(&term[j], &t, 4);
         }
+        s_term[j * kBlock + tid] = term[j];  // slot(k) = (k % PER) * kBlock + k / PER: conflict-free
       }
-      // running sum known to everyone
-      if (tid == 0) { s_has[0] = has; if (has) s_res[0] = *reinterpret_cast<float*>(&acc); }
+      if ((tid & 1) == 0) s_pres[tid >> 1] = 0;
+      if (tid == 0) { s_next = 0; s_flag = 1; }  // s_flag: groups to fold serially after a stop
       __syncthreads();
-      const bool has0 = s_has[0];
-      const float S0 = has0 ? s_res[0] : 0.f;
-      const uint32_t sb = __float_as_uint(S0);
-      const int eS = (int)((sb >> 23) & 0xff);
-      bool ok = has0 && !(sb >> 31) && eS > 0 && eS < 255;
-      ulp_map mine = {0u, 0u};
-      if (ok) {
+      if (presmask) atomicOr(&s_pres[tid >> 1], presmask << ((tid & 1) * 16));
+      __syncthreads();
+      if (dbg & DBG_SKIP_FOLD) { if (dbg & DBG_FIRST_CHUNK_ONLY) break; continue; }
+
+      while (true) {
+        const int g0 = s_next;
+        if (g0 >= ngroups) break;
+        const bool has0 = s_has[0] != 0;
+        const uint32_t sb = s_Sbits;
+        const int span = s_flag;
+        const int eS = (int)((sb >> 23) & 0xff);
+        const bool s_ok = has0 && !(sb >> 31) && eS > 0 && eS < 255 && !(dbg & DBG_NO_REPLAY);
+        int fail = g0;  // first group that cannot be taken in this binade
+        if (s_ok) {
+          ulp_map mine = {0u, 0u};
+          bool ok = true;
+          if (tid >= g0 && tid < ngroups) {
 #pragma unroll
-        for (int j = 0; j < PER; j++) {
-          if (pres[j]) {
-            ulp_map t;
-            if (!ulp_term(__float_as_uint(term[j]), eS, t)) ok = false;
-            else mine = ulp_compose(mine, t);
+            for (int j = 0; j < PER; j++)
+              if ((presmask >> j) & 1u) {
+                ulp_map t;
+                if (!ulp_term(__float_as_uint(term[j]), eS, t)) ok = false; else mine = ulp_compose(mine, t);
+              }
           }
-        }
-      }
-      __syncthreads();  // s_has[0]/s_res[0] read by all before reuse
-      if (tid == 0) s_flag = 1;
-      __syncthreads();
-      if (!ok) s_flag = 0;
-      // ordered combine across the wave (lane order), then across waves
-      ulp_map v = mine;
+          // ordered inclusive scan over lanes, then over waves
+          ulp_map v = mine;
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        ulp_map o;
-        o.de = __shfl_down(v.de, off, 64);
-        o.dod = __shfl_down(v.dod, off, 64);
-        if (((tid & 63) & (2 * off - 1)) == 0) v = ulp_compose(v, o);
-      }
-      if ((tid & 63) == 0) s_map[tid >> 6] = v;
-      __syncthreads();
-      if (tid == 0) {
-        if (s_flag) {
-          ulp_map t = s_map[0];
-          for (int w = 1; w < kBlock / 64; w++) t = ulp_compose(t, s_map[w]);
-          uint32_t Sint = (sb & 0x7fffffu) | 0x800000u;  // S in ulps, in [2^23, 2^24)
-          uint32_t add = (Sint & 1u) ? t.dod : t.de;     // saturated at 2^24 (ulp_compose)
-          uint32_t Snew = Sint + add;
-          if (add < 0x800000u && Snew < 0x1000000u) {
-            float r = __uint_as_float((sb & 0xff800000u) | (Snew & 0x7fffffu));
-            memcpy(&acc, &r, sizeof(float));
-            s_flag = 2;  // accepted
-          } else {
-            s_flag = 0;
+          for (int off = 1; off < 64; off <<= 1) {
+            ulp_map o;
+            o.de = __shfl_up(v.de, off, 64);
+            o.dod = __shfl_up(v.dod, off, 64);
+            if (lane >= off) v = ulp_compose(o, v);
+          }
+          if (lane == 63) s_wave[tid >> 6] = v;
+          if (tid == 0) s_fail = ngroups;
+          __syncthreads();
+          ulp_map pre = {0u, 0u};
+          for (int w = 0; w < (tid >> 6); w++) pre = ulp_compose(pre, s_wave[w]);
+          v = ulp_compose(pre, v);  // maps of groups g0..tid composed
+          const uint32_t Sint = (sb & 0x7fffffu) | 0x800000u;  // S in ulps, in [2^23, 2^24)
+          const uint32_t add = (Sint & 1u) ? v.dod : v.de;
+          const uint32_t Safter = Sint + add;  // add saturates at 2^24: no wrap
+          const bool bad = !ok || Safter >= 0x1000000u;
+          if (tid >= g0 && tid < ngroups && bad) atomicMin(&s_fail, tid);
+          __syncthreads();
+          fail = s_fail;
+          if (fail > g0 && tid == fail - 1) {  // accept groups [g0, fail)
+            s_Sbits = (sb & 0xff800000u) | (Safter & 0x7fffffu);
+            atomicAdd(&g_longrow_counters[0], (unsigned long long)(fail - g0));
           }
         }
+        __syncthreads();
+        if (tid < 64) {
+          // wave 0 folds `span` groups from `fail` on, in order, out of registers; the span
+          // doubles while the replay makes no progress and resets once it does
+          int nspan = (fail - g0 >= 8) ? 1 : span;
+          if (!has0) nspan = nspan < 64 ? 64 : nspan;  // row start: S grows fastest here
+          const int gend = fail + nspan < ngroups ? fail + nspan : ngroups;
+          if (fail < ngroups) {
+            uint32_t sb2 = s_Sbits;
+            bool h = s_has[0] != 0;
+            U S;
+            memcpy(&S, &sb2, 4);
+            const int kend = gend * PER < n ? gend * PER : n;
+            for (int kb = fail * PER; kb < kend; kb += 64) {
+              const int k = kb + lane;
+              bool pr = false;
+              U a;
+              if (k < kend && ((s_pres[k >> 5] >> (k & 31)) & 1u)) {
+                pr = true;
+                memcpy(&a, &s_term[(k % PER) * kBlock + k / PER], 4);
+              }
+              unsigned long long mask = __ballot(pr);
+              if (!h && mask) {
+                const int i = __ffsll((long long)mask) - 1;
+                S = wave_bcast(a, i);
+                h = true;
+                mask &= mask - 1;
+              }
+              while (mask) {
+                const int i = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                U t = wave_bcast(a, i);
+                p.P::reduce_function(S, t);
+              }
+            }
+            if (lane == 0) {
+              memcpy(&sb2, &S, 4);
+              s_Sbits = sb2;
+              s_has[0] = h;
+              s_next = gend;
+              s_flag = (fail - g0 >= 8) ? 1 : (nspan * 2 > 256 ? 256 : nspan * 2);
+              atomicAdd(&g_longrow_counters[1], (unsigned long long)(gend - fail));
+            }
+          } else if (lane == 0) {
+            s_next = ngroups;
+          }
+        }
+        __syncthreads();
       }
-      __syncthreads();
-      done = (s_flag == 2);
+      if (dbg & DBG_FIRST_CHUNK_ONLY) break;
     }
-    if (!done && tid == 0) {
-      for (int k = 0; k < n; k++) {
-        int c = s_col[k];
-        if (c < 0) continue;
-        T m = x[c];
-        fold_one<P, T, U, V, E>(p, m, edge_at<E>(A.vals, base + k), vprow, acc, has);
-      }
+    __syncthreads();
+    if (tid == 0 && s_has[0]) {
+      uint32_t sb = s_Sbits;
+      U r;
+      memcpy(&r, &sb, 4);
+      y[row] = r;
+      atomicOr(&ybits[row >> 5], 1u << (row & 31));
     }
-  }
-  if (tid == 0 && has) {
-    y[row] = acc;
-    atomicOr(&ybits[row >> 5], 1u << (row & 31));
   }
 }
 

@@ -80,15 +80,31 @@ void gm_host_free(void* p);
 #define GM_DIR_OUT 1 /* rows = destinations, cols = sources: GraphMat's AT, used by OUT_EDGES programs */
 #define GM_DIR_IN 2  /* rows = sources, cols = destinations: GraphMat's A, used by IN_EDGES programs  */
 
+/* Device order.  All device arrays (vertex state, x, y, presence bits, CSR rows and column
+ * ids) are indexed by DEVICE ids.  GM_LAYOUT_NATIVE: device id = native id and the shard owns
+ * [row_lo,row_hi) as given.  GM_LAYOUT_DEGREE (what bench.py uses): vertices are ranked by
+ * total degree (descending, ties by native id) and rank k becomes device id
+ * (k % nshards) * S + k / nshards with S = shard size (multiple of 64): every shard gets an
+ * equal slice with its busiest vertices first (their x entries stay cache resident) and an
+ * equal share of the edges; the library fills in row_lo/row_hi/ndevice.  In both layouts a
+ * row's edges are stored -- and reduced -- in ascending NATIVE column order, so results do
+ * not depend on the layout.  gm_graph_maps() gives the two maps. */
+#define GM_LAYOUT_NATIVE 0
+#define GM_LAYOUT_DEGREE 1
+
 typedef struct {
   int32_t nvertices;     /* global vertex count */
   int32_t nparts;        /* layout parameter of the id permutation (see above)            */
-  int32_t row_lo;        /* this shard owns native rows [row_lo,row_hi); multiples of 64   */
-  int32_t row_hi;        /*   (0,nvertices for a single GPU)                               */
+  int32_t row_lo;        /* this shard owns device rows [row_lo,row_hi); multiples of 64   */
+  int32_t row_hi;        /*   (input for GM_LAYOUT_NATIVE, output for GM_LAYOUT_DEGREE)    */
   int32_t directions;    /* GM_DIR_OUT | GM_DIR_IN                                         */
   int32_t val_bytes;     /* sizeof(edge value), 0 = drop edge values                       */
   int32_t ids_on_device; /* 1: src/dst/val are device pointers, 0: host pointers           */
   int32_t ids_are_native;/* 1: src/dst are already 0-based native ids (skip permutation)   */
+  int32_t layout;        /* GM_LAYOUT_NATIVE or GM_LAYOUT_DEGREE                           */
+  int32_t nshards;       /* GM_LAYOUT_DEGREE: number of shards (GPUs), >= 1                */
+  int32_t shard;         /* GM_LAYOUT_DEGREE: which shard this graph object holds          */
+  int32_t ndevice;       /* output: size of the device id space (>= nvertices)             */
 } gm_graph_desc_t;
 
 /* One direction of the adjacency as laid out in HBM (see DESIGN.md "data layout"). */
@@ -96,30 +112,46 @@ typedef struct {
   int64_t nnz;            /* edges in this shard and direction                            */
   int32_t nrows;          /* row_hi - row_lo                                              */
   int32_t row_base;       /* row_lo                                                       */
-  int32_t ncols;          /* global vertex count                                          */
+  int32_t ncols;          /* size of the device id space (x has this many entries)        */
   int32_t val_bytes;
   const int64_t* rowptr;  /* [nrows+1]                                                    */
-  const int32_t* colidx;  /* [nnz] native column ids, ascending inside a row, duplicates
-                             in input order: the reference's reduction order               */
+  const int32_t* colidx;  /* [nnz] DEVICE column ids, stored in ascending NATIVE column order
+                             inside a row, duplicates in input order: the reference's
+                             reduction order                                               */
   const void* vals;       /* [nnz] edge values or NULL                                    */
-  const int32_t* blk_row; /* [nblk+1] row-block boundaries (local row ids)                */
+  /* work decomposition of the multiply+reduce kernels (include/graphmat/kernels.hpp):  */
+  const int32_t* seg_row; /* [nseg+1] boundaries of runs of consecutive rows (local ids); a
+                             run is either one row of more than GM_SHORT_ROW edges or up to 256
+                             short rows holding < 2*GM_BLOCK_NNZ edges                      */
+  int32_t nseg;
+  const int32_t* blk_seg; /* [nblk] indices into seg_row of the short-row runs (row-blocks)  */
   int32_t nblk;
-  const int32_t* long_row;/* [nlong] local rows with more than GM_LONG_ROW edges          */
-  int32_t nlong;
+  const int32_t* mid_row; /* [nmid] rows with GM_SHORT_ROW < edges <= GM_GIANT_ROW: one wave each */
+  int32_t nmid;
+  const int32_t* giant_row;/* [ngiant] rows with more than GM_GIANT_ROW edges: one workgroup each */
+  int32_t ngiant;
 } gm_csr_t;
 
-#define GM_BLOCK_NNZ 1024 /* a row-block holds < 2*GM_BLOCK_NNZ edges and <= 256 rows  */
-#define GM_LONG_ROW 1024  /* rows above this get a workgroup of their own               */
+#define GM_BLOCK_NNZ 1024   /* a row-block holds < 2*GM_BLOCK_NNZ edges and <= 256 rows     */
+#define GM_SHORT_ROW 64     /* rows up to this many edges are folded one lane per row        */
+#define GM_GIANT_ROW 16384  /* rows above this get a workgroup of their own                  */
 
 /* src/dst: 1-based vertex ids as in the .mtx (or native ids, see desc).  Edges whose
- * row falls outside [row_lo,row_hi) are dropped per direction, so every rank may pass
- * the full edge list.  The input arrays are not modified. */
+ * row falls outside the shard are dropped per direction, so every rank passes the full
+ * edge list (GM_LAYOUT_DEGREE needs it to rank the vertices).  The input arrays are not
+ * modified. */
 int gm_graph_create(gm_graph_t** g, const gm_graph_desc_t* desc, int64_t nnz, const int32_t* src,
                     const int32_t* dst, const void* val, gm_stream_t stream);
 int gm_graph_destroy(gm_graph_t* g);
 int gm_graph_desc(const gm_graph_t* g, gm_graph_desc_t* out);
 int gm_graph_csr(const gm_graph_t* g, int direction, gm_csr_t* out);
-/* copy a direction's CSR back to the host in native ids (tests, Graph::getEdgelist) */
+/* d_dev_of_native[native id] = device id (nvertices entries), d_native_of_dev[device id] =
+ * native id or -1 for an unused slot (ndevice entries).  Both NULL for GM_LAYOUT_NATIVE
+ * (identity).  Device pointers owned by the graph. */
+int gm_graph_maps(const gm_graph_t* g, const int32_t** d_dev_of_native, const int32_t** d_native_of_dev);
+/* host copies of the maps (identity is written for GM_LAYOUT_NATIVE); either may be NULL */
+int gm_graph_maps_to_host(const gm_graph_t* g, int32_t* h_dev_of_native, int32_t* h_native_of_dev);
+/* copy a direction's CSR back to the host, rows and columns in device ids (tests, Graph::getEdgelist) */
 int gm_graph_csr_to_host(const gm_graph_t* g, int direction, int64_t* h_rowptr, int32_t* h_colidx, void* h_vals);
 
 /* overwrite a direction's edge values from a host array laid out like gm_graph_csr_to_host's
@@ -147,8 +179,8 @@ typedef int (*gm_exchange_fn)(void* ctx, int kind, void* d_ptr, int64_t elt_byte
 int gm_graph_set_exchange(gm_graph_t* g, gm_exchange_fn fn, void* ctx);
 
 /* ---- fixed-menu vertex programs ------------------------------------------------------
- * Vertex state arrays are DEVICE arrays over the shard's rows in native order
- * (entry i = native vertex row_lo+i).  iterations <= 0 runs until convergence
+ * Vertex state arrays are DEVICE arrays over the shard's rows in device order
+ * (entry i = device id row_lo+i; see gm_graph_maps).  iterations <= 0 runs until convergence
  * (GraphMatRuntime.h:254-260); *iters_done (may be NULL) receives the count.
  * d_active: presence bit vector over the shard's rows (bit i&31 of word i>>5),
  * in/out, as Graph::active; NULL = all vertices active on entry. */
@@ -184,8 +216,10 @@ int gm_set_option(const char* key, int value);
  * HIP-event times (ms) summed over iterations; kernel launches counted. */
 typedef struct {
   int32_t iterations;
-  float send_ms, spmv_ms, apply_ms, total_ms;
+  float send_ms, spmv_ms, apply_ms, total_ms; /* spmv_ms = rowblock_ms + wave_ms + giant_ms */
   int32_t spmv_launches;
+  float rowblock_ms, wave_ms, giant_ms;       /* the three multiply+reduce kernels, separately */
+  int32_t rowblock_launches, wave_launches, giant_launches;
 } gm_run_stats_t;
 int gm_graph_enable_timing(gm_graph_t* g, int on);
 int gm_graph_last_stats(const gm_graph_t* g, gm_run_stats_t* out);
@@ -196,6 +230,14 @@ int gm_graph_last_stats(const gm_graph_t* g, gm_run_stats_t* out);
  * slot in [0, GM_WS_SLOTS). */
 #define GM_WS_SLOTS 8
 int gm_graph_workspace(gm_graph_t* g, int slot, size_t bytes, void** d_ptr);
+/* Let the caller provide a scratch slot (e.g. a torch tensor it also hands to its collective
+ * library): slot 1 = message values x (nvertices * elt bytes), slot 2 = x presence bits
+ * ((nvertices+31)/32+2 words).  The library uses the buffer while it is large enough and never
+ * frees it.  d_ptr = NULL returns the slot to library ownership. */
+int gm_graph_adopt_workspace(gm_graph_t* g, int slot, void* d_ptr, size_t bytes);
+/* counters of the giant-row kernel since the last call (then reset): 16-edge groups
+ * out[0] taken by the exact parallel fp32 replay, out[1] folded serially */
+int gm_debug_counters(int64_t out[4]);
 /* invoke the exchange callback if one is set (no-op returning 0 otherwise) */
 int gm_graph_exchange(gm_graph_t* g, int kind, void* d_ptr, int64_t elt_bytes, uint32_t* d_bits, int* h_flag);
 int gm_graph_has_exchange(const gm_graph_t* g);

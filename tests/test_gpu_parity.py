@@ -86,29 +86,35 @@ def test_rmat_device_generator_matches_numpy(env):
         assert (ds.cpu().numpy() == s).all() and (dd.cpu().numpy() == d).all() and (dv.cpu().numpy() == v).all()
 
 
-@pytest.mark.parametrize("threads", [1, 3])
-def test_csr_build_order(env, threads):
-    """columns ascending inside a row, duplicates kept in input order, both directions."""
+@pytest.mark.parametrize("threads,layout", [(1, 0), (3, 0), (1, 1), (2, 1)])
+def test_csr_build_order(env, threads, layout):
+    """rows in device order; inside a row the columns follow ascending NATIVE id (the reference's
+    reduction order), duplicates kept in input order; both directions, both layouts."""
     api, _ = env
     nv, s, d, v = gen.rmat_edges(10, 16, 3, weights="hash")
     v = np.arange(len(s), dtype=np.int32)  # unique values expose the duplicate order
-    g = api.Graph(nv, s, d, v, ref_threads=threads)
+    g = api.Graph(nv, s, d, v, ref_threads=threads, layout=layout)
+    don, nod = g.maps_to_host()
+    assert sorted(don.tolist()) == list(range(nv)) and (nod[don] == np.arange(nv)).all()
     nat = api.native_index(nv, threads * 16)
     sn, dn = nat[s - 1], nat[d - 1]
     for direction, rows, cols in ((api.GM_DIR_OUT, dn, sn), (api.GM_DIR_IN, sn, dn)):
         rp, ci, vv = g.csr_to_host(direction)
-        order = np.lexsort((np.arange(len(s)), cols, rows))  # stable: row, col, input position
-        assert (ci == cols[order]).all() and (vv == v[order]).all()
-        assert (rp == np.searchsorted(rows[order], np.arange(nv + 1))).all()
+        order = np.lexsort((np.arange(len(s)), cols, don[rows]))  # stable: device row, native col, input position
+        assert (ci == don[cols[order]]).all() and (vv == v[order]).all()
+        assert (rp == np.searchsorted(don[rows[order]], np.arange(nv + 1))).all()
+    if layout == 1:  # busiest vertices first
+        deg = np.bincount(sn, minlength=nv) + np.bincount(dn, minlength=nv)
+        assert (np.diff(deg[nod]) <= 0).all()
 
 
 # ---------------- programs on synthetic graphs -----------------------------------------------------
-@pytest.mark.parametrize("scale,threads", [(10, 1), (12, 4), (14, 1), (16, 2)])
-def test_pagerank_bit_exact_rmat(env, scale, threads):
+@pytest.mark.parametrize("scale,threads,layout", [(10, 1, 1), (12, 4, 0), (14, 1, 1), (16, 2, 1), (16, 1, 0)])
+def test_pagerank_bit_exact_rmat(env, scale, threads, layout):
     api, ob = env
     nv, s, d, v = gen.rmat_edges(scale, 16, seed=scale)
     og = ob.OracleGraph(nv, s, d, v, threads)
-    g = api.Graph(nv, s, d, v, ref_threads=threads)
+    g = api.Graph(nv, s, d, v, ref_threads=threads, layout=layout)
     for force in (0, 1):
         api._lib.lib().gm_set_option(b"force_ordered", force)
         pr, deg, it = g.pagerank(10)
@@ -127,12 +133,12 @@ def test_pagerank_until_convergence(env):
     assert it == oit and (f32bits(pr) == f32bits(opr)).all()
 
 
-@pytest.mark.parametrize("scale,threads", [(10, 1), (13, 4), (16, 1)])
-def test_bfs_bit_exact_rmat(env, scale, threads):
+@pytest.mark.parametrize("scale,threads,layout", [(10, 1, 1), (13, 4, 0), (16, 1, 1)])
+def test_bfs_bit_exact_rmat(env, scale, threads, layout):
     api, ob = env
     nv, s, d, v = gen.rmat_edges(scale, 16, seed=100 + scale)
     og = ob.OracleGraph(nv, s, d, v, threads)
-    g = api.Graph(nv, s, d, v, ref_threads=threads)
+    g = api.Graph(nv, s, d, v, ref_threads=threads, layout=layout)
     for source in (1, 2, int(s[len(s) // 2])):
         depth, parent, it = g.bfs(source)
         od, op, oit, _ = og.bfs(source)
@@ -178,8 +184,8 @@ def _pagerank_custom(api, ob, nv, s, d, pr0, deg, alpha, iters, threads=1):
     import torch
     g = api.Graph(nv, s, d, np.ones(len(s), np.int32), ref_threads=threads)
     st = torch.zeros((nv, 2), dtype=torch.int32, device=g.device)
-    st[:, 0] = g.to_native_order(f32bits(pr0).view(np.int32))
-    st[:, 1] = g.to_native_order(np.asarray(deg, np.int32))
+    st[:, 0] = g.to_device_order(f32bits(pr0).view(np.int32))
+    st[:, 1] = g.to_device_order(np.asarray(deg, np.int32))
     out = []
     for force in (0, 1):
         api._lib.lib().gm_set_option(b"force_ordered", force)
