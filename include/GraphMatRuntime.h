@@ -19,6 +19,7 @@
 #include "Graph.h"
 #include "GraphProgram.h"
 #include "SPMV.h"
+#include "graphmat/device_globals.hpp"
 
 namespace GraphMat {
 
@@ -86,6 +87,7 @@ void run_graph_program(
   }
   g.vertexproperty->segment->need_device();
   g.active->segment->need_device();
+  detail::refresh_device_globals();  // host namespace-scope variables the program reads (e.g. MAX_DIST)
   gettimeofday(&init_end, 0);
 #ifdef __TIMING
   printf("Nvertices = %d \n", g.getNumberOfVertices());

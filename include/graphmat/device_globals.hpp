@@ -1,0 +1,178 @@
+// graphmat/device_globals.hpp -- keep device copies of host namespace-scope variables fresh.
+//
+// GraphMat applications are plain host C++; their vertex-program methods may read
+// namespace-scope variables (the reference's src/BFS.cpp:38 and src/SSSP.cpp:41 define a
+// non-const global MAX_DIST that apply()/the constructors compare against).  Compiled with
+// `hipcc --hipstdpar`, such a variable gets a separate, zero-initialised copy in the device
+// code object.  Before every run this header copies the current host value of each such
+// variable into its device copy, so unchanged application sources behave as on the CPU:
+//   1. the executable's own image (/proc/self/exe) is read once: host symbol table, and the
+//      gfx950 code object(s) inside its .hip_fatbin offload bundle with their symbol tables;
+//   2. a registered anchor variable defined below gives one (link address, run-time device
+//      address) pair, i.e. the load bias of the code object that holds this translation
+//      unit's kernels (a code object is loaded as one block: its code addresses globals
+//      PC-relatively);
+//   3. every writable OBJECT symbol of that code object which has a same-named, same-sized
+//      OBJECT symbol on the host is refreshed with hipMemcpy.
+// Limits: single translation unit applications; uncompressed offload
+// bundles (hipcc's default); the executable must keep its symbol table (not stripped).
+#pragma once
+#include <elf.h>
+#include <hip/hip_runtime.h>
+#include <link.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+namespace GraphMat {
+namespace detail {
+
+static __device__ unsigned int gm_code_object_anchor;
+// keeps the anchor alive in this translation unit's code object; never launched
+static __global__ void gm_anchor_touch(unsigned int v) { gm_code_object_anchor = v; }
+
+struct MirroredGlobal {
+  void* dev;
+  const void* host;
+  size_t size;
+  std::string name;
+};
+
+inline bool read_file(const char* path, std::vector<unsigned char>& out) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize(n > 0 ? (size_t)n : 0);
+  bool ok = n > 0 && fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+  fclose(f);
+  return ok;
+}
+
+struct ElfSym {
+  std::string name;
+  uint64_t value, size;
+  unsigned type, shndx;
+  uint64_t sec_flags;
+  uint32_t sec_type;
+};
+
+// OBJECT symbols of an ELF64 image held in memory
+inline void elf_objects(const unsigned char* img, size_t len, std::vector<ElfSym>& out) {
+  if (len < sizeof(Elf64_Ehdr) || memcmp(img, ELFMAG, SELFMAG) != 0 || img[EI_CLASS] != ELFCLASS64) return;
+  const Elf64_Ehdr* eh = (const Elf64_Ehdr*)img;
+  if (eh->e_shoff == 0 || eh->e_shoff + (uint64_t)eh->e_shnum * sizeof(Elf64_Shdr) > len) return;
+  const Elf64_Shdr* sh = (const Elf64_Shdr*)(img + eh->e_shoff);
+  for (int i = 0; i < eh->e_shnum; i++) {
+    if (sh[i].sh_type != SHT_SYMTAB) continue;
+    if (sh[i].sh_link >= eh->e_shnum) continue;
+    const Elf64_Shdr& st = sh[sh[i].sh_link];
+    if (sh[i].sh_offset + sh[i].sh_size > len || st.sh_offset + st.sh_size > len) continue;
+    const Elf64_Sym* sym = (const Elf64_Sym*)(img + sh[i].sh_offset);
+    const char* str = (const char*)(img + st.sh_offset);
+    size_t n = sh[i].sh_size / sizeof(Elf64_Sym);
+    for (size_t k = 0; k < n; k++) {
+      if (ELF64_ST_TYPE(sym[k].st_info) != STT_OBJECT || sym[k].st_size == 0) continue;
+      if (sym[k].st_shndx == SHN_UNDEF || sym[k].st_shndx >= eh->e_shnum || sym[k].st_name >= st.sh_size) continue;
+      ElfSym e;
+      e.name = str + sym[k].st_name;
+      e.value = sym[k].st_value;
+      e.size = sym[k].st_size;
+      e.type = ELF64_ST_TYPE(sym[k].st_info);
+      e.shndx = sym[k].st_shndx;
+      e.sec_flags = sh[sym[k].st_shndx].sh_flags;
+      e.sec_type = sh[sym[k].st_shndx].sh_type;
+      out.push_back(e);
+    }
+  }
+}
+
+inline int phdr_cb(struct dl_phdr_info* info, size_t, void* data) {
+  *(uint64_t*)data = (uint64_t)info->dlpi_addr;  // first entry = the main executable
+  return 1;
+}
+
+// Builds the mirror list once per process (per translation unit that includes this header).
+inline std::vector<MirroredGlobal>& mirrored_globals() {
+  static std::vector<MirroredGlobal> list;
+  static bool done = false;
+  if (done) return list;
+  done = true;
+  (void)&gm_anchor_touch;
+  void* anchor_dev = nullptr;
+  if (hipGetSymbolAddress(&anchor_dev, HIP_SYMBOL(gm_code_object_anchor)) != hipSuccess || !anchor_dev) return list;
+  std::vector<unsigned char> exe;
+  if (!read_file("/proc/self/exe", exe)) return list;
+  std::vector<ElfSym> host;
+  elf_objects(exe.data(), exe.size(), host);
+  if (host.empty()) return list;  // stripped
+  uint64_t base = 0;
+  dl_iterate_phdr(phdr_cb, &base);
+  static const char magic[] = "__CLANG_OFFLOAD_BUNDLE__";
+  const size_t mlen = sizeof(magic) - 1;
+  for (size_t pos = 0; pos + mlen + 8 <= exe.size();) {
+    const unsigned char* hit = (const unsigned char*)memmem(exe.data() + pos, exe.size() - pos, magic, mlen);
+    if (!hit) break;
+    const size_t b = (size_t)(hit - exe.data());
+    pos = b + mlen;
+    uint64_t nent = 0;
+    memcpy(&nent, exe.data() + b + mlen, 8);
+    size_t p = b + mlen + 8;
+    for (uint64_t e = 0; e < nent && p + 24 <= exe.size(); e++) {
+      uint64_t off, size, tl;
+      memcpy(&off, exe.data() + p, 8);
+      memcpy(&size, exe.data() + p + 8, 8);
+      memcpy(&tl, exe.data() + p + 16, 8);
+      p += 24;
+      if (p + tl > exe.size()) break;
+      std::string triple((const char*)exe.data() + p, (size_t)tl);
+      p += tl;
+      if (triple.find("amdgcn") == std::string::npos || size == 0 || b + off + size > exe.size()) continue;
+      std::vector<ElfSym> dev;
+      elf_objects(exe.data() + b + off, (size_t)size, dev);
+      const ElfSym* anchor = nullptr;
+      for (const ElfSym& s : dev)
+        if (s.name.find("gm_code_object_anchor") != std::string::npos) anchor = &s;
+      if (!anchor) continue;
+      const uint64_t bias = (uint64_t)anchor_dev - anchor->value;
+      for (const ElfSym& s : dev) {
+        if (!(s.sec_flags & SHF_WRITE)) continue;  // .data / .bss only
+        if (s.name.find("gm_code_object_anchor") != std::string::npos || s.name.find("g_longrow_counters") != std::string::npos ||
+            s.name.compare(0, 10, "__hip_cuid") == 0)
+          continue;
+        for (const ElfSym& h : host) {
+          if (h.name == s.name && h.size == s.size && (h.sec_flags & SHF_ALLOC)) {
+            MirroredGlobal m;
+            m.dev = (void*)(bias + s.value);
+            m.host = (const void*)(base + h.value);
+            m.size = (size_t)s.size;
+            m.name = s.name;
+            list.push_back(m);
+            break;
+          }
+        }
+      }
+      return list;  // the code object holding this translation unit's anchor has been handled
+    }
+  }
+  return list;
+}
+
+// Called at every run_graph_program entry (host values may change between runs).
+inline void refresh_device_globals() {
+  for (const MirroredGlobal& m : mirrored_globals()) {
+    if (hipMemcpy(m.dev, m.host, m.size, hipMemcpyHostToDevice) != hipSuccess) {
+      printf("GraphMat(HIP): could not mirror global '%s' to the device\n", m.name.c_str());
+      (void)hipGetLastError();
+    }
+  }
+  if (getenv("GRAPHMAT_VERBOSE"))
+    for (const MirroredGlobal& m : mirrored_globals()) printf("GraphMat(HIP): mirrored global %s (%zu bytes)\n", m.name.c_str(), m.size);
+}
+
+}  // namespace detail
+}  // namespace GraphMat

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Builds application binaries against include/ with `hipcc --hipstdpar` (gfx950):
+
+  * apps/*.cpp            -- this project's own example programs (always)
+  * <reference>/src/{PageRank,BFS,SGD,SSSP}.cpp -- the reference's UNCHANGED application
+    sources, compiled where they lie when the reference tree is present (build container
+    only).  Outputs go to build/ref_apps/ (git-ignored; they travel to the GPU box like any
+    other built artefact).  Nothing from the reference is copied into the repository.
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("GRAPHMAT_REFERENCE", "/root/reference")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "--hipstdpar", "-ffp-contract=off", "-w", "-DGRAPHMAT_NO_MPI",
+         "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "graphmat_amd"), "-lgraphmat_hip"]
+
+
+def _compile(src, out, rpath):
+    if os.path.exists(out) and os.path.getmtime(out) >= max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "graphmat_amd", "libgraphmat_hip.so"))):
+        return
+    cmd = [HIPCC] + FLAGS + [src, "-o", out, "-Wl,-rpath," + rpath]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout.decode())
+        raise RuntimeError("hipcc failed on %s" % src)
+
+
+def build(verbose=False):
+    built = []
+    appdir = os.path.join(ROOT, "apps")
+    outdir = os.path.join(ROOT, "build", "apps")
+    os.makedirs(outdir, exist_ok=True)
+    for f in sorted(os.listdir(appdir)):
+        if f.endswith(".cpp"):
+            out = os.path.join(outdir, f[:-4])
+            _compile(os.path.join(appdir, f), out, "$ORIGIN/../../graphmat_amd")
+            built.append(out)
+    if os.path.isdir(os.path.join(REF, "src")):
+        outdir = os.path.join(ROOT, "build", "ref_apps")
+        os.makedirs(outdir, exist_ok=True)
+        for app in ("PageRank", "BFS", "SGD", "SSSP"):
+            out = os.path.join(outdir, app)
+            _compile(os.path.join(REF, "src", app + ".cpp"), out, "$ORIGIN/../../graphmat_amd")
+            built.append(out)
+    if verbose:
+        print("\n".join(built))
+    return built
+
+
+if __name__ == "__main__":
+    build(verbose=True)
