@@ -80,10 +80,18 @@ def main():
     if rank == 0:
         __graft_entry__.build()
     import torch.distributed as dist
+    # GM_BENCH_BACKEND=gloo lets the sharded path be exercised on a 1-GPU box (all ranks on
+    # cuda:0, collectives through the host); the driver's multi-GPU runs use nccl = RCCL.
+    backend = os.environ.get("GM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         dist.barrier()
     from graphmat_amd import _lib, api
     from graphmat_amd.dist import MessageExchange
@@ -155,7 +163,7 @@ def main():
     stats = g.last_stats()
     L.gm_debug_counters(cnt64)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

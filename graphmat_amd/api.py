@@ -78,6 +78,7 @@ class Graph:
         self.layout, self.nshards, self.shard = layout, nshards, shard
         self._dov = None
         self._cb = None
+        self.gather_fn = None  # sharded graphs: local rows tensor -> all rows tensor (see dist.attach_exchange)
 
     def close(self):
         if getattr(self, "h", None):
@@ -107,15 +108,23 @@ class Graph:
         return self._dov
 
     def to_device_order(self, arr_vertex_order, fill=0):
-        """array indexed by vertex-1 -> device tensor indexed by device id (single-shard graphs)."""
-        assert self.rows == self.ndevice, "vertex-order conversion needs the whole graph on one device"
+        """array indexed by vertex-1 -> device tensor over THIS shard's rows (device order)."""
         t = torch.as_tensor(arr_vertex_order).to(self.device)
         out = torch.full((self.ndevice,) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=self.device)
         out[self.dev_of_vertex] = t
-        return out
+        return out[self.row_lo:self.row_hi].contiguous()
 
-    def to_vertex_order(self, t_dev):
-        return t_dev[self.dev_of_vertex]
+    def to_vertex_order(self, t_rows):
+        """tensor over this shard's rows -> tensor indexed by vertex-1 (gathers the shards first)."""
+        if self.rows != self.ndevice:
+            assert self.gather_fn is not None, "sharded graph: attach an exchange (dist.attach_exchange) first"
+            t_rows = self.gather_fn(t_rows.contiguous())
+        return t_rows[self.dev_of_vertex]
+
+    def _local_slot(self, vertex):
+        """row index inside this shard of a vertex, or None if another shard owns it"""
+        d = int(self.dev_of_vertex[vertex - 1])
+        return d - self.row_lo if self.row_lo <= d < self.row_hi else None
 
     def csr(self, direction):
         c = _lib.Csr()
@@ -176,9 +185,10 @@ class Graph:
         ids = torch.arange(1, self.nv + 1, dtype=torch.int64, device=self.device)
         st[:, 2] = self.to_device_order(ids)  # id of the vertex living in each device slot
         act = torch.zeros((n + 31) // 32 + 2, dtype=torch.int32, device=self.device)
-        s_nat = int(self.dev_of_vertex[source - 1])
-        st[s_nat, 0] = 0
-        act[s_nat >> 5] = int(np.uint32(1 << (s_nat & 31)).view(np.int32))
+        s_nat = self._local_slot(source)
+        if s_nat is not None:
+            st[s_nat, 0] = 0
+            act[s_nat >> 5] = int(np.uint32(1 << (s_nat & 31)).view(np.int32))
         it = C.c_int(0)
         check(self.L.gm_run_bfs(self.h, st.data_ptr(), act.data_ptr(), -1, C.byref(it), _stream()))
         depth = self.to_vertex_order(st[:, 0] & 0xFFFFFFFF).cpu().numpy().astype(np.uint32)
@@ -190,9 +200,10 @@ class Graph:
         n = self.rows
         dist = torch.full((n,), -1, dtype=torch.int32, device=self.device)  # 0xFFFFFFFF
         act = torch.zeros((n + 31) // 32 + 2, dtype=torch.int32, device=self.device)
-        s_nat = int(self.dev_of_vertex[source - 1])
-        dist[s_nat] = 0
-        act[s_nat >> 5] = int(np.uint32(1 << (s_nat & 31)).view(np.int32))
+        s_nat = self._local_slot(source)
+        if s_nat is not None:
+            dist[s_nat] = 0
+            act[s_nat >> 5] = int(np.uint32(1 << (s_nat & 31)).view(np.int32))
         it = C.c_int(0)
         check(self.L.gm_run_sssp(self.h, dist.data_ptr(), act.data_ptr(), -1, C.byref(it), _stream()))
         return self.to_vertex_order(dist).cpu().numpy().view(np.uint32), it.value

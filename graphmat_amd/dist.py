@@ -104,3 +104,32 @@ class MessageExchange:
                 print("graphmat_amd.dist: exchange failed:", repr(e), flush=True)
                 return 1
         return _lib.EXCHANGE_FN(fn)
+
+
+def attach_exchange(g, group=None, max_elt_bytes=8):
+    """Make a sharded api.Graph (GM_LAYOUT_DEGREE, nshards = world size) exchange its messages
+    over torch.distributed: allocates the global x buffers, hands them to the library, installs
+    the callback and a gather function for results."""
+    import ctypes as C
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    assert g.nshards == world and g.shard == rank
+    S = g.row_hi - g.row_lo
+    ranges = [(r * S, (r + 1) * S) for r in range(world)]
+    x_bytes = torch.zeros(g.ndevice * max_elt_bytes + 64, dtype=torch.uint8, device=g.device)
+    x_bits = torch.zeros((g.ndevice + 31) // 32 + 2, dtype=torch.int32, device=g.device)
+    L = _lib.lib()
+    _lib.check(L.gm_graph_adopt_workspace(g.h, 1, x_bytes.data_ptr(), x_bytes.numel()))
+    _lib.check(L.gm_graph_adopt_workspace(g.h, 2, x_bits.data_ptr(), x_bits.numel() * 4))
+    ex = MessageExchange(ranges, rank, x_bytes, x_bits, group)
+    cb = ex.callback()
+    g._cb = (cb, ex)  # keep alive
+    _lib.check(L.gm_graph_set_exchange(g.h, cb, None))
+
+    def gather(t_rows):
+        parts = [torch.empty_like(t_rows) for _ in range(world)]
+        dist.all_gather(parts, t_rows, group=group)
+        return torch.cat(parts, 0)
+
+    g.gather_fn = gather
+    return ex

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Sharded run (one process per shard) checked against the oracle.
+
+Launched by tests/test_gpu_multi.py as
+  python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 ... tools/multi_check.py
+On a 1-GPU box every rank uses cuda:0 and the collectives run over gloo (NCCL refuses two ranks
+on one device); on an N-GPU node set GM_BACKEND=nccl.  Prints MULTI_OK on rank 0."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    backend = os.environ.get("GM_BACKEND", "gloo")
+    ndev = torch.cuda.device_count()
+    device = int(os.environ.get("LOCAL_RANK", "0")) % ndev
+    torch.cuda.set_device(device)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    from graphmat_amd import api, generators
+    from graphmat_amd.dist import attach_exchange
+    from oracle import binding as ob
+    scale = int(os.environ.get("GM_SCALE", "14"))
+    nv, s, d, v = generators.rmat_edges(scale, 16, seed=21, weights="hash")
+    g = api.Graph(nv, s, d, v, ref_threads=2, device=device, layout=api.GM_LAYOUT_DEGREE, nshards=world, shard=rank)
+    ex = attach_exchange(g)
+    og = ob.OracleGraph(nv, s, d, v, ref_threads=2)
+    ok = True
+    pr, deg, it = g.pagerank(8)
+    opr, oit, _ = og.pagerank(8)
+    ok &= bool((deg == og.degree()).all()) and it == oit and bool((pr.view(np.uint32) == opr.view(np.uint32)).all())
+    pr2, _, it2 = g.pagerank(-1)  # until convergence: exercises the flag all-reduce
+    opr2, oit2, _ = og.pagerank(-1)
+    ok &= it2 == oit2 and bool((pr2.view(np.uint32) == opr2.view(np.uint32)).all())
+    for src in (1, 7):
+        depth, parent, itb = g.bfs(src)
+        od, op, oitb, _ = og.bfs(src)
+        ok &= itb == oitb and bool((depth == od).all()) and bool((parent == op).all())
+    dist_, its = g.sssp(1)
+    odist, oits = og.sssp(1)
+    ok &= its == oits and bool((dist_ == odist).all())
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print("MULTI_OK" if int(flag) == 1 else "MULTI_FAIL", "world=%d exchanges=%d rows/shard=%d" % (world, ex.calls, g.rows), flush=True)
+    dist.destroy_process_group()
+    sys.exit(0 if int(flag) == 1 else 1)
+
+
+if __name__ == "__main__":
+    main()
