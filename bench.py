@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--cpu-scale", type=int, default=20, help="RMAT scale of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--no-timing", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--short-row", type=int, default=0, help="experiment: rows up to this many edges go to row-blocks")
+    ap.add_argument("--giant-row", type=int, default=0, help="experiment: rows above this many edges get a workgroup")
     ap.add_argument("--native-layout", action="store_true", help="device order = native order (single GPU; for A/B)")
     ap.add_argument("--debug-flags", type=int, default=0, help="ablation only (results become invalid): 1 skip fold, 2 skip gathers")
     args = ap.parse_args()
@@ -99,6 +101,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if args.short_row:
+        _lib.check(L.gm_set_option(b"short_row", args.short_row))
+    if args.giant_row:
+        _lib.check(L.gm_set_option(b"giant_row", args.giant_row))
     # ---- synthetic input, generated in HBM ------------------------------------------------
     t0 = time.time()
     nv, src, dst, _ = api.rmat_on_device(args.scale, args.edge_factor, args.seed, weights=False, device=local_rank)
@@ -133,8 +139,8 @@ def main():
     rowptr = np.zeros(c_out.nrows + 1, np.int64)
     _lib.check(L.gm_graph_csr_to_host(g.h, api.GM_DIR_OUT, rowptr.ctypes.data, None, None))
     degs = np.diff(rowptr)
-    e_giant = int(degs[degs > 16384].sum())
-    e_mid = int(degs[degs > 64].sum()) - e_giant
+    e_giant = int(degs[degs > (args.giant_row or 16384)].sum())
+    e_mid = int(degs[degs > (args.short_row or 64)].sum()) - e_giant
     e_long = e_mid + e_giant
     max_deg = int(degs.max()) if degs.size else 0
     del rowptr, degs

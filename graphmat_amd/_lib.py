@@ -25,7 +25,9 @@ class Csr(C.Structure):
     _fields_ = [("nnz", C.c_int64), ("nrows", C.c_int32), ("row_base", C.c_int32), ("ncols", C.c_int32),
                 ("val_bytes", C.c_int32), ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("vals", C.c_void_p),
                 ("seg_row", C.c_void_p), ("nseg", C.c_int32), ("blk_seg", C.c_void_p), ("nblk", C.c_int32),
-                ("mid_row", C.c_void_p), ("nmid", C.c_int32), ("giant_row", C.c_void_p), ("ngiant", C.c_int32)]
+                ("mid_row", C.c_void_p), ("nmid", C.c_int32), ("giant_row", C.c_void_p), ("ngiant", C.c_int32),
+                ("gchunk_row", C.c_void_p), ("gchunk_edge", C.c_void_p), ("gterm_off", C.c_void_p),
+                ("ngchunk", C.c_int32), ("giant_edges", C.c_int64)]
 
 
 class RunStats(C.Structure):

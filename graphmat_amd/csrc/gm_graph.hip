@@ -23,6 +23,9 @@
 
 namespace gm {
 
+int g_short_row = GM_SHORT_ROW;   // tunable through gm_set_option (experiments); defaults are the documented ones
+int g_giant_row = GM_GIANT_ROW;
+
 constexpr int kT = 256;
 inline int grid_for(int64_t n) { return (int)((n + kT - 1) / kT); }
 
@@ -121,32 +124,41 @@ k_rowptr(const uint64_t* __restrict__ keys, int64_t n, int nrows, int64_t* __res
 
 // segment starts (runs of rows, see gm_csr_t) and row classes
 __global__ void __launch_bounds__(kT)
-k_row_flags(const int64_t* __restrict__ rowptr, int nrows, unsigned char* __restrict__ start,
-            unsigned char* __restrict__ ismid, unsigned char* __restrict__ isgiant) {
+k_row_flags(const int64_t* __restrict__ rowptr, int nrows, int short_row, int giant_row,
+            unsigned char* __restrict__ start, unsigned char* __restrict__ ismid, unsigned char* __restrict__ isgiant) {
   int r = blockIdx.x * kT + threadIdx.x;
   if (r >= nrows) return;
   int64_t a = rowptr[r], b = rowptr[r + 1];
-  bool lng = (b - a) > GM_SHORT_ROW;
+  bool lng = (b - a) > short_row;
   bool st = (r == 0) || ((r & 255) == 0) || lng;
   if (!st) {
     int64_t pa = rowptr[r - 1];
-    bool prev_long = (a - pa) > GM_SHORT_ROW;
+    bool prev_long = (a - pa) > short_row;
     st = prev_long || (a / GM_BLOCK_NNZ != pa / GM_BLOCK_NNZ);
   }
   start[r] = st ? 1 : 0;
-  ismid[r] = (lng && (b - a) <= GM_GIANT_ROW) ? 1 : 0;
-  isgiant[r] = ((b - a) > GM_GIANT_ROW) ? 1 : 0;
+  ismid[r] = (lng && (b - a) <= giant_row) ? 1 : 0;
+  isgiant[r] = ((b - a) > giant_row) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(kT)
+k_giant_extent(const int32_t* __restrict__ giant_row, int ngiant, const int64_t* __restrict__ rowptr,
+               int64_t* __restrict__ ext) {
+  int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= ngiant) return;
+  ext[2 * i] = rowptr[giant_row[i]];
+  ext[2 * i + 1] = rowptr[giant_row[i] + 1];
 }
 
 // a segment is a row-block iff its first row is short and it holds at least one edge
 __global__ void __launch_bounds__(kT)
-k_seg_flags(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ seg_row, int nseg,
+k_seg_flags(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ seg_row, int nseg, int short_row,
             unsigned char* __restrict__ isblk) {
   int i = blockIdx.x * kT + threadIdx.x;
   if (i >= nseg) return;
   int r0 = seg_row[i], r1 = seg_row[i + 1];
   int64_t n = rowptr[r1] - rowptr[r0];
-  bool longrow = (r1 - r0 == 1) && n > GM_SHORT_ROW;
+  bool longrow = (r1 - r0 == 1) && n > short_row;
   isblk[i] = (!longrow && n > 0) ? 1 : 0;
 }
 
@@ -227,8 +239,8 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   if ((rc = cnt.alloc(32))) return rc;
   unsigned int nseg = 0, nblk = 0, nmid = 0, ngiant = 0;
   if (nrows > 0) {
-    hipLaunchKernelGGL(k_row_flags, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr.as<int64_t>(), nrows,
-                       f0.as<unsigned char>(), f1.as<unsigned char>(), f2.as<unsigned char>());
+    hipLaunchKernelGGL(k_row_flags, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr.as<int64_t>(), nrows, g_short_row,
+                       g_giant_row, f0.as<unsigned char>(), f1.as<unsigned char>(), f2.as<unsigned char>());
     GM_TRY_HIP(hipGetLastError());
     rocprim::counting_iterator<int32_t> ids(0);
     size_t tb = 0;
@@ -252,7 +264,7 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
     // row-blocks = the segments that hold short rows with at least one edge
     if ((rc = blkl.alloc((size_t)(nseg + 1) * 4))) return rc;
     hipLaunchKernelGGL(k_seg_flags, dim3(grid_for(nseg)), dim3(kT), 0, s, rowptr.as<int64_t>(), seg.as<int32_t>(),
-                       (int)nseg, f0.as<unsigned char>());
+                       (int)nseg, g_short_row, f0.as<unsigned char>());
     GM_TRY_HIP(rocprim::select(tmp.p, tb, ids, f0.as<unsigned char>(), blkl.as<int32_t>(), cnt.as<unsigned int>() + 3,
                                (size_t)nseg, s));
     GM_TRY_HIP(hipMemcpyAsync(h, cnt.as<unsigned int>() + 3, 4, hipMemcpyDeviceToHost, s));
@@ -262,6 +274,34 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
     if ((rc = blkl.alloc(16))) return rc;
   }
 
+  // pieces of the giant rows for the parallel products pass
+  DevBuf gcr, gce, gto;
+  std::vector<int32_t> h_gcr;
+  std::vector<int64_t> h_gce, h_gto(1, 0);
+  if (ngiant > 0) {
+    DevBuf ext;
+    if ((rc = ext.alloc((size_t)ngiant * 16))) return rc;
+    hipLaunchKernelGGL(k_giant_extent, dim3(grid_for(ngiant)), dim3(kT), 0, s, giant.as<int32_t>(), (int)ngiant,
+                       rowptr.as<int64_t>(), ext.as<int64_t>());
+    std::vector<int64_t> h_ext((size_t)ngiant * 2);
+    GM_TRY_HIP(hipMemcpyAsync(h_ext.data(), ext.p, (size_t)ngiant * 16, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    for (unsigned i = 0; i < ngiant; i++) {
+      for (int64_t e = h_ext[2 * i]; e < h_ext[2 * i + 1]; e += GM_GIANT_CHUNK) {
+        h_gcr.push_back((int32_t)i);
+        h_gce.push_back(e);
+      }
+      h_gto.push_back(h_gto.back() + ((h_ext[2 * i + 1] - h_ext[2 * i]) + 63) / 64 * 64);
+    }
+  }
+  if ((rc = gcr.alloc(h_gcr.size() * 4)) || (rc = gce.alloc(h_gce.size() * 8)) || (rc = gto.alloc(h_gto.size() * 8))) return rc;
+  if (!h_gcr.empty()) {
+    GM_TRY_HIP(hipMemcpyAsync(gcr.p, h_gcr.data(), h_gcr.size() * 4, hipMemcpyHostToDevice, s));
+    GM_TRY_HIP(hipMemcpyAsync(gce.p, h_gce.data(), h_gce.size() * 8, hipMemcpyHostToDevice, s));
+  }
+  GM_TRY_HIP(hipMemcpyAsync(gto.p, h_gto.data(), h_gto.size() * 8, hipMemcpyHostToDevice, s));
+  GM_TRY_HIP(hipStreamSynchronize(s));
+
   out->rowptr = (int64_t*)rowptr.release();
   out->colidx = (int32_t*)colidx.release();
   out->vals = keep_vals ? vals.release() : nullptr;
@@ -269,6 +309,9 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   out->blk_seg = (int32_t*)blkl.release();
   out->mid_row = (int32_t*)mid.release();
   out->giant_row = (int32_t*)giant.release();
+  out->gchunk_row = (int32_t*)gcr.release();
+  out->gchunk_edge = (int64_t*)gce.release();
+  out->gterm_off = (int64_t*)gto.release();
   out->present = true;
   gm_csr_t& v = out->view;
   v.nnz = (int64_t)kept;
@@ -287,6 +330,11 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   v.nmid = (int32_t)nmid;
   v.giant_row = out->giant_row;
   v.ngiant = (int32_t)ngiant;
+  v.gchunk_row = out->gchunk_row;
+  v.gchunk_edge = out->gchunk_edge;
+  v.gterm_off = out->gterm_off;
+  v.ngchunk = (int32_t)h_gcr.size();
+  v.giant_edges = h_gto.back();
   return GM_OK;
 }
 
@@ -336,6 +384,9 @@ static void free_csr(CsrOwned* c) {
   if (c->blk_seg) (void)hipFree(c->blk_seg);
   if (c->mid_row) (void)hipFree(c->mid_row);
   if (c->giant_row) (void)hipFree(c->giant_row);
+  if (c->gchunk_row) (void)hipFree(c->gchunk_row);
+  if (c->gchunk_edge) (void)hipFree(c->gchunk_edge);
+  if (c->gterm_off) (void)hipFree(c->gterm_off);
   *c = CsrOwned();
 }
 

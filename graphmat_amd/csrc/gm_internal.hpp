@@ -46,6 +46,9 @@ struct CsrOwned {
   int32_t* blk_seg = nullptr;
   int32_t* mid_row = nullptr;
   int32_t* giant_row = nullptr;
+  int32_t* gchunk_row = nullptr;
+  int64_t* gchunk_edge = nullptr;
+  int64_t* gterm_off = nullptr;
   bool present = false;
 };
 

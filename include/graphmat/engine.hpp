@@ -78,8 +78,9 @@ struct PhaseTimer {
 
 // one multiply+reduce pass over one direction of the adjacency
 template <class P, class T, class U, class V, class E, bool USE_VP>
-void launch_spmv(const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits, const V* vp, U* y,
-                 uint32_t* ybits, int accumulate, hipStream_t s, int* launches, PhaseTimer* timer = nullptr) {
+void launch_spmv(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits,
+                 const V* vp, U* y, uint32_t* ybits, int accumulate, hipStream_t s, int* launches,
+                 PhaseTimer* timer = nullptr) {
   constexpr int RK = (int)program_traits<P>::reduce;
   if (A.nnz == 0) return;
   if (A.nblk > 0) {
@@ -101,8 +102,24 @@ void launch_spmv(const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const
     // otherwise the ordered wave fold (always correct)
     if constexpr ((RK == REDUCE_F32_ADD && sizeof(U) == 4) ||
                   ((RK == REDUCE_COMMUTATIVE || RK == REDUCE_LAST) && sizeof(U) <= 8)) {
-      hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kBlock), 0, s, pa,
-                         A, x, xbits, vp, y, ybits, accumulate, debug_flags());
+      U* terms = nullptr;
+      unsigned long long* tpres = nullptr;
+      if constexpr (RK == REDUCE_F32_ADD) {
+        // pass 1: products of all giant-row edges, spread over the whole chip
+        void *p6 = nullptr, *p7 = nullptr;
+        gm_graph_workspace(g, 6, (size_t)A.giant_edges * sizeof(U) + 64, &p6);
+        terms = (U*)p6;
+        if (xbits != nullptr) {
+          gm_graph_workspace(g, 7, (size_t)A.giant_edges / 8 + 64, &p7);
+          tpres = (unsigned long long*)p7;
+        }
+        hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, s, pa,
+                           A, x, xbits, vp, terms, tpres, debug_flags());
+        (*launches)++;
+      }
+      hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kGiant), 0, s, pa,
+                         A, x, xbits, vp, y, ybits, accumulate, debug_flags(), (const U*)terms,
+                         (const unsigned long long*)tpres);
     } else {
       hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, REDUCE_ORDERED>),
                          dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, s, pa, A, A.giant_row, A.ngiant, x,
@@ -170,13 +187,13 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     // multiply + reduce (:160-176)
     const uint32_t* xb = dense_x ? nullptr : xbits;
     if (order == OUT_EDGES || order == ALL_EDGES) {
-      if (use_vp) launch_spmv<P, T, U, V, E, true>(pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches, &timer);
-      else launch_spmv<P, T, U, V, E, false>(pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches, &timer);
+      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches, &timer);
+      else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches, &timer);
     }
     if (order == IN_EDGES || order == ALL_EDGES) {
       int acc = (order == ALL_EDGES) ? 1 : 0;
-      if (use_vp) launch_spmv<P, T, U, V, E, true>(pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer);
-      else launch_spmv<P, T, U, V, E, false>(pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer);
+      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer);
+      else launch_spmv<P, T, U, V, E, false>(g, pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer);
     }
     // setAllInactive (:184) + apply (:195-225): the active vector is rewritten by k_apply
     hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, (const U*)y,

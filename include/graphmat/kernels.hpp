@@ -64,6 +64,10 @@ inline ProgArg<P> make_prog_arg(const P* p) {
   return a;
 }
 
+// column ids (and other read-once streams) are loaded non-temporally: 4 B/edge of streaming
+// data would otherwise keep evicting the re-used lines of the message vector from the L2s
+__device__ __forceinline__ int stream_load(const int32_t* __restrict__ p) { return __builtin_nontemporal_load(p); }
+
 __device__ __forceinline__ bool bit_get(const uint32_t* __restrict__ bits, int i) {
   return (bits[i >> 5] >> (i & 31)) & 1u;
 }
@@ -184,7 +188,7 @@ k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32
 #pragma unroll
   for (int j = 0; j < PER; j++) {
     int k = threadIdx.x + j * kBlock;
-    c[j] = (k < n) ? A.colidx[e0 + k] : -1;
+    c[j] = (k < n) ? stream_load(&A.colidx[e0 + k]) : -1;
   }
   if (!dense) {
 #pragma unroll
@@ -342,18 +346,18 @@ k_spmv_wave(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nli
     if (accumulate && bit_get(ybits, row)) { acc = y[row]; has = true; }
     // software pipeline: column ids two chunks ahead, gathers one chunk ahead
     int64_t base = e0;
-    int c_cur = (base + lane < e1) ? A.colidx[base + lane] : -1;
+    int c_cur = (base + lane < e1) ? stream_load(&A.colidx[base + lane]) : -1;
     if (c_cur >= 0 && !dense && !bit_get(xbits, c_cur)) c_cur = -1;
     T m_cur;
     if (c_cur >= 0 && !(dbg & DBG_SKIP_GATHER)) m_cur = x[c_cur];
-    int c_nxt = (base + 64 + lane < e1) ? A.colidx[base + 64 + lane] : -1;
+    int c_nxt = (base + 64 + lane < e1) ? stream_load(&A.colidx[base + 64 + lane]) : -1;
     while (base < e1) {
       // issue the next chunk's gathers and the column ids after that
       if (c_nxt >= 0 && !dense && !bit_get(xbits, c_nxt)) c_nxt = -1;
       T m_nxt;
       if (c_nxt >= 0 && !(dbg & DBG_SKIP_GATHER)) m_nxt = x[c_nxt];
       const int64_t b2 = base + 128;
-      int c_nn = (b2 + lane < e1) ? A.colidx[b2 + lane] : -1;
+      int c_nn = (b2 + lane < e1) ? stream_load(&A.colidx[b2 + lane]) : -1;
       // products of the current chunk
       const bool pres = c_cur >= 0;
       U term;
@@ -443,22 +447,73 @@ __device__ __forceinline__ bool ulp_term(uint32_t abits, int eS, ulp_map& out) {
 }
 
 // ------------------------------------------------------------------------------------
+// giant rows, pass 1 (REDUCE_F32_ADD): the gathers and products of a giant row are spread
+// over many workgroups (one per GM_GIANT_CHUNK edges) because a single CU can only issue
+// about one gather per 2.7 cycles; the products go to a scratch stream in edge order
+// (plus presence words when x is sparse) that the ordered fold of pass 2 merely streams.
+template <class P, class T, class U, class V, class E, bool USE_VP>
+__global__ void __launch_bounds__(kBlock)
+k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
+              const V* __restrict__ vp, U* __restrict__ terms, unsigned long long* __restrict__ tpres, int dbg) {
+  constexpr int PER = GM_GIANT_CHUNK / kBlock;
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int gi = A.gchunk_row[blockIdx.x];
+  const int row = A.giant_row[gi];
+  const int64_t eb = A.gchunk_edge[blockIdx.x];
+  const int64_t e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
+  const int n = (int)((e1 - eb) < GM_GIANT_CHUNK ? (e1 - eb) : GM_GIANT_CHUNK);
+  const int64_t out0 = A.gterm_off[gi] + (eb - e0);  // multiple of 64
+  V vprow;
+  if constexpr (USE_VP) vprow = vp[row];
+  int c[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    int k = threadIdx.x + j * kBlock;
+    c[j] = (k < n) ? stream_load(&A.colidx[eb + k]) : -1;
+  }
+  if (xbits != nullptr) {
+#pragma unroll
+    for (int j = 0; j < PER; j++)
+      if (c[j] >= 0 && !bit_get(xbits, c[j])) c[j] = -1;
+  }
+  T m[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++)
+    if (c[j] >= 0) { if (dbg & DBG_SKIP_GATHER) memset(&m[j], 0, sizeof(T)); else m[j] = x[c[j]]; }
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    int k = threadIdx.x + j * kBlock;
+    if (c[j] >= 0) {
+      U t;
+      p.P::process_message(m[j], edge_at<E>(A.vals, eb + k), vprow, t);
+      terms[out0 + k] = t;
+    }
+    if (tpres != nullptr) {
+      unsigned long long w = __ballot(c[j] >= 0);
+      if ((threadIdx.x & 63) == 0 && (k & ~63) < n) tpres[(out0 + (k & ~63)) >> 6] = w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // multiply+reduce for one giant row per workgroup (REDUCE_COMMUTATIVE, REDUCE_LAST and
 // REDUCE_F32_ADD; giant rows of plain REDUCE_ORDERED programs go to k_spmv_wave).
+constexpr int kGiant = 512;                     // threads per workgroup of k_spmv_giant
 constexpr int kLongPer = 16;                    // consecutive edges per lane and chunk
-constexpr int kLongChunk = kLongPer * kBlock;   // 4096 edges per chunk
+constexpr int kLongChunk = kLongPer * kGiant;   // 8192 edges per chunk
 
 template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kGiant)
 k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
-               const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg) {
+               const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg,
+               const U* __restrict__ terms, const unsigned long long* __restrict__ tpres) {
   constexpr bool SMALL_U = sizeof(U) <= 8;
   constexpr int CH = kLongChunk, PER = kLongPer;
   // ordered kinds stage the per-edge products (U) of a chunk in LDS for the serial fold
-  __shared__ __attribute__((aligned(16))) unsigned char s_term_raw[(SMALL_U && RK != REDUCE_LAST) ? CH * sizeof(U) : 16];
+  __shared__ __attribute__((aligned(16))) unsigned char s_term_raw[RK == REDUCE_F32_ADD ? CH * 4 : (RK == REDUCE_COMMUTATIVE && SMALL_U) ? kGiant * sizeof(U) : 16];
   __shared__ uint32_t s_pres[CH / 32];
-  __shared__ int s_has[kBlock];
-  __shared__ ulp_map s_wave[kBlock / 64];
+  __shared__ int s_has[kGiant];
+  __shared__ ulp_map s_wave[kGiant / 64];
   __shared__ int s_flag, s_next, s_fail;
   __shared__ uint32_t s_Sbits;
 
@@ -475,7 +530,7 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
     U* s_res = reinterpret_cast<U*>(s_term_raw);
     bool has = false;
     U acc;
-    for (int64_t k = e0 + tid; k < e1; k += kBlock) {
+    for (int64_t k = e0 + tid; k < e1; k += kGiant) {
       int c = A.colidx[k];
       if (xbits != nullptr && !bit_get(xbits, c)) continue;
       T m = x[c];
@@ -488,7 +543,7 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
     s_has[tid] = has;
     if (has) s_res[tid] = acc;
     __syncthreads();
-    for (int s = kBlock / 2; s > 0; s >>= 1) {
+    for (int s = kGiant / 2; s > 0; s >>= 1) {
       if (tid < s && s_has[tid + s]) {
         if (s_has[tid]) { U a = s_res[tid]; p.P::reduce_function(a, s_res[tid + s]); s_res[tid] = a; }
         else { s_res[tid] = s_res[tid + s]; s_has[tid] = 1; }
@@ -507,7 +562,7 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
     for (int64_t hi = e1; hi > e0; hi -= CH) {
       int64_t lo = hi - CH < e0 ? e0 : hi - CH;
       int best = -1;
-      for (int64_t k = lo + tid; k < hi; k += kBlock) {
+      for (int64_t k = lo + tid; k < hi; k += kGiant) {
         int c = A.colidx[k];
         if (xbits == nullptr || bit_get(xbits, c)) best = (int)(k - lo);
       }
@@ -539,43 +594,51 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
       s_Sbits = sb;
       s_has[0] = h;
     }
+    // pass 2: stream this row's products (written by k_giant_terms) one chunk ahead of the fold.
+    // Global loads are coalesced (lane t takes elements j*kGiant+t); the chunk is laid out
+    // linearly in LDS, from which every lane then reads its PER consecutive products.
+    const int k0 = tid * PER;
+    const int64_t t0 = A.gterm_off[blockIdx.x];  // multiple of 64
+    const int64_t deg = e1 - e0;
+    auto load_chunk = [&](int64_t rel, float (&tt)[PER]) {
+#pragma unroll
+      for (int j = 0; j < PER; j++) {
+        const int64_t k = rel + j * kGiant + tid;
+        tt[j] = 0.f;
+        if (k < deg) { U u = terms[t0 + k]; memcpy(&tt[j], &u, 4); }
+      }
+    };
+    float term[PER], pre[PER];
+    load_chunk(0, pre);
     for (int64_t base = e0; base < e1; base += CH) {
       const int n = (int)((e1 - base) < CH ? (e1 - base) : CH);
       const int ngroups = (n + PER - 1) / PER;
+      const int64_t rel = base - e0;
       __syncthreads();  // previous chunk fully consumed
-      int c[PER];
-      const int k0 = tid * PER;
 #pragma unroll
-      for (int j = 0; j < PER; j++) c[j] = (k0 + j < n) ? A.colidx[base + k0 + j] : -1;
-      if (xbits != nullptr) {
-#pragma unroll
-        for (int j = 0; j < PER; j++)
-          if (c[j] >= 0 && !bit_get(xbits, c[j])) c[j] = -1;
-      }
+      for (int j = 0; j < PER; j++) s_term[j * kGiant + tid] = pre[j];  // linear: slot(k) = k
+      load_chunk(rel + CH, pre);
       uint32_t presmask = 0;
-#pragma unroll
-      for (int j = 0; j < PER; j++) presmask |= (c[j] >= 0 ? 1u : 0u) << j;
-      T m[PER];
-#pragma unroll
-      for (int j = 0; j < PER; j++)
-        if (c[j] >= 0) { if (dbg & DBG_SKIP_GATHER) memset(&m[j], 0, sizeof(T)); else m[j] = x[c[j]]; }
-      float term[PER];
-#pragma unroll
-      for (int j = 0; j < PER; j++) {
-        term[j] = 0.f;
-        if (c[j] >= 0) {
-          U t;
-          p.P::process_message(m[j], edge_at<E>(A.vals, base + k0 + j), vprow, t);
-          memcpy(&term[j], &t, 4);
+      if (k0 < n) {
+        const int cnt = (n - k0) < PER ? (n - k0) : PER;
+        presmask = cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u);
+        if (tpres != nullptr) {
+          const int64_t bit = t0 + rel + k0;  // multiple of 16
+          presmask &= (uint32_t)((tpres[bit >> 6] >> (bit & 63)) & 0xffffu);
         }
-        s_term[j * kBlock + tid] = term[j];  // slot(k) = (k % PER) * kBlock + k / PER: conflict-free
       }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < PER; j++) term[j] = s_term[k0 + j];
       if ((tid & 1) == 0) s_pres[tid >> 1] = 0;
       if (tid == 0) { s_next = 0; s_flag = 1; }  // s_flag: groups to fold serially after a stop
       __syncthreads();
       if (presmask) atomicOr(&s_pres[tid >> 1], presmask << ((tid & 1) * 16));
       __syncthreads();
-      if (dbg & DBG_SKIP_FOLD) { if (dbg & DBG_FIRST_CHUNK_ONLY) break; continue; }
+      if (dbg & DBG_SKIP_FOLD) {
+        if (dbg & DBG_FIRST_CHUNK_ONLY) break;
+        continue;
+      }
 
       while (true) {
         const int g0 = s_next;
@@ -643,7 +706,7 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
               U a;
               if (k < kend && ((s_pres[k >> 5] >> (k & 31)) & 1u)) {
                 pr = true;
-                memcpy(&a, &s_term[(k % PER) * kBlock + k / PER], 4);
+                memcpy(&a, &s_term[k], 4);
               }
               unsigned long long mask = __ballot(pr);
               if (!h && mask) {

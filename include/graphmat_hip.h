@@ -130,7 +130,16 @@ typedef struct {
   int32_t nmid;
   const int32_t* giant_row;/* [ngiant] rows with more than GM_GIANT_ROW edges: one workgroup each */
   int32_t ngiant;
+  /* giant rows are multiplied in two passes: a parallel pass over GM_GIANT_CHUNK-edge pieces
+   * that writes the per-edge products to a scratch stream, then the ordered fold per row */
+  const int32_t* gchunk_row;  /* [ngchunk] index into giant_row of the piece's row           */
+  const int64_t* gchunk_edge; /* [ngchunk] first edge (absolute CSR position) of the piece    */
+  const int64_t* gterm_off;   /* [ngiant+1] offset of each giant row's products in the scratch */
+  int32_t ngchunk;
+  int64_t giant_edges;        /* = gterm_off[ngiant]                                          */
 } gm_csr_t;
+
+#define GM_GIANT_CHUNK 4096 /* edges per piece of the parallel giant-row pass */
 
 #define GM_BLOCK_NNZ 1024   /* a row-block holds < 2*GM_BLOCK_NNZ edges and <= 256 rows     */
 #define GM_SHORT_ROW 64     /* rows up to this many edges are folded one lane per row        */
