@@ -251,6 +251,10 @@ int gm_run_sgd(gm_graph_t* g, void* d_latent, int K, int real_bytes, double lamb
     gm::SgdP<float, 20> p((float)lambda, (float)step);
     return gm::run_fixed(p, g, (gm::Latent<float, 20>*)d_latent, (uint32_t*)nullptr, iterations, iters_done, s);
   }
+  if (K == 128 && real_bytes == 4) {
+    gm::SgdP<float, 128> p((float)lambda, (float)step);
+    return gm::run_fixed(p, g, (gm::Latent<float, 128>*)d_latent, (uint32_t*)nullptr, iterations, iters_done, s);
+  }
   gm::set_error("gm_run_sgd: (K=%d, real_bytes=%d) is not in the fixed menu", K, real_bytes);
   return GM_ERR_UNSUPPORTED;
 }
@@ -264,6 +268,10 @@ int gm_run_rmse(gm_graph_t* g, void* d_latent, int K, int real_bytes, gm_stream_
   if (K == 20 && real_bytes == 4) {
     gm::RmseP<float, 20> p;
     return gm::run_fixed(p, g, (gm::Latent<float, 20>*)d_latent, (uint32_t*)nullptr, 1, nullptr, s);
+  }
+  if (K == 128 && real_bytes == 4) {
+    gm::RmseP<float, 128> p;
+    return gm::run_fixed(p, g, (gm::Latent<float, 128>*)d_latent, (uint32_t*)nullptr, 1, nullptr, s);
   }
   gm::set_error("gm_run_rmse: (K=%d, real_bytes=%d) is not in the fixed menu", K, real_bytes);
   return GM_ERR_UNSUPPORTED;

@@ -243,3 +243,41 @@ def test_edge_cases(env):
     g0 = api.Graph(64, np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
     pr, deg, it = g0.pagerank(-1)
     assert it == 1 and (pr == np.float32(0.3)).all() and (deg == 0).all()
+
+
+def test_fullscale_property_checker_agrees_with_oracle_regime():
+    """The independent torch property checks used at RMAT-26 (tools/fullscale_checks.py) pass at a
+    scale where the oracle parity is also tested (they must agree on what 'correct' means)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fullscale_checks.py"), "--scale", "16",
+                          "--ref-threads", "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert out.returncode == 0 and "ALL PASS" in out.stdout.decode(), out.stdout.decode()[-2000:]
+
+
+@pytest.mark.parametrize("K,dtype", [(20, np.float32), (128, np.float32), (20, np.float64)])
+def test_sgd_synthetic_ratings(env, K, dtype):
+    """SGD / RMSE (3-operand multiply: process_message sees the destination's latent vector) on a
+    synthetic bipartite ratings graph, incl. the K=128 fp32 shape of BASELINE config 5.
+    Tolerance 1e-6 relative (north_star); the folds are in reference order, observed exact."""
+    api, ob = env
+    rng = np.random.default_rng(7)
+    nu, ni, nr = 300, 60, 4000
+    s = rng.integers(1, nu + 1, nr).astype(np.int32)
+    d = (nu + rng.integers(1, ni + 1, nr)).astype(np.int32)
+    v = rng.integers(1, 6, nr).astype(np.int32)
+    nv = nu + ni
+    lv = rng.random((nv, K)).astype(dtype)
+    g = api.Graph(nv, s, d, v, ref_threads=1)
+    og = ob.OracleGraph(nv, s, d, v, 1)
+    e0, sq0 = g.rmse_sum(lv)
+    oe0, osq0 = og.rmse_sum(lv)
+    np.testing.assert_allclose(sq0, osq0, rtol=1e-6, atol=0)
+    assert abs(e0 - oe0) <= 1e-6 * abs(oe0)
+    step = 1e-4 if dtype == np.float32 else 3.5e-7
+    lv2, it = g.sgd(lv, 0.001, step, 3)
+    olv2, oit = og.sgd(lv, 0.001, step, 3)
+    assert it == oit == 3
+    np.testing.assert_allclose(lv2, olv2, rtol=1e-6, atol=0)
+    assert not np.array_equal(lv2, lv)
