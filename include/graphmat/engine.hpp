@@ -53,6 +53,15 @@ struct PhaseTimer {
     ev.push_back(e);
     tags.push_back(tag);
   }
+  // explicit interval on another stream (the giant-row passes run on an auxiliary stream)
+  std::vector<hipEvent_t> aux_ev;  // begin, end, begin, end ...
+  void aux_mark(hipStream_t as) {
+    if (!on) return;
+    hipEvent_t e;
+    GM_HIP_OK(hipEventCreate(&e));
+    GM_HIP_OK(hipEventRecord(e, as));
+    aux_ev.push_back(e);
+  }
   void finish(gm_run_stats_t* st) {
     if (!on || ev.empty()) return;
     GM_HIP_OK(hipEventSynchronize(ev.back()));
@@ -66,6 +75,15 @@ struct PhaseTimer {
       else if (tags[i] == TAG_GIANT) { st->giant_ms += ms; st->giant_launches++; }
       else if (tags[i] == TAG_APPLY) st->apply_ms += ms;
     }
+    for (size_t i = 0; i + 1 < aux_ev.size(); i += 2) {
+      GM_HIP_OK(hipEventSynchronize(aux_ev[i + 1]));
+      float ms = 0;
+      GM_HIP_OK(hipEventElapsedTime(&ms, aux_ev[i], aux_ev[i + 1]));
+      st->giant_ms += ms;
+      st->giant_launches++;
+    }
+    for (hipEvent_t e : aux_ev) (void)hipEventDestroy(e);
+    aux_ev.clear();
     st->spmv_ms = st->rowblock_ms + st->wave_ms + st->giant_ms;
     float t = 0;
     GM_HIP_OK(hipEventElapsedTime(&t, ev.front(), ev.back()));
@@ -76,28 +94,39 @@ struct PhaseTimer {
   }
 };
 
+// auxiliary stream for the giant-row passes: their long serial chains overlap the
+// throughput-bound row-block and wave kernels instead of running after them
+struct AuxStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  void create() {
+    GM_HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    GM_HIP_OK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    GM_HIP_OK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+  }
+  void destroy() {
+    if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); (void)hipEventDestroy(fork); (void)hipEventDestroy(join); }
+    s = nullptr;
+  }
+};
+
 // one multiply+reduce pass over one direction of the adjacency
 template <class P, class T, class U, class V, class E, bool USE_VP>
 void launch_spmv(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits,
                  const V* vp, U* y, uint32_t* ybits, int accumulate, hipStream_t s, int* launches,
-                 PhaseTimer* timer = nullptr) {
+                 PhaseTimer* timer = nullptr, AuxStream* aux = nullptr) {
   constexpr int RK = (int)program_traits<P>::reduce;
-  if (A.nnz == 0) return;
-  if (A.nblk > 0) {
-    hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A, x,
-                       xbits, vp, y, ybits, accumulate, debug_flags());
-    (*launches)++;
-    if (timer) timer->mark(TAG_ROWBLOCK);
-  }
   constexpr int WPB = dev::kBlock / 64;  // rows (waves) per workgroup of k_spmv_wave
-  if (A.nmid > 0) {
-    hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, RK>), dim3((A.nmid + WPB - 1) / WPB),
-                       dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
-                       debug_flags());
-    (*launches)++;
-    if (timer) timer->mark(TAG_WAVE);
-  }
+  if (A.nnz == 0) return;
+  const bool overlap = aux != nullptr && aux->s != nullptr && A.ngiant > 0 && (A.nblk > 0 || A.nmid > 0);
   if (A.ngiant > 0) {
+    hipStream_t gs = s;
+    if (overlap) {
+      GM_HIP_OK(hipEventRecord(aux->fork, s));
+      GM_HIP_OK(hipStreamWaitEvent(aux->s, aux->fork, 0));
+      gs = aux->s;
+      if (timer) timer->aux_mark(gs);
+    }
     // giant rows: a workgroup each when the reduction kind has a block-wide strategy,
     // otherwise the ordered wave fold (always correct)
     if constexpr ((RK == REDUCE_F32_ADD && sizeof(U) == 4) ||
@@ -113,21 +142,40 @@ void launch_spmv(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, co
           gm_graph_workspace(g, 7, (size_t)A.giant_edges / 8 + 64, &p7);
           tpres = (unsigned long long*)p7;
         }
-        hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, s, pa,
+        hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa,
                            A, x, xbits, vp, terms, tpres, debug_flags());
         (*launches)++;
       }
-      hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kGiant), 0, s, pa,
+      hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa,
                          A, x, xbits, vp, y, ybits, accumulate, debug_flags(), (const U*)terms,
                          (const unsigned long long*)tpres);
     } else {
       hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, REDUCE_ORDERED>),
-                         dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, s, pa, A, A.giant_row, A.ngiant, x,
+                         dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, A.giant_row, A.ngiant, x,
                          xbits, vp, y, ybits, accumulate, debug_flags());
     }
     (*launches)++;
-    if (timer) timer->mark(TAG_GIANT);
+    if (overlap) {
+      if (timer) timer->aux_mark(gs);
+      GM_HIP_OK(hipEventRecord(aux->join, gs));
+    } else if (timer) {
+      timer->mark(TAG_GIANT);
+    }
   }
+  if (A.nblk > 0) {
+    hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A, x,
+                       xbits, vp, y, ybits, accumulate, debug_flags());
+    (*launches)++;
+    if (timer) timer->mark(TAG_ROWBLOCK);
+  }
+  if (A.nmid > 0) {
+    hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, RK>), dim3((A.nmid + WPB - 1) / WPB),
+                       dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
+                       debug_flags());
+    (*launches)++;
+    if (timer) timer->mark(TAG_WAVE);
+  }
+  if (overlap) GM_HIP_OK(hipStreamWaitEvent(s, aux->join, 0));
 }
 
 // The iteration loop.  d_vp / d_active cover the shard's rows in native order.
@@ -165,6 +213,8 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   gm_run_stats_t st;
   memset(&st, 0, sizeof(st));
   PhaseTimer timer(gm_graph_timing_enabled(g) != 0, s);
+  AuxStream aux;
+  if (!(debug_flags() & dev::DBG_NO_OVERLAP)) aux.create();
 
   int it = 0;
   while (true) {
@@ -187,13 +237,13 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     // multiply + reduce (:160-176)
     const uint32_t* xb = dense_x ? nullptr : xbits;
     if (order == OUT_EDGES || order == ALL_EDGES) {
-      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches, &timer);
-      else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches, &timer);
+      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches, &timer, &aux);
+      else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches, &timer, &aux);
     }
     if (order == IN_EDGES || order == ALL_EDGES) {
       int acc = (order == ALL_EDGES) ? 1 : 0;
-      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer);
-      else launch_spmv<P, T, U, V, E, false>(g, pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer);
+      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux);
+      else launch_spmv<P, T, U, V, E, false>(g, pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux);
     }
     // setAllInactive (:184) + apply (:195-225): the active vector is rewritten by k_apply
     hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, (const U*)y,
@@ -222,6 +272,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     }
   }
   GM_HIP_OK(hipStreamSynchronize(s));
+  aux.destroy();
   st.iterations = it;
   timer.finish(&st);
   gm_graph_record_stats(g, &st);

@@ -154,7 +154,7 @@ __device__ __forceinline__ E edge_at(const void* __restrict__ vals, int64_t k) {
 
 // ------------------------------------------------------------------------------------
 // debug/ablation switches (gm_set_option("debug_flags", ...)); 0 in production
-enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8 };
+enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16 };
 
 // ------------------------------------------------------------------------------------
 // multiply+reduce over row-blocks (rows of at most GM_SHORT_ROW edges).
@@ -170,8 +170,13 @@ k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32
   constexpr bool STAGE = stageable<T>::value;
   constexpr int PER = kStage / kBlock;  // 8 slots per lane
   typedef typename raw_of<STAGE ? (int)sizeof(T) : 1>::type raw_t;
-  __shared__ int s_col[kStage];
-  __shared__ raw_t s_msg[STAGE ? kStage : 1];
+  // slot(k) = k + k/32: consecutive rows of EQUAL length d (the degree-ranked device order
+  // produces long runs of them) start d*(1+1/32) slots apart, so the lane-per-row reads of
+  // phase 2 do not pile onto one LDS bank when d is a multiple of 32, 16, 8 ...
+  constexpr int kPad = kStage + kStage / 32;
+  __shared__ int s_col[kPad];
+  __shared__ raw_t s_msg[STAGE ? kPad : 1];
+#define GM_SLOT(k) ((k) + ((k) >> 5))
 
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int sg = A.blk_seg[blockIdx.x];
@@ -205,13 +210,13 @@ k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32
 #pragma unroll
     for (int j = 0; j < PER; j++) {
       int k = threadIdx.x + j * kBlock;
-      if (k < n) { s_msg[k] = m[j]; if (!dense) s_col[k] = c[j]; }
+      if (k < n) { s_msg[GM_SLOT(k)] = m[j]; if (!dense) s_col[GM_SLOT(k)] = c[j]; }
     }
   } else {
 #pragma unroll
     for (int j = 0; j < PER; j++) {
       int k = threadIdx.x + j * kBlock;
-      if (k < n) s_col[k] = c[j];
+      if (k < n) s_col[GM_SLOT(k)] = c[j];
     }
   }
   __syncthreads();
@@ -228,11 +233,11 @@ k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32
     for (int k = kb; k < ke; k++) {
       T m;
       if constexpr (STAGE) {
-        if (!dense && s_col[k] < 0) continue;
-        raw_t r = s_msg[k];
+        if (!dense && s_col[GM_SLOT(k)] < 0) continue;
+        raw_t r = s_msg[GM_SLOT(k)];
         memcpy(&m, &r, sizeof(T));
       } else {
-        int cc = s_col[k];
+        int cc = s_col[GM_SLOT(k)];
         if (cc < 0) continue;
         m = x[cc];
       }
@@ -243,6 +248,7 @@ k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32
       atomicOr(&ybits[row >> 5], 1u << (row & 31));
     }
   }
+#undef GM_SLOT
 }
 
 // ------------------------------------------------------------------------------------
