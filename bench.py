@@ -226,9 +226,10 @@ def main():
     if rank == 0:
         r = roof or {}
         log(rank, "summary scale=%d gpus=%d dbg=%d ms/step=%.3f GTEPS=%.1f rowblock=%.3fms wave=%.3fms giant=%.3fms send=%.3f "
-                  "apply=%.3f replayed=%d serial=%d" % (args.scale, world, args.debug_flags, ms_per_step, gteps,
+                  "apply=%.3f replayed=%d serial=%d edges(rb/wave/giant)=%d/%d/%d rows(blk/wave/giant)=%d/%d/%d" % (args.scale, world, args.debug_flags, ms_per_step, gteps,
                                                         r.get("avg_launch_ms", 0), r.get("wave_avg_ms", 0), r.get("giant_avg_ms", 0),
-                                                        r.get("send_avg_ms", 0), r.get("apply_avg_ms", 0), int(cnt64[0]), int(cnt64[1])))
+                                                        r.get("send_avg_ms", 0), r.get("apply_avg_ms", 0), int(cnt64[0]), int(cnt64[1]),
+                                                        e_short, e_mid, e_giant, c_out.nblk, c_out.nmid, c_out.ngiant))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -23,7 +23,7 @@ class GraphDesc(C.Structure):
 
 class Csr(C.Structure):
     _fields_ = [("nnz", C.c_int64), ("nrows", C.c_int32), ("row_base", C.c_int32), ("ncols", C.c_int32),
-                ("val_bytes", C.c_int32), ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("vals", C.c_void_p),
+                ("val_bytes", C.c_int32), ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("vals", C.c_void_p), ("rowbits", C.c_void_p),
                 ("seg_row", C.c_void_p), ("nseg", C.c_int32), ("blk_seg", C.c_void_p), ("nblk", C.c_int32),
                 ("mid_row", C.c_void_p), ("nmid", C.c_int32), ("giant_row", C.c_void_p), ("ngiant", C.c_int32),
                 ("gchunk_row", C.c_void_p), ("gchunk_edge", C.c_void_p), ("gterm_off", C.c_void_p),
@@ -55,6 +55,7 @@ SIGNATURES = {
     "gm_graph_destroy": (C.c_int, [_P]),
     "gm_graph_desc": (C.c_int, [_P, C.POINTER(GraphDesc)]),
     "gm_graph_csr": (C.c_int, [_P, C.c_int, C.POINTER(Csr)]),
+    "gm_graph_rowbits_all": (C.c_int, [_P, C.POINTER(_P)]),
     "gm_graph_csr_to_host": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "gm_graph_maps": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "gm_graph_maps_to_host": (C.c_int, [_P, _P, _P]),

@@ -141,6 +141,23 @@ k_row_flags(const int64_t* __restrict__ rowptr, int nrows, int short_row, int gi
   isgiant[r] = ((b - a) > giant_row) ? 1 : 0;
 }
 
+// presence bits of the non-empty rows (bit r&31 of word r>>5)
+__global__ void __launch_bounds__(kT)
+k_rowbits(const int64_t* __restrict__ rowptr, int nrows, uint32_t* __restrict__ bits) {
+  int r = blockIdx.x * kT + threadIdx.x;
+  bool ne = r < nrows && rowptr[r + 1] > rowptr[r];
+  unsigned long long m = __ballot(ne);
+  if ((threadIdx.x & 63) == 0 && r < nrows) {
+    bits[r >> 5] = (uint32_t)m;
+    if (r + 32 < nrows) bits[(r >> 5) + 1] = (uint32_t)(m >> 32);
+  }
+}
+__global__ void __launch_bounds__(kT)
+k_or_words(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t* __restrict__ o, int n) {
+  int i = blockIdx.x * kT + threadIdx.x;
+  if (i < n) o[i] = a[i] | b[i];
+}
+
 __global__ void __launch_bounds__(kT)
 k_giant_extent(const int32_t* __restrict__ giant_row, int ngiant, const int64_t* __restrict__ rowptr,
                int64_t* __restrict__ ext) {
@@ -228,6 +245,12 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
                      nrows, rowptr.as<int64_t>());
   GM_TRY_HIP(hipGetLastError());
 
+  DevBuf rbits;
+  if ((rc = rbits.alloc(((size_t)(nrows + 31) / 32 + 2) * 4))) return rc;
+  GM_TRY_HIP(hipMemsetAsync(rbits.p, 0, ((size_t)(nrows + 31) / 32 + 2) * 4, s));
+  if (nrows > 0)
+    hipLaunchKernelGGL(k_rowbits, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr.as<int64_t>(), nrows, rbits.as<uint32_t>());
+
   // work decomposition: segments, row-blocks, wave rows, giant rows
   DevBuf f0, f1, f2, seg, blkl, mid, giant;
   if ((rc = f0.alloc((size_t)nrows + 1))) return rc;
@@ -305,6 +328,7 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   out->rowptr = (int64_t*)rowptr.release();
   out->colidx = (int32_t*)colidx.release();
   out->vals = keep_vals ? vals.release() : nullptr;
+  out->rowbits = (uint32_t*)rbits.release();
   out->seg_row = (int32_t*)seg.release();
   out->blk_seg = (int32_t*)blkl.release();
   out->mid_row = (int32_t*)mid.release();
@@ -322,6 +346,7 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   v.rowptr = out->rowptr;
   v.colidx = out->colidx;
   v.vals = out->vals;
+  v.rowbits = out->rowbits;
   v.seg_row = out->seg_row;
   v.nseg = (int32_t)nseg;
   v.blk_seg = out->blk_seg;
@@ -380,6 +405,7 @@ static void free_csr(CsrOwned* c) {
   if (c->rowptr) (void)hipFree(c->rowptr);
   if (c->colidx) (void)hipFree(c->colidx);
   if (c->vals) (void)hipFree(c->vals);
+  if (c->rowbits) (void)hipFree(c->rowbits);
   if (c->seg_row) (void)hipFree(c->seg_row);
   if (c->blk_seg) (void)hipFree(c->blk_seg);
   if (c->mid_row) (void)hipFree(c->mid_row);
@@ -452,6 +478,12 @@ int gm_graph_create(gm_graph_t** gout, const gm_graph_desc_t* desc, int64_t nnz,
   if (desc->directions & GM_DIR_OUT) rc = gm::build_direction(g, 1, nnz, d_src, d_dst, d_val, s, &g->out);
   if (rc == GM_OK && (desc->directions & GM_DIR_IN)) rc = gm::build_direction(g, 0, nnz, d_src, d_dst, d_val, s, &g->in);
   if (rc != GM_OK) { gm_graph_destroy(g); return rc; }
+  if (g->out.present && g->in.present) {
+    const int nw = (g->desc.row_hi - g->desc.row_lo + 31) / 32 + 2;
+    if (hipMalloc((void**)&g->rowbits_all, (size_t)nw * 4) != hipSuccess) { gm::set_error("rowbits alloc failed"); gm_graph_destroy(g); return GM_ERR_NOMEM; }
+    hipLaunchKernelGGL(gm::k_or_words, dim3(gm::grid_for(nw)), dim3(gm::kT), 0, s, (const uint32_t*)g->out.rowbits,
+                       (const uint32_t*)g->in.rowbits, g->rowbits_all, nw);
+  }
   if (hipStreamSynchronize(s) != hipSuccess) { gm::set_error("graph build: stream sync failed"); gm_graph_destroy(g); return GM_ERR_HIP; }
   *gout = g;
   return GM_OK;
@@ -463,6 +495,7 @@ int gm_graph_destroy(gm_graph_t* g) {
   gm::free_csr(&g->in);
   if (g->dev_of_native) (void)hipFree(g->dev_of_native);
   if (g->native_of_dev) (void)hipFree(g->native_of_dev);
+  if (g->rowbits_all) (void)hipFree(g->rowbits_all);
   for (int i = 0; i < GM_WS_SLOTS; i++)
     if (g->ws[i] && !g->ws_external[i]) (void)hipFree(g->ws[i]);
   delete g;
@@ -480,6 +513,13 @@ int gm_graph_csr(const gm_graph_t* g, int direction, gm_csr_t* out) {
   const gm::CsrOwned* c = direction == GM_DIR_OUT ? &g->out : direction == GM_DIR_IN ? &g->in : nullptr;
   if (!c || !c->present) { gm::set_error("gm_graph_csr: direction %d not built", direction); return GM_ERR_INVALID; }
   *out = c->view;
+  return GM_OK;
+}
+
+int gm_graph_rowbits_all(const gm_graph_t* g, const uint32_t** d_bits) {
+  if (!g || !d_bits) { gm::set_error("gm_graph_rowbits_all: null argument"); return GM_ERR_INVALID; }
+  if (!g->rowbits_all) { gm::set_error("gm_graph_rowbits_all: graph was not built with both directions"); return GM_ERR_INVALID; }
+  *d_bits = g->rowbits_all;
   return GM_OK;
 }
 

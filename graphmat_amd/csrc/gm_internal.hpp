@@ -42,6 +42,7 @@ struct CsrOwned {
   int64_t* rowptr = nullptr;
   int32_t* colidx = nullptr;
   void* vals = nullptr;
+  uint32_t* rowbits = nullptr;
   int32_t* seg_row = nullptr;
   int32_t* blk_seg = nullptr;
   int32_t* mid_row = nullptr;
@@ -59,6 +60,7 @@ struct gm_graph {
   gm::CsrOwned out, in;
   int32_t* dev_of_native;  // nullptr = identity
   int32_t* native_of_dev;
+  uint32_t* rowbits_all;
   void* ws[GM_WS_SLOTS];
   size_t ws_bytes[GM_WS_SLOTS];
   int ws_external[GM_WS_SLOTS];

@@ -163,8 +163,12 @@ void launch_spmv(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, co
     }
   }
   if (A.nblk > 0) {
-    hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A, x,
-                       xbits, vp, y, ybits, accumulate, debug_flags());
+    if (xbits == nullptr)
+      hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP, true>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A,
+                         x, xbits, vp, y, ybits, accumulate, debug_flags());
+    else
+      hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP, false>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A,
+                         x, xbits, vp, y, ybits, accumulate, debug_flags());
     (*launches)++;
     if (timer) timer->mark(TAG_ROWBLOCK);
   }
@@ -219,8 +223,10 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   int it = 0;
   while (true) {
     dev::ProgArg<P> pa = dev::make_prog_arg(gp);  // re-captured every iteration (do_every_iteration may change it)
-    // Clear(&x) / Clear(&y) (:139-140): x presence words are fully rewritten by send
-    GM_HIP_OK(hipMemsetAsync(ybits, 0, (size_t)nwords * 4, s));
+    // Clear(&x) / Clear(&y) (:139-140): x presence words are fully rewritten by send.  With
+    // every x entry present (ALL_VERTICES) y's presence is the static set of non-empty rows.
+    const bool static_bits = (act == ALL_VERTICES);
+    if (!static_bits) GM_HIP_OK(hipMemsetAsync(ybits, 0, (size_t)nwords * 4, s));
     GM_HIP_OK(hipMemsetAsync(d_changed, 0, sizeof(int), s));
     timer.mark(TAG_START);
     // send (:145)
@@ -236,18 +242,28 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     timer.mark(TAG_SEND);
     // multiply + reduce (:160-176)
     const uint32_t* xb = dense_x ? nullptr : xbits;
+    const uint32_t* apply_bits = ybits;
     if (order == OUT_EDGES || order == ALL_EDGES) {
-      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches, &timer, &aux);
-      else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, x, xb, d_vp, y, ybits, 0, s, &st.spmv_launches, &timer, &aux);
+      const int acc = static_bits ? dev::ACC_STATIC_BITS : 0;
+      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux);
+      else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux);
+      if (static_bits) apply_bits = Aout.rowbits;
     }
     if (order == IN_EDGES || order == ALL_EDGES) {
-      int acc = (order == ALL_EDGES) ? 1 : 0;
-      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux);
-      else launch_spmv<P, T, U, V, E, false>(g, pa, Ain, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux);
+      int acc = (order == ALL_EDGES) ? dev::ACC_READ_PREV : 0;
+      uint32_t* yb = ybits;
+      if (static_bits) {
+        acc |= dev::ACC_STATIC_BITS;
+        yb = const_cast<uint32_t*>(Aout.rowbits);  // only read (presence of the OUT pass's results)
+        apply_bits = Ain.rowbits;
+        if (order == ALL_EDGES && gm_graph_rowbits_all(g, &apply_bits) != GM_OK) { printf("%s\n", gm_last_error()); exit(1); }
+      }
+      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux);
+      else launch_spmv<P, T, U, V, E, false>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux);
     }
     // setAllInactive (:184) + apply (:195-225): the active vector is rewritten by k_apply
     hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, (const U*)y,
-                       (const uint32_t*)ybits, d_vp, d_active, n, d_changed);
+                       apply_bits, d_vp, d_active, n, d_changed);
     timer.mark(TAG_APPLY);
     int converged = 0;
     if (iterations <= 0) {  // the flag only matters when running until convergence (:257-259)

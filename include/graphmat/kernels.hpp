@@ -154,6 +154,10 @@ __device__ __forceinline__ E edge_at(const void* __restrict__ vals, int64_t k) {
 
 // ------------------------------------------------------------------------------------
 // debug/ablation switches (gm_set_option("debug_flags", ...)); 0 in production
+// `accumulate` argument of the multiply kernels: ACC_READ_PREV = y may already hold results of an
+// earlier pass (their presence is read from ybits); ACC_STATIC_BITS = do not write presence
+// bits (every x entry is present, so y's presence equals the graph's static row bits)
+enum { ACC_READ_PREV = 1, ACC_STATIC_BITS = 2 };
 enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16 };
 
 // ------------------------------------------------------------------------------------
@@ -163,7 +167,7 @@ enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_
 //   accumulate : y may already hold partial results (second pass of ALL_EDGES)
 // Phase 1 keeps many independent loads in flight per lane: all column ids of the lane's
 // slots first, then all gathers, then the LDS stores.
-template <class P, class T, class U, class V, class E, bool USE_VP>
+template <class P, class T, class U, class V, class E, bool USE_VP, bool DENSE>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
                 const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg) {
@@ -187,7 +191,7 @@ k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32
   const int64_t e0 = A.rowptr[r0], e1 = A.rowptr[r1];
   const int n = (int)(e1 - e0);
   if (n == 0 || n > kStage) return;  // cannot happen for a row-block (see gm_csr_t)
-  const bool dense = (xbits == nullptr);
+  constexpr bool dense = DENSE;  // every x entry present (xbits == nullptr)
 
   int c[PER];
 #pragma unroll
@@ -223,29 +227,78 @@ k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32
   if (dbg & DBG_SKIP_FOLD) return;
 
   // phase 2: one lane per row folds its segment in ascending column order
+  bool wrote = false;
   if (row < r1 && rp1 > rp0) {
     const int kb = (int)(rp0 - e0), ke = (int)(rp1 - e0);
-    bool has = accumulate && bit_get(ybits, row);
+    bool has = (accumulate & ACC_READ_PREV) && bit_get(ybits, row);
     U acc;
     if (has) acc = y[row];
     V vprow;
     if constexpr (USE_VP) vprow = vp[row];
-    for (int k = kb; k < ke; k++) {
-      T m;
-      if constexpr (STAGE) {
-        if (!dense && s_col[GM_SLOT(k)] < 0) continue;
+    if constexpr (STAGE && DENSE) {
+      // all messages present and staged: LDS reads four at a time, then the ordered folds
+      int k = kb;
+      if (!has) {
+        T m;
         raw_t r = s_msg[GM_SLOT(k)];
         memcpy(&m, &r, sizeof(T));
-      } else {
-        int cc = s_col[GM_SLOT(k)];
-        if (cc < 0) continue;
-        m = x[cc];
+        p.P::process_message(m, edge_at<E>(A.vals, e0 + k), vprow, acc);
+        has = true;
+        k++;
       }
-      fold_one<P, T, U, V, E>(p, m, edge_at<E>(A.vals, e0 + k), vprow, acc, has);
+      for (; k + 4 <= ke; k += 4) {
+        raw_t r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) r[u] = s_msg[GM_SLOT(k + u)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          T m;
+          memcpy(&m, &r[u], sizeof(T));
+          U res;
+          p.P::process_message(m, edge_at<E>(A.vals, e0 + k + u), vprow, res);
+          p.P::reduce_function(acc, res);
+        }
+      }
+      for (; k < ke; k++) {
+        T m;
+        raw_t r = s_msg[GM_SLOT(k)];
+        memcpy(&m, &r, sizeof(T));
+        U res;
+        p.P::process_message(m, edge_at<E>(A.vals, e0 + k), vprow, res);
+        p.P::reduce_function(acc, res);
+      }
+    } else {
+      for (int k = kb; k < ke; k++) {
+        T m;
+        if constexpr (STAGE) {
+          if (s_col[GM_SLOT(k)] < 0) continue;
+          raw_t r = s_msg[GM_SLOT(k)];
+          memcpy(&m, &r, sizeof(T));
+        } else {
+          int cc = s_col[GM_SLOT(k)];
+          if (cc < 0) continue;
+          m = x[cc];
+        }
+        fold_one<P, T, U, V, E>(p, m, edge_at<E>(A.vals, e0 + k), vprow, acc, has);
+      }
     }
     if (has) {
       y[row] = acc;
-      atomicOr(&ybits[row >> 5], 1u << (row & 31));
+      wrote = true;
+    }
+  }
+  // presence bits: the 64 rows of a wave are consecutive, so one atomicOr per 32-row word
+  // (not per row: same-word atomics from 32 lanes serialise in the L2)
+  {
+    const unsigned long long hm = __ballot(wrote);
+    const int lane = threadIdx.x & 63;
+    if (hm != 0ull && !(accumulate & ACC_STATIC_BITS) && (lane == 0 || (row & 31) == 0)) {
+      const int in_word = 32 - (row & 31);
+      const int left = 64 - lane;
+      const int cnt = in_word < left ? in_word : left;
+      const unsigned long long mask = (cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull);
+      const uint32_t bits = (uint32_t)(((hm >> lane) & mask) << (row & 31));
+      if (bits) atomicOr(&ybits[row >> 5], bits);  // (skipped below when the bits are static)
     }
   }
 #undef GM_SLOT
@@ -312,7 +365,7 @@ k_spmv_wave(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nli
           U res;
           p.P::process_message(m, edge_at<E>(A.vals, k), vprow, res);
           y[row] = res;
-          atomicOr(&ybits[row >> 5], 1u << (row & 31));
+          if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
         }
         return;
       }
@@ -335,13 +388,13 @@ k_spmv_wave(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nli
       if (oh) { if (has) p.P::reduce_function(acc, o); else { acc = o; has = true; } }
     }
     if (lane == 0) {
-      if (accumulate && bit_get(ybits, row)) {
+      if ((accumulate & ACC_READ_PREV) && bit_get(ybits, row)) {
         U prev = y[row];
         if (has) { U t = acc; acc = prev; p.P::reduce_function(acc, t); } else { acc = prev; has = true; }
       }
       if (has) {
         y[row] = acc;
-        atomicOr(&ybits[row >> 5], 1u << (row & 31));
+        if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
       }
     }
     return;
@@ -349,7 +402,7 @@ k_spmv_wave(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nli
     // ordered: every lane carries the same running value
     bool has = false;
     U acc;
-    if (accumulate && bit_get(ybits, row)) { acc = y[row]; has = true; }
+    if ((accumulate & ACC_READ_PREV) && bit_get(ybits, row)) { acc = y[row]; has = true; }
     // software pipeline: column ids two chunks ahead, gathers one chunk ahead
     int64_t base = e0;
     int c_cur = (base + lane < e1) ? stream_load(&A.colidx[base + lane]) : -1;
@@ -395,7 +448,7 @@ k_spmv_wave(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nli
     }
     if (lane == 0 && has) {
       y[row] = acc;
-      atomicOr(&ybits[row >> 5], 1u << (row & 31));
+      if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
     }
   }
 }
@@ -542,7 +595,7 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
       T m = x[c];
       fold_one<P, T, U, V, E>(p, m, edge_at<E>(A.vals, k), vprow, acc, has);
     }
-    if (tid == 0 && accumulate && bit_get(ybits, row)) {
+    if (tid == 0 && (accumulate & ACC_READ_PREV) && bit_get(ybits, row)) {
       U prev = y[row];
       if (has) { U t = acc; acc = prev; p.P::reduce_function(acc, t); } else { acc = prev; has = true; }
     }
@@ -558,7 +611,7 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
     }
     if (tid == 0 && s_has[0]) {
       y[row] = s_res[0];
-      atomicOr(&ybits[row >> 5], 1u << (row & 31));
+      if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
     }
     return;
   } else if constexpr (RK == REDUCE_LAST) {
@@ -582,7 +635,7 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
           U res;
           p.P::process_message(m, edge_at<E>(A.vals, k), vprow, res);
           y[row] = res;
-          atomicOr(&ybits[row >> 5], 1u << (row & 31));
+          if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
         }
         return;
       }
@@ -595,7 +648,7 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
     const int lane = tid & 63;
     if (tid == 0) {
       uint32_t sb = 0;
-      bool h = accumulate && bit_get(ybits, row);
+      bool h = (accumulate & ACC_READ_PREV) && bit_get(ybits, row);
       if (h) { U prev = y[row]; memcpy(&sb, &prev, 4); }
       s_Sbits = sb;
       s_has[0] = h;
@@ -750,7 +803,7 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
       U r;
       memcpy(&r, &sb, 4);
       y[row] = r;
-      atomicOr(&ybits[row >> 5], 1u << (row & 31));
+      if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
     }
   }
 }

@@ -119,6 +119,8 @@ typedef struct {
                              inside a row, duplicates in input order: the reference's
                              reduction order                                               */
   const void* vals;       /* [nnz] edge values or NULL                                    */
+  const uint32_t* rowbits;/* presence bits of the non-empty rows: what y's presence vector is
+                             after a multiply with every x entry present                    */
   /* work decomposition of the multiply+reduce kernels (include/graphmat/kernels.hpp):  */
   const int32_t* seg_row; /* [nseg+1] boundaries of runs of consecutive rows (local ids); a
                              run is either one row of more than GM_SHORT_ROW edges or up to 256
@@ -154,6 +156,8 @@ int gm_graph_create(gm_graph_t** g, const gm_graph_desc_t* desc, int64_t nnz, co
 int gm_graph_destroy(gm_graph_t* g);
 int gm_graph_desc(const gm_graph_t* g, gm_graph_desc_t* out);
 int gm_graph_csr(const gm_graph_t* g, int direction, gm_csr_t* out);
+/* rowbits of GM_DIR_OUT | rowbits of GM_DIR_IN (graphs built with both directions; ALL_EDGES programs) */
+int gm_graph_rowbits_all(const gm_graph_t* g, const uint32_t** d_bits);
 /* d_dev_of_native[native id] = device id (nvertices entries), d_native_of_dev[device id] =
  * native id or -1 for an unused slot (ndevice entries).  Both NULL for GM_LAYOUT_NATIVE
  * (identity).  Device pointers owned by the graph. */
