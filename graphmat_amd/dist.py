@@ -56,6 +56,7 @@ class MessageExchange:
         self.group = group
         self.flag = torch.zeros(1, dtype=torch.int32, device=x_bytes.device)
         self.calls = 0
+        self.no_fast_path = False
 
     def _equal_slices(self):
         n = len(self.ranges)
@@ -63,17 +64,21 @@ class MessageExchange:
         return S > 0 and all(lo == r * S and hi == (r + 1) * S for r, (lo, hi) in enumerate(self.ranges)) and n > 1
 
     def all_gather_slices(self, elt_bytes):
-        if self._equal_slices() and dist.get_backend(self.group) == "nccl":
+        if self._equal_slices() and dist.get_backend(self.group) == "nccl" and not self.no_fast_path:
             # equal slices (GM_LAYOUT_DEGREE): one in-place all-gather per array
-            n = len(self.ranges)
-            S = self.ranges[0][1]
-            lo = self.rank * S
-            dist.all_gather_into_tensor(self.x_bytes[: n * S * elt_bytes], self.x_bytes[lo * elt_bytes: (lo + S) * elt_bytes],
-                                        group=self.group)
-            W = S // 32
-            dist.all_gather_into_tensor(self.x_bits[: n * W], self.x_bits[self.rank * W: (self.rank + 1) * W],
-                                        group=self.group)
-            return
+            try:
+                n = len(self.ranges)
+                S = self.ranges[0][1]
+                lo = self.rank * S
+                dist.all_gather_into_tensor(self.x_bytes[: n * S * elt_bytes],
+                                            self.x_bytes[lo * elt_bytes: (lo + S) * elt_bytes], group=self.group)
+                W = S // 32
+                dist.all_gather_into_tensor(self.x_bits[: n * W], self.x_bits[self.rank * W: (self.rank + 1) * W],
+                                            group=self.group)
+                return
+            except Exception as e:  # fall back to per-slice broadcasts (same result)
+                print("graphmat_amd.dist: all_gather_into_tensor path failed (%r); using broadcasts" % (e,), flush=True)
+                self.no_fast_path = True
         hs = []
         for r, (lo, hi) in enumerate(self.ranges):
             if hi <= lo:

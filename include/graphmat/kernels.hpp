@@ -403,48 +403,57 @@ k_spmv_wave(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nli
     bool has = false;
     U acc;
     if ((accumulate & ACC_READ_PREV) && bit_get(ybits, row)) { acc = y[row]; has = true; }
-    // software pipeline: column ids two chunks ahead, gathers one chunk ahead
-    int64_t base = e0;
-    int c_cur = (base + lane < e1) ? stream_load(&A.colidx[base + lane]) : -1;
-    if (c_cur >= 0 && !dense && !bit_get(xbits, c_cur)) c_cur = -1;
-    T m_cur;
-    if (c_cur >= 0 && !(dbg & DBG_SKIP_GATHER)) m_cur = x[c_cur];
-    int c_nxt = (base + 64 + lane < e1) ? stream_load(&A.colidx[base + 64 + lane]) : -1;
-    while (base < e1) {
-      // issue the next chunk's gathers and the column ids after that
-      if (c_nxt >= 0 && !dense && !bit_get(xbits, c_nxt)) c_nxt = -1;
-      T m_nxt;
-      if (c_nxt >= 0 && !(dbg & DBG_SKIP_GATHER)) m_nxt = x[c_nxt];
-      const int64_t b2 = base + 128;
-      int c_nn = (b2 + lane < e1) ? stream_load(&A.colidx[b2 + lane]) : -1;
-      // products of the current chunk
-      const bool pres = c_cur >= 0;
-      U term;
-      if (pres) p.P::process_message(m_cur, edge_at<E>(A.vals, base + lane), vprow, term);
-      unsigned long long mask = __ballot(pres);
-      if (!(dbg & DBG_SKIP_FOLD)) {
-        if (!has && mask) {  // first message of the row assigns
-          const int i = __ffsll((long long)mask) - 1;
-          acc = wave_bcast(term, i);
-          has = true;
-          mask &= mask - 1;
-        }
-        if (mask == ~0ull) {
+    // software pipeline, D chunks of 64 edges deep: slot u holds the gathered messages of chunk
+    // i+u and the column ids of chunk i+u+D, so a gather has D-1 folds to complete under
+    constexpr int D = 4;
+    auto load_col = [&](int64_t k) -> int { return (k < e1) ? stream_load(&A.colidx[k]) : -1; };
+    int c[D], cn[D];
+    T m[D];
 #pragma unroll
-          for (int i = 0; i < 64; i++) { U t = wave_bcast(term, i); p.P::reduce_function(acc, t); }
-        } else {
-          while (mask) {
-            const int i = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            U t = wave_bcast(term, i);
-            p.P::reduce_function(acc, t);
+    for (int u = 0; u < D; u++) c[u] = load_col(e0 + 64 * u + lane);
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+      if (c[u] >= 0 && !dense && !bit_get(xbits, c[u])) c[u] = -1;
+      if (c[u] >= 0 && !(dbg & DBG_SKIP_GATHER)) m[u] = x[c[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < D; u++) cn[u] = load_col(e0 + 64 * (D + u) + lane);
+    for (int64_t base = e0; base < e1; base += 64 * D) {
+#pragma unroll
+      for (int u = 0; u < D; u++) {
+        const int64_t cb = base + 64 * u;
+        if (cb < e1) {
+          // products of this chunk, then the ordered fold out of the lanes' registers
+          const bool pres = c[u] >= 0;
+          U term;
+          if (pres) p.P::process_message(m[u], edge_at<E>(A.vals, cb + lane), vprow, term);
+          unsigned long long mask = __ballot(pres);
+          if (!(dbg & DBG_SKIP_FOLD)) {
+            if (!has && mask) {  // first message of the row assigns
+              const int i = __ffsll((long long)mask) - 1;
+              acc = wave_bcast(term, i);
+              has = true;
+              mask &= mask - 1;
+            }
+            if (mask == ~0ull) {
+#pragma unroll
+              for (int i = 0; i < 64; i++) { U t = wave_bcast(term, i); p.P::reduce_function(acc, t); }
+            } else {
+              while (mask) {
+                const int i = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                U t = wave_bcast(term, i);
+                p.P::reduce_function(acc, t);
+              }
+            }
           }
         }
+        // refill slot u: gathers of chunk i+D, column ids of chunk i+2D
+        c[u] = cn[u];
+        if (c[u] >= 0 && !dense && !bit_get(xbits, c[u])) c[u] = -1;
+        if (c[u] >= 0 && !(dbg & DBG_SKIP_GATHER)) m[u] = x[c[u]];
+        cn[u] = load_col(cb + 64 * 2 * D + lane);
       }
-      c_cur = c_nxt;
-      m_cur = m_nxt;
-      c_nxt = c_nn;
-      base += 64;
     }
     if (lane == 0 && has) {
       y[row] = acc;

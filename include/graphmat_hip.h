@@ -145,7 +145,7 @@ typedef struct {
 
 #define GM_BLOCK_NNZ 1024   /* a row-block holds < 2*GM_BLOCK_NNZ edges and <= 256 rows     */
 #define GM_SHORT_ROW 64     /* rows up to this many edges are folded one lane per row        */
-#define GM_GIANT_ROW 16384  /* rows above this get a workgroup of their own                  */
+#define GM_GIANT_ROW 32768  /* rows above this get a workgroup of their own                  */
 
 /* src/dst: 1-based vertex ids as in the .mtx (or native ids, see desc).  Edges whose
  * row falls outside the shard are dropped per direction, so every rank passes the full
