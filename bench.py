@@ -146,7 +146,7 @@ def main():
         x_bits = torch.zeros((g.ndevice + 31) // 32 + 2, dtype=torch.int32, device=dev)
         _lib.check(L.gm_graph_adopt_workspace(g.h, 1, x_bytes.data_ptr(), x_bytes.numel()))
         _lib.check(L.gm_graph_adopt_workspace(g.h, 2, x_bits.data_ptr(), x_bits.numel() * 4))
-        ex = MessageExchange(ranges, rank, x_bytes, x_bits)
+        ex = MessageExchange(ranges, rank, x_bytes, x_bits, live_rows=g.xchg_rows)
         cb = ex.callback()
         g._cb = cb
         _lib.check(L.gm_graph_set_exchange(g.h, cb, None))
@@ -239,6 +239,7 @@ def main():
                                "edge factor %d, seed %d, duplicates and self loops kept" % (args.scale, args.edge_factor, args.seed),
                    "V": nv, "E": E, "parallelism": "1d-rows x%d" % world, "id_layout_nparts": nparts,
                    "device_order": "native" if args.native_layout else "degree-ranked, dealt over shards",
+                   "rows_per_shard": S, "exchanged_rows_per_shard": int(g.xchg_rows),
                    "max_in_degree_rank0": max_deg,
                    "giant_row_groups_replayed": int(cnt64[0]), "giant_row_groups_serial": int(cnt64[1])},
         "iter_hbm_gbps": round(iter_bytes / (ms_per_step * 1e-3) / 1e9, 1),

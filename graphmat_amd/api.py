@@ -68,12 +68,13 @@ class Graph:
             nnz = src.size
         self.nnz_input = int(nnz)
         d = _lib.GraphDesc(self.nv, self.nparts, int(lo), int(hi), directions, 4 if vp else 0,
-                           1 if on_dev else 0, 0, layout, nshards, shard, 0)
+                           1 if on_dev else 0, 0, layout, nshards, shard, 0, 0)
         h = C.c_void_p()
         check(self.L.gm_graph_create(C.byref(h), C.byref(d), nnz, sp, dp, vp, _stream()))
         self.h = h
         check(self.L.gm_graph_desc(self.h, C.byref(d)))
         self.row_lo, self.row_hi, self.ndevice = d.row_lo, d.row_hi, d.ndevice
+        self.xchg_rows = d.xchg_rows
         self.rows = self.row_hi - self.row_lo
         self.layout, self.nshards, self.shard = layout, nshards, shard
         self._dov = None

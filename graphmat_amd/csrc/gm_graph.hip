@@ -43,6 +43,13 @@ k_degree(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64
 }
 
 __global__ void __launch_bounds__(kT)
+k_count_nonzero(const uint32_t* __restrict__ deg, int nv, unsigned long long* __restrict__ out) {
+  int v = blockIdx.x * kT + threadIdx.x;
+  unsigned long long m = __ballot(v < nv && deg[v] != 0u);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+
+__global__ void __launch_bounds__(kT)
 k_rank_keys(const uint32_t* __restrict__ deg, int nv, uint32_t* __restrict__ keys, int32_t* __restrict__ ids) {
   int v = blockIdx.x * kT + threadIdx.x;
   if (v >= nv) return;
@@ -392,7 +399,22 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
   hipLaunchKernelGGL(k_deal, dim3(grid_for(nv)), dim3(kT), 0, s, order.as<int32_t>(), nv, G, S, don.as<int32_t>(),
                      nod.as<int32_t>());
   GM_TRY_HIP(hipGetLastError());
+  // vertices with at least one edge come first in every slice: the rest is never gathered
+  DevBuf nzd;
+  if ((rc = nzd.alloc(8))) return rc;
+  GM_TRY_HIP(hipMemsetAsync(nzd.p, 0, 8, s));
+  hipLaunchKernelGGL(k_count_nonzero, dim3(grid_for(nv)), dim3(kT), 0, s, deg.as<uint32_t>(), nv,
+                     nzd.as<unsigned long long>());
+  unsigned long long nz = 0;
+  GM_TRY_HIP(hipMemcpyAsync(&nz, nzd.p, 8, hipMemcpyDeviceToHost, s));
   GM_TRY_HIP(hipStreamSynchronize(s));
+  {
+    long long per = ((long long)nz + G - 1) / G;
+    per = (per + 63) / 64 * 64;
+    const long long slice = (G > 1) ? S : nv;
+    D.xchg_rows = (int32_t)(per < slice ? per : slice);
+    if (D.xchg_rows < 64 && slice >= 64) D.xchg_rows = 64;
+  }
   g->dev_of_native = (int32_t*)don.release();
   g->native_of_dev = (int32_t*)nod.release();
   D.ndevice = vd;
@@ -473,6 +495,7 @@ int gm_graph_create(gm_graph_t** gout, const gm_graph_desc_t* desc, int64_t nnz,
     }
   }
   g->desc.ndevice = desc->nvertices;
+  g->desc.xchg_rows = desc->row_hi - desc->row_lo;
   if (desc->layout == GM_LAYOUT_DEGREE) rc = gm::build_degree_layout(g, nnz, d_src, d_dst, s);
   if (rc != GM_OK) { gm_graph_destroy(g); return rc; }
   if (desc->directions & GM_DIR_OUT) rc = gm::build_direction(g, 1, nnz, d_src, d_dst, d_val, s, &g->out);

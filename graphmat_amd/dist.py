@@ -48,8 +48,11 @@ class MessageExchange:
     the graph (gm_graph_adopt_workspace), so the pointers the callback receives are these.
     """
 
-    def __init__(self, ranges, rank, x_bytes, x_bits, group=None):
+    def __init__(self, ranges, rank, x_bytes, x_bits, group=None, live_rows=None):
+        """live_rows: only the first live_rows entries of every slice need to travel (the
+        library's gm_graph_desc_t.xchg_rows); None = whole slices."""
         self.ranges = [(int(a), int(b)) for a, b in ranges]
+        self.live = None if live_rows is None else int(live_rows)
         self.rank = rank
         self.x_bytes = x_bytes
         self.x_bits = x_bits
@@ -57,6 +60,8 @@ class MessageExchange:
         self.flag = torch.zeros(1, dtype=torch.int32, device=x_bytes.device)
         self.calls = 0
         self.no_fast_path = False
+        self._stage = None
+        self._stage_bits = None
 
     def _equal_slices(self):
         n = len(self.ranges)
@@ -69,18 +74,37 @@ class MessageExchange:
             try:
                 n = len(self.ranges)
                 S = self.ranges[0][1]
-                lo = self.rank * S
-                dist.all_gather_into_tensor(self.x_bytes[: n * S * elt_bytes],
-                                            self.x_bytes[lo * elt_bytes: (lo + S) * elt_bytes], group=self.group)
-                W = S // 32
-                dist.all_gather_into_tensor(self.x_bits[: n * W], self.x_bits[self.rank * W: (self.rank + 1) * W],
-                                            group=self.group)
+                L = S if self.live is None else min(self.live, S)
+                if L == S:
+                    lo = self.rank * S
+                    dist.all_gather_into_tensor(self.x_bytes[: n * S * elt_bytes],
+                                                self.x_bytes[lo * elt_bytes: (lo + S) * elt_bytes], group=self.group)
+                    W = S // 32
+                    dist.all_gather_into_tensor(self.x_bits[: n * W], self.x_bits[self.rank * W: (self.rank + 1) * W],
+                                                group=self.group)
+                else:
+                    # only the live prefix of every slice travels: gather into a compact staging
+                    # buffer, then scatter the prefixes back to their slice positions
+                    if self._stage is None or self._stage.numel() < n * L * elt_bytes:
+                        self._stage = torch.empty(n * L * 8, dtype=torch.uint8, device=self.x_bytes.device)
+                        self._stage_bits = torch.empty(n * (L // 32), dtype=torch.int32, device=self.x_bytes.device)
+                    lo = self.rank * S
+                    st = self._stage[: n * L * elt_bytes]
+                    dist.all_gather_into_tensor(st, self.x_bytes[lo * elt_bytes: (lo + L) * elt_bytes], group=self.group)
+                    xv = self.x_bytes[: n * S * elt_bytes].view(n, S * elt_bytes)
+                    xv[:, : L * elt_bytes].copy_(st.view(n, L * elt_bytes))
+                    W, WL = S // 32, L // 32
+                    sb = self._stage_bits[: n * WL]
+                    dist.all_gather_into_tensor(sb, self.x_bits[self.rank * W: self.rank * W + WL], group=self.group)
+                    self.x_bits[: n * W].view(n, W)[:, :WL].copy_(sb.view(n, WL))
                 return
             except Exception as e:  # fall back to per-slice broadcasts (same result)
                 print("graphmat_amd.dist: all_gather_into_tensor path failed (%r); using broadcasts" % (e,), flush=True)
                 self.no_fast_path = True
         hs = []
         for r, (lo, hi) in enumerate(self.ranges):
+            if self.live is not None:
+                hi = min(hi, lo + self.live)
             if hi <= lo:
                 continue
             hs.append(dist.broadcast(self.x_bytes[lo * elt_bytes: hi * elt_bytes], src=r, group=self.group,
@@ -126,7 +150,7 @@ def attach_exchange(g, group=None, max_elt_bytes=8):
     L = _lib.lib()
     _lib.check(L.gm_graph_adopt_workspace(g.h, 1, x_bytes.data_ptr(), x_bytes.numel()))
     _lib.check(L.gm_graph_adopt_workspace(g.h, 2, x_bits.data_ptr(), x_bits.numel() * 4))
-    ex = MessageExchange(ranges, rank, x_bytes, x_bits, group)
+    ex = MessageExchange(ranges, rank, x_bytes, x_bits, group, live_rows=g.xchg_rows)
     cb = ex.callback()
     g._cb = (cb, ex)  # keep alive
     _lib.check(L.gm_graph_set_exchange(g.h, cb, None))

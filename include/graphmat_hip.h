@@ -105,6 +105,10 @@ typedef struct {
   int32_t nshards;       /* GM_LAYOUT_DEGREE: number of shards (GPUs), >= 1                */
   int32_t shard;         /* GM_LAYOUT_DEGREE: which shard this graph object holds          */
   int32_t ndevice;       /* output: size of the device id space (>= nvertices)             */
+  int32_t xchg_rows;     /* output: only the first xchg_rows entries of every shard's slice of
+                            x (and their presence words) are ever read by other shards: with
+                            GM_LAYOUT_DEGREE the vertices without any edge sit at the tail of
+                            each slice.  Multiple of 64; = slice size for GM_LAYOUT_NATIVE.   */
 } gm_graph_desc_t;
 
 /* One direction of the adjacency as laid out in HBM (see DESIGN.md "data layout"). */
