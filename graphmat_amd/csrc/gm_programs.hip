@@ -150,6 +150,11 @@ template <> struct program_traits<gm::PageRankP<0> > { static constexpr reduce_k
 template <> struct program_traits<gm::PageRankP<1> > { static constexpr reduce_kind reduce = REDUCE_ORDERED; };
 template <> struct program_traits<gm::BfsP> { static constexpr reduce_kind reduce = REDUCE_LAST; };
 template <> struct program_traits<gm::SsspP> { static constexpr reduce_kind reduce = REDUCE_COMMUTATIVE; };
+// BFS apply() ignores messages once a vertex has a depth: such rows skip the multiply
+template <> struct program_row_filter<gm::BfsP> {
+  static constexpr bool enabled = true;
+  HD static bool wants(const gm::BfsP&, const gm::BFSv& v) { return v.depth == UINT_MAX; }
+};
 }  // namespace GraphMat
 
 namespace gm {

@@ -164,10 +164,10 @@ void launch_spmv(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, co
   }
   if (A.nblk > 0) {
     if (xbits == nullptr)
-      hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP, true>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A,
+      hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP, true, RK>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A,
                          x, xbits, vp, y, ybits, accumulate, debug_flags());
     else
-      hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP, false>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A,
+      hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP, false, RK>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A,
                          x, xbits, vp, y, ybits, accumulate, debug_flags());
     (*launches)++;
     if (timer) timer->mark(TAG_ROWBLOCK);

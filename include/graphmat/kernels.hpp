@@ -45,6 +45,17 @@ struct program_traits {
   static constexpr reduce_kind reduce = REDUCE_ORDERED;
 };
 
+// Optional row filter: a program may declare that apply(y, vp) is a no-op whenever
+// wants(prog, vp) is false (BFS: a vertex that already has a depth ignores further messages).
+// Such rows then skip the multiply altogether -- the "bottom-up" optimisation -- without
+// changing any result.  Specialise with enabled = true and a __host__ __device__ wants().
+template <class P>
+struct program_row_filter {
+  static constexpr bool enabled = false;
+  template <class V>
+  __host__ __device__ static bool wants(const P&, const V&) { return true; }
+};
+
 namespace dev {
 
 // [0] chunks accepted by the exact fp32 replay, [1] chunks folded serially (long rows)
@@ -167,7 +178,7 @@ enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_
 //   accumulate : y may already hold partial results (second pass of ALL_EDGES)
 // Phase 1 keeps many independent loads in flight per lane: all column ids of the lane's
 // slots first, then all gathers, then the LDS stores.
-template <class P, class T, class U, class V, class E, bool USE_VP, bool DENSE>
+template <class P, class T, class U, class V, class E, bool USE_VP, bool DENSE, int RK>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
                 const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg) {
@@ -192,6 +203,11 @@ k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32
   const int n = (int)(e1 - e0);
   if (n == 0 || n > kStage) return;  // cannot happen for a row-block (see gm_csr_t)
   constexpr bool dense = DENSE;  // every x entry present (xbits == nullptr)
+  bool wanted = true;
+  if constexpr (program_row_filter<P>::enabled) {
+    wanted = row < r1 && rp1 > rp0 && program_row_filter<P>::wants(p, vp[row]);
+    if (!__syncthreads_or(wanted)) return;  // no row of this block would use a message
+  }
 
   int c[PER];
 #pragma unroll
@@ -228,14 +244,31 @@ k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32
 
   // phase 2: one lane per row folds its segment in ascending column order
   bool wrote = false;
-  if (row < r1 && rp1 > rp0) {
+  if (row < r1 && rp1 > rp0 && wanted) {
     const int kb = (int)(rp0 - e0), ke = (int)(rp1 - e0);
     bool has = (accumulate & ACC_READ_PREV) && bit_get(ybits, row);
     U acc;
     if (has) acc = y[row];
     V vprow;
     if constexpr (USE_VP) vprow = vp[row];
-    if constexpr (STAGE && DENSE) {
+    if constexpr (RK == REDUCE_LAST) {
+      // reduce is a=b: the last present message of the segment wins; walk it backwards
+      for (int k = ke - 1; k >= kb; k--) {
+        T m;
+        if constexpr (STAGE) {
+          if (!dense && s_col[GM_SLOT(k)] < 0) continue;
+          raw_t r = s_msg[GM_SLOT(k)];
+          memcpy(&m, &r, sizeof(T));
+        } else {
+          int cc = s_col[GM_SLOT(k)];
+          if (cc < 0) continue;
+          m = x[cc];
+        }
+        p.P::process_message(m, edge_at<E>(A.vals, e0 + k), vprow, acc);
+        has = true;
+        break;
+      }
+    } else if constexpr (STAGE && DENSE) {
       // all messages present and staged: LDS reads four at a time, then the ordered folds
       int k = kb;
       if (!has) {
@@ -346,6 +379,8 @@ k_spmv_wave(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nli
   if (w >= nlist) return;
   const int lane = threadIdx.x & 63;
   const int row = rows[w];
+  if constexpr (program_row_filter<P>::enabled)
+    if (!program_row_filter<P>::wants(p, vp[row])) return;
   const int64_t e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
   const bool dense = (xbits == nullptr);
   V vprow;
@@ -587,6 +622,8 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
 
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int row = A.giant_row[blockIdx.x];
+  if constexpr (program_row_filter<P>::enabled)
+    if (!program_row_filter<P>::wants(p, vp[row])) return;
   const int64_t e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
   const int tid = threadIdx.x;
   V vprow;

@@ -69,3 +69,31 @@ def test_package_has_no_oracle_dependency():
                 if f.endswith((".py", ".hip", ".hpp", ".h")):
                     txt = open(os.path.join(dirpath, f), errors="ignore").read()
                     assert "gm_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_error_convention_invalid_arguments(lib):
+    """C-ABI error convention: status code + gm_last_error text, nothing thrown, no GPU touched
+    for argument errors (these run on the CPU-only box)."""
+    import ctypes as C
+    from graphmat_amd import _lib
+    h = C.c_void_p()
+    # nvertices <= 0
+    d = _lib.GraphDesc(0, 16, 0, 0, 3, 0, 0, 0, 0, 1, 0, 0, 0)
+    assert lib.gm_graph_create(C.byref(h), C.byref(d), 0, None, None, None, None) == 1
+    assert b"invalid descriptor" in lib.gm_last_error()
+    # unaligned shard boundary in the native layout
+    d = _lib.GraphDesc(1000, 16, 10, 1000, 3, 0, 0, 0, 0, 1, 0, 0, 0)
+    assert lib.gm_graph_create(C.byref(h), C.byref(d), 0, None, None, None, None) == 1
+    assert b"multiples of 64" in lib.gm_last_error()
+    # unknown layout / bad shard
+    d = _lib.GraphDesc(1000, 16, 0, 1000, 3, 0, 0, 0, 7, 1, 0, 0, 0)
+    assert lib.gm_graph_create(C.byref(h), C.byref(d), 0, None, None, None, None) == 1
+    d = _lib.GraphDesc(1000, 16, 0, 1000, 3, 0, 0, 0, 1, 4, 4, 0, 0)
+    assert lib.gm_graph_create(C.byref(h), C.byref(d), 0, None, None, None, None) == 1
+    assert b"invalid shard" in lib.gm_last_error()
+    # null handles
+    assert lib.gm_graph_desc(None, C.byref(d)) == 1
+    assert lib.gm_run_pagerank(None, None, 0.3, 1, None, None) == 1
+    assert lib.gm_run_sgd(None, None, 20, 8, 0.0, 0.0, 1, None, None) != 0
+    assert lib.gm_set_option(b"no_such_option", 1) == 1
+    assert lib.gm_graph_destroy(None) == 0
