@@ -114,3 +114,11 @@ def test_own_generic_program_label_propagation(golden_dir, tmp_path):
     for c in range(ncomp):
         members = np.where(ref_lab == c)[0]
         assert (lab[members] == members.min() + 1).all()
+
+
+@pytest.mark.gpu
+def test_cpp_surface_selftest():
+    """apps/api_selftest.cpp: Graph<V,E> get/set, getEdgelist, applyToAll*, activity, a (mul,add)
+    SpMV and chain BFS through include/*.h -- the reference's unit tests re-expressed."""
+    text = _run(_need(os.path.join(OWN_APPS, "api_selftest")))
+    assert "SELFTEST PASS" in text, text
