@@ -57,6 +57,7 @@ SIGNATURES = {
     "gm_graph_csr": (C.c_int, [_P, C.c_int, C.POINTER(Csr)]),
     "gm_graph_rowbits_all": (C.c_int, [_P, C.POINTER(_P)]),
     "gm_graph_csr_to_host": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "gm_graph_relayout_like": (C.c_int, [_P, _P, _P]),
     "gm_graph_maps": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "gm_graph_maps_to_host": (C.c_int, [_P, _P, _P]),
     "gm_graph_set_vals": (C.c_int, [_P, C.c_int, _P]),

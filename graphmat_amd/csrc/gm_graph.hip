@@ -423,6 +423,23 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
   return GM_OK;
 }
 
+// edges of a CSR direction back as native (src, dst) pairs, in CSR order
+__global__ void __launch_bounds__(kT)
+k_csr_to_coo(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, int nrows, int row_base,
+             const int32_t* __restrict__ native_of_dev, int rows_are_dst, int32_t* __restrict__ src,
+             int32_t* __restrict__ dst) {
+  const int row = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int lane = threadIdx.x & 63;
+  const int rn = native_of_dev ? native_of_dev[row_base + row] : row_base + row;
+  for (int64_t e = rowptr[row] + lane; e < rowptr[row + 1]; e += 64) {
+    int c = colidx[e];
+    int cn = native_of_dev ? native_of_dev[c] : c;
+    src[e] = rows_are_dst ? cn : rn;
+    dst[e] = rows_are_dst ? rn : cn;
+  }
+}
+
 static void free_csr(CsrOwned* c) {
   if (c->rowptr) (void)hipFree(c->rowptr);
   if (c->colidx) (void)hipFree(c->colidx);
@@ -536,6 +553,67 @@ int gm_graph_csr(const gm_graph_t* g, int direction, gm_csr_t* out) {
   const gm::CsrOwned* c = direction == GM_DIR_OUT ? &g->out : direction == GM_DIR_IN ? &g->in : nullptr;
   if (!c || !c->present) { gm::set_error("gm_graph_csr: direction %d not built", direction); return GM_ERR_INVALID; }
   *out = c->view;
+  return GM_OK;
+}
+
+int gm_graph_relayout_like(gm_graph_t* g, const gm_graph_t* like, gm_stream_t stream) {
+  if (!g || !like) { gm::set_error("gm_graph_relayout_like: null graph"); return GM_ERR_INVALID; }
+  if (g == like) return GM_OK;
+  const gm_graph_desc_t &a = g->desc, &b = like->desc;
+  if (a.nvertices != b.nvertices || a.nparts != b.nparts || a.row_lo != 0 || a.row_hi != a.ndevice || b.row_lo != 0 ||
+      b.row_hi != b.ndevice || a.ndevice != b.ndevice) {
+    gm::set_error("gm_graph_relayout_like: graphs must have the same vertices and be unsharded");
+    return GM_ERR_INVALID;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  gm::CsrOwned* from = g->in.present ? &g->in : &g->out;
+  const int64_t nnz = from->view.nnz;
+  gm::DevBuf src, dst;
+  int rc;
+  if ((rc = src.alloc((size_t)nnz * 4)) || (rc = dst.alloc((size_t)nnz * 4))) return rc;
+  if (from->view.nrows > 0)
+    hipLaunchKernelGGL(gm::k_csr_to_coo, dim3((from->view.nrows + 3) / 4), dim3(gm::kT), 0, s, from->view.rowptr,
+                       from->view.colidx, from->view.nrows, from->view.row_base, (const int32_t*)g->native_of_dev,
+                       from == &g->out ? 1 : 0, src.as<int32_t>(), dst.as<int32_t>());
+  GM_TRY_HIP(hipGetLastError());
+  // the edge values travel in the same (CSR) order; keep them alive while rebuilding
+  void* vals = from->vals;
+  from->vals = nullptr;
+  const int val_bytes = from->view.val_bytes;
+  gm::CsrOwned old_out = g->out, old_in = g->in;
+  g->out = gm::CsrOwned();
+  g->in = gm::CsrOwned();
+  // adopt the other graph's device order
+  if (g->dev_of_native) (void)hipFree(g->dev_of_native);
+  if (g->native_of_dev) (void)hipFree(g->native_of_dev);
+  g->dev_of_native = nullptr;
+  g->native_of_dev = nullptr;
+  if (like->dev_of_native) {
+    GM_TRY_HIP(hipMalloc((void**)&g->dev_of_native, (size_t)b.nvertices * 4));
+    GM_TRY_HIP(hipMalloc((void**)&g->native_of_dev, (size_t)b.ndevice * 4));
+    GM_TRY_HIP(hipMemcpyAsync(g->dev_of_native, like->dev_of_native, (size_t)b.nvertices * 4, hipMemcpyDeviceToDevice, s));
+    GM_TRY_HIP(hipMemcpyAsync(g->native_of_dev, like->native_of_dev, (size_t)b.ndevice * 4, hipMemcpyDeviceToDevice, s));
+  }
+  g->desc.layout = b.layout;
+  g->desc.xchg_rows = b.xchg_rows;
+  const int saved_native = g->desc.ids_are_native, saved_vb = g->desc.val_bytes;
+  g->desc.ids_are_native = 1;
+  g->desc.val_bytes = val_bytes;
+  rc = GM_OK;
+  if (g->desc.directions & GM_DIR_OUT) rc = gm::build_direction(g, 1, nnz, src.as<int32_t>(), dst.as<int32_t>(), vals, s, &g->out);
+  if (rc == GM_OK && (g->desc.directions & GM_DIR_IN)) rc = gm::build_direction(g, 0, nnz, src.as<int32_t>(), dst.as<int32_t>(), vals, s, &g->in);
+  g->desc.ids_are_native = saved_native;
+  g->desc.val_bytes = saved_vb;
+  if (vals) (void)hipFree(vals);
+  gm::free_csr(&old_out);
+  gm::free_csr(&old_in);
+  if (rc != GM_OK) return rc;
+  if (g->rowbits_all && g->out.present && g->in.present) {
+    const int nw = (g->desc.row_hi - g->desc.row_lo + 31) / 32 + 2;
+    hipLaunchKernelGGL(gm::k_or_words, dim3(gm::grid_for(nw)), dim3(gm::kT), 0, s, (const uint32_t*)g->out.rowbits,
+                       (const uint32_t*)g->in.rowbits, g->rowbits_all, nw);
+  }
+  GM_TRY_HIP(hipStreamSynchronize(s));
   return GM_OK;
 }
 

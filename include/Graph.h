@@ -346,6 +346,14 @@ void Graph<V, E>::reset() {
 
 template <class V, class E>
 void Graph<V, E>::shareVertexProperty(Graph<V, E>& g) {
+  // the shared vector is indexed in g's device order: bring this graph's adjacency into it
+  if (A != nullptr && g.A != nullptr && A != g.A) {
+    if (gm_graph_relayout_like(A, g.A, nullptr) != GM_OK) {
+      printf("GraphMat(HIP): shareVertexProperty: %s\n", gm_last_error());
+      exit(1);
+    }
+    dev_of_native = g.dev_of_native;
+  }
   if (vertexproperty != nullptr && vertexpropertyowner) delete vertexproperty;
   vertexproperty = g.vertexproperty;
   vertexpropertyowner = false;

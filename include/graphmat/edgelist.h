@@ -101,5 +101,17 @@ void load_edgelist(const char* dir, edgelist_t<T>* edgelist, bool binaryformat =
   printf("Got: %d edges\n", edgelist->nnz);
 }
 
+// keep the edges for which the predicate holds (public name of the reference's
+// include/GMDP/utils/edgelist_transformation.h:431-443; used by src/DeltaStepping.cpp)
+template <typename T>
+edgelist_t<T> filter_edges(edgelist_t<T>* edgelist, bool (*filter_function)(edge_t<T>, void*), void* param = NULL) {
+  edgelist_t<T> kept(edgelist->m, edgelist->n, edgelist->nnz);
+  int k = 0;
+  for (int i = 0; i < edgelist->nnz; i++)
+    if (filter_function(edgelist->edges[i], param)) kept.edges[k++] = edgelist->edges[i];
+  kept.nnz = k;
+  return kept;
+}
+
 }  // namespace GraphMat
 #endif

@@ -162,6 +162,10 @@ int gm_graph_desc(const gm_graph_t* g, gm_graph_desc_t* out);
 int gm_graph_csr(const gm_graph_t* g, int direction, gm_csr_t* out);
 /* rowbits of GM_DIR_OUT | rowbits of GM_DIR_IN (graphs built with both directions; ALL_EDGES programs) */
 int gm_graph_rowbits_all(const gm_graph_t* g, const uint32_t** d_bits);
+/* Rebuild g's adjacency in the device order of `like` (same vertex count and nparts, single
+ * shard): afterwards device arrays of the two graphs are interchangeable, which is what
+ * Graph::shareVertexProperty (include/Graph.h:300-305 of the reference) needs. */
+int gm_graph_relayout_like(gm_graph_t* g, const gm_graph_t* like, gm_stream_t stream);
 /* d_dev_of_native[native id] = device id (nvertices entries), d_native_of_dev[device id] =
  * native id or -1 for an unused slot (ndevice entries).  Both NULL for GM_LAYOUT_NATIVE
  * (identity).  Device pointers owned by the graph. */

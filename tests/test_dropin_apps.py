@@ -122,3 +122,77 @@ def test_cpp_surface_selftest():
     SpMV and chain BFS through include/*.h -- the reference's unit tests re-expressed."""
     text = _run(_need(os.path.join(OWN_APPS, "api_selftest")))
     assert "SELFTEST PASS" in text, text
+
+
+# ---- three more of the reference's applications, unchanged (SURVEY.md section 8f.1) ---------------
+@pytest.mark.gpu
+def test_reference_topological_sort_app_unchanged(golden_dir):
+    """src/TopologicalSort.cpp on the DAG fixture: order = Kahn level (1 + max over in-neighbours)."""
+    from graphmat_amd.mtx import read_mtx_bin
+    path = os.path.join(golden_dir, "2_10_upper_triangle.bin.mtx")
+    text = _run(_need(os.path.join(REF_APPS, "TopologicalSort")), path)
+    nv, s, d, v = read_mtx_bin(path)
+    level = np.zeros(nv + 1, np.int64)
+    for a, b in sorted(zip(s.tolist(), d.tolist())):  # src < dst in this fixture: one pass in src order suffices
+        level[b] = max(level[b], level[a] + 1)
+    got = re.findall(r"^Top Sort order (\d+) : (\d+)$", text, flags=re.M)
+    assert len(got) == 10
+    assert [int(o) for _, o in got] == level[1:11].tolist()
+
+
+@pytest.mark.gpu
+def test_reference_delta_stepping_app_unchanged(golden_dir):
+    """src/DeltaStepping.cpp: two graphs (light/heavy edges) sharing one vertex-property vector
+    (Graph::shareVertexProperty); distances equal the SSSP oracle's."""
+    from graphmat_amd.mtx import read_mtx_bin
+    from oracle import binding as ob
+    path = os.path.join(golden_dir, "2_10_upper_triangle.bin.mtx")
+    nv, s, d, v = read_mtx_bin(path)
+    dist, _ = ob.OracleGraph(nv, s, d, v, 1).sssp(1)
+    for delta in (10, 40):
+        text = _run(_need(os.path.join(REF_APPS, "DeltaStepping")), path, delta, 1)
+        assert "Reachable vertices = %d" % int((dist != 0xFFFFFFFF).sum()) in text
+        got = re.findall(r"^(\d+) : distance = (\d+|INF)$", text, flags=re.M)
+        assert len(got) == 25
+        for vtx, dv in got:
+            exp = dist[int(vtx) - 1]
+            assert (dv == "INF" and exp == 0xFFFFFFFF) or int(dv) == exp
+
+
+@pytest.mark.gpu
+def test_reference_incremental_pagerank_app_unchanged(golden_dir):
+    """src/IncrementalPageRank.cpp (fp64 deltas, ACTIVE_ONLY): printed ranks equal a numpy
+    restatement of the same recurrence."""
+    from graphmat_amd.mtx import read_mtx_bin
+    path = os.path.join(golden_dir, "test.bin.mtx")
+    text = _run(_need(os.path.join(REF_APPS, "IncrementalPageRank")), path)
+    nv, s, d, v = read_mtx_bin(path)
+    outdeg = np.bincount(s - 1, minlength=nv)
+    delta = np.full(nv, 0.3)
+    pr = np.full(nv, 0.3)
+    active = np.ones(nv, bool)
+    alpha = 0.3
+    iters = 0
+    while True:
+        msg = np.where(outdeg > 0, delta / np.maximum(outdeg, 1), 0.0)
+        y = np.zeros(nv)
+        got = np.zeros(nv, bool)
+        for a, b in zip(s - 1, d - 1):
+            if active[a]:
+                y[b] += msg[a]
+                got[b] = True
+        old = pr.copy()
+        for i in np.where(got)[0]:
+            if abs(delta[i]) > 1e-8:
+                delta[i] = 0.0
+            delta[i] += (1.0 - alpha) * y[i]
+            if abs(delta[i]) > 1e-8:
+                pr[i] += delta[i]
+        active = np.abs(pr - old) > 1e-8
+        iters += 1
+        if not active.any():
+            break
+    rows = re.findall(r"^(\d+) : (\d+) ([0-9.]+)$", text, flags=re.M)
+    assert [int(r[1]) for r in rows] == outdeg.tolist()
+    assert [r[2] for r in rows] == ["%f" % x for x in pr]
+    assert "Completed %d iterations" % iters in text

@@ -2,7 +2,7 @@
 """Builds application binaries against include/ with `hipcc --hipstdpar` (gfx950):
 
   * apps/*.cpp            -- this project's own example programs (always)
-  * <reference>/src/{PageRank,BFS,SGD,SSSP}.cpp -- the reference's UNCHANGED application
+  * <reference>/src/{PageRank,BFS,SGD,SSSP,IncrementalPageRank,TopologicalSort,DeltaStepping}.cpp -- the reference's UNCHANGED application
     sources, compiled where they lie when the reference tree is present (build container
     only).  Outputs go to build/ref_apps/ (git-ignored; they travel to the GPU box like any
     other built artefact).  Nothing from the reference is copied into the repository.
@@ -42,7 +42,7 @@ def build(verbose=False):
     if os.path.isdir(os.path.join(REF, "src")):
         outdir = os.path.join(ROOT, "build", "ref_apps")
         os.makedirs(outdir, exist_ok=True)
-        for app in ("PageRank", "BFS", "SGD", "SSSP"):
+        for app in ("PageRank", "BFS", "SGD", "SSSP", "IncrementalPageRank", "TopologicalSort", "DeltaStepping"):
             out = os.path.join(outdir, app)
             _compile(os.path.join(REF, "src", app + ".cpp"), out, "$ORIGIN/../../graphmat_amd")
             built.append(out)
