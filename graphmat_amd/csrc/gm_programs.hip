@@ -159,6 +159,181 @@ template <> struct program_row_filter<gm::BfsP> {
 
 namespace gm {
 
+// ---------------- dedicated SGD / RMSE kernels for wide fp32 latent vectors -----------------------
+// (BASELINE config 5: K = 128).  Same arithmetic, in the same order, as SgdP / RmseP above (and
+// as the reference's src/SGD.cpp:93-115,135-152): per edge a sequential K-term dot product, the
+// scaled message, and a sequential accumulation over a row's edges -- so results are identical
+// to the generic kernels'; only the mapping to the machine differs:
+//   * x (the message vector = a copy of the latent vectors) is laid out with a row stride of K
+//     floats (512 B for K = 128), without the sqerr field, so a row is one aligned burst;
+//   * one wave per row, 64 edges at a time: phase A gives every lane one edge and lets it walk
+//     its x row sequentially against the row's own vector held in LDS (the ordered dot product);
+//     phase B gives every lane K/64 components and walks the 64 edges in order, re-reading each
+//     x row as one coalesced burst (L2 hit) and accumulating error-scaled messages.
+// HBM-bound: 4K flop against one 4K-byte row per edge; MFMA has nothing to chew on (each dot is a
+// 1 x K by K x 1 product with no operand shared between edges), see DESIGN.md.
+constexpr int kSgdBlock = 256;
+
+template <int K>
+__global__ void __launch_bounds__(kSgdBlock)
+k_sgd_send(const float* __restrict__ vp, float* __restrict__ x, int n) {  // x[v][0..K) = vp[v].lv
+  const int64_t i = (int64_t)blockIdx.x * kSgdBlock + threadIdx.x;
+  if (i >= (int64_t)n * K) return;
+  const int v = (int)(i / K), c = (int)(i % K);
+  x[i] = vp[(int64_t)v * (K + 1) + c];
+}
+
+// MODE 0: SGD messages into y (row stride K);  MODE 1: RMSE, squared errors summed into y1[row]
+template <int K, int MODE>
+__global__ void __launch_bounds__(kSgdBlock)
+k_sgd_multiply(gm_csr_t A, const float* __restrict__ x, const float* __restrict__ vp, float* __restrict__ y,
+               const uint32_t* __restrict__ prev_bits, int accumulate) {
+  constexpr int PER = K / 64;  // components per lane
+  __shared__ float s_v[kSgdBlock / 64][K];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (kSgdBlock / 64) + wv;
+  if (row >= A.nrows) return;
+  const int64_t e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
+  if (e1 == e0) return;
+  const float* vrow = vp + (int64_t)row * (K + 1);
+#pragma unroll
+  for (int j = 0; j < PER; j++) s_v[wv][lane + 64 * j] = vrow[lane + 64 * j];
+  __builtin_amdgcn_wave_barrier();
+  bool has = accumulate && ((prev_bits[row >> 5] >> (row & 31)) & 1u);
+  float acc[PER];
+  float sq = 0.f;
+  if (MODE == 0) {
+#pragma unroll
+    for (int j = 0; j < PER; j++) acc[j] = has ? y[(int64_t)row * K + lane + 64 * j] : 0.f;
+  } else if (has) {
+    sq = y[row];
+  }
+  const int* vals = (const int*)A.vals;
+  for (int64_t base = e0; base < e1; base += 64) {
+    const int n = (int)((e1 - base) < 64 ? (e1 - base) : 64);
+    // phase A: lane = edge; sequential dot product, no contraction
+    int col = 0;
+    float err = 0.f;
+    if (lane < n) {
+      col = A.colidx[base + lane];
+      const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)col * K);
+      float est = 0.f;
+#pragma unroll 4
+      for (int i = 0; i < K / 4; i++) {
+        const float4 q = xr[i];
+        const float4 w = *reinterpret_cast<const float4*>(&s_v[wv][4 * i]);
+        est += q.x * w.x;
+        est += q.y * w.y;
+        est += q.z * w.z;
+        est += q.w * w.w;
+      }
+      err = (float)vals[base + lane] - est;
+    }
+    if (MODE == 1) {
+      const float e2 = err * err;
+      for (int e = 0; e < n; e++) {
+        const float t = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(e2), e));
+        if (has) sq += t; else { sq = t; has = true; }
+      }
+    } else {
+      // phase B: lane = components; the 64 edges in order
+      for (int e = 0; e < n; e++) {
+        const int ce = __builtin_amdgcn_readlane(col, e);
+        const float ee = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(err), e));
+        const float* xr = x + (int64_t)ce * K;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+          const float r = xr[lane + 64 * j] * ee;
+          acc[j] = has ? acc[j] + r : r;
+        }
+        has = true;
+      }
+    }
+  }
+  if (MODE == 0) {
+#pragma unroll
+    for (int j = 0; j < PER; j++) y[(int64_t)row * K + lane + 64 * j] = acc[j];
+  } else if (lane == 0) {
+    y[row] = sq;
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(kSgdBlock)
+k_sgd_apply(const float* __restrict__ y, const uint32_t* __restrict__ bits, float* __restrict__ vp, int n, float lambda,
+            float step) {
+  const int64_t i = (int64_t)blockIdx.x * kSgdBlock + threadIdx.x;
+  if (i >= (int64_t)n * K) return;
+  const int v = (int)(i / K), c = (int)(i % K);
+  if (!((bits[v >> 5] >> (v & 31)) & 1u)) return;
+  float* p = vp + (int64_t)v * (K + 1) + c;
+  *p += step * (-lambda * *p + y[i]);  // src/SGD.cpp:111-115
+}
+__global__ void __launch_bounds__(kSgdBlock)
+k_rmse_apply(const float* __restrict__ y1, const uint32_t* __restrict__ bits, float* __restrict__ vp, int n, int stride) {
+  const int v = blockIdx.x * kSgdBlock + threadIdx.x;
+  if (v < n && ((bits[v >> 5] >> (v & 31)) & 1u)) vp[(int64_t)v * stride + stride - 1] = y1[v];  // sqerr field
+}
+
+// fixed iteration count, single GPU (the sharded case goes through the generic engine)
+template <int K>
+int run_sgd_wide(gm_graph_t* g, float* d_latent, float lambda, float step, int iterations, int* iters_done, hipStream_t s) {
+  const gm_graph_desc_t& d = g->desc;
+  const int n = d.row_hi - d.row_lo;
+  void *px = nullptr, *py = nullptr;
+  int rc;
+  if ((rc = gm_graph_workspace(g, 1, (size_t)d.ndevice * K * 4 + 64, &px))) return rc;
+  if ((rc = gm_graph_workspace(g, 3, (size_t)n * K * 4 + 64, &py))) return rc;
+  const int wgrid = (n + kSgdBlock / 64 - 1) / (kSgdBlock / 64);
+  const int egrid = (int)(((int64_t)n * K + kSgdBlock - 1) / kSgdBlock);
+  gm_run_stats_t st;
+  memset(&st, 0, sizeof(st));
+  hipEvent_t ev0, ev1;
+  GM_TRY_HIP(hipEventCreate(&ev0));
+  GM_TRY_HIP(hipEventCreate(&ev1));
+  GM_TRY_HIP(hipEventRecord(ev0, s));
+  for (int it = 0; it < iterations; it++) {
+    hipLaunchKernelGGL((k_sgd_send<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)d_latent, (float*)px, n);
+    hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3(wgrid), dim3(kSgdBlock), 0, s, g->out.view, (const float*)px,
+                       (const float*)d_latent, (float*)py, (const uint32_t*)nullptr, 0);
+    hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3(wgrid), dim3(kSgdBlock), 0, s, g->in.view, (const float*)px,
+                       (const float*)d_latent, (float*)py, (const uint32_t*)g->out.rowbits, 1);
+    hipLaunchKernelGGL((k_sgd_apply<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)py,
+                       (const uint32_t*)g->rowbits_all, d_latent, n, lambda, step);
+  }
+  GM_TRY_HIP(hipEventRecord(ev1, s));
+  GM_TRY_HIP(hipEventSynchronize(ev1));
+  GM_TRY_HIP(hipEventElapsedTime(&st.total_ms, ev0, ev1));
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  st.iterations = iterations;
+  g->stats = st;
+  if (iters_done) *iters_done = iterations;
+  return GM_OK;
+}
+template <int K>
+int run_rmse_wide(gm_graph_t* g, float* d_latent, hipStream_t s) {
+  const gm_graph_desc_t& d = g->desc;
+  const int n = d.row_hi - d.row_lo;
+  void *px = nullptr, *py = nullptr;
+  int rc;
+  if ((rc = gm_graph_workspace(g, 1, (size_t)d.ndevice * K * 4 + 64, &px))) return rc;
+  if ((rc = gm_graph_workspace(g, 3, (size_t)n * K * 4 + 64, &py))) return rc;
+  const int wgrid = (n + kSgdBlock / 64 - 1) / (kSgdBlock / 64);
+  const int egrid = (int)(((int64_t)n * K + kSgdBlock - 1) / kSgdBlock);
+  hipLaunchKernelGGL((k_sgd_send<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)d_latent, (float*)px, n);
+  hipLaunchKernelGGL((k_sgd_multiply<K, 1>), dim3(wgrid), dim3(kSgdBlock), 0, s, g->in.view, (const float*)px,
+                     (const float*)d_latent, (float*)py, (const uint32_t*)nullptr, 0);
+  hipLaunchKernelGGL(k_rmse_apply, dim3((n + kSgdBlock - 1) / kSgdBlock), dim3(kSgdBlock), 0, s, (const float*)py,
+                     (const uint32_t*)g->in.rowbits, d_latent, n, K + 1);
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  return GM_OK;
+}
+static bool wide_path_ok(const gm_graph_t* g) {
+  return g && g->out.present && g->in.present && g->xfn == nullptr && g->desc.val_bytes == 4 && g->out.vals && g->in.vals &&
+         g->desc.row_lo == 0 && g->desc.row_hi == g->desc.ndevice && !g_force_ordered;
+}
+
 // run a program on caller-provided device state through the common engine
 template <class P, class V>
 int run_fixed(P& prog, gm_graph_t* g, V* d_vp, uint32_t* d_active, int iterations, int* iters_done, hipStream_t s) {
@@ -256,6 +431,8 @@ int gm_run_sgd(gm_graph_t* g, void* d_latent, int K, int real_bytes, double lamb
     gm::SgdP<float, 20> p((float)lambda, (float)step);
     return gm::run_fixed(p, g, (gm::Latent<float, 20>*)d_latent, (uint32_t*)nullptr, iterations, iters_done, s);
   }
+  if (K == 128 && real_bytes == 4 && iterations > 0 && gm::wide_path_ok(g) && d_latent)
+    return gm::run_sgd_wide<128>(g, (float*)d_latent, (float)lambda, (float)step, iterations, iters_done, s);
   if (K == 128 && real_bytes == 4) {
     gm::SgdP<float, 128> p((float)lambda, (float)step);
     return gm::run_fixed(p, g, (gm::Latent<float, 128>*)d_latent, (uint32_t*)nullptr, iterations, iters_done, s);
@@ -274,6 +451,7 @@ int gm_run_rmse(gm_graph_t* g, void* d_latent, int K, int real_bytes, gm_stream_
     gm::RmseP<float, 20> p;
     return gm::run_fixed(p, g, (gm::Latent<float, 20>*)d_latent, (uint32_t*)nullptr, 1, nullptr, s);
   }
+  if (K == 128 && real_bytes == 4 && gm::wide_path_ok(g) && d_latent) return gm::run_rmse_wide<128>(g, (float*)d_latent, s);
   if (K == 128 && real_bytes == 4) {
     gm::RmseP<float, 128> p;
     return gm::run_fixed(p, g, (gm::Latent<float, 128>*)d_latent, (uint32_t*)nullptr, 1, nullptr, s);

@@ -256,12 +256,16 @@ def test_fullscale_property_checker_agrees_with_oracle_regime():
     assert out.returncode == 0 and "ALL PASS" in out.stdout.decode(), out.stdout.decode()[-2000:]
 
 
-@pytest.mark.parametrize("K,dtype", [(20, np.float32), (128, np.float32), (20, np.float64)])
-def test_sgd_synthetic_ratings(env, K, dtype):
+@pytest.mark.parametrize("K,dtype,generic", [(20, np.float32, 0), (128, np.float32, 0), (128, np.float32, 1),
+                                             (20, np.float64, 0)])
+def test_sgd_synthetic_ratings(env, K, dtype, generic):
     """SGD / RMSE (3-operand multiply: process_message sees the destination's latent vector) on a
     synthetic bipartite ratings graph, incl. the K=128 fp32 shape of BASELINE config 5.
     Tolerance 1e-6 relative (north_star); the folds are in reference order, observed exact."""
     api, ob = env
+    # K=128 fp32 has a dedicated kernel pair (gm_programs.hip k_sgd_*); generic=1 forces the same
+    # program through the generic engine instead: both must equal the oracle
+    api._lib.lib().gm_set_option(b"force_ordered", generic)
     rng = np.random.default_rng(7)
     nu, ni, nr = 300, 60, 4000
     s = rng.integers(1, nu + 1, nr).astype(np.int32)
@@ -279,5 +283,8 @@ def test_sgd_synthetic_ratings(env, K, dtype):
     lv2, it = g.sgd(lv, 0.001, step, 3)
     olv2, oit = og.sgd(lv, 0.001, step, 3)
     assert it == oit == 3
+    api._lib.lib().gm_set_option(b"force_ordered", 0)
     np.testing.assert_allclose(lv2, olv2, rtol=1e-6, atol=0)
     assert not np.array_equal(lv2, lv)
+    if K == 128:
+        assert np.array_equal(lv2, olv2), "K=128 fp32: folds are in reference order, expected bit-exact"
