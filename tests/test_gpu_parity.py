@@ -288,3 +288,28 @@ def test_sgd_synthetic_ratings(env, K, dtype, generic):
     assert not np.array_equal(lv2, lv)
     if K == 128:
         assert np.array_equal(lv2, olv2), "K=128 fp32: folds are in reference order, expected bit-exact"
+
+
+def test_config2_rmat22_against_oracle(env):
+    """BASELINE config 2 at full size: PageRank on RMAT-22 (67 M edges), bit-exact fp32 against the
+    oracle (fixed count and until convergence), plus BFS depth/parent.  The edges come from the
+    device generator (bit-identical to the numpy one, tested above)."""
+    api, ob = env
+    nv, src, dst, _ = api.rmat_on_device(22, 16, 1)
+    s, d = src.cpu().numpy(), dst.cpu().numpy()
+    ob.lib().gmo_set_num_threads(16)
+    og = ob.OracleGraph(nv, s, d, None, ref_threads=1)
+    g = api.Graph(nv, src, dst, None, ref_threads=1, keep_values=False)
+    del src, dst
+    pr, deg, it = g.pagerank(10)
+    odeg = og.degree()
+    opr, oit, _ = og.pagerank(10, degree=odeg)
+    assert (deg == odeg).all() and it == oit == 10
+    assert (f32bits(pr) == f32bits(opr)).all(), "RMAT-22 PageRank differs from the oracle"
+    pr, deg, it = g.pagerank(-1)
+    opr, oit, _ = og.pagerank(-1, degree=odeg)
+    assert it == oit, "until-convergence iteration count differs (%d vs %d)" % (it, oit)
+    assert (f32bits(pr) == f32bits(opr)).all()
+    depth, parent, it = g.bfs(1)
+    od, op, oit, _ = og.bfs(1)
+    assert it == oit and (depth == od).all() and (parent == op).all()
