@@ -156,7 +156,13 @@ def main():
     rowptr = np.zeros(c_out.nrows + 1, np.int64)
     _lib.check(L.gm_graph_csr_to_host(g.h, api.GM_DIR_OUT, rowptr.ctypes.data, None, None))
     degs = np.diff(rowptr)
-    e_giant = int(degs[degs > (args.giant_row or 32768)].sum())
+    # the library picked the giant threshold itself unless --giant-row was given: recover it
+    thr = args.giant_row
+    if not thr:
+        thr = 4096
+        while (degs > thr).sum() > 1024 and thr < (1 << 30):
+            thr *= 2
+    e_giant = int(degs[degs > thr].sum())
     e_mid = int(degs[degs > (args.short_row or 64)].sum()) - e_giant
     e_long = e_mid + e_giant
     max_deg = int(degs.max()) if degs.size else 0

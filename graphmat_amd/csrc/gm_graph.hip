@@ -24,7 +24,7 @@
 namespace gm {
 
 int g_short_row = GM_SHORT_ROW;   // tunable through gm_set_option (experiments); defaults are the documented ones
-int g_giant_row = GM_GIANT_ROW;
+int g_giant_row = 0;  // 0 = choose per graph (see pick_giant_threshold)
 
 constexpr int kT = 256;
 inline int grid_for(int64_t n) { return (int)((n + kT - 1) / kT); }
@@ -127,6 +127,21 @@ k_rowptr(const uint64_t* __restrict__ keys, int64_t n, int nrows, int64_t* __res
     if (keys[mid] < target) lo = mid + 1; else hi = mid;
   }
   rowptr[r] = lo;
+}
+
+// log2 histogram of the row lengths (bin b counts rows with 2^b <= edges < 2^(b+1))
+__global__ void __launch_bounds__(kT)
+k_deg_hist(const int64_t* __restrict__ rowptr, int nrows, unsigned int* __restrict__ hist) {
+  __shared__ unsigned int sh[64];
+  if (threadIdx.x < 64) sh[threadIdx.x] = 0;
+  __syncthreads();
+  int r = blockIdx.x * kT + threadIdx.x;
+  if (r < nrows) {
+    long long d = rowptr[r + 1] - rowptr[r];
+    if (d > 0) atomicAdd(&sh[63 - __clzll(d)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
 }
 
 // segment starts (runs of rows, see gm_csr_t) and row classes
@@ -258,6 +273,27 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   if (nrows > 0)
     hipLaunchKernelGGL(k_rowbits, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr.as<int64_t>(), nrows, rbits.as<uint32_t>());
 
+  // Giant-row threshold.  The per-row workgroups of k_spmv_giant are the right tool for the few
+  // rows whose serial chain would otherwise dominate, and the wrong one for thousands of merely
+  // long rows, so the threshold is the smallest power of two >= 4096 that leaves at most 1024
+  // rows above it (GM_GIANT_ROW documents the typical outcome at RMAT-24..27).
+  int giant_row = g_giant_row;
+  if (giant_row <= 0) {
+    DevBuf hist;
+    if ((rc = hist.alloc(64 * 4))) return rc;
+    GM_TRY_HIP(hipMemsetAsync(hist.p, 0, 64 * 4, s));
+    if (nrows > 0)
+      hipLaunchKernelGGL(k_deg_hist, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr.as<int64_t>(), nrows,
+                         hist.as<unsigned int>());
+    unsigned int h[64];
+    GM_TRY_HIP(hipMemcpyAsync(h, hist.p, 64 * 4, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    int b = 40;
+    unsigned long long above = 0;
+    while (b > 12 && above + h[b - 1] <= 1024) { above += h[b - 1]; b--; }
+    giant_row = (b >= 31) ? 0x7fffffff : (1 << b);  // rows of >= 2^b edges (~ > giant_row) are giant
+  }
+
   // work decomposition: segments, row-blocks, wave rows, giant rows
   DevBuf f0, f1, f2, seg, blkl, mid, giant;
   if ((rc = f0.alloc((size_t)nrows + 1))) return rc;
@@ -270,7 +306,7 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   unsigned int nseg = 0, nblk = 0, nmid = 0, ngiant = 0;
   if (nrows > 0) {
     hipLaunchKernelGGL(k_row_flags, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr.as<int64_t>(), nrows, g_short_row,
-                       g_giant_row, f0.as<unsigned char>(), f1.as<unsigned char>(), f2.as<unsigned char>());
+                       giant_row, f0.as<unsigned char>(), f1.as<unsigned char>(), f2.as<unsigned char>());
     GM_TRY_HIP(hipGetLastError());
     rocprim::counting_iterator<int32_t> ids(0);
     size_t tb = 0;

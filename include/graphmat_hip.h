@@ -149,7 +149,9 @@ typedef struct {
 
 #define GM_BLOCK_NNZ 1024   /* a row-block holds < 2*GM_BLOCK_NNZ edges and <= 256 rows     */
 #define GM_SHORT_ROW 64     /* rows up to this many edges are folded one lane per row        */
-#define GM_GIANT_ROW 32768  /* rows above this get a workgroup of their own                  */
+#define GM_GIANT_ROW 32768  /* rows above this get a workgroup of their own; chosen per graph and
+                               direction (smallest power of two >= 4096 leaving <= 1024 such rows):
+                               32768 is what RMAT-24..27 get, 8192 RMAT-22, 4096 RMAT-20           */
 
 /* src/dst: 1-based vertex ids as in the .mtx (or native ids, see desc).  Edges whose
  * row falls outside the shard are dropped per direction, so every rank passes the full
