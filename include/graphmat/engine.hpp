@@ -204,11 +204,50 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   const int nwords = (n + 31) / 32;
   const bool multi = gm_graph_has_exchange(g) != 0;
 
+  // top-down push steps for tiny active sets (kernels.hpp: k_push_*): REDUCE_LAST programs over
+  // OUT_EDGES, running until convergence (the host already syncs once per iteration), unsharded,
+  // when the by-source adjacency is available
+  bool can_push = false;
+  gm_csr_t Asrc;
+  memset(&Asrc, 0, sizeof(Asrc));
+  const int32_t *dev_of_native = nullptr, *native_of_dev = nullptr;
+  if constexpr (program_traits<P>::reduce == REDUCE_LAST) {
+    can_push = order == OUT_EDGES && act == ACTIVE_ONLY && iterations <= 0 && !multi && !(debug_flags() & dev::DBG_NO_PUSH) &&
+               gm_graph_csr(g, GM_DIR_IN, &Asrc) == GM_OK && desc.row_lo == 0 && desc.row_hi == desc.ndevice;
+    if (can_push) gm_graph_maps(g, &dev_of_native, &native_of_dev);
+  }
+  unsigned long long* d_best = nullptr;
+  int32_t* d_list = nullptr;
+  unsigned long long* h_stats = nullptr;  // pinned: [0] changed flag (as int), [2],[3] frontier vertices / out-edges
+
   void* flag_v = nullptr;
   gm_graph_workspace(g, 0, 256, &flag_v);
-  int* d_changed = (int*)flag_v;
+  int* d_changed = (int*)flag_v;  // words: [0] changed flag, [2] list counter, [4..7] frontier stats (2 x u64)
+  unsigned int* d_count = (unsigned int*)flag_v + 2;
+  unsigned long long* d_stats = (unsigned long long*)flag_v + 2;  // byte offset 16
   int* h_changed = nullptr;
-  GM_HIP_OK(hipHostMalloc((void**)&h_changed, sizeof(int), hipHostMallocDefault));
+  GM_HIP_OK(hipHostMalloc((void**)&h_changed, 64, hipHostMallocDefault));
+  h_stats = (unsigned long long*)h_changed;
+  unsigned long long frontier_v = 0, frontier_e = 0, frontier_maxdeg = 0;
+  const int stats_grid = grid_for(n) < 2048 ? grid_for(n) : 2048;
+  if (can_push) {
+    void *pb = nullptr, *pl = nullptr;
+    if (gm_graph_workspace(g, 6, (size_t)n * 8 + 64, &pb) != GM_OK || gm_graph_workspace(g, 7, (size_t)n * 4 + 64, &pl) != GM_OK) {
+      can_push = false;
+    } else {
+      d_best = (unsigned long long*)pb;
+      d_list = (int32_t*)pl;
+      GM_HIP_OK(hipMemsetAsync(d_best, 0, (size_t)n * 8, s));
+      GM_HIP_OK(hipMemsetAsync(d_stats, 0, 24, s));
+      hipLaunchKernelGGL(dev::k_frontier_stats, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active,
+                         Asrc.rowptr, n, d_stats);
+      GM_HIP_OK(hipMemcpyAsync(h_stats + 2, d_stats, 24, hipMemcpyDeviceToHost, s));
+      GM_HIP_OK(hipStreamSynchronize(s));
+      frontier_v = h_stats[2];
+      frontier_e = h_stats[3];
+      frontier_maxdeg = h_stats[4];
+    }
+  }
 
   if (act == ALL_VERTICES) {  // GraphMatRuntime.h:121-123 g.setAllActive()
     hipLaunchKernelGGL(dev::k_fill_u32, dim3(grid_for(nwords)), dim3(dev::kBlock), 0, s, d_active, (int64_t)nwords,
@@ -243,13 +282,32 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     // multiply + reduce (:160-176)
     const uint32_t* xb = dense_x ? nullptr : xbits;
     const uint32_t* apply_bits = ybits;
-    if (order == OUT_EDGES || order == ALL_EDGES) {
+    // small frontiers only: few sources (compact list, bids) and few out-edges
+    const bool push = can_push && frontier_v > 0 && frontier_v <= 65536ull && frontier_e * 20ull < (unsigned long long)Aout.nnz;
+    if (push) {
+      if constexpr (program_traits<P>::reduce == REDUCE_LAST) {
+        GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
+        hipLaunchKernelGGL(dev::k_frontier_list, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active, n,
+                           d_list, d_count);
+        const unsigned pieces = (unsigned)((frontier_maxdeg + dev::kBlock * 4 - 1) / (dev::kBlock * 4));
+        hipLaunchKernelGGL(dev::k_push_bid, dim3((unsigned)frontier_v, pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc,
+                           (const int32_t*)d_list, (int)frontier_v, native_of_dev, d_best);
+        if (use_vp)
+          hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, true>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, Asrc,
+                             (const T*)x, dev_of_native, (const V*)d_vp, d_best, y, ybits, n);
+        else
+          hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, false>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, Asrc,
+                             (const T*)x, dev_of_native, (const V*)d_vp, d_best, y, ybits, n);
+        st.spmv_launches += 3;
+        timer.mark(TAG_WAVE);
+      }
+    } else if (order == OUT_EDGES || order == ALL_EDGES) {
       const int acc = static_bits ? dev::ACC_STATIC_BITS : 0;
       if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux);
       else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux);
       if (static_bits) apply_bits = Aout.rowbits;
     }
-    if (order == IN_EDGES || order == ALL_EDGES) {
+    if (!push && (order == IN_EDGES || order == ALL_EDGES)) {
       int acc = (order == ALL_EDGES) ? dev::ACC_READ_PREV : 0;
       uint32_t* yb = ybits;
       if (static_bits) {
@@ -267,8 +325,15 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     timer.mark(TAG_APPLY);
     int converged = 0;
     if (iterations <= 0) {  // the flag only matters when running until convergence (:257-259)
+      if (can_push) {  // size of the next active set, fetched with the flag
+        GM_HIP_OK(hipMemsetAsync(d_stats, 0, 24, s));
+        hipLaunchKernelGGL(dev::k_frontier_stats, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active,
+                           Asrc.rowptr, n, d_stats);
+        GM_HIP_OK(hipMemcpyAsync(h_stats + 2, d_stats, 24, hipMemcpyDeviceToHost, s));
+      }
       GM_HIP_OK(hipMemcpyAsync(h_changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, s));
       GM_HIP_OK(hipStreamSynchronize(s));
+      if (can_push) { frontier_v = h_stats[2]; frontier_e = h_stats[3]; frontier_maxdeg = h_stats[4]; }
       converged = (*h_changed == 0) ? 1 : 0;
       if (multi) gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &converged);  // :226 Allreduce(LAND)
     }

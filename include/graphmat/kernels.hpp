@@ -169,7 +169,7 @@ __device__ __forceinline__ E edge_at(const void* __restrict__ vals, int64_t k) {
 // earlier pass (their presence is read from ybits); ACC_STATIC_BITS = do not write presence
 // bits (every x entry is present, so y's presence equals the graph's static row bits)
 enum { ACC_READ_PREV = 1, ACC_STATIC_BITS = 2 };
-enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16 };
+enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32 };
 
 // ------------------------------------------------------------------------------------
 // multiply+reduce over row-blocks (rows of at most GM_SHORT_ROW edges).
@@ -851,6 +851,116 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
       y[row] = r;
       if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Top-down ("push") step for REDUCE_LAST programs with a tiny active set (first and last BFS
+// levels): instead of every row scanning its in-edges for a present message, every active
+// source walks its out-edges (the GM_DIR_IN adjacency: rows = sources) and bids for each
+// destination with atomicMax on (native id of the source + 1) << 32 | edge position.  The
+// maximum is exactly the message the ordered pull would have kept -- the present in-neighbour
+// with the largest native id, latest duplicate edge -- so results are identical.  A resolve
+// pass then evaluates process_message once per reached destination.
+
+// frontier statistics: number of active vertices, of their out-edges, and the largest out-degree.
+// Grid-stride with one set of atomics per workgroup (launch <= 2048 workgroups).
+__global__ void __launch_bounds__(kBlock)
+k_frontier_stats(const uint32_t* __restrict__ active, const int64_t* __restrict__ src_rowptr, int n,
+                 unsigned long long* __restrict__ stats /* [0] vertices, [1] out-edges, [2] max out-degree */) {
+  __shared__ unsigned long long s_c[kBlock / 64], s_e[kBlock / 64], s_m[kBlock / 64];
+  unsigned long long cnt = 0, edges = 0, mx = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    if (bit_get(active, (int)i)) {
+      unsigned long long d = (unsigned long long)(src_rowptr[i + 1] - src_rowptr[i]);
+      cnt++;
+      edges += d;
+      mx = d > mx ? d : mx;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    cnt += __shfl_down(cnt, off, 64);
+    edges += __shfl_down(edges, off, 64);
+    unsigned long long o = __shfl_down(mx, off, 64);
+    mx = o > mx ? o : mx;
+  }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_c[wv] = cnt; s_e[wv] = edges; s_m[wv] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; w++) { cnt += s_c[w]; edges += s_e[w]; mx = s_m[w] > mx ? s_m[w] : mx; }
+    if (cnt) {
+      atomicAdd(&stats[0], cnt);
+      atomicAdd(&stats[1], edges);
+      atomicMax(&stats[2], mx);
+    }
+  }
+}
+
+// compact list of the active vertices (order irrelevant); one atomic per wave that has any
+__global__ void __launch_bounds__(kBlock)
+k_frontier_list(const uint32_t* __restrict__ active, int n, int32_t* __restrict__ list, unsigned int* __restrict__ count) {
+  for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n; base += (int64_t)gridDim.x * kBlock) {
+    const int i = (int)base + threadIdx.x;
+    const bool act = i < n && bit_get(active, i);
+    const unsigned long long m = __ballot(act);
+    if (m) {
+      const int lane = threadIdx.x & 63;
+      unsigned int start = 0;
+      if (lane == 0) start = atomicAdd(count, (unsigned int)__popcll(m));
+      start = (unsigned int)__shfl((int)start, 0, 64);
+      if (act) list[start + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = i;
+    }
+  }
+}
+
+// bids: blockIdx.x = active source, blockIdx.y = 1024-edge piece of its out-edges
+__global__ void __launch_bounds__(kBlock)
+k_push_bid(gm_csr_t S /* rows = sources */, const int32_t* __restrict__ list, int nlist,
+           const int32_t* __restrict__ native_of_dev, unsigned long long* __restrict__ best) {
+  const int u = list[blockIdx.x];
+  const int64_t e0 = S.rowptr[u] + (int64_t)blockIdx.y * (kBlock * 4), e1 = S.rowptr[u + 1];
+  if (e0 >= e1) return;
+  const unsigned long long hi = (unsigned long long)((native_of_dev ? native_of_dev[u] : u) + 1) << 32;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int64_t e = e0 + threadIdx.x + j * kBlock;
+    if (e < e1) atomicMax(&best[S.colidx[e]], hi | (unsigned long long)(uint32_t)e);
+  }
+}
+
+template <class P, class T, class U, class V, class E, bool USE_VP>
+__global__ void __launch_bounds__(kBlock)
+k_push_resolve(ProgArg<P> pa, gm_csr_t S, const T* __restrict__ x, const int32_t* __restrict__ dev_of_native,
+               const V* __restrict__ vp, unsigned long long* __restrict__ best, U* __restrict__ y,
+               uint32_t* __restrict__ ybits, int n) {
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int v = blockIdx.x * kBlock + threadIdx.x;
+  bool got = false;
+  if (v < n) {
+    const unsigned long long key = best[v];
+    if (key != 0ull) {
+      best[v] = 0ull;  // leave the scratch clean for the next push step
+      bool wanted = true;
+      if constexpr (program_row_filter<P>::enabled) wanted = program_row_filter<P>::wants(p, vp[v]);
+      if (wanted) {
+        const int un = (int)(key >> 32) - 1;
+        const int64_t e = (int64_t)(uint32_t)key;
+        const int ud = dev_of_native ? dev_of_native[un] : un;
+        T m = x[ud];
+        V vprow;
+        if constexpr (USE_VP) vprow = vp[v];
+        U res;
+        p.P::process_message(m, edge_at<E>(S.vals, e), vprow, res);
+        y[v] = res;
+        got = true;
+      }
+    }
+  }
+  const unsigned long long bm = __ballot(got);  // ybits were cleared before the step: plain word stores
+  if ((threadIdx.x & 63) == 0 && v < n && bm) {
+    if ((uint32_t)bm) ybits[v >> 5] = (uint32_t)bm;
+    if ((uint32_t)(bm >> 32)) ybits[(v >> 5) + 1] = (uint32_t)(bm >> 32);
   }
 }
 

@@ -10,7 +10,7 @@ def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--scale", type=int, default=26); args = ap.parse_args()
     from graphmat_amd import api
     nv, src, dst, _ = api.rmat_on_device(args.scale, 16, 1)
-    g = api.Graph(nv, src, dst, None, keep_values=False, directions=api.GM_DIR_OUT)
+    g = api.Graph(nv, src, dst, None, keep_values=False)  # both directions: the push step needs the by-source adjacency
     g.enable_timing(True)
     for source in (1, 12345, 777):
         depth, parent, it = g.bfs(source)
