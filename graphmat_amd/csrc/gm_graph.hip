@@ -631,7 +631,8 @@ int gm_graph_relayout_like(gm_graph_t* g, const gm_graph_t* like, gm_stream_t st
     GM_TRY_HIP(hipMemcpyAsync(g->native_of_dev, like->native_of_dev, (size_t)b.ndevice * 4, hipMemcpyDeviceToDevice, s));
   }
   g->desc.layout = b.layout;
-  g->desc.xchg_rows = b.xchg_rows;
+  // the other graph's order ranks ITS edges: this graph's vertices with edges may sit anywhere in it
+  g->desc.xchg_rows = b.row_hi - b.row_lo;
   const int saved_native = g->desc.ids_are_native, saved_vb = g->desc.val_bytes;
   g->desc.ids_are_native = 1;
   g->desc.val_bytes = val_bytes;

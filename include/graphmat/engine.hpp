@@ -203,6 +203,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   const int n = desc.row_hi - desc.row_lo;
   const int nwords = (n + 31) / 32;
   const bool multi = gm_graph_has_exchange(g) != 0;
+  const int n_live = (desc.xchg_rows > 0 && desc.xchg_rows < n && (desc.xchg_rows & 63) == 0) ? desc.xchg_rows : n;
 
   // top-down push steps for tiny active sets (kernels.hpp: k_push_*): REDUCE_LAST programs over
   // OUT_EDGES, running until convergence (the host already syncs once per iteration), unsharded,
@@ -270,8 +271,10 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     timer.mark(TAG_START);
     // send (:145)
     const bool dense_x = (act == ALL_VERTICES);
-    hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
-                       dense_x ? (const uint32_t*)nullptr : (const uint32_t*)d_active, x, xbits, n, desc.row_lo);
+    // rows past n_live have no edge in either direction (degree-ranked order puts them at the
+    // tail): nobody reads their messages and they never receive one
+    hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
+                       dense_x ? (const uint32_t*)nullptr : (const uint32_t*)d_active, x, xbits, n_live, desc.row_lo);
     if (multi) {
       if (gm_graph_exchange(g, GM_XCHG_MESSAGES, x, (int64_t)sizeof(T), xbits, nullptr) != 0) {
         printf("GraphMat(HIP): message exchange callback failed\n");
@@ -320,8 +323,10 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       else launch_spmv<P, T, U, V, E, false>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux);
     }
     // setAllInactive (:184) + apply (:195-225): the active vector is rewritten by k_apply
-    hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, (const U*)y,
-                       apply_bits, d_vp, d_active, n, d_changed);
+    hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const U*)y,
+                       apply_bits, d_vp, d_active, n_live, d_changed);
+    if (n_live < n)  // setAllInactive for the rows k_apply does not visit
+      GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
     timer.mark(TAG_APPLY);
     int converged = 0;
     if (iterations <= 0) {  // the flag only matters when running until convergence (:257-259)
