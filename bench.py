@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--short-row", type=int, default=0, help="experiment: rows up to this many edges go to row-blocks")
     ap.add_argument("--giant-row", type=int, default=0, help="experiment: rows above this many edges get a workgroup")
+    ap.add_argument("--rank-by", type=int, default=0, help="experiment: device order ranked by 0 total, 1 out-, 2 in-degree")
     ap.add_argument("--native-layout", action="store_true", help="device order = native order (single GPU; for A/B)")
     ap.add_argument("--debug-flags", type=int, default=0, help="ablation only (results become invalid): 1 skip fold, 2 skip gathers")
     args = ap.parse_args()
@@ -122,6 +123,8 @@ def main():
         _lib.check(L.gm_set_option(b"short_row", args.short_row))
     if args.giant_row:
         _lib.check(L.gm_set_option(b"giant_row", args.giant_row))
+    if args.rank_by:
+        _lib.check(L.gm_set_option(b"rank_by", args.rank_by))
     # ---- synthetic input, generated in HBM ------------------------------------------------
     t0 = time.time()
     nv, src, dst, _ = api.rmat_on_device(args.scale, args.edge_factor, args.seed, weights=False, device=local_rank)

@@ -25,6 +25,7 @@ namespace gm {
 
 int g_short_row = GM_SHORT_ROW;   // tunable through gm_set_option (experiments); defaults are the documented ones
 int g_giant_row = 0;  // 0 = choose per graph (see pick_giant_threshold)
+int g_rank_by = 0;    // experiment: 0 rank vertices by total degree, 1 by out-degree, 2 by in-degree
 
 constexpr int kT = 256;
 inline int grid_for(int64_t n) { return (int)((n + kT - 1) / kT); }
@@ -32,14 +33,15 @@ inline int grid_for(int64_t n) { return (int)((n + kT - 1) / kT); }
 // total degree (in + out) per native vertex, for the GM_LAYOUT_DEGREE ranking
 __global__ void __launch_bounds__(kT)
 k_degree(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t nnz, int nparts, int nv,
-         int ids_are_native, uint32_t* __restrict__ deg) {
+         int ids_are_native, uint32_t* __restrict__ deg, int rank_by) {
   int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x;
   if (e >= nnz) return;
   int s = src[e], d = dst[e];
   int sn = ids_are_native ? s : to_native0(s, nparts, nv);
   int dn = ids_are_native ? d : to_native0(d, nparts, nv);
-  atomicAdd(&deg[sn], 1u);
-  atomicAdd(&deg[dn], 1u);
+  // total degree decides who is "live"; the ranking experiments weight one side
+  atomicAdd(&deg[sn], rank_by == 1 ? 65537u : rank_by == 2 ? 1u : 1u);
+  atomicAdd(&deg[dn], rank_by == 2 ? 65537u : 1u);
 }
 
 __global__ void __launch_bounds__(kT)
@@ -423,7 +425,7 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
   GM_TRY_HIP(hipMemsetAsync(nod.p, 0xff, (size_t)vd * 4, s));  // -1 = unused slot
   if (nnz > 0)
     hipLaunchKernelGGL(k_degree, dim3(grid_for(nnz)), dim3(kT), 0, s, d_src, d_dst, nnz, D.nparts, nv, D.ids_are_native,
-                       deg.as<uint32_t>());
+                       deg.as<uint32_t>(), g_rank_by);
   hipLaunchKernelGGL(k_rank_keys, dim3(grid_for(nv)), dim3(kT), 0, s, deg.as<uint32_t>(), nv, keys_in.as<uint32_t>(),
                      ids_in.as<int32_t>());
   size_t tb = 0;
