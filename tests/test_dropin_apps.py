@@ -196,3 +196,11 @@ def test_reference_incremental_pagerank_app_unchanged(golden_dir):
     assert [int(r[1]) for r in rows] == outdeg.tolist()
     assert [r[2] for r in rows] == ["%f" % x for x in pr]
     assert "Completed %d iterations" % iters in text
+
+
+@pytest.mark.gpu
+def test_sparse_float_sum_exactness_app():
+    """apps/active_float_sum.cpp: REDUCE_F32_ADD user program with a sparse message vector; giant,
+    wave and short rows all equal a host fold in native order, bit for bit."""
+    text = _run(_need(os.path.join(OWN_APPS, "active_float_sum")))
+    assert "FLOATSUM PASS" in text, text[-1500:]
