@@ -313,3 +313,26 @@ def test_config2_rmat22_against_oracle(env):
     depth, parent, it = g.bfs(1)
     od, op, oit, _ = og.bfs(1)
     assert it == oit and (depth == od).all() and (parent == op).all()
+
+
+def test_sgd_with_giant_rows(env):
+    """3-operand ordered fold on rows longer than the giant threshold (two items rated by thousands
+    of users): such rows of a plain REDUCE_ORDERED program take the wave kernel."""
+    api, ob = env
+    rng = np.random.default_rng(11)
+    nu, ni, nr = 9000, 2, 14000
+    s = rng.integers(1, nu + 1, nr).astype(np.int32)
+    d = (nu + rng.integers(1, ni + 1, nr)).astype(np.int32)
+    v = rng.integers(1, 6, nr).astype(np.int32)
+    nv = nu + ni
+    lv = rng.random((nv, 20)).astype(np.float64)
+    g = api.Graph(nv, s, d, v)
+    c = g.csr(api.GM_DIR_OUT)
+    assert c.ngiant >= 2
+    og = ob.OracleGraph(nv, s, d, v, 1)
+    lv2, it = g.sgd(lv, 0.001, 3.5e-7, 2)
+    olv2, oit = og.sgd(lv, 0.001, 3.5e-7, 2)
+    np.testing.assert_allclose(lv2, olv2, rtol=1e-6, atol=0)
+    e, sq = g.rmse_sum(lv2)
+    oe, osq = og.rmse_sum(olv2)
+    np.testing.assert_allclose(sq, osq, rtol=1e-6, atol=0)
