@@ -43,10 +43,10 @@ void spmv_pass(Graph<V, E>& G, const Prog* gp, int dir, XV* x, YV* y, int accumu
   U* yv = (U*)y->segment->value;
   if (gp->getProcessMessageRequiresVertexprop())
     launch_spmv<Prog, T, U, V, E, true>(G.A, pa, c, xv, x->segment->bit_vector, (const V*)G.vertexproperty->segment->value,
-                                        yv, y->segment->bit_vector, accumulate, 0, &launches);
+                                        yv, y->segment->bit_vector, accumulate, 0, &launches, nullptr, nullptr, reduce_kind_of<Prog, U>(gp));
   else
     launch_spmv<Prog, T, U, V, E, false>(G.A, pa, c, xv, x->segment->bit_vector, (const V*)G.vertexproperty->segment->value,
-                                         yv, y->segment->bit_vector, accumulate, 0, &launches);
+                                         yv, y->segment->bit_vector, accumulate, 0, &launches, nullptr, nullptr, reduce_kind_of<Prog, U>(gp));
   GM_HIP_OK(hipStreamSynchronize(0));
   y->segment->device_modified();
 }

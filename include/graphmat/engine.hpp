@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "kernels.hpp"
@@ -110,12 +111,73 @@ struct AuxStream {
   }
 };
 
-// one multiply+reduce pass over one direction of the adjacency
-template <class P, class T, class U, class V, class E, bool USE_VP>
-void launch_spmv(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits,
-                 const V* vp, U* y, uint32_t* ybits, int accumulate, hipStream_t s, int* launches,
-                 PhaseTimer* timer = nullptr, AuxStream* aux = nullptr) {
-  constexpr int RK = (int)program_traits<P>::reduce;
+// ---- which exact strategy may evaluate a program's reduce_function ------------------------------
+// A program can say so (program_traits<P>::reduce).  Otherwise the runtime asks the function
+// itself: reduce_function is an ordinary host-callable method, so it is run on the host on
+// random operands and compared, bit for bit, with float a+b, with a=b, and (integral types) with
+// wrapping +, min and max.  Only an exact match on every sample selects the corresponding
+// strategy; anything else keeps the always-correct ordered fold.  GRAPHMAT_NO_PROBE=1 disables it.
+template <class P, class U>
+int probe_reduce_kind(const P* gp) {
+  const char* off = getenv("GRAPHMAT_NO_PROBE");
+  if (off && off[0] == '1') return REDUCE_ORDERED;
+  if constexpr (!std::is_trivially_copyable<U>::value || sizeof(U) > 8) {
+    return REDUCE_ORDERED;
+  } else {
+    unsigned long long st = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    bool is_last = true, is_fadd = std::is_same<U, float>::value, is_iadd = std::is_integral<U>::value,
+         is_min = std::is_integral<U>::value, is_max = std::is_integral<U>::value;
+    for (int k = 0; k < 96; k++) {
+      U a, b;
+      if constexpr (std::is_same<U, float>::value) {
+        // magnitudes over many binades, both signs, a few ties-prone small integers
+        const int ea = (int)(next() % 40) - 20, eb = (int)(next() % 40) - 20;
+        a = (float)((double)(next() % 16777216) * (1.0 / 16777216.0)) * (float)(1ull << 20) * ((next() & 1) ? 1.f : -1.f);
+        b = (float)((double)(next() % 16777216) * (1.0 / 16777216.0)) * (float)(1ull << 20) * ((next() & 1) ? 1.f : -1.f);
+        a = ea >= 0 ? a * (float)(1 << ea) : a / (float)(1 << -ea);
+        b = eb >= 0 ? b * (float)(1 << eb) : b / (float)(1 << -eb);
+        if (k % 7 == 0) { a = (float)(next() % 9); b = (float)(next() % 9) + 0.5f; }
+      } else {
+        unsigned long long ra = next(), rb = next();
+        if (k % 5 == 0) { ra &= 0xff; rb &= 0xff; }
+        memcpy(&a, &ra, sizeof(U));
+        memcpy(&b, &rb, sizeof(U));
+        if constexpr (std::is_floating_point<U>::value) { a = (U)(double)(long long)(ra % 1000003); b = (U)(double)(long long)(rb % 1000003) / (U)7; }
+      }
+      U c = a;
+      gp->P::reduce_function(c, b);
+      if (memcmp(&c, &b, sizeof(U)) != 0) is_last = false;
+      if constexpr (std::is_same<U, float>::value) {
+        volatile float sum = a + b;
+        float sv = sum;
+        if (memcmp(&c, &sv, 4) != 0) is_fadd = false;
+      }
+      if constexpr (std::is_integral<U>::value) {
+        typedef typename std::make_unsigned<U>::type UU;
+        U add = (U)((UU)a + (UU)b), mn = a < b ? a : b, mx = a < b ? b : a;
+        if (c != add) is_iadd = false;
+        if (c != mn) is_min = false;
+        if (c != mx) is_max = false;
+      }
+    }
+    if (is_last) return REDUCE_LAST;
+    if (is_fadd) return REDUCE_F32_ADD;
+    if (is_iadd || is_min || is_max) return REDUCE_COMMUTATIVE;
+    return REDUCE_ORDERED;
+  }
+}
+template <class P, class U>
+int reduce_kind_of(const P* gp) {
+  if constexpr ((int)program_traits<P>::reduce != (int)REDUCE_AUTO) return (int)program_traits<P>::reduce;
+  else return probe_reduce_kind<P, U>(gp);
+}
+
+// one multiply+reduce pass over one direction of the adjacency, strategy RK
+template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
+void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits,
+                    const V* vp, U* y, uint32_t* ybits, int accumulate, hipStream_t s, int* launches, PhaseTimer* timer,
+                    AuxStream* aux) {
   constexpr int WPB = dev::kBlock / 64;  // rows (waves) per workgroup of k_spmv_wave
   if (A.nnz == 0) return;
   const bool overlap = aux != nullptr && aux->s != nullptr && A.ngiant > 0 && (A.nblk > 0 || A.nmid > 0);
@@ -182,6 +244,35 @@ void launch_spmv(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, co
   if (overlap) GM_HIP_OK(hipStreamWaitEvent(s, aux->join, 0));
 }
 
+// rk: REDUCE_* chosen for this run.  Programs with a declared kind only instantiate that one.
+template <class P, class T, class U, class V, class E, bool USE_VP>
+void launch_spmv(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits,
+                 const V* vp, U* y, uint32_t* ybits, int accumulate, hipStream_t s, int* launches,
+                 PhaseTimer* timer = nullptr, AuxStream* aux = nullptr, int rk = REDUCE_ORDERED) {
+  if constexpr ((int)program_traits<P>::reduce != (int)REDUCE_AUTO) {
+    launch_spmv_rk<P, T, U, V, E, USE_VP, (int)program_traits<P>::reduce>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s,
+                                                                          launches, timer, aux);
+  } else {
+    if constexpr (std::is_same<U, float>::value) {
+      if (rk == REDUCE_F32_ADD) {
+        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_F32_ADD>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux);
+        return;
+      }
+    }
+    if constexpr (std::is_trivially_copyable<U>::value && sizeof(U) <= 8) {
+      if (rk == REDUCE_LAST) {
+        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_LAST>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux);
+        return;
+      }
+      if (rk == REDUCE_COMMUTATIVE) {
+        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_COMMUTATIVE>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux);
+        return;
+      }
+    }
+    launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_ORDERED>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux);
+  }
+}
+
 // The iteration loop.  d_vp / d_active cover the shard's rows in native order.
 // x/xbits are global-size scratch, y/ybits shard-size scratch.  Returns iterations done.
 template <class P, class T, class U, class V, class E>
@@ -212,7 +303,9 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   gm_csr_t Asrc;
   memset(&Asrc, 0, sizeof(Asrc));
   const int32_t *dev_of_native = nullptr, *native_of_dev = nullptr;
-  if constexpr (program_traits<P>::reduce == REDUCE_LAST) {
+  const int rk = reduce_kind_of<P, U>(gp);
+  if (getenv("GRAPHMAT_VERBOSE")) printf("GraphMat(HIP): reduce strategy %d (0 ordered, 1 commutative, 2 last, 3 float add)\n", rk);
+  if (rk == REDUCE_LAST) {
     can_push = order == OUT_EDGES && act == ACTIVE_ONLY && iterations <= 0 && !multi && !(debug_flags() & dev::DBG_NO_PUSH) &&
                gm_graph_csr(g, GM_DIR_IN, &Asrc) == GM_OK && desc.row_lo == 0 && desc.row_hi == desc.ndevice;
     if (can_push) gm_graph_maps(g, &dev_of_native, &native_of_dev);
@@ -288,7 +381,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     // small frontiers only: few sources (compact list, bids) and few out-edges
     const bool push = can_push && frontier_v > 0 && frontier_v <= 65536ull && frontier_e * 20ull < (unsigned long long)Aout.nnz;
     if (push) {
-      if constexpr (program_traits<P>::reduce == REDUCE_LAST) {
+      {
         GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
         hipLaunchKernelGGL(dev::k_frontier_list, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active, n,
                            d_list, d_count);
@@ -306,8 +399,8 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       }
     } else if (order == OUT_EDGES || order == ALL_EDGES) {
       const int acc = static_bits ? dev::ACC_STATIC_BITS : 0;
-      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux);
-      else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux);
+      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk);
+      else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk);
       if (static_bits) apply_bits = Aout.rowbits;
     }
     if (!push && (order == IN_EDGES || order == ALL_EDGES)) {
@@ -319,8 +412,8 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         apply_bits = Ain.rowbits;
         if (order == ALL_EDGES && gm_graph_rowbits_all(g, &apply_bits) != GM_OK) { printf("%s\n", gm_last_error()); exit(1); }
       }
-      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux);
-      else launch_spmv<P, T, U, V, E, false>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux);
+      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux, rk);
+      else launch_spmv<P, T, U, V, E, false>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux, rk);
     }
     // setAllInactive (:184) + apply (:195-225): the active vector is rewritten by k_apply
     hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const U*)y,

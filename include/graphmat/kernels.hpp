@@ -32,6 +32,7 @@ namespace GraphMat {
 
 // How a program's reduce_function may be evaluated.  The default is always safe.
 enum reduce_kind {
+  REDUCE_AUTO = -1,        // let the runtime probe reduce_function on the host (engine.hpp)
   REDUCE_ORDERED = 0,      // fold strictly in ascending column order (any functor)
   REDUCE_COMMUTATIVE = 1,  // associative+commutative and exact (integer +, min, max): any order
   REDUCE_LAST = 2,         // reduce(a,b) is a=b: the result is the last present message
@@ -42,7 +43,7 @@ enum reduce_kind {
 // program type.  Nothing here changes results, only how they are computed.
 template <class P>
 struct program_traits {
-  static constexpr reduce_kind reduce = REDUCE_ORDERED;
+  static constexpr reduce_kind reduce = REDUCE_AUTO;
 };
 
 // Optional row filter: a program may declare that apply(y, vp) is a no-op whenever
