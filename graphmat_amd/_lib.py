@@ -78,6 +78,7 @@ SIGNATURES = {
     "gm_graph_exchange": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.POINTER(C.c_int)]),
     "gm_graph_has_exchange": (C.c_int, [_P]),
     "gm_graph_timing_enabled": (C.c_int, [_P]),
+    "gm_graph_run_resources": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "gm_graph_record_stats": (C.c_int, [_P, C.POINTER(RunStats)]),
     "gm_reduce_sum_f64": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_double), _P]),
     "gm_reduce_sum_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_double), _P]),

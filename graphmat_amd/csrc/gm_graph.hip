@@ -563,7 +563,32 @@ int gm_graph_create(gm_graph_t** gout, const gm_graph_desc_t* desc, int64_t nnz,
                        (const uint32_t*)g->in.rowbits, g->rowbits_all, nw);
   }
   if (hipStreamSynchronize(s) != hipSuccess) { gm::set_error("graph build: stream sync failed"); gm_graph_destroy(g); return GM_ERR_HIP; }
+  void* unused[4];
+  if ((rc = gm_graph_run_resources(g, &unused[0], &unused[1], &unused[2], &unused[3])) != GM_OK) { gm_graph_destroy(g); return rc; }
   *gout = g;
+  return GM_OK;
+}
+
+int gm_graph_run_resources(gm_graph_t* g, void** aux_stream, void** fork_event, void** join_event, void** pinned64) {
+  if (!g || !aux_stream || !fork_event || !join_event || !pinned64) { gm::set_error("gm_graph_run_resources: null argument"); return GM_ERR_INVALID; }
+  if (!g->aux_stream) {
+    GM_TRY_HIP(hipStreamCreateWithFlags(&g->aux_stream, hipStreamNonBlocking));
+    GM_TRY_HIP(hipEventCreateWithFlags(&g->aux_fork, hipEventDisableTiming));
+    GM_TRY_HIP(hipEventCreateWithFlags(&g->aux_join, hipEventDisableTiming));
+    GM_TRY_HIP(hipHostMalloc(&g->pinned_flag, 64, hipHostMallocDefault));
+    memset(g->pinned_flag, 0, 64);
+    // first device-to-pinned-host copy of a process sets up the copy path (milliseconds): do it now
+    void* d = nullptr;
+    GM_TRY_HIP(hipMalloc(&d, 64));
+    GM_TRY_HIP(hipMemsetAsync(d, 0, 64, 0));
+    GM_TRY_HIP(hipMemcpyAsync(g->pinned_flag, d, 64, hipMemcpyDeviceToHost, 0));
+    GM_TRY_HIP(hipStreamSynchronize(0));
+    (void)hipFree(d);
+  }
+  *aux_stream = (void*)g->aux_stream;
+  *fork_event = (void*)g->aux_fork;
+  *join_event = (void*)g->aux_join;
+  *pinned64 = g->pinned_flag;
   return GM_OK;
 }
 
@@ -576,6 +601,13 @@ int gm_graph_destroy(gm_graph_t* g) {
   if (g->rowbits_all) (void)hipFree(g->rowbits_all);
   for (int i = 0; i < GM_WS_SLOTS; i++)
     if (g->ws[i] && !g->ws_external[i]) (void)hipFree(g->ws[i]);
+  if (g->aux_stream) {
+    (void)hipStreamSynchronize(g->aux_stream);
+    (void)hipStreamDestroy(g->aux_stream);
+    (void)hipEventDestroy(g->aux_fork);
+    (void)hipEventDestroy(g->aux_join);
+    (void)hipHostFree(g->pinned_flag);
+  }
   delete g;
   return GM_OK;
 }

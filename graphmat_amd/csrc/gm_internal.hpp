@@ -68,4 +68,9 @@ struct gm_graph {
   void* xctx;
   int timing;
   gm_run_stats_t stats;
+  // per-graph run resources (gm_graph_run_resources): created with the graph so that no
+  // stream / pinned-memory creation lands inside a timed run_graph_program call
+  hipStream_t aux_stream;
+  hipEvent_t aux_fork, aux_join;
+  void* pinned_flag;
 };

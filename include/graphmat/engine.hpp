@@ -7,6 +7,7 @@
 #pragma once
 #include <stdio.h>
 #include <stdlib.h>
+#include <sys/time.h>
 
 #include <type_traits>
 #include <vector>
@@ -97,17 +98,17 @@ struct PhaseTimer {
 
 // auxiliary stream for the giant-row passes: their long serial chains overlap the
 // throughput-bound row-block and wave kernels instead of running after them
+// (the stream and its events belong to the graph: gm_graph_run_resources)
 struct AuxStream {
   hipStream_t s = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
-  void create() {
-    GM_HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    GM_HIP_OK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-    GM_HIP_OK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+  void attach(void* stream, void* fork_ev, void* join_ev) {
+    s = (hipStream_t)stream;
+    fork = (hipEvent_t)fork_ev;
+    join = (hipEvent_t)join_ev;
   }
-  void destroy() {
-    if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); (void)hipEventDestroy(fork); (void)hipEventDestroy(join); }
-    s = nullptr;
+  void finish() {
+    if (s) (void)hipStreamSynchronize(s);
   }
 };
 
@@ -278,6 +279,16 @@ void launch_spmv(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, co
 template <class P, class T, class U, class V, class E>
 int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act, bool use_vp, V* d_vp,
                   uint32_t* d_active, T* x, uint32_t* xbits, U* y, uint32_t* ybits, int iterations, hipStream_t s) {
+  const bool verbose = getenv("GRAPHMAT_VERBOSE") != nullptr;
+  struct timeval tv0;
+  gettimeofday(&tv0, 0);
+  auto tick = [&](const char* what, int k) {  // GRAPHMAT_VERBOSE=1: host-side timeline of one run
+    if (!verbose) return;
+    (void)hipStreamSynchronize(s);
+    struct timeval tv1;
+    gettimeofday(&tv1, 0);
+    printf("GraphMat(HIP): +%9.3f ms  %s %d\n", (tv1.tv_sec - tv0.tv_sec) * 1e3 + (tv1.tv_usec - tv0.tv_usec) * 1e-3, what, k);
+  };
   gm_graph_desc_t desc;
   gm_graph_desc(g, &desc);
   gm_csr_t Aout, Ain;
@@ -304,7 +315,8 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   memset(&Asrc, 0, sizeof(Asrc));
   const int32_t *dev_of_native = nullptr, *native_of_dev = nullptr;
   const int rk = reduce_kind_of<P, U>(gp);
-  if (getenv("GRAPHMAT_VERBOSE")) printf("GraphMat(HIP): reduce strategy %d (0 ordered, 1 commutative, 2 last, 3 float add)\n", rk);
+  tick("reduce_function probed", rk);
+  if (verbose) printf("GraphMat(HIP): reduce strategy %d (0 ordered, 1 commutative, 2 last, 3 float add)\n", rk);
   if (rk == REDUCE_LAST) {
     can_push = order == OUT_EDGES && act == ACTIVE_ONLY && iterations <= 0 && !multi && !(debug_flags() & dev::DBG_NO_PUSH) &&
                gm_graph_csr(g, GM_DIR_IN, &Asrc) == GM_OK && desc.row_lo == 0 && desc.row_hi == desc.ndevice;
@@ -319,8 +331,12 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   int* d_changed = (int*)flag_v;  // words: [0] changed flag, [2] list counter, [4..7] frontier stats (2 x u64)
   unsigned int* d_count = (unsigned int*)flag_v + 2;
   unsigned long long* d_stats = (unsigned long long*)flag_v + 2;  // byte offset 16
-  int* h_changed = nullptr;
-  GM_HIP_OK(hipHostMalloc((void**)&h_changed, 64, hipHostMallocDefault));
+  void *res_stream = nullptr, *res_fork = nullptr, *res_join = nullptr, *res_pinned = nullptr;
+  if (gm_graph_run_resources(g, &res_stream, &res_fork, &res_join, &res_pinned) != GM_OK) {
+    printf("GraphMat(HIP): %s\n", gm_last_error());
+    exit(1);
+  }
+  int* h_changed = (int*)res_pinned;
   h_stats = (unsigned long long*)h_changed;
   unsigned long long frontier_v = 0, frontier_e = 0, frontier_maxdeg = 0;
   const int stats_grid = grid_for(n) < 2048 ? grid_for(n) : 2048;
@@ -351,10 +367,13 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   memset(&st, 0, sizeof(st));
   PhaseTimer timer(gm_graph_timing_enabled(g) != 0, s);
   AuxStream aux;
-  if (!(debug_flags() & dev::DBG_NO_OVERLAP)) aux.create();
+  tick("first frontier counted", (int)frontier_v);
+  if (!(debug_flags() & dev::DBG_NO_OVERLAP)) aux.attach(res_stream, res_fork, res_join);
 
   int it = 0;
+  tick("setup done", 0);
   while (true) {
+    tick("iteration", it);
     dev::ProgArg<P> pa = dev::make_prog_arg(gp);  // re-captured every iteration (do_every_iteration may change it)
     // Clear(&x) / Clear(&y) (:139-140): x presence words are fully rewritten by send.  With
     // every x entry present (ALL_VERTICES) y's presence is the static set of non-empty rows.
@@ -451,11 +470,12 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     }
   }
   GM_HIP_OK(hipStreamSynchronize(s));
-  aux.destroy();
+  tick("loop done", it);
+  aux.finish();
   st.iterations = it;
   timer.finish(&st);
   gm_graph_record_stats(g, &st);
-  (void)hipHostFree(h_changed);
+  tick("teardown done", 0);
   return it;
 }
 

@@ -258,6 +258,12 @@ int gm_graph_workspace(gm_graph_t* g, int slot, size_t bytes, void** d_ptr);
  * ((nvertices+31)/32+2 words).  The library uses the buffer while it is large enough and never
  * frees it.  d_ptr = NULL returns the slot to library ownership. */
 int gm_graph_adopt_workspace(gm_graph_t* g, int slot, void* d_ptr, size_t bytes);
+/* Per-graph run resources, created once with the graph and destroyed with it: an auxiliary
+ * non-blocking hipStream_t (the giant-row passes overlap the other multiply kernels on it),
+ * two hipEvent_t (fork / join of that stream) and 64 bytes of pinned host memory (the
+ * convergence flag and frontier statistics are copied there every iteration).  Returned as
+ * void* so this header stays free of HIP types. */
+int gm_graph_run_resources(gm_graph_t* g, void** aux_stream, void** fork_event, void** join_event, void** pinned64);
 /* counters of the giant-row kernel since the last call (then reset): 16-edge groups
  * out[0] taken by the exact parallel fp32 replay, out[1] folded serially */
 int gm_debug_counters(int64_t out[4]);
