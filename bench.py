@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--short-row", type=int, default=0, help="experiment: rows up to this many edges go to row-blocks")
     ap.add_argument("--giant-row", type=int, default=0, help="experiment: rows above this many edges get a workgroup")
+    ap.add_argument("--rank-cap", type=int, default=0, help="experiment: rank only vertices of degree >= cap, others stay in native order")
     ap.add_argument("--rank-by", type=int, default=0, help="experiment: device order ranked by 0 total, 1 out-, 2 in-degree")
     ap.add_argument("--native-layout", action="store_true", help="device order = native order (single GPU; for A/B)")
     ap.add_argument("--debug-flags", type=int, default=0, help="ablation only (results become invalid): 1 skip fold, 2 skip gathers")
@@ -123,6 +124,8 @@ def main():
         _lib.check(L.gm_set_option(b"short_row", args.short_row))
     if args.giant_row:
         _lib.check(L.gm_set_option(b"giant_row", args.giant_row))
+    if args.rank_cap:
+        _lib.check(L.gm_set_option(b"rank_cap", args.rank_cap))
     if args.rank_by:
         _lib.check(L.gm_set_option(b"rank_by", args.rank_by))
     # ---- synthetic input, generated in HBM ------------------------------------------------

@@ -51,6 +51,9 @@ SIGNATURES = {
     "gm_mtx_read": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(_P),
                               C.POINTER(_P), C.POINTER(_P)]),
     "gm_host_free": (None, [_P]),
+    "gm_edgelist_read": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int64), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    "gm_edgelist_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, _P, _P]),
     "gm_graph_create": (C.c_int, [C.POINTER(_P), C.POINTER(GraphDesc), C.c_int64, _P, _P, _P, _P]),
     "gm_graph_destroy": (C.c_int, [_P]),
     "gm_graph_desc": (C.c_int, [_P, C.POINTER(GraphDesc)]),

@@ -157,6 +157,191 @@ int gm_mtx_read(const char* path, int val_bytes, int* nv, int64_t* nnz, int32_t*
 }
 void gm_host_free(void* p) { free(p); }
 
+namespace {
+int val_kind_bytes(int kind) {
+  if (kind == GM_VAL_I32 || kind == GM_VAL_U32 || kind == GM_VAL_F32) return 4;
+  if (kind == GM_VAL_F64) return 8;
+  if (kind > 0x100 && kind <= 0x100 + 4096) return kind - 0x100;
+  return -1;
+}
+void store_one(void* dst, int kind) {  // the value an unweighted edge gets: (T)1
+  if (kind == GM_VAL_I32) { int32_t v = 1; memcpy(dst, &v, 4); }
+  else if (kind == GM_VAL_U32) { uint32_t v = 1; memcpy(dst, &v, 4); }
+  else if (kind == GM_VAL_F32) { float v = 1.f; memcpy(dst, &v, 4); }
+  else if (kind == GM_VAL_F64) { double v = 1.0; memcpy(dst, &v, 8); }
+}
+struct Growing {  // three parallel malloc'ed arrays
+  int32_t *s = nullptr, *d = nullptr;
+  unsigned char* v = nullptr;
+  int64_t n = 0, cap = 0;
+  int vb;
+  explicit Growing(int vb_) : vb(vb_) {}
+  bool reserve(int64_t want) {
+    if (want <= cap) return true;
+    int64_t nc = cap ? cap * 2 : 1024;
+    if (nc < want) nc = want;
+    int32_t* ns = (int32_t*)realloc(s, (size_t)nc * 4 + 4);
+    if (ns) s = ns;
+    int32_t* nd = (int32_t*)realloc(d, (size_t)nc * 4 + 4);
+    if (nd) d = nd;
+    unsigned char* nv = (unsigned char*)realloc(v, (size_t)nc * vb + 8);
+    if (nv) v = nv;
+    if (!ns || !nd || !nv) return false;
+    cap = nc;
+    return true;
+  }
+  void release() { free(s); free(d); free(v); s = d = nullptr; v = nullptr; }
+};
+}  // namespace
+
+int gm_edgelist_read(const char* path, int binary, int header, int weights, int val_kind, int* m, int* n, int64_t* nnz,
+                     int32_t** h_src, int32_t** h_dst, void** h_val) {
+  const int vb = val_kind_bytes(val_kind);
+  if (!path || !m || !n || !nnz || !h_src || !h_dst || !h_val || vb <= 0) { gm::set_error("gm_edgelist_read: invalid argument"); return GM_ERR_INVALID; }
+  if (!binary && val_kind > 0x100) { gm::set_error("gm_edgelist_read: opaque values need a binary file"); return GM_ERR_INVALID; }
+  FILE* fp = fopen(path, binary ? "rb" : "r");
+  if (!fp) { gm::set_error("Could not open file: %s", path); return GM_ERR_IO; }
+  fseek(fp, 0, SEEK_END);
+  const long fsize = ftell(fp);
+  fseek(fp, 0, SEEK_SET);
+  char* buf = (char*)malloc((size_t)(fsize > 0 ? fsize : 0) + 2);
+  if (!buf) { fclose(fp); gm::set_error("gm_edgelist_read: out of host memory"); return GM_ERR_NOMEM; }
+  const size_t len = fsize > 0 ? fread(buf, 1, (size_t)fsize, fp) : 0;
+  fclose(fp);
+  buf[len] = 0;
+  Growing g(vb);
+  int hm = 0, hn = 0;
+  int64_t hcount = -1;
+  int maxs = 0, maxd = 0;
+  int rc = GM_OK;
+  if (binary) {
+    size_t pos = 0;
+    if (header) {
+      int32_t h[3];
+      if (len < 12) { free(buf); gm::set_error("%s: bad binary header", path); return GM_ERR_IO; }
+      memcpy(h, buf, 12);
+      hm = h[0]; hn = h[1]; hcount = (uint32_t)h[2];
+      pos = 12;
+    }
+    const size_t rec = 8 + (weights ? (size_t)vb : 0);
+    int64_t avail = (int64_t)((len - pos) / rec);
+    if (hcount >= 0 && avail < hcount) { free(buf); gm::set_error("%s: header says %lld edges, file holds %lld", path, (long long)hcount, (long long)avail); return GM_ERR_IO; }
+    const int64_t cnt = hcount >= 0 ? hcount : avail;
+    if (!g.reserve(cnt > 0 ? cnt : 1)) rc = GM_ERR_NOMEM;
+    for (int64_t i = 0; rc == GM_OK && i < cnt; i++) {
+      const char* r = buf + pos + (size_t)i * rec;
+      memcpy(&g.s[i], r, 4);
+      memcpy(&g.d[i], r + 4, 4);
+      if (weights) memcpy(g.v + (size_t)i * vb, r + 8, vb);
+      else store_one(g.v + (size_t)i * vb, val_kind);
+      if (g.s[i] > maxs) maxs = g.s[i];
+      if (g.d[i] > maxd) maxd = g.d[i];
+    }
+    g.n = cnt;
+  } else {
+    char* p = buf;
+    auto next_long = [&](long long* out) {
+      char* e = nullptr;
+      long long v = strtoll(p, &e, 10);
+      if (e == p) return false;
+      p = e;
+      *out = v;
+      return true;
+    };
+    if (header) {
+      long long a, b, c;
+      if (!next_long(&a) || !next_long(&b) || !next_long(&c)) { free(buf); gm::set_error("%s: bad text header", path); return GM_ERR_IO; }
+      hm = (int)a; hn = (int)b; hcount = c;
+    }
+    while (hcount < 0 || g.n < hcount) {
+      long long a, b;
+      if (!next_long(&a) || !next_long(&b)) break;
+      if (!g.reserve(g.n + 1)) { rc = GM_ERR_NOMEM; break; }
+      unsigned char* vd = g.v + (size_t)g.n * vb;
+      if (weights) {
+        char* e = nullptr;
+        if (val_kind == GM_VAL_I32) { int32_t v = (int32_t)strtol(p, &e, 10); memcpy(vd, &v, 4); }
+        else if (val_kind == GM_VAL_U32) { uint32_t v = (uint32_t)strtoul(p, &e, 10); memcpy(vd, &v, 4); }
+        else if (val_kind == GM_VAL_F32) { float v = strtof(p, &e); memcpy(vd, &v, 4); }
+        else { double v = strtod(p, &e); memcpy(vd, &v, 8); }
+        if (e == p) break;  // a line without its value ends the list, like a failed fscanf
+        p = e;
+      } else {
+        store_one(vd, val_kind);
+      }
+      g.s[g.n] = (int32_t)a;
+      g.d[g.n] = (int32_t)b;
+      if (a > maxs) maxs = (int)a;
+      if (b > maxd) maxd = (int)b;
+      g.n++;
+    }
+    if (rc == GM_OK && hcount >= 0 && g.n < hcount) {
+      gm::set_error("%s: header says %lld edges, file holds %lld", path, (long long)hcount, (long long)g.n);
+      rc = GM_ERR_IO;
+    }
+    if (rc == GM_OK && !g.reserve(1)) rc = GM_ERR_NOMEM;
+  }
+  free(buf);
+  if (rc != GM_OK) {
+    if (rc == GM_ERR_NOMEM) gm::set_error("gm_edgelist_read: out of host memory");
+    g.release();
+    return rc;
+  }
+  *m = header ? hm : maxs;
+  *n = header ? hn : maxd;
+  *nnz = g.n;
+  *h_src = g.s;
+  *h_dst = g.d;
+  *h_val = g.v;
+  return GM_OK;
+}
+
+int gm_edgelist_write(const char* path, int binary, int header, int weights, int val_kind, int m, int n, int64_t nnz,
+                      const int32_t* h_src, const int32_t* h_dst, const void* h_val) {
+  const int vb = val_kind_bytes(val_kind);
+  if (!path || nnz < 0 || (nnz && (!h_src || !h_dst)) || vb <= 0 || (weights && nnz && !h_val)) { gm::set_error("gm_edgelist_write: invalid argument"); return GM_ERR_INVALID; }
+  if (!binary && weights && val_kind > 0x100) { gm::set_error("gm_edgelist_write: opaque values need a binary file"); return GM_ERR_INVALID; }
+  FILE* fp = fopen(path, binary ? "wb" : "w");
+  if (!fp) { gm::set_error("Could not open file for writing: %s", path); return GM_ERR_IO; }
+  bool ok = true;
+  const unsigned char* vals = (const unsigned char*)h_val;
+  if (binary) {
+    if (header) {
+      int32_t h[3] = {m, n, (int32_t)nnz};
+      ok = fwrite(h, 4, 3, fp) == 3;
+    }
+    const size_t rec = 8 + (weights ? (size_t)vb : 0);
+    const int64_t chunk = 1 << 16;
+    unsigned char* out = (unsigned char*)malloc((size_t)chunk * rec);
+    if (!out) { fclose(fp); gm::set_error("gm_edgelist_write: out of host memory"); return GM_ERR_NOMEM; }
+    for (int64_t base = 0; ok && base < nnz; base += chunk) {
+      const int64_t cnt = nnz - base < chunk ? nnz - base : chunk;
+      for (int64_t i = 0; i < cnt; i++) {
+        unsigned char* r = out + (size_t)i * rec;
+        memcpy(r, &h_src[base + i], 4);
+        memcpy(r + 4, &h_dst[base + i], 4);
+        if (weights) memcpy(r + 8, vals + (size_t)(base + i) * vb, vb);
+      }
+      ok = fwrite(out, rec, (size_t)cnt, fp) == (size_t)cnt;
+    }
+    free(out);
+  } else {
+    if (header) ok = fprintf(fp, "%d %d %u\n", m, n, (unsigned)nnz) > 0;
+    for (int64_t i = 0; ok && i < nnz; i++) {
+      int w;
+      if (!weights) w = fprintf(fp, "%d %d\n", h_src[i], h_dst[i]);
+      else if (val_kind == GM_VAL_I32) { int32_t v; memcpy(&v, vals + i * 4, 4); w = fprintf(fp, "%d %d %d\n", h_src[i], h_dst[i], v); }
+      else if (val_kind == GM_VAL_U32) { uint32_t v; memcpy(&v, vals + i * 4, 4); w = fprintf(fp, "%d %d %u\n", h_src[i], h_dst[i], v); }
+      else if (val_kind == GM_VAL_F32) { float v; memcpy(&v, vals + i * 4, 4); w = fprintf(fp, "%d %d %.8f\n", h_src[i], h_dst[i], v); }
+      else { double v; memcpy(&v, vals + i * 8, 8); w = fprintf(fp, "%d %d %.15lf\n", h_src[i], h_dst[i], v); }
+      ok = w > 0;
+    }
+  }
+  if (fclose(fp) != 0) ok = false;
+  if (!ok) { gm::set_error("%s: write failed", path); return GM_ERR_IO; }
+  return GM_OK;
+}
+
 int gm_rmat_generate(int scale, uint64_t seed, int64_t first_edge, int64_t count, int32_t* d_src, int32_t* d_dst,
                      int32_t* d_val, int weights_mode, gm_stream_t stream) {
   if (scale < 1 || scale > 30 || count < 0 || first_edge < 0 || !d_src || !d_dst) {

@@ -25,6 +25,7 @@ namespace gm {
 
 int g_short_row = GM_SHORT_ROW;   // tunable through gm_set_option (experiments); defaults are the documented ones
 int g_giant_row = 0;  // 0 = choose per graph (see pick_giant_threshold)
+int g_rank_cap = 0;   // experiment: > 0 ranks only vertices of total degree >= cap; the others keep native order behind them
 int g_rank_by = 0;    // experiment: 0 rank vertices by total degree, 1 by out-degree, 2 by in-degree
 
 constexpr int kT = 256;
@@ -52,10 +53,12 @@ k_count_nonzero(const uint32_t* __restrict__ deg, int nv, unsigned long long* __
 }
 
 __global__ void __launch_bounds__(kT)
-k_rank_keys(const uint32_t* __restrict__ deg, int nv, uint32_t* __restrict__ keys, int32_t* __restrict__ ids) {
+k_rank_keys(const uint32_t* __restrict__ deg, int nv, uint32_t* __restrict__ keys, int32_t* __restrict__ ids, uint32_t cap) {
   int v = blockIdx.x * kT + threadIdx.x;
   if (v >= nv) return;
-  keys[v] = 0xffffffffu - deg[v];  // ascending sort => descending degree; stable => ties by native id
+  uint32_t d = deg[v];
+  if (cap > 0 && d > 0 && d < cap) d = 1;
+  keys[v] = 0xffffffffu - d;  // ascending sort => descending degree; stable => ties by native id
   ids[v] = v;
 }
 
@@ -427,7 +430,7 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     hipLaunchKernelGGL(k_degree, dim3(grid_for(nnz)), dim3(kT), 0, s, d_src, d_dst, nnz, D.nparts, nv, D.ids_are_native,
                        deg.as<uint32_t>(), g_rank_by);
   hipLaunchKernelGGL(k_rank_keys, dim3(grid_for(nv)), dim3(kT), 0, s, deg.as<uint32_t>(), nv, keys_in.as<uint32_t>(),
-                     ids_in.as<int32_t>());
+                     ids_in.as<int32_t>(), (uint32_t)(g_rank_by == 0 ? g_rank_cap : 0));
   size_t tb = 0;
   GM_TRY_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in.as<uint32_t>(), keys_out.as<uint32_t>(), ids_in.as<int32_t>(),
                                        order.as<int32_t>(), (size_t)nv, 0u, 32u, s));

@@ -18,7 +18,7 @@
 
 namespace gm {
 
-extern int g_short_row, g_giant_row, g_rank_by;
+extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap;
 static int g_force_ordered = 0;
 
 // ---------------- PageRank (reference: src/PageRank.cpp:34-112) ----------------------------
@@ -381,6 +381,7 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "force_ordered")) { gm::g_force_ordered = value; return GM_OK; }
   if (key && !strcmp(key, "short_row") && value >= 1 && value <= GM_BLOCK_NNZ) { gm::g_short_row = value; return GM_OK; }
   if (key && !strcmp(key, "giant_row") && value >= 64) { gm::g_giant_row = value; return GM_OK; }
+  if (key && !strcmp(key, "rank_cap") && value >= 0) { gm::g_rank_cap = value; return GM_OK; }
   if (key && !strcmp(key, "rank_by") && value >= 0 && value <= 2) { gm::g_rank_by = value; return GM_OK; }
   if (key && !strcmp(key, "debug_flags")) { GraphMat::detail::debug_flags() = value; return GM_OK; }
   gm::set_error("gm_set_option: unknown option");

@@ -38,6 +38,7 @@
 #endif
 
 #include "graphmat/edgelist.h"
+#include "graphmat/edgelist_transformations.h"
 #include "graphmat/device_globals.hpp"
 #include "graphmat/engine.hpp"
 
@@ -334,15 +335,64 @@ void Graph<V, E>::ReadMTX(const char* filename) {
   A_edges.clear();
 }
 
-template <class V, class E>
-void Graph<V, E>::ReadGraphMatBin(const char*) {
-  std::cout << "GraphMat(HIP): GraphMat-bin archives (boost::serialization) are not supported" << std::endl;
-  exit(1);
+// GraphMat-bin: the reference archives its partitioned matrices with boost::serialization
+// (Graph.h:152-208), a format tied to its in-memory classes.  This engine's file of the same
+// role holds the edge list in original vertex ids (the device layout is rebuilt on read, so a
+// file does not depend on the layout parameters): 8-byte magic, int32 sizeof(E), int32
+// nvertices, int64 nnz, int32 num_threads at the time of writing, int32 0, then src[nnz],
+// dst[nnz] (int32 each) and val[nnz].  Like the reference: one file per rank (<name><rank>),
+// vertex properties and activity are not stored and come back default-initialised.
+namespace detail {
+static const char kGraphBinMagic[8] = {'G', 'M', 'H', 'I', 'P', 'B', 'N', '1'};
 }
 template <class V, class E>
-void Graph<V, E>::WriteGraphMatBin(const char*) {
-  std::cout << "GraphMat(HIP): GraphMat-bin archives (boost::serialization) are not supported" << std::endl;
-  exit(1);
+void Graph<V, E>::ReadGraphMatBin(const char* filename) {
+  std::stringstream fname_ss;
+  fname_ss << filename << GraphMat::get_global_myrank();
+  std::cout << "Reading file " << fname_ss.str() << std::endl;
+  FILE* fp = fopen(fname_ss.str().c_str(), "rb");
+  if (!fp) { std::cout << "Could not open file: " << fname_ss.str() << std::endl; exit(1); }
+  char magic[8];
+  int32_t head[2], tail[2];
+  int64_t count = 0;
+  bool ok = fread(magic, 1, 8, fp) == 8 && memcmp(magic, detail::kGraphBinMagic, 8) == 0 && fread(head, 4, 2, fp) == 2 &&
+            fread(&count, 8, 1, fp) == 1 && fread(tail, 4, 2, fp) == 2;
+  if (!ok || head[0] != (int32_t)sizeof(E) || head[1] <= 0 || count < 0) {
+    std::cout << "Error reading file - not a GraphMat(HIP) graph file for this edge type" << std::endl;
+    exit(1);
+  }
+  GraphMat::edgelist_t<E> el(head[1], head[1], (int)count);
+  std::vector<int32_t> s((size_t)count), d((size_t)count);
+  std::vector<E> v((size_t)count);
+  ok = fread(s.data(), 4, (size_t)count, fp) == (size_t)count && fread(d.data(), 4, (size_t)count, fp) == (size_t)count &&
+       fread((void*)v.data(), sizeof(E), (size_t)count, fp) == (size_t)count;
+  fclose(fp);
+  if (!ok) { std::cout << "Error reading file - truncated" << std::endl; exit(1); }
+  for (int64_t k = 0; k < count; k++) el.edges[k] = edge_t<E>(s[k], d[k], v[k]);
+  ReadEdgelist(el);
+  el.clear();
+}
+template <class V, class E>
+void Graph<V, E>::WriteGraphMatBin(const char* filename) {
+  std::stringstream fname_ss;
+  fname_ss << filename << GraphMat::get_global_myrank();
+  std::cout << "Writing file " << fname_ss.str() << std::endl;
+  GraphMat::edgelist_t<E> el;
+  getEdgelist(el);
+  const size_t count = (size_t)el.nnz;
+  std::vector<int32_t> s(count), d(count);
+  std::vector<E> v(count);
+  for (size_t k = 0; k < count; k++) { s[k] = el.edges[k].src; d[k] = el.edges[k].dst; v[k] = el.edges[k].val; }
+  el.clear();
+  FILE* fp = fopen(fname_ss.str().c_str(), "wb");
+  if (!fp) { std::cout << "Could not open file for writing: " << fname_ss.str() << std::endl; exit(1); }
+  const int32_t head[2] = {(int32_t)sizeof(E), (int32_t)nvertices}, tail[2] = {(int32_t)num_threads, 0};
+  const int64_t cnt = (int64_t)count;
+  bool ok = fwrite(detail::kGraphBinMagic, 1, 8, fp) == 8 && fwrite(head, 4, 2, fp) == 2 && fwrite(&cnt, 8, 1, fp) == 1 &&
+            fwrite(tail, 4, 2, fp) == 2 && fwrite(s.data(), 4, count, fp) == count && fwrite(d.data(), 4, count, fp) == count &&
+            fwrite((const void*)v.data(), sizeof(E), count, fp) == count;
+  if (fclose(fp) != 0) ok = false;
+  if (!ok) { std::cout << "Error writing file " << fname_ss.str() << std::endl; exit(1); }
 }
 
 template <class V, class E>

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <sstream>
 #include <string>
+#include <type_traits>
 
 #include "../graphmat_hip.h"
 
@@ -45,16 +46,24 @@ struct edgelist_t {
   }
 };
 
-// Binary .mtx with header and weights.  File naming follows the reference: rank r
-// reads <prefix><r>, <prefix><r+nranks>, ... until one is missing.  As a
+namespace detail {
+template <typename T>
+inline int edge_value_kind() {
+  if (std::is_same<T, int>::value) return GM_VAL_I32;
+  if (std::is_same<T, unsigned int>::value) return GM_VAL_U32;
+  if (std::is_same<T, float>::value) return GM_VAL_F32;
+  if (std::is_same<T, double>::value) return GM_VAL_F64;
+  return GM_VAL_RAW((int)sizeof(T));  // opaque: binary files only
+}
+}  // namespace detail
+
+// Edge-list files: binary or text, with or without the "m n nnz" header, with or without
+// edge values (every combination the reference's loader takes).  File naming follows the
+// reference: rank r reads <prefix><r>, <prefix><r+nranks>, ... until one is missing.  As a
 // convenience a plain <prefix> (no suffix) is read when <prefix>0 does not exist.
 template <typename T>
 void load_edgelist(const char* dir, edgelist_t<T>* edgelist, bool binaryformat = true, bool header = true,
                    bool edgeweights = true) {
-  if (!binaryformat || !header || !edgeweights) {
-    printf("GraphMat(HIP): only binary .mtx with header and weights is supported by this loader\n");
-    exit(1);
-  }
   edgelist->m = edgelist->n = edgelist->nnz = 0;
   edgelist->edges = nullptr;
   const int nrank = get_global_nrank(), myrank = get_global_myrank();
@@ -73,11 +82,12 @@ void load_edgelist(const char* dir, edgelist_t<T>* edgelist, bool binaryformat =
     }
     fclose(probe);
     printf("Reading file: %s\n", fname.c_str());
-    int nv = 0;
+    int fm = 0, fn = 0;
     int64_t nnz = 0;
     int32_t *s = nullptr, *d = nullptr;
     void* v = nullptr;
-    if (gm_mtx_read(fname.c_str(), (int)sizeof(T), &nv, &nnz, &s, &d, &v) != GM_OK) {
+    if (gm_edgelist_read(fname.c_str(), binaryformat ? 1 : 0, header ? 1 : 0, edgeweights ? 1 : 0,
+                         detail::edge_value_kind<T>(), &fm, &fn, &nnz, &s, &d, &v) != GM_OK) {
       printf("%s\n", gm_last_error());
       exit(1);
     }
@@ -93,12 +103,39 @@ void load_edgelist(const char* dir, edgelist_t<T>* edgelist, bool binaryformat =
     gm_host_free(d);
     gm_host_free(v);
     edgelist->nnz += (int)nnz;
-    if (nv > edgelist->m) edgelist->m = nv;
-    if (nv > edgelist->n) edgelist->n = nv;
+    if (fm > edgelist->m) edgelist->m = fm;
+    if (fn > edgelist->n) edgelist->n = fn;
     if (fname == dir) break;
   }
   printf("Got: %d by %d  vertices\n", edgelist->m, edgelist->n);
   printf("Got: %d edges\n", edgelist->nnz);
+}
+
+// one file per rank, <prefix><rank> (write_edgelist of the reference, edgelist.h:208-240)
+template <typename T>
+void write_edgelist(const char* dir, const edgelist_t<T>& edgelist, bool binaryformat = true, bool header = true,
+                    bool edgeweights = true) {
+  std::stringstream fname_ss;
+  fname_ss << dir << get_global_myrank();
+  printf("Writing file: %s\n", fname_ss.str().c_str());
+  const size_t ne = (size_t)edgelist.nnz;
+  int32_t* s = static_cast<int32_t*>(malloc(ne * 4 + 4));
+  int32_t* d = static_cast<int32_t*>(malloc(ne * 4 + 4));
+  char* v = static_cast<char*>(malloc(ne * sizeof(T) + 8));
+  for (size_t k = 0; k < ne; k++) {
+    s[k] = edgelist.edges[k].src;
+    d[k] = edgelist.edges[k].dst;
+    memcpy(v + k * sizeof(T), &edgelist.edges[k].val, sizeof(T));
+  }
+  int rc = gm_edgelist_write(fname_ss.str().c_str(), binaryformat ? 1 : 0, header ? 1 : 0, edgeweights ? 1 : 0,
+                             detail::edge_value_kind<T>(), edgelist.m, edgelist.n, (int64_t)ne, s, d, v);
+  free(s);
+  free(d);
+  free(v);
+  if (rc != GM_OK) {
+    printf("%s\n", gm_last_error());
+    exit(1);
+  }
 }
 
 // keep the edges for which the predicate holds (public name of the reference's

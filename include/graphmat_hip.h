@@ -76,6 +76,26 @@ int gm_mtx_read(const char* path, int val_bytes, int* nv, int64_t* nnz, int32_t*
                 void** h_val);
 void gm_host_free(void* p);
 
+/* ---- edge-list files in every variant the reference reads and writes
+ * (load_edgelist / write_edgelist, include/GMDP/utils/edgelist.h:89-334; the formats
+ * src/graph_converter.cpp:161-222 converts between) -----------------------------------
+ * binary: optional header of three int32 (m, n, nnz), then records (int32 src, int32 dst
+ *         [, value]);  text: optional header line "m n nnz", then lines "src dst [value]".
+ * val_kind says how a value is stored/parsed; GM_VAL_RAW(bytes) is an opaque fixed-size
+ * value (binary files only).  Reading: without a header m = largest src, n = largest dst and
+ * records run to the end of the file; without weights every value is 1 (of val_kind).  With a
+ * header the header's count governs, as in gm_mtx_read.  Arrays are malloc'ed (gm_host_free). */
+#define GM_VAL_I32 1
+#define GM_VAL_U32 2
+#define GM_VAL_F32 3
+#define GM_VAL_F64 4
+#define GM_VAL_RAW(bytes) (0x100 + (bytes))
+int gm_edgelist_read(const char* path, int binary, int header, int weights, int val_kind, int* m, int* n,
+                     int64_t* nnz, int32_t** h_src, int32_t** h_dst, void** h_val);
+/* text values are printed like the reference does: %d, %u, %.8f (float), %.15lf (double) */
+int gm_edgelist_write(const char* path, int binary, int header, int weights, int val_kind, int m, int n, int64_t nnz,
+                      const int32_t* h_src, const int32_t* h_dst, const void* h_val);
+
 /* ---- graph ---------------------------------------------------------------------- */
 #define GM_DIR_OUT 1 /* rows = destinations, cols = sources: GraphMat's AT, used by OUT_EDGES programs */
 #define GM_DIR_IN 2  /* rows = sources, cols = destinations: GraphMat's A, used by IN_EDGES programs  */

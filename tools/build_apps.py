@@ -18,15 +18,32 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "--hipstdpar", "-ffp-cont
          "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "graphmat_amd"), "-lgraphmat_hip"]
 
 
+def _newest_header():
+    newest = 0.0
+    for d, _, files in os.walk(os.path.join(ROOT, "include")):
+        for f in files:
+            newest = max(newest, os.path.getmtime(os.path.join(d, f)))
+    return newest
+
+
 def _compile(src, out, rpath):
     if os.path.exists(out) and os.path.getmtime(out) >= max(
-            os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "graphmat_amd", "libgraphmat_hip.so"))):
+            os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "graphmat_amd", "libgraphmat_hip.so")), _newest_header()):
         return
     cmd = [HIPCC] + FLAGS + [src, "-o", out, "-Wl,-rpath," + rpath]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         sys.stderr.write(r.stdout.decode())
         raise RuntimeError("hipcc failed on %s" % src)
+
+
+def build_one(name):
+    """Build a single program of apps/ (used by tests that need just one tool)."""
+    outdir = os.path.join(ROOT, "build", "apps")
+    os.makedirs(outdir, exist_ok=True)
+    out = os.path.join(outdir, name)
+    _compile(os.path.join(ROOT, "apps", name + ".cpp"), out, "$ORIGIN/../../graphmat_amd")
+    return out
 
 
 def build(verbose=False):
