@@ -166,10 +166,10 @@ namespace gm {
 // to the generic kernels'; only the mapping to the machine differs:
 //   * x (the message vector = a copy of the latent vectors) is laid out with a row stride of K
 //     floats (512 B for K = 128), without the sqerr field, so a row is one aligned burst;
-//   * one wave per row, 64 edges at a time: phase A gives every lane one edge and lets it walk
-//     its x row sequentially against the row's own vector held in LDS (the ordered dot product);
-//     phase B gives every lane K/64 components and walks the 64 edges in order, re-reading each
-//     x row as one coalesced burst (L2 hit) and accumulating error-scaled messages.
+//   * one wave per row, 32 edges at a time, their x rows fetched once as coalesced bursts into an
+//     LDS tile (next tile in flight meanwhile): phase A gives every lane one edge and walks its x
+//     row sequentially against the row's own vector (the ordered dot product); phase B gives
+//     every lane K/64 components and walks the edges in order, accumulating error-scaled messages.
 // HBM-bound: 4K flop against one 4K-byte row per edge; MFMA has nothing to chew on (each dot is a
 // 1 x K by K x 1 product with no operand shared between edges), see DESIGN.md.
 constexpr int kSgdBlock = 256;
@@ -184,21 +184,36 @@ k_sgd_send(const float* __restrict__ vp, float* __restrict__ x, int n) {  // x[v
 }
 
 // MODE 0: SGD messages into y (row stride K);  MODE 1: RMSE, squared errors summed into y1[row]
+// One wave per row, kSgdTile edges per step.  The step's x rows are fetched exactly once, as
+// whole coalesced bursts (each load instruction covers 64/(K/4) complete rows), and parked in the
+// wave's LDS tile; the next step's rows are already in flight while this step computes:
+//   phase A  lane = edge: the ordered K-term dot product of its x row (LDS) with the row's own
+//            vector (LDS, broadcast), then err = rating - estimate;
+//   phase B  lane = K/64 components: the tile's edges in stored order, y += x_row * err, x from LDS.
+constexpr int kSgdMulBlock = 128;  // 2 waves: 2 x (32 x (K+4) + K) floats of LDS = 34.8 KB at K = 128
+constexpr int kSgdTile = 32;
+
 template <int K, int MODE>
-__global__ void __launch_bounds__(kSgdBlock)
+__global__ void __launch_bounds__(kSgdMulBlock)
 k_sgd_multiply(gm_csr_t A, const float* __restrict__ x, const float* __restrict__ vp, float* __restrict__ y,
                const uint32_t* __restrict__ prev_bits, int accumulate) {
-  constexpr int PER = K / 64;  // components per lane
-  __shared__ float s_v[kSgdBlock / 64][K];
+  static_assert(K % 64 == 0 && 256 % K == 0, "K must be 64, 128 or 256");
+  constexpr int PER = K / 64;        // components per lane in phase B
+  constexpr int LPR = K / 4;         // lanes that cover one x row with a float4 each
+  constexpr int RPL = 64 / LPR;      // rows per load instruction
+  constexpr int NLD = kSgdTile / RPL;  // load instructions per tile
+  constexpr int XS = K + 4;          // LDS row stride in floats (keeps float4 alignment, staggers banks)
+  constexpr int WPB = kSgdMulBlock / 64;
+  __shared__ float s_v[WPB][K];
+  __shared__ __attribute__((aligned(16))) float s_x[WPB][kSgdTile][XS];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (kSgdBlock / 64) + wv;
+  const int row = blockIdx.x * WPB + wv;
   if (row >= A.nrows) return;
   const int64_t e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
   if (e1 == e0) return;
   const float* vrow = vp + (int64_t)row * (K + 1);
 #pragma unroll
   for (int j = 0; j < PER; j++) s_v[wv][lane + 64 * j] = vrow[lane + 64 * j];
-  __builtin_amdgcn_wave_barrier();
   bool has = accumulate && ((prev_bits[row >> 5] >> (row & 31)) & 1u);
   float acc[PER];
   float sq = 0.f;
@@ -209,25 +224,49 @@ k_sgd_multiply(gm_csr_t A, const float* __restrict__ x, const float* __restrict_
     sq = y[row];
   }
   const int* vals = (const int*)A.vals;
-  for (int64_t base = e0; base < e1; base += 64) {
-    const int n = (int)((e1 - base) < 64 ? (e1 - base) : 64);
-    // phase A: lane = edge; sequential dot product, no contraction
-    int col = 0;
+  const int sub = lane / LPR, part = lane % LPR;  // which of the RPL rows of a load, which float4 of it
+
+  int col = 0, rating = 0;
+  float4 q[NLD];
+  auto fetch = [&](int64_t base) {  // column ids + ratings of the tile, then its x rows
+    const int n = (int)((e1 - base) < kSgdTile ? (e1 - base) : kSgdTile);
+    col = 0;
+    rating = 0;
+    if (lane < n) {
+      col = __builtin_nontemporal_load(A.colidx + base + lane);
+      rating = __builtin_nontemporal_load(vals + base + lane);
+    }
+#pragma unroll
+    for (int r = 0; r < NLD; r++) {
+      const int e = r * RPL + sub;
+      const int c = __shfl(col, e);
+      q[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < n) q[r] = *reinterpret_cast<const float4*>(x + (int64_t)c * K + 4 * part);
+    }
+  };
+  fetch(e0);
+  for (int64_t base = e0; base < e1; base += kSgdTile) {
+    const int n = (int)((e1 - base) < kSgdTile ? (e1 - base) : kSgdTile);
+    const int my_rating = rating;
+    __builtin_amdgcn_wave_barrier();  // earlier reads of the tile are done (LDS is in order per wave)
+#pragma unroll
+    for (int r = 0; r < NLD; r++) *reinterpret_cast<float4*>(&s_x[wv][r * RPL + sub][4 * part]) = q[r];
+    __builtin_amdgcn_wave_barrier();
+    if (base + kSgdTile < e1) fetch(base + kSgdTile);  // next tile's rows fly during the phases below
+    // phase A
     float err = 0.f;
     if (lane < n) {
-      col = A.colidx[base + lane];
-      const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)col * K);
       float est = 0.f;
-#pragma unroll 4
+#pragma unroll 8
       for (int i = 0; i < K / 4; i++) {
-        const float4 q = xr[i];
+        const float4 xq = *reinterpret_cast<const float4*>(&s_x[wv][lane][4 * i]);
         const float4 w = *reinterpret_cast<const float4*>(&s_v[wv][4 * i]);
-        est += q.x * w.x;
-        est += q.y * w.y;
-        est += q.z * w.z;
-        est += q.w * w.w;
+        est += xq.x * w.x;
+        est += xq.y * w.y;
+        est += xq.z * w.z;
+        est += xq.w * w.w;
       }
-      err = (float)vals[base + lane] - est;
+      err = (float)my_rating - est;
     }
     if (MODE == 1) {
       const float e2 = err * err;
@@ -236,14 +275,12 @@ k_sgd_multiply(gm_csr_t A, const float* __restrict__ x, const float* __restrict_
         if (has) sq += t; else { sq = t; has = true; }
       }
     } else {
-      // phase B: lane = components; the 64 edges in order
+      // phase B
       for (int e = 0; e < n; e++) {
-        const int ce = __builtin_amdgcn_readlane(col, e);
         const float ee = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(err), e));
-        const float* xr = x + (int64_t)ce * K;
 #pragma unroll
         for (int j = 0; j < PER; j++) {
-          const float r = xr[lane + 64 * j] * ee;
+          const float r = s_x[wv][e][lane + 64 * j] * ee;
           acc[j] = has ? acc[j] + r : r;
         }
         has = true;
@@ -284,7 +321,7 @@ int run_sgd_wide(gm_graph_t* g, float* d_latent, float lambda, float step, int i
   int rc;
   if ((rc = gm_graph_workspace(g, 1, (size_t)d.ndevice * K * 4 + 64, &px))) return rc;
   if ((rc = gm_graph_workspace(g, 3, (size_t)n * K * 4 + 64, &py))) return rc;
-  const int wgrid = (n + kSgdBlock / 64 - 1) / (kSgdBlock / 64);
+  const int wgrid = (n + kSgdMulBlock / 64 - 1) / (kSgdMulBlock / 64);
   const int egrid = (int)(((int64_t)n * K + kSgdBlock - 1) / kSgdBlock);
   gm_run_stats_t st;
   memset(&st, 0, sizeof(st));
@@ -294,9 +331,9 @@ int run_sgd_wide(gm_graph_t* g, float* d_latent, float lambda, float step, int i
   GM_TRY_HIP(hipEventRecord(ev0, s));
   for (int it = 0; it < iterations; it++) {
     hipLaunchKernelGGL((k_sgd_send<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)d_latent, (float*)px, n);
-    hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3(wgrid), dim3(kSgdBlock), 0, s, g->out.view, (const float*)px,
+    hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3(wgrid), dim3(kSgdMulBlock), 0, s, g->out.view, (const float*)px,
                        (const float*)d_latent, (float*)py, (const uint32_t*)nullptr, 0);
-    hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3(wgrid), dim3(kSgdBlock), 0, s, g->in.view, (const float*)px,
+    hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3(wgrid), dim3(kSgdMulBlock), 0, s, g->in.view, (const float*)px,
                        (const float*)d_latent, (float*)py, (const uint32_t*)g->out.rowbits, 1);
     hipLaunchKernelGGL((k_sgd_apply<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)py,
                        (const uint32_t*)g->rowbits_all, d_latent, n, lambda, step);
@@ -319,10 +356,10 @@ int run_rmse_wide(gm_graph_t* g, float* d_latent, hipStream_t s) {
   int rc;
   if ((rc = gm_graph_workspace(g, 1, (size_t)d.ndevice * K * 4 + 64, &px))) return rc;
   if ((rc = gm_graph_workspace(g, 3, (size_t)n * K * 4 + 64, &py))) return rc;
-  const int wgrid = (n + kSgdBlock / 64 - 1) / (kSgdBlock / 64);
+  const int wgrid = (n + kSgdMulBlock / 64 - 1) / (kSgdMulBlock / 64);
   const int egrid = (int)(((int64_t)n * K + kSgdBlock - 1) / kSgdBlock);
   hipLaunchKernelGGL((k_sgd_send<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)d_latent, (float*)px, n);
-  hipLaunchKernelGGL((k_sgd_multiply<K, 1>), dim3(wgrid), dim3(kSgdBlock), 0, s, g->in.view, (const float*)px,
+  hipLaunchKernelGGL((k_sgd_multiply<K, 1>), dim3(wgrid), dim3(kSgdMulBlock), 0, s, g->in.view, (const float*)px,
                      (const float*)d_latent, (float*)py, (const uint32_t*)nullptr, 0);
   hipLaunchKernelGGL(k_rmse_apply, dim3((n + kSgdBlock - 1) / kSgdBlock), dim3(kSgdBlock), 0, s, (const float*)py,
                      (const uint32_t*)g->in.rowbits, d_latent, n, K + 1);
