@@ -176,11 +176,26 @@ constexpr int kSgdBlock = 256;
 
 template <int K>
 __global__ void __launch_bounds__(kSgdBlock)
-k_sgd_send(const float* __restrict__ vp, float* __restrict__ x, int n) {  // x[v][0..K) = vp[v].lv
+k_sgd_send(const float* __restrict__ vp, float* __restrict__ x, int n) {  // x[v][0..K) = vp[v].lv (x: this shard's slice)
   const int64_t i = (int64_t)blockIdx.x * kSgdBlock + threadIdx.x;
   if (i >= (int64_t)n * K) return;
   const int v = (int)(i / K), c = (int)(i % K);
   x[i] = vp[(int64_t)v * (K + 1) + c];
+}
+
+// x holds every shard's slice (ndevice rows); ours was just written, the others arrive through the
+// exchange callback (an all-gather of K*4-byte elements).  The presence words travel with it
+// (the callback's contract) but all vertices send, so nobody reads them.
+static int sgd_exchange(gm_graph_t* g, float* x, int K) {
+  if (!g->xfn) return GM_OK;
+  void* bits = nullptr;
+  int rc;
+  if ((rc = gm_graph_workspace(g, 2, ((size_t)(g->desc.ndevice + 31) / 32 + 2) * 4, &bits))) return rc;
+  if (gm_graph_exchange(g, GM_XCHG_MESSAGES, x, (int64_t)K * 4, (uint32_t*)bits, nullptr) != 0) {
+    set_error("gm_run_sgd: message exchange callback failed");
+    return GM_ERR_INVALID;
+  }
+  return GM_OK;
 }
 
 // MODE 0: SGD messages into y (row stride K);  MODE 1: RMSE, squared errors summed into y1[row]
@@ -312,7 +327,7 @@ k_rmse_apply(const float* __restrict__ y1, const uint32_t* __restrict__ bits, fl
   if (v < n && ((bits[v >> 5] >> (v & 31)) & 1u)) vp[(int64_t)v * stride + stride - 1] = y1[v];  // sqerr field
 }
 
-// fixed iteration count, single GPU (the sharded case goes through the generic engine)
+// fixed iteration count; sharded graphs exchange x once per iteration
 template <int K>
 int run_sgd_wide(gm_graph_t* g, float* d_latent, float lambda, float step, int iterations, int* iters_done, hipStream_t s) {
   const gm_graph_desc_t& d = g->desc;
@@ -330,7 +345,9 @@ int run_sgd_wide(gm_graph_t* g, float* d_latent, float lambda, float step, int i
   GM_TRY_HIP(hipEventCreate(&ev1));
   GM_TRY_HIP(hipEventRecord(ev0, s));
   for (int it = 0; it < iterations; it++) {
-    hipLaunchKernelGGL((k_sgd_send<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)d_latent, (float*)px, n);
+    hipLaunchKernelGGL((k_sgd_send<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)d_latent,
+                       (float*)px + (size_t)d.row_lo * K, n);
+    if ((rc = sgd_exchange(g, (float*)px, K))) return rc;
     hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3(wgrid), dim3(kSgdMulBlock), 0, s, g->out.view, (const float*)px,
                        (const float*)d_latent, (float*)py, (const uint32_t*)nullptr, 0);
     hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3(wgrid), dim3(kSgdMulBlock), 0, s, g->in.view, (const float*)px,
@@ -358,7 +375,9 @@ int run_rmse_wide(gm_graph_t* g, float* d_latent, hipStream_t s) {
   if ((rc = gm_graph_workspace(g, 3, (size_t)n * K * 4 + 64, &py))) return rc;
   const int wgrid = (n + kSgdMulBlock / 64 - 1) / (kSgdMulBlock / 64);
   const int egrid = (int)(((int64_t)n * K + kSgdBlock - 1) / kSgdBlock);
-  hipLaunchKernelGGL((k_sgd_send<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)d_latent, (float*)px, n);
+  hipLaunchKernelGGL((k_sgd_send<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)d_latent,
+                     (float*)px + (size_t)d.row_lo * K, n);
+  if ((rc = sgd_exchange(g, (float*)px, K))) return rc;
   hipLaunchKernelGGL((k_sgd_multiply<K, 1>), dim3(wgrid), dim3(kSgdMulBlock), 0, s, g->in.view, (const float*)px,
                      (const float*)d_latent, (float*)py, (const uint32_t*)nullptr, 0);
   hipLaunchKernelGGL(k_rmse_apply, dim3((n + kSgdBlock - 1) / kSgdBlock), dim3(kSgdBlock), 0, s, (const float*)py,
@@ -367,8 +386,9 @@ int run_rmse_wide(gm_graph_t* g, float* d_latent, hipStream_t s) {
   return GM_OK;
 }
 static bool wide_path_ok(const gm_graph_t* g) {
-  return g && g->out.present && g->in.present && g->xfn == nullptr && g->desc.val_bytes == 4 && g->out.vals && g->in.vals &&
-         g->desc.row_lo == 0 && g->desc.row_hi == g->desc.ndevice && !g_force_ordered;
+  const bool whole = g && g->desc.row_lo == 0 && g->desc.row_hi == g->desc.ndevice;
+  return g && g->out.present && g->in.present && g->desc.val_bytes == 4 && g->out.vals && g->in.vals &&
+         (whole || g->xfn != nullptr) && !g_force_ordered;
 }
 
 // run a program on caller-provided device state through the common engine

@@ -86,7 +86,7 @@ class MessageExchange:
                     # only the live prefix of every slice travels: gather into a compact staging
                     # buffer, then scatter the prefixes back to their slice positions
                     if self._stage is None or self._stage.numel() < n * L * elt_bytes:
-                        self._stage = torch.empty(n * L * 8, dtype=torch.uint8, device=self.x_bytes.device)
+                        self._stage = torch.empty(n * L * max(elt_bytes, 8), dtype=torch.uint8, device=self.x_bytes.device)
                         self._stage_bits = torch.empty(n * (L // 32), dtype=torch.int32, device=self.x_bytes.device)
                     lo = self.rank * S
                     st = self._stage[: n * L * elt_bytes]
