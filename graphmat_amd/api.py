@@ -9,6 +9,8 @@ in ORIGINAL vertex order (index v-1 for vertex id v), like getVertexproperty(v).
 """
 import ctypes as C
 
+import time
+
 import numpy as np
 import torch
 
@@ -191,7 +193,11 @@ class Graph:
             st[s_nat, 0] = 0
             act[s_nat >> 5] = int(np.uint32(1 << (s_nat & 31)).view(np.int32))
         it = C.c_int(0)
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
         check(self.L.gm_run_bfs(self.h, st.data_ptr(), act.data_ptr(), -1, C.byref(it), _stream()))
+        torch.cuda.synchronize(self.device)
+        self.last_wall_ms = (time.perf_counter() - t0) * 1e3  # the whole call: set-up passes, every level, host syncs
         depth = self.to_vertex_order(st[:, 0] & 0xFFFFFFFF).cpu().numpy().astype(np.uint32)
         parent = self.to_vertex_order(st[:, 1].contiguous()).cpu().numpy().view(np.uint64)
         return depth, parent, it.value

@@ -572,14 +572,14 @@ int gm_graph_create(gm_graph_t** gout, const gm_graph_desc_t* desc, int64_t nnz,
   return GM_OK;
 }
 
-int gm_graph_run_resources(gm_graph_t* g, void** aux_stream, void** fork_event, void** join_event, void** pinned64) {
-  if (!g || !aux_stream || !fork_event || !join_event || !pinned64) { gm::set_error("gm_graph_run_resources: null argument"); return GM_ERR_INVALID; }
+int gm_graph_run_resources(gm_graph_t* g, void** aux_stream, void** fork_event, void** join_event, void** pinned) {
+  if (!g || !aux_stream || !fork_event || !join_event || !pinned) { gm::set_error("gm_graph_run_resources: null argument"); return GM_ERR_INVALID; }
   if (!g->aux_stream) {
     GM_TRY_HIP(hipStreamCreateWithFlags(&g->aux_stream, hipStreamNonBlocking));
     GM_TRY_HIP(hipEventCreateWithFlags(&g->aux_fork, hipEventDisableTiming));
     GM_TRY_HIP(hipEventCreateWithFlags(&g->aux_join, hipEventDisableTiming));
-    GM_TRY_HIP(hipHostMalloc(&g->pinned_flag, 64, hipHostMallocDefault));
-    memset(g->pinned_flag, 0, 64);
+    GM_TRY_HIP(hipHostMalloc(&g->pinned_flag, 4096, hipHostMallocDefault));
+    memset(g->pinned_flag, 0, 4096);
     // first device-to-pinned-host copy of a process sets up the copy path (milliseconds): do it now
     void* d = nullptr;
     GM_TRY_HIP(hipMalloc(&d, 64));
@@ -591,7 +591,7 @@ int gm_graph_run_resources(gm_graph_t* g, void** aux_stream, void** fork_event, 
   *aux_stream = (void*)g->aux_stream;
   *fork_event = (void*)g->aux_fork;
   *join_event = (void*)g->aux_join;
-  *pinned64 = g->pinned_flag;
+  *pinned = g->pinned_flag;
   return GM_OK;
 }
 

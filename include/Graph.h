@@ -308,12 +308,12 @@ void Graph<V, E>::ReadEdgelist(GraphMat::edgelist_t<E> A_edges) {
     // the push step's bid and list arrays): allocated here so the first run does not pay hipMalloc
     void* p = nullptr;
     const size_t n = (size_t)nvertices, words = ((n + 31) / 32 + 2) * 4;
-    const size_t want[GM_WS_SLOTS] = {256, n * 8 + 16, words, n * 8 + 16, words, 0, n * 8 + 64, n * 4 + 64};
+    const size_t want[GM_WS_SLOTS] = {4096, n * 8 + 16, words, n * 8 + 16, words, 0, n * 8 + 64, n * 4 + 64};
     for (int slot = 0; slot < GM_WS_SLOTS; slot++)
       if (want[slot]) (void)gm_graph_workspace(A, slot, want[slot], &p);
     // the first launch of one of the engine's kernels makes the HIP runtime resolve this
     // executable's kernel table (~8 ms measured with the reference's BFS.cpp): pay it here
-    if (gm_graph_workspace(A, 0, 256, &p) == GM_OK) {
+    if (gm_graph_workspace(A, 0, 4096, &p) == GM_OK) {
       hipLaunchKernelGGL(dev::k_fill_u32, dim3(1), dim3(dev::kBlock), 0, 0, (uint32_t*)p, (int64_t)64, 0u);
       (void)hipDeviceSynchronize();
     }

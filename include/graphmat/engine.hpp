@@ -178,7 +178,7 @@ int reduce_kind_of(const P* gp) {
 template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
 void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits,
                     const V* vp, U* y, uint32_t* ybits, int accumulate, hipStream_t s, int* launches, PhaseTimer* timer,
-                    AuxStream* aux) {
+                    AuxStream* aux, const uint32_t* want = nullptr, bool grouped = false) {
   constexpr int WPB = dev::kBlock / 64;  // rows (waves) per workgroup of k_spmv_wave
   if (A.nnz == 0) return;
   const bool overlap = aux != nullptr && aux->s != nullptr && A.ngiant > 0 && (A.nblk > 0 || A.nmid > 0);
@@ -211,11 +211,11 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
       }
       hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa,
                          A, x, xbits, vp, y, ybits, accumulate, debug_flags(), (const U*)terms,
-                         (const unsigned long long*)tpres);
+                         (const unsigned long long*)tpres, want);
     } else {
       hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, REDUCE_ORDERED>),
                          dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, A.giant_row, A.ngiant, x,
-                         xbits, vp, y, ybits, accumulate, debug_flags());
+                         xbits, vp, y, ybits, accumulate, debug_flags(), want);
     }
     (*launches)++;
     if (overlap) {
@@ -228,17 +228,28 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
   if (A.nblk > 0) {
     if (xbits == nullptr)
       hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP, true, RK>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A,
-                         x, xbits, vp, y, ybits, accumulate, debug_flags());
+                         x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
     else
       hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP, false, RK>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A,
-                         x, xbits, vp, y, ybits, accumulate, debug_flags());
+                         x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
     (*launches)++;
     if (timer) timer->mark(TAG_ROWBLOCK);
   }
   if (A.nmid > 0) {
-    hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, RK>), dim3((A.nmid + WPB - 1) / WPB),
-                       dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
-                       debug_flags());
+    bool launched = false;
+    if constexpr (program_row_filter<P>::enabled) {
+      if (grouped && want != nullptr) {  // few rows still wanted: 64 list entries per wave
+        const int groups = (A.nmid + 63) / 64;
+        hipLaunchKernelGGL((dev::k_spmv_wave_grouped<P, T, U, V, E, USE_VP, RK>), dim3((groups + WPB - 1) / WPB),
+                           dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
+                           debug_flags(), want);
+        launched = true;
+      }
+    }
+    if (!launched)
+      hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, RK>), dim3((A.nmid + WPB - 1) / WPB),
+                         dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
+                         debug_flags(), want);
     (*launches)++;
     if (timer) timer->mark(TAG_WAVE);
   }
@@ -249,28 +260,29 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
 template <class P, class T, class U, class V, class E, bool USE_VP>
 void launch_spmv(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits,
                  const V* vp, U* y, uint32_t* ybits, int accumulate, hipStream_t s, int* launches,
-                 PhaseTimer* timer = nullptr, AuxStream* aux = nullptr, int rk = REDUCE_ORDERED) {
+                 PhaseTimer* timer = nullptr, AuxStream* aux = nullptr, int rk = REDUCE_ORDERED, const uint32_t* want = nullptr,
+                 bool grouped = false) {
   if constexpr ((int)program_traits<P>::reduce != (int)REDUCE_AUTO) {
     launch_spmv_rk<P, T, U, V, E, USE_VP, (int)program_traits<P>::reduce>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s,
-                                                                          launches, timer, aux);
+                                                                          launches, timer, aux, want, grouped);
   } else {
     if constexpr (std::is_same<U, float>::value) {
       if (rk == REDUCE_F32_ADD) {
-        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_F32_ADD>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux);
+        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_F32_ADD>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped);
         return;
       }
     }
     if constexpr (std::is_trivially_copyable<U>::value && sizeof(U) <= 8) {
       if (rk == REDUCE_LAST) {
-        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_LAST>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux);
+        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_LAST>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped);
         return;
       }
       if (rk == REDUCE_COMMUTATIVE) {
-        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_COMMUTATIVE>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux);
+        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_COMMUTATIVE>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped);
         return;
       }
     }
-    launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_ORDERED>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux);
+    launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_ORDERED>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped);
   }
 }
 
@@ -327,10 +339,12 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   unsigned long long* h_stats = nullptr;  // pinned: [0] changed flag (as int), [2],[3] frontier vertices / out-edges
 
   void* flag_v = nullptr;
-  gm_graph_workspace(g, 0, 256, &flag_v);
-  int* d_changed = (int*)flag_v;  // words: [0] changed flag, [2] list counter, [4..7] frontier stats (2 x u64)
+  gm_graph_workspace(g, 0, 4096, &flag_v);
+  int* d_changed = (int*)flag_v;  // words: [0] changed flag, [2] list counter, [4..9] frontier stats (3 x u64)
   unsigned int* d_count = (unsigned int*)flag_v + 2;
   unsigned long long* d_stats = (unsigned long long*)flag_v + 2;  // byte offset 16
+  unsigned long long* d_striped = (unsigned long long*)flag_v + 64;  // byte offset 512: kStatSlots x 4 u64 (k_apply)
+  const size_t striped_bytes = (size_t)dev::kStatSlots * 4 * sizeof(unsigned long long);
   void *res_stream = nullptr, *res_fork = nullptr, *res_join = nullptr, *res_pinned = nullptr;
   if (gm_graph_run_resources(g, &res_stream, &res_fork, &res_join, &res_pinned) != GM_OK) {
     printf("GraphMat(HIP): %s\n", gm_last_error());
@@ -338,6 +352,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   }
   int* h_changed = (int*)res_pinned;
   h_stats = (unsigned long long*)h_changed;
+  unsigned long long* h_striped = (unsigned long long*)res_pinned + 64;
   unsigned long long frontier_v = 0, frontier_e = 0, frontier_maxdeg = 0;
   const int stats_grid = grid_for(n) < 2048 ? grid_for(n) : 2048;
   if (can_push) {
@@ -369,6 +384,18 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   AuxStream aux;
   tick("first frontier counted", (int)frontier_v);
   if (!(debug_flags() & dev::DBG_NO_OVERLAP)) aux.attach(res_stream, res_fork, res_join);
+
+  // row-filter bits (program_row_filter): one pass over the vertex properties now, kept current by k_apply
+  uint32_t* d_want = nullptr;
+  if constexpr (program_row_filter<P>::enabled) {
+    void* pw = nullptr;
+    if (gm_graph_workspace(g, 8, ((size_t)(n + 31) / 32 + 2) * 4, &pw) == GM_OK) {
+      d_want = (uint32_t*)pw;
+      dev::ProgArg<P> pa0 = dev::make_prog_arg(gp);
+      hipLaunchKernelGGL((dev::k_want_init<P, V>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa0, (const V*)d_vp, n, d_want);
+    }
+  }
+  const bool grouped_waves = !(debug_flags() & dev::DBG_NO_GROUPED);
 
   int it = 0;
   tick("setup done", 0);
@@ -418,8 +445,8 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       }
     } else if (order == OUT_EDGES || order == ALL_EDGES) {
       const int acc = static_bits ? dev::ACC_STATIC_BITS : 0;
-      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk);
-      else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk);
+      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
+      else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
       if (static_bits) apply_bits = Aout.rowbits;
     }
     if (!push && (order == IN_EDGES || order == ALL_EDGES)) {
@@ -431,26 +458,34 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         apply_bits = Ain.rowbits;
         if (order == ALL_EDGES && gm_graph_rowbits_all(g, &apply_bits) != GM_OK) { printf("%s\n", gm_last_error()); exit(1); }
       }
-      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux, rk);
-      else launch_spmv<P, T, U, V, E, false>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux, rk);
+      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
+      else launch_spmv<P, T, U, V, E, false>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
     }
     // setAllInactive (:184) + apply (:195-225): the active vector is rewritten by k_apply
-    hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const U*)y,
-                       apply_bits, d_vp, d_active, n_live, d_changed);
+    // (when top-down steps are possible the kernel also sizes the next active set)
+    const bool want_stats = can_push && iterations <= 0;
+    if (want_stats) GM_HIP_OK(hipMemsetAsync(d_striped, 0, striped_bytes, s));
+    const int apply_grid = grid_for(n_live) < dev::kApplyMaxBlocks ? grid_for(n_live) : dev::kApplyMaxBlocks;
+    hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y,
+                       apply_bits, d_vp, d_active, n_live, d_changed, want_stats ? Asrc.rowptr : (const int64_t*)nullptr,
+                       want_stats ? d_striped : (unsigned long long*)nullptr, d_want);
     if (n_live < n)  // setAllInactive for the rows k_apply does not visit
       GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
     timer.mark(TAG_APPLY);
     int converged = 0;
     if (iterations <= 0) {  // the flag only matters when running until convergence (:257-259)
-      if (can_push) {  // size of the next active set, fetched with the flag
-        GM_HIP_OK(hipMemsetAsync(d_stats, 0, 24, s));
-        hipLaunchKernelGGL(dev::k_frontier_stats, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active,
-                           Asrc.rowptr, n, d_stats);
-        GM_HIP_OK(hipMemcpyAsync(h_stats + 2, d_stats, 24, hipMemcpyDeviceToHost, s));
-      }
+      if (can_push)  // size of the next active set (written by k_apply), fetched with the flag
+        GM_HIP_OK(hipMemcpyAsync(h_striped, d_striped, striped_bytes, hipMemcpyDeviceToHost, s));
       GM_HIP_OK(hipMemcpyAsync(h_changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, s));
       GM_HIP_OK(hipStreamSynchronize(s));
-      if (can_push) { frontier_v = h_stats[2]; frontier_e = h_stats[3]; frontier_maxdeg = h_stats[4]; }
+      if (can_push) {
+        frontier_v = frontier_e = frontier_maxdeg = 0;
+        for (int k = 0; k < dev::kStatSlots; k++) {
+          frontier_v += h_striped[4 * k];
+          frontier_e += h_striped[4 * k + 1];
+          frontier_maxdeg = h_striped[4 * k + 2] > frontier_maxdeg ? h_striped[4 * k + 2] : frontier_maxdeg;
+        }
+      }
       converged = (*h_changed == 0) ? 1 : 0;
       if (multi) gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &converged);  // :226 Allreduce(LAND)
     }

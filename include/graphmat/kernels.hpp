@@ -59,6 +59,20 @@ struct program_row_filter {
 
 namespace dev {
 
+// Row filter lookup (program_row_filter).  The engine keeps one bit per row, "this row still wants
+// messages" (k_want_init / k_apply), so the multiply kernels test a bit of an L2-resident bitmap
+// instead of fetching the row's vertex property; `want` == nullptr evaluates the filter directly.
+template <class P, class V>
+__device__ __forceinline__ bool row_wanted(const P& p, const V* __restrict__ vp, const uint32_t* __restrict__ want, int row) {
+  if constexpr (program_row_filter<P>::enabled) {
+    if (want != nullptr) return (want[row >> 5] >> (row & 31)) & 1u;
+    return program_row_filter<P>::wants(p, vp[row]);
+  } else {
+    return true;
+  }
+}
+
+
 // [0] chunks accepted by the exact fp32 replay, [1] chunks folded serially (long rows)
 static __device__ unsigned long long g_longrow_counters[4];
 
@@ -122,26 +136,91 @@ k_send(ProgArg<P> pa, const V* __restrict__ vp, const uint32_t* __restrict__ act
 // apply on rows whose y bit is set; a changed vertex (V::operator!=) becomes active and
 // raises the changed flag (zeroed by the host before the launch).  The active vector is fully rewritten (the reference clears
 // it right before, GraphMatRuntime.h:184).
+// row-filter bits of all rows (program_row_filter), computed once per run; k_apply keeps them current
+template <class P, class V>
+__global__ void __launch_bounds__(kBlock)
+k_want_init(ProgArg<P> pa, const V* __restrict__ vp, int n, uint32_t* __restrict__ want) {
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  bool w = false;
+  if constexpr (program_row_filter<P>::enabled) w = i < n && program_row_filter<P>::wants(p, vp[i]);
+  const unsigned long long m = __ballot(w);
+  if ((threadIdx.x & 63) == 0 && i < n) {
+    want[i >> 5] = (uint32_t)m;
+    want[(i >> 5) + 1] = (uint32_t)(m >> 32);
+  }
+}
+
+// With `stats` (programs that may take top-down steps) the kernel also sizes the next active set:
+// vertices, their out-edges, largest out-degree.  The kernel is grid-stride (64-row groups stay
+// with one wave, so the active words are written whole); a workgroup adds its totals with one
+// set of atomics at the end, into one of kStatSlots counter triples that the host sums.
+constexpr int kStatSlots = 64;
+constexpr int kApplyMaxBlocks = 4096;
 template <class P, class U, class V>
 __global__ void __launch_bounds__(kBlock)
 k_apply(ProgArg<P> pa, const U* __restrict__ y, const uint32_t* __restrict__ ybits, V* __restrict__ vp,
-        uint32_t* __restrict__ active, int n, int* __restrict__ changed_flag) {
-  int i = blockIdx.x * kBlock + threadIdx.x;
-  bool changed = false;
-  if (i < n && bit_get(ybits, i)) {
-    ProgArg<P> local = pa;  // apply() is non-const in the API: give it a private copy
-    P& p = *reinterpret_cast<P*>(local.b);
-    V old_prop = vp[i];
-    V cur = old_prop;
-    p.P::apply(y[i], cur);
-    vp[i] = cur;
-    if (old_prop != cur) changed = true;
+        uint32_t* __restrict__ active, int n, int* __restrict__ changed_flag, const int64_t* __restrict__ src_rowptr,
+        unsigned long long* __restrict__ stats /* kStatSlots x {vertices, out-edges, max out-degree, -} or null */,
+        uint32_t* __restrict__ want /* row-filter bits to keep up to date, or null */) {
+  __shared__ unsigned long long s_c[kBlock / 64], s_e[kBlock / 64], s_m[kBlock / 64];
+  unsigned long long cnt = 0, edges = 0, mx = 0;
+  bool any = false;
+  for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n; base += (int64_t)gridDim.x * kBlock) {
+    const int i = (int)base + threadIdx.x;
+    bool changed = false, applied = false, still = false;
+    if (i < n && bit_get(ybits, i)) {
+      ProgArg<P> local = pa;  // apply() is non-const in the API: give it a private copy
+      P& p = *reinterpret_cast<P*>(local.b);
+      V old_prop = vp[i];
+      V cur = old_prop;
+      p.P::apply(y[i], cur);
+      vp[i] = cur;
+      if (old_prop != cur) changed = true;
+      applied = true;
+      if constexpr (program_row_filter<P>::enabled) still = program_row_filter<P>::wants(p, cur);
+    }
+    if constexpr (program_row_filter<P>::enabled) {
+      if (want != nullptr) {  // the wave owns the two words of its 64 rows
+        const unsigned long long ma = __ballot(applied), mw = __ballot(still);
+        if ((threadIdx.x & 63) == 0 && i < n && ma != 0ull) {
+          want[i >> 5] = (want[i >> 5] & ~(uint32_t)ma) | (uint32_t)mw;
+          if (i + 32 < n) want[(i >> 5) + 1] = (want[(i >> 5) + 1] & ~(uint32_t)(ma >> 32)) | (uint32_t)(mw >> 32);
+        }
+      }
+    }
+    const unsigned long long m = __ballot(changed);
+    if ((threadIdx.x & 63) == 0 && i < n) {
+      active[i >> 5] = (uint32_t)m;
+      if (i + 32 < n) active[(i >> 5) + 1] = (uint32_t)(m >> 32);
+      if (m) any = true;
+    }
+    if (stats != nullptr && changed) {
+      const unsigned long long d = (unsigned long long)(src_rowptr[i + 1] - src_rowptr[i]);
+      cnt++;
+      edges += d;
+      mx = d > mx ? d : mx;
+    }
   }
-  unsigned long long m = __ballot(changed);
-  if ((threadIdx.x & 63) == 0 && i < n) {
-    active[i >> 5] = (uint32_t)m;
-    if (i + 32 < n) active[(i >> 5) + 1] = (uint32_t)(m >> 32);
-    if (m) *changed_flag = 1;
+  if (any) *changed_flag = 1;
+  if (stats == nullptr) return;
+  for (int off = 32; off > 0; off >>= 1) {
+    cnt += __shfl_down(cnt, off, 64);
+    edges += __shfl_down(edges, off, 64);
+    const unsigned long long o = __shfl_down(mx, off, 64);
+    mx = o > mx ? o : mx;
+  }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_c[wv] = cnt; s_e[wv] = edges; s_m[wv] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; w++) { cnt += s_c[w]; edges += s_e[w]; mx = s_m[w] > mx ? s_m[w] : mx; }
+    if (cnt) {
+      unsigned long long* slot = stats + 4 * (blockIdx.x % kStatSlots);
+      atomicAdd(&slot[0], cnt);
+      atomicAdd(&slot[1], edges);
+      atomicMax(&slot[2], mx);
+    }
   }
 }
 
@@ -170,7 +249,7 @@ __device__ __forceinline__ E edge_at(const void* __restrict__ vals, int64_t k) {
 // earlier pass (their presence is read from ybits); ACC_STATIC_BITS = do not write presence
 // bits (every x entry is present, so y's presence equals the graph's static row bits)
 enum { ACC_READ_PREV = 1, ACC_STATIC_BITS = 2 };
-enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32 };
+enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64 };
 
 // ------------------------------------------------------------------------------------
 // multiply+reduce over row-blocks (rows of at most GM_SHORT_ROW edges).
@@ -182,8 +261,10 @@ enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_
 template <class P, class T, class U, class V, class E, bool USE_VP, bool DENSE, int RK>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
-                const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg) {
-  constexpr bool STAGE = stageable<T>::value;
+                const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg,
+                const uint32_t* __restrict__ want) {
+  // a=b needs one message per row (the last present one): gather it in phase 2 instead of all of them
+  constexpr bool STAGE = stageable<T>::value && RK != REDUCE_LAST;
   constexpr int PER = kStage / kBlock;  // 8 slots per lane
   typedef typename raw_of<STAGE ? (int)sizeof(T) : 1>::type raw_t;
   // slot(k) = k + k/32: consecutive rows of EQUAL length d (the degree-ranked device order
@@ -206,7 +287,7 @@ k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32
   constexpr bool dense = DENSE;  // every x entry present (xbits == nullptr)
   bool wanted = true;
   if constexpr (program_row_filter<P>::enabled) {
-    wanted = row < r1 && rp1 > rp0 && program_row_filter<P>::wants(p, vp[row]);
+    wanted = row < r1 && rp1 > rp0 && row_wanted(p, vp, want, row);
     if (!__syncthreads_or(wanted)) return;  // no row of this block would use a message
   }
 
@@ -370,41 +451,51 @@ __device__ __forceinline__ U wave_shfl_down(const U& v, int delta) {
 // products are folded in order by broadcasting them one by one out of the lanes'
 // registers (v_readlane), every lane carrying the same running value: no LDS, no
 // barriers, a few cycles per edge.  Loads run two chunks ahead of the fold.
+// wave_row: the work of one wave on one row [e0, e1)
 template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
-__global__ void __launch_bounds__(kBlock)
-k_spmv_wave(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nlist, const T* __restrict__ x,
-            const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
-            uint32_t* __restrict__ ybits, int accumulate, int dbg) {
-  const P& p = *reinterpret_cast<const P*>(pa.b);
-  const int w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (w >= nlist) return;
-  const int lane = threadIdx.x & 63;
-  const int row = rows[w];
-  if constexpr (program_row_filter<P>::enabled)
-    if (!program_row_filter<P>::wants(p, vp[row])) return;
-  const int64_t e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
+__device__ __forceinline__ void wave_row(const P& p, const gm_csr_t& A, const int row, const int64_t e0, const int64_t e1,
+                                         const int lane, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
+                                         const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits,
+                                         const int accumulate, const int dbg) {
   const bool dense = (xbits == nullptr);
   V vprow;
   if constexpr (USE_VP) vprow = vp[row];
 
   if constexpr (RK == REDUCE_LAST) {
-    // reduce is a=b: the last present edge of the row wins; scan backwards
-    for (int64_t hi = e1; hi > e0; hi -= 64) {
-      const int64_t k = hi - 64 + lane;
-      int c = -1;
-      bool pres = false;
-      if (k >= e0) { c = A.colidx[k]; pres = dense || bit_get(xbits, c); }
-      const unsigned long long mask = __ballot(pres);
-      if (mask) {
-        if (lane == 63 - __clzll(mask)) {
-          T m = x[c];
-          U res;
-          p.P::process_message(m, edge_at<E>(A.vals, k), vprow, res);
-          y[row] = res;
-          if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
-        }
-        return;
+    // reduce is a=b: the last present edge of the row wins; scan backwards.  Most rows that find
+    // a message find it in their last chunk, so the scan starts one chunk at a time; a row that
+    // keeps failing (early bottom-up levels: nearly every row scans all its edges) doubles the
+    // number of chunks it has in flight, up to four, instead of paying two dependent memory
+    // latencies per 64 edges.
+    constexpr int DMAX = 4;
+    int depth = 1;
+    for (int64_t hi = e1; hi > e0;) {
+      int c[DMAX];
+      bool pres[DMAX];
+#pragma unroll
+      for (int u = 0; u < DMAX; u++) {
+        const int64_t k = hi - 64 * (u + 1) + lane;
+        c[u] = (u < depth && k >= e0) ? stream_load(&A.colidx[k]) : -1;
       }
+#pragma unroll
+      for (int u = 0; u < DMAX; u++) pres[u] = c[u] >= 0 && (dense || bit_get(xbits, c[u]));
+#pragma unroll
+      for (int u = 0; u < DMAX; u++) {
+        const unsigned long long mask = __ballot(pres[u]);
+        if (mask) {
+          if (lane == 63 - __clzll(mask)) {
+            const int64_t k = hi - 64 * (u + 1) + lane;
+            T m = x[c[u]];
+            U res;
+            p.P::process_message(m, edge_at<E>(A.vals, k), vprow, res);
+            y[row] = res;
+            if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
+          }
+          return;
+        }
+      }
+      hi -= 64 * depth;
+      depth = depth < DMAX ? depth * 2 : DMAX;
     }
     return;  // nothing present: with accumulate an earlier pass's value simply stays
   } else if constexpr (RK == REDUCE_COMMUTATIVE) {
@@ -495,6 +586,52 @@ k_spmv_wave(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nli
       y[row] = acc;
       if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
     }
+  }
+}
+
+
+template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_wave(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nlist, const T* __restrict__ x,
+            const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
+            uint32_t* __restrict__ ybits, int accumulate, int dbg, const uint32_t* __restrict__ want) {
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (w >= nlist) return;
+  const int row = rows[w];
+  if (!row_wanted(p, vp, want, row)) return;
+  wave_row<P, T, U, V, E, USE_VP, RK>(p, A, row, A.rowptr[row], A.rowptr[row + 1], threadIdx.x & 63, x, xbits, vp, y, ybits,
+                                      accumulate, dbg);
+}
+
+// The same for programs with a row filter once most rows have dropped out: a wave takes 64
+// entries of the row list, tests their filter bits with one lane each, and then works through
+// the rows that are still wanted one after the other -- a level of BFS in which few rows are
+// unvisited costs a 64th of the waves (launching a wave per row just to find it filtered out was
+// most of the time of such levels).
+template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_wave_grouped(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nlist, const T* __restrict__ x,
+                    const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
+                    uint32_t* __restrict__ ybits, int accumulate, int dbg, const uint32_t* __restrict__ want) {
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int lane = threadIdx.x & 63;
+  const int idx = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64 + lane;
+  int row = 0;
+  int64_t e0 = 0, e1 = 0;
+  bool wanted = false;
+  if (idx < nlist) {
+    row = rows[idx];
+    wanted = row_wanted(p, vp, want, row);
+    if (wanted) { e0 = A.rowptr[row]; e1 = A.rowptr[row + 1]; }
+  }
+  unsigned long long todo = __ballot(wanted);
+  while (todo) {
+    const int r = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int rr = __builtin_amdgcn_readlane(row, r);
+    const int64_t a = wave_bcast(e0, r), b = wave_bcast(e1, r);
+    wave_row<P, T, U, V, E, USE_VP, RK>(p, A, rr, a, b, lane, x, xbits, vp, y, ybits, accumulate, dbg);
   }
 }
 
@@ -610,7 +747,7 @@ template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
 __global__ void __launch_bounds__(kGiant)
 k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
                const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg,
-               const U* __restrict__ terms, const unsigned long long* __restrict__ tpres) {
+               const U* __restrict__ terms, const unsigned long long* __restrict__ tpres, const uint32_t* __restrict__ want) {
   constexpr bool SMALL_U = sizeof(U) <= 8;
   constexpr int CH = kLongChunk, PER = kLongPer;
   // ordered kinds stage the per-edge products (U) of a chunk in LDS for the serial fold
@@ -623,8 +760,7 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
 
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int row = A.giant_row[blockIdx.x];
-  if constexpr (program_row_filter<P>::enabled)
-    if (!program_row_filter<P>::wants(p, vp[row])) return;
+  if (!row_wanted(p, vp, want, row)) return;
   const int64_t e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
   const int tid = threadIdx.x;
   V vprow;

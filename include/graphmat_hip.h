@@ -271,7 +271,7 @@ int gm_graph_last_stats(const gm_graph_t* g, gm_run_stats_t* out);
  * Device scratch owned by the graph, grown on demand and reused across runs (the
  * reference allocates x/y per run_graph_program call, GraphMatRuntime.h:110-120).
  * slot in [0, GM_WS_SLOTS). */
-#define GM_WS_SLOTS 8
+#define GM_WS_SLOTS 10
 int gm_graph_workspace(gm_graph_t* g, int slot, size_t bytes, void** d_ptr);
 /* Let the caller provide a scratch slot (e.g. a torch tensor it also hands to its collective
  * library): slot 1 = message values x (nvertices * elt bytes), slot 2 = x presence bits
@@ -280,10 +280,10 @@ int gm_graph_workspace(gm_graph_t* g, int slot, size_t bytes, void** d_ptr);
 int gm_graph_adopt_workspace(gm_graph_t* g, int slot, void* d_ptr, size_t bytes);
 /* Per-graph run resources, created once with the graph and destroyed with it: an auxiliary
  * non-blocking hipStream_t (the giant-row passes overlap the other multiply kernels on it),
- * two hipEvent_t (fork / join of that stream) and 64 bytes of pinned host memory (the
+ * two hipEvent_t (fork / join of that stream) and 4096 bytes of pinned host memory (the
  * convergence flag and frontier statistics are copied there every iteration).  Returned as
  * void* so this header stays free of HIP types. */
-int gm_graph_run_resources(gm_graph_t* g, void** aux_stream, void** fork_event, void** join_event, void** pinned64);
+int gm_graph_run_resources(gm_graph_t* g, void** aux_stream, void** fork_event, void** join_event, void** pinned);
 /* counters of the giant-row kernel since the last call (then reset): 16-edge groups
  * out[0] taken by the exact parallel fp32 replay, out[1] folded serially */
 int gm_debug_counters(int64_t out[4]);
