@@ -408,6 +408,7 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   v.gterm_off = out->gterm_off;
   v.ngchunk = (int32_t)h_gcr.size();
   v.giant_edges = h_gto.back();
+  v.short_row = g_short_row;
   return GM_OK;
 }
 

@@ -225,7 +225,15 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
       timer->mark(TAG_GIANT);
     }
   }
-  if (A.nblk > 0) {
+  if (A.nblk > 0 && RK == REDUCE_LAST) {
+    // a=b: one lane per row over the whole row range (short rows pick themselves by their length)
+    if constexpr (RK == REDUCE_LAST) {
+      hipLaunchKernelGGL((dev::k_spmv_short_last<P, T, U, V, E, USE_VP>), dim3(grid_for(A.nrows)), dim3(dev::kBlock), 0, s,
+                         pa, A, x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
+      (*launches)++;
+      if (timer) timer->mark(TAG_ROWBLOCK);
+    }
+  } else if (A.nblk > 0) {
     if (xbits == nullptr)
       hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP, true, RK>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A,
                          x, xbits, vp, y, ybits, accumulate, debug_flags(), want);

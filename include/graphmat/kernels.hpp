@@ -50,6 +50,9 @@ struct program_traits {
 // wants(prog, vp) is false (BFS: a vertex that already has a depth ignores further messages).
 // Such rows then skip the multiply altogether -- the "bottom-up" optimisation -- without
 // changing any result.  Specialise with enabled = true and a __host__ __device__ wants().
+// wants() must depend on the vertex property alone (not on program members that
+// do_every_iteration changes): the engine caches it as one bit per row, recomputed at the start
+// of a run and whenever apply() touches the row.
 template <class P>
 struct program_row_filter {
   static constexpr bool enabled = false;
@@ -251,6 +254,69 @@ __device__ __forceinline__ E edge_at(const void* __restrict__ vals, int64_t k) {
 enum { ACC_READ_PREV = 1, ACC_STATIC_BITS = 2 };
 enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64 };
 
+// presence bits of a wave's 64 consecutive rows: one atomicOr per 32-row word (not per row:
+// same-word atomics from 32 lanes serialise in the L2); nothing when the bits are static
+__device__ __forceinline__ void publish_row_bits(bool wrote, int row, uint32_t* __restrict__ ybits, int accumulate) {
+  const unsigned long long hm = __ballot(wrote);
+  const int lane = threadIdx.x & 63;
+  if (hm != 0ull && !(accumulate & 2 /* ACC_STATIC_BITS */) && (lane == 0 || (row & 31) == 0)) {
+    const int in_word = 32 - (row & 31);
+    const int left = 64 - lane;
+    const int cnt = in_word < left ? in_word : left;
+    const unsigned long long mask = (cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull);
+    const uint32_t bits = (uint32_t)(((hm >> lane) & mask) << (row & 31));
+    if (bits) atomicOr(&ybits[row >> 5], bits);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Short rows of REDUCE_LAST programs (reduce is a=b: a row needs only its LAST present message).
+// No row-blocks, no staging: one lane per row of the whole row range; a lane whose row is short
+// (1..short_row edges; longer rows belong to the wave / giant kernels) and still wanted walks it
+// backwards, eight edges per step (independent loads), and stops at the first present
+// in-neighbour.  Rows that are filtered out cost one bit of a coalesced word; short rows average
+// a handful of edges, so most finish in one step, and in the levels where the frontier is large
+// the scan ends after an edge or two instead of testing every edge.
+template <class P, class T, class U, class V, class E, bool USE_VP>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_short_last(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
+                  const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg,
+                  const uint32_t* __restrict__ want) {
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int row = blockIdx.x * kBlock + threadIdx.x;
+  const bool dense = (xbits == nullptr);
+  bool wrote = false;
+  if (row < A.nrows && row_wanted(p, vp, want, row)) {
+    const int64_t rp0 = A.rowptr[row], rp1 = A.rowptr[row + 1];
+    if (rp1 > rp0 && rp1 - rp0 <= (int64_t)A.short_row) {
+      constexpr int B = 8;
+      int64_t kk = -1;
+      int cc = -1;
+      for (int64_t hi = rp1; hi > rp0 && cc < 0; hi -= B) {
+        int c[B];
+#pragma unroll
+        for (int j = 0; j < B; j++) c[j] = (hi - 1 - j >= rp0) ? A.colidx[hi - 1 - j] : -1;
+        bool pr[B];
+#pragma unroll
+        for (int j = 0; j < B; j++) pr[j] = c[j] >= 0 && (dense || ((dbg & DBG_SKIP_GATHER) ? (c[j] == 0x7fffffff) : bit_get(xbits, c[j])));
+#pragma unroll
+        for (int j = B - 1; j >= 0; j--)
+          if (pr[j]) { cc = c[j]; kk = hi - 1 - j; }  // ends with the smallest j = the edge nearest the row's end
+      }
+      if (cc >= 0 && !(dbg & DBG_SKIP_FOLD)) {
+        V vprow;
+        if constexpr (USE_VP) vprow = vp[row];
+        T m = x[cc];
+        U res;
+        p.P::process_message(m, edge_at<E>(A.vals, kk), vprow, res);
+        y[row] = res;
+        wrote = true;
+      }
+    }
+  }
+  publish_row_bits(wrote, row, ybits, accumulate);
+}
+
 // ------------------------------------------------------------------------------------
 // multiply+reduce over row-blocks (rows of at most GM_SHORT_ROW edges).
 //   USE_VP : 3-operand form, process_message sees vp[row] (spmspv3.h:70)
@@ -402,20 +468,7 @@ k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32
       wrote = true;
     }
   }
-  // presence bits: the 64 rows of a wave are consecutive, so one atomicOr per 32-row word
-  // (not per row: same-word atomics from 32 lanes serialise in the L2)
-  {
-    const unsigned long long hm = __ballot(wrote);
-    const int lane = threadIdx.x & 63;
-    if (hm != 0ull && !(accumulate & ACC_STATIC_BITS) && (lane == 0 || (row & 31) == 0)) {
-      const int in_word = 32 - (row & 31);
-      const int left = 64 - lane;
-      const int cnt = in_word < left ? in_word : left;
-      const unsigned long long mask = (cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull);
-      const uint32_t bits = (uint32_t)(((hm >> lane) & mask) << (row & 31));
-      if (bits) atomicOr(&ybits[row >> 5], bits);  // (skipped below when the bits are static)
-    }
-  }
+  publish_row_bits(wrote, row, ybits, accumulate);
 #undef GM_SLOT
 }
 

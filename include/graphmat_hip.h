@@ -163,6 +163,7 @@ typedef struct {
   const int64_t* gterm_off;   /* [ngiant+1] offset of each giant row's products in the scratch */
   int32_t ngchunk;
   int64_t giant_edges;        /* = gterm_off[ngiant]                                          */
+  int32_t short_row;          /* rows of up to this many edges are in row-blocks, longer ones in mid/giant_row */
 } gm_csr_t;
 
 #define GM_GIANT_CHUNK 4096 /* edges per piece of the parallel giant-row pass */
