@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--ref-threads", type=int, default=1, help="layout parameter of the id permutation (oracle config)")
     ap.add_argument("--cpu-scale", type=int, default=22, help="RMAT scale of the cpu_baseline sample (0 = skip)")
-    ap.add_argument("--cpu-iters", type=int, default=30)
+    ap.add_argument("--cpu-iters", type=int, default=300, help="iterations of the cpu_baseline sample (~10-15 s of CPU work)")
     ap.add_argument("--no-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--short-row", type=int, default=0, help="experiment: rows up to this many edges go to row-blocks")
     ap.add_argument("--giant-row", type=int, default=0, help="experiment: rows above this many edges get a workgroup")
