@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--giant-row", type=int, default=0, help="experiment: rows above this many edges get a workgroup")
     ap.add_argument("--rank-cap", type=int, default=0, help="experiment: rank only vertices of degree >= cap, others stay in native order")
     ap.add_argument("--rank-by", type=int, default=0, help="experiment: device order ranked by 0 total, 1 out-, 2 in-degree")
+    ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: plain exchange between send and multiply (no two-stage overlap)")
     ap.add_argument("--native-layout", action="store_true", help="device order = native order (single GPU; for A/B)")
     ap.add_argument("--debug-flags", type=int, default=0, help="ablation only (results become invalid): 1 skip fold, 2 skip gathers")
     args = ap.parse_args()
@@ -152,7 +153,13 @@ def main():
         x_bits = torch.zeros((g.ndevice + 31) // 32 + 2, dtype=torch.int32, device=dev)
         _lib.check(L.gm_graph_adopt_workspace(g.h, 1, x_bytes.data_ptr(), x_bytes.numel()))
         _lib.check(L.gm_graph_adopt_workspace(g.h, 2, x_bits.data_ptr(), x_bits.numel() * 4))
-        ex = MessageExchange(ranges, rank, x_bytes, x_bits, live_rows=g.xchg_rows)
+        # second message buffer: lets the library exchange one stage's messages while the other
+        # stage computes (graphmat_hip.h GM_XCHG_PART); --no-overlap keeps the plain exchange
+        x_bytes2 = None
+        if not args.no_overlap:
+            x_bytes2 = torch.zeros(g.ndevice * 4 + 64, dtype=torch.uint8, device=dev)
+            _lib.check(L.gm_graph_adopt_workspace(g.h, 9, x_bytes2.data_ptr(), x_bytes2.numel()))
+        ex = MessageExchange(ranges, rank, x_bytes, x_bits, live_rows=g.xchg_rows, x_bytes2=x_bytes2)
         cb = ex.callback()
         g._cb = cb
         _lib.check(L.gm_graph_set_exchange(g.h, cb, None))
@@ -177,7 +184,32 @@ def main():
     # ---- state, Degree pass, warm-up ---------------------------------------------------------
     st = g.new_pr_state()
     g.run_degree(st)
+    overlapped = False
+    if world > 1 and ex is not None and ex.x_bytes2 is not None:
+        # the overlapped schedule must give the plain loop's bits; if it does not (or cannot run
+        # here), say so and time the plain loop
+        ok = 1
+        try:
+            a, b = st.clone(), st.clone()
+            g.run_pagerank(a, 3)
+            overlapped = ex.parts > 0
+            L.gm_set_option(b"debug_flags", 128)
+            g.run_pagerank(b, 3)
+            L.gm_set_option(b"debug_flags", 0)
+            ok = 1 if bool(torch.equal(a, b)) else 0
+            del a, b
+        except Exception as e:  # pragma: no cover
+            log(rank, "overlapped exchange check failed: %r" % (e,))
+            ok = 0
+        okt = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) != 1:
+            log(rank, "overlapped two-stage schedule disagrees with the plain loop: using the plain loop")
+            args.debug_flags |= 128
+            overlapped = False
     if args.warmup > 0:
+        if args.debug_flags & 128:
+            L.gm_set_option(b"debug_flags", args.debug_flags)
         g.run_pagerank(st, args.warmup)
     cnt64 = (C.c_int64 * 4)()
     L.gm_debug_counters(cnt64)  # reset
@@ -249,7 +281,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "PageRank (alpha=0.3, fp32, fixed iteration count) on RMAT scale-%d, a/b/c=.57/.19/.19, "
                                "edge factor %d, seed %d, duplicates and self loops kept" % (args.scale, args.edge_factor, args.seed),
-                   "V": nv, "E": E, "parallelism": "1d-rows x%d" % world, "id_layout_nparts": nparts,
+                   "V": nv, "E": E, "parallelism": "1d-rows x%d" % world, "exchange": ("two-stage overlapped all-gather" if overlapped else
+                                                                             ("all-gather between send and multiply" if world > 1 else "none")), "id_layout_nparts": nparts,
                    "device_order": "native" if args.native_layout else "degree-ranked, dealt over shards",
                    "rows_per_shard": S, "exchanged_rows_per_shard": int(g.xchg_rows),
                    "max_in_degree_rank0": max_deg,
@@ -258,7 +291,7 @@ def main():
         "iter_hbm_frac": round(iter_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4),
         "roofline": roof,
     }
-    if args.debug_flags:
+    if args.debug_flags & ~(128 | 64 | 32 | 16):  # flags that only choose between exact strategies keep the result valid
         out["INVALID_ablation_debug_flags"] = args.debug_flags
     if rank == 0 and world == 1 and args.cpu_scale > 0:
         out["cpu_baseline"] = cpu_baseline(args.cpu_scale, args.cpu_iters, rank)

@@ -10,6 +10,8 @@ GM_DIR_OUT = 1
 GM_DIR_IN = 2
 GM_XCHG_MESSAGES = 0
 GM_XCHG_CONVERGED = 1
+GM_XCHG_PART = 2
+GM_XCHG_WAIT = 3
 GM_LAYOUT_NATIVE = 0
 GM_LAYOUT_DEGREE = 1
 
@@ -81,6 +83,8 @@ SIGNATURES = {
     "gm_graph_exchange": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.POINTER(C.c_int)]),
     "gm_graph_has_exchange": (C.c_int, [_P]),
     "gm_graph_timing_enabled": (C.c_int, [_P]),
+    "gm_graph_split": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gm_graph_workspace_info": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "gm_graph_run_resources": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "gm_graph_record_stats": (C.c_int, [_P, C.POINTER(RunStats)]),
     "gm_reduce_sum_f64": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_double), _P]),

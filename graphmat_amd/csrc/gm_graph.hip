@@ -756,6 +756,61 @@ int gm_graph_workspace(gm_graph_t* g, int slot, size_t bytes, void** d_ptr) {
   return GM_OK;
 }
 
+int gm_graph_workspace_info(const gm_graph_t* g, int slot, void** d_ptr, size_t* bytes, int* external) {
+  if (!g || slot < 0 || slot >= GM_WS_SLOTS || !d_ptr || !bytes || !external) { gm::set_error("gm_graph_workspace_info: invalid argument"); return GM_ERR_INVALID; }
+  *d_ptr = g->ws[slot];
+  *bytes = g->ws_bytes[slot];
+  *external = g->ws_external[slot];
+  return GM_OK;
+}
+
+int gm_graph_split(const gm_graph_t* g, int direction, int head_permille, int32_t* row_split, int32_t* blk_split,
+                   int32_t* mid_split) {
+  if (!g || !row_split || !blk_split || !mid_split || head_permille < 1 || head_permille > 999) { gm::set_error("gm_graph_split: invalid argument"); return GM_ERR_INVALID; }
+  const gm::CsrOwned* c = direction == GM_DIR_OUT ? &g->out : direction == GM_DIR_IN ? &g->in : nullptr;
+  if (!c || !c->present) { gm::set_error("gm_graph_split: direction %d not built", direction); return GM_ERR_INVALID; }
+  const gm_csr_t& A = c->view;
+  auto rd64 = [&](const int64_t* p, int64_t i, int64_t* out) { return hipMemcpy(out, p + i, 8, hipMemcpyDeviceToHost); };
+  auto rd32 = [&](const int32_t* p, int64_t i, int32_t* out) { return hipMemcpy(out, p + i, 4, hipMemcpyDeviceToHost); };
+  const int64_t target = (A.nnz * head_permille + 999) / 1000;
+  // smallest multiple of 64 (capped at nrows) with rowptr[row] >= target
+  int64_t lo = 0, hi = ((int64_t)A.nrows + 63) / 64;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) / 2;
+    const int64_t r = mid * 64 < A.nrows ? mid * 64 : A.nrows;
+    int64_t v = 0;
+    GM_TRY_HIP(rd64(A.rowptr, r, &v));
+    if (v >= target) hi = mid; else lo = mid + 1;
+  }
+  int64_t rs = lo * 64 < A.nrows ? lo * 64 : A.nrows;
+  if (*row_split > 0) rs = (int64_t)(*row_split) < A.nrows ? (int64_t)(*row_split) / 64 * 64 : A.nrows;  // caller's choice
+  // first row-block whose rows end beyond rs
+  int64_t bl = 0, bh = A.nblk;
+  while (bl < bh) {
+    const int64_t mid = (bl + bh) / 2;
+    int32_t sg = 0, r1 = 0;
+    GM_TRY_HIP(rd32(A.blk_seg, mid, &sg));
+    GM_TRY_HIP(rd32(A.seg_row, (int64_t)sg + 1, &r1));
+    if ((int64_t)r1 > rs) bh = mid; else bl = mid + 1;
+  }
+  int64_t ml = 0, mh = A.nmid;
+  while (ml < mh) {
+    const int64_t mid = (ml + mh) / 2;
+    int32_t r = 0;
+    GM_TRY_HIP(rd32(A.mid_row, mid, &r));
+    if ((int64_t)r >= rs) mh = mid; else ml = mid + 1;
+  }
+  if (A.ngiant > 0) {
+    int32_t last = 0;
+    GM_TRY_HIP(rd32(A.giant_row, (int64_t)A.ngiant - 1, &last));
+    if ((int64_t)last >= rs) { gm::set_error("gm_graph_split: a giant row lies in the tail"); return GM_ERR_INVALID; }
+  }
+  *row_split = (int32_t)rs;
+  *blk_split = (int32_t)bl;
+  *mid_split = (int32_t)ml;
+  return GM_OK;
+}
+
 int gm_graph_adopt_workspace(gm_graph_t* g, int slot, void* d_ptr, size_t bytes) {
   if (!g || slot < 0 || slot >= GM_WS_SLOTS) { gm::set_error("gm_graph_adopt_workspace: invalid argument"); return GM_ERR_INVALID; }
   if (g->ws[slot] && !g->ws_external[slot]) (void)hipFree(g->ws[slot]);

@@ -48,9 +48,11 @@ class MessageExchange:
     the graph (gm_graph_adopt_workspace), so the pointers the callback receives are these.
     """
 
-    def __init__(self, ranges, rank, x_bytes, x_bits, group=None, live_rows=None):
+    def __init__(self, ranges, rank, x_bytes, x_bits, group=None, live_rows=None, x_bytes2=None):
         """live_rows: only the first live_rows entries of every slice need to travel (the
-        library's gm_graph_desc_t.xchg_rows); None = whole slices."""
+        library's gm_graph_desc_t.xchg_rows); None = whole slices.
+        x_bytes2: second message buffer (adopted as workspace slot 9) for the overlapped two-stage
+        schedule (GM_XCHG_PART / GM_XCHG_WAIT)."""
         self.ranges = [(int(a), int(b)) for a, b in ranges]
         self.live = None if live_rows is None else int(live_rows)
         self.rank = rank
@@ -62,6 +64,56 @@ class MessageExchange:
         self.no_fast_path = False
         self._stage = None
         self._stage_bits = None
+        self.x_bytes2 = x_bytes2
+        self.parts = 0
+        self._pending = []       # (work handle, deferred copy or None)
+        self._part_stage = None
+
+    def _buffer_of(self, d_ptr):
+        if d_ptr == self.x_bytes.data_ptr():
+            return self.x_bytes
+        if self.x_bytes2 is not None and d_ptr == self.x_bytes2.data_ptr():
+            return self.x_bytes2
+        return None
+
+    def start_part(self, buf, first, count, elt_bytes):
+        """Every shard's rows [first, first+count) of its slice of `buf` are to reach all shards;
+        returns once the transfer has been started."""
+        n = len(self.ranges)
+        S = self.ranges[0][1] - self.ranges[0][0]
+        self.parts += 1
+        if self._equal_slices() and dist.get_backend(self.group) == "nccl" and not self.no_fast_path:
+            try:
+                total = S if self.live is None else min(self.live, S)
+                need = n * total * elt_bytes
+                if self._part_stage is None or self._part_stage.numel() < need:
+                    self._part_stage = torch.empty(need, dtype=torch.uint8, device=buf.device)
+                # each part owns its own region of the staging buffer
+                st = self._part_stage[n * first * elt_bytes: n * (first + count) * elt_bytes]
+                lo = self.rank * S + first
+                w = dist.all_gather_into_tensor(st, buf[lo * elt_bytes: (lo + count) * elt_bytes], group=self.group,
+                                                async_op=True)
+
+                def scatter(st=st, buf=buf, first=first, count=count):
+                    xv = buf[: n * S * elt_bytes].view(n, S * elt_bytes)
+                    xv[:, first * elt_bytes: (first + count) * elt_bytes].copy_(st.view(n, count * elt_bytes))
+                self._pending.append((w, scatter))
+                return
+            except Exception as e:
+                print("graphmat_amd.dist: async all_gather_into_tensor failed (%r); using broadcasts" % (e,), flush=True)
+                self.no_fast_path = True
+        for r in range(n):
+            lo = r * S + first
+            self._pending.append((dist.broadcast(buf[lo * elt_bytes: (lo + count) * elt_bytes], src=r, group=self.group,
+                                                 async_op=True), None))
+
+    def wait_parts(self):
+        pending, self._pending = self._pending, []
+        for w, _ in pending:
+            w.wait()
+        for _, after in pending:
+            if after is not None:
+                after()
 
     def _equal_slices(self):
         n = len(self.ranges)
@@ -126,6 +178,13 @@ class MessageExchange:
                     if d_ptr != self.x_bytes.data_ptr() or d_bits != self.x_bits.data_ptr():
                         return 2
                     self.all_gather_slices(int(elt_bytes))
+                elif kind == _lib.GM_XCHG_PART:
+                    buf = self._buffer_of(d_ptr)
+                    if buf is None:
+                        return 2
+                    self.start_part(buf, int(h_flag[0]), int(h_flag[1]), int(elt_bytes))
+                elif kind == _lib.GM_XCHG_WAIT:
+                    self.wait_parts()
                 else:
                     h_flag[0] = self.all_reduce_converged(h_flag[0])
                 return 0
@@ -135,10 +194,12 @@ class MessageExchange:
         return _lib.EXCHANGE_FN(fn)
 
 
-def attach_exchange(g, group=None, max_elt_bytes=8):
+def attach_exchange(g, group=None, max_elt_bytes=8, overlap=True):
     """Make a sharded api.Graph (GM_LAYOUT_DEGREE, nshards = world size) exchange its messages
     over torch.distributed: allocates the global x buffers, hands them to the library, installs
-    the callback and a gather function for results."""
+    the callback and a gather function for results.  overlap: also give the library a second
+    message buffer so fixed-count ALL_VERTICES programs can exchange one stage's messages while
+    the other stage computes."""
     import ctypes as C
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -150,7 +211,11 @@ def attach_exchange(g, group=None, max_elt_bytes=8):
     L = _lib.lib()
     _lib.check(L.gm_graph_adopt_workspace(g.h, 1, x_bytes.data_ptr(), x_bytes.numel()))
     _lib.check(L.gm_graph_adopt_workspace(g.h, 2, x_bits.data_ptr(), x_bits.numel() * 4))
-    ex = MessageExchange(ranges, rank, x_bytes, x_bits, group, live_rows=g.xchg_rows)
+    x_bytes2 = None
+    if overlap:
+        x_bytes2 = torch.zeros(g.ndevice * max_elt_bytes + 64, dtype=torch.uint8, device=g.device)
+        _lib.check(L.gm_graph_adopt_workspace(g.h, 9, x_bytes2.data_ptr(), x_bytes2.numel()))
+    ex = MessageExchange(ranges, rank, x_bytes, x_bits, group, live_rows=g.xchg_rows, x_bytes2=x_bytes2)
     cb = ex.callback()
     g._cb = (cb, ex)  # keep alive
     _lib.check(L.gm_graph_set_exchange(g.h, cb, None))

@@ -405,6 +405,83 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   }
   const bool grouped_waves = !(debug_flags() & dev::DBG_NO_GROUPED);
 
+  // ---- overlapped two-stage schedule for sharded fixed-count ALL_VERTICES / OUT_EDGES runs ------
+  // (graphmat_hip.h: GM_XCHG_PART).  Stage 1 multiplies, applies and sends the TAIL rows (most of
+  // the rows, a third of the edges) and starts their exchange; stage 2 does the same for the HEAD
+  // rows (the busy ones) while stage 1's messages travel.  Each row is still folded by one kernel
+  // in stored order, so results are those of the plain loop below.
+  if (multi && act == ALL_VERTICES && order == OUT_EDGES && iterations > 0 && !(debug_flags() & dev::DBG_NO_PIPELINE)) {
+    void* x2v = nullptr;
+    size_t x2_bytes = 0;
+    int x2_ext = 0;
+    int32_t rs = 0, bs = 0, ms = 0;
+    // every shard must use the same split (the parts are the same rows of every slice): take the
+    // largest of the shards' own choices, then check that it suits everybody
+    bool staged = false;
+    if (gm_graph_workspace_info(g, 9, &x2v, &x2_bytes, &x2_ext) == GM_OK && x2_ext && x2v != nullptr &&
+        x2_bytes >= (size_t)desc.ndevice * sizeof(T)) {
+      int mine = (gm_graph_split(g, GM_DIR_OUT, 650, &rs, &bs, &ms) == GM_OK) ? -rs : 0;
+      gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &mine);  // MIN of -rs = -(largest rs)
+      rs = -mine;
+      int fine = (rs >= 64 && rs < n_live && gm_graph_split(g, GM_DIR_OUT, 650, &rs, &bs, &ms) == GM_OK) ? 1 : 0;
+      gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &fine);
+      staged = fine == 1;
+    }
+    if (staged) {
+      if (verbose) printf("GraphMat(HIP): two-stage schedule, head rows [0,%d) tail rows [%d,%d)\n", rs, rs, n_live);
+      T* xcur = x;
+      T* xnext = (T*)x2v;
+      gm_csr_t At = Aout, Ah = Aout;
+      At.blk_seg += bs; At.nblk -= bs; At.mid_row += ms; At.nmid -= ms; At.ngiant = 0; At.ngchunk = 0;
+      Ah.nblk = bs; Ah.nmid = ms;
+      auto fail = [&](const char* what) { printf("GraphMat(HIP): %s\n", what); exit(1); };
+      auto stage = [&](const dev::ProgArg<P>& pa, const gm_csr_t& A, int r0, int r1, bool more) {
+        if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, A, xcur, nullptr, d_vp, y, ybits, dev::ACC_STATIC_BITS, s, &st.spmv_launches, &timer, &aux, rk);
+        else launch_spmv<P, T, U, V, E, false>(g, pa, A, xcur, nullptr, d_vp, y, ybits, dev::ACC_STATIC_BITS, s, &st.spmv_launches, &timer, &aux, rk);
+        const int cnt = r1 - r0;
+        const int ag = grid_for(cnt) < dev::kApplyMaxBlocks ? grid_for(cnt) : dev::kApplyMaxBlocks;
+        hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(ag), dim3(dev::kBlock), 0, s, pa, (const U*)(y + r0), Aout.rowbits + r0 / 32,
+                           d_vp + r0, d_active + r0 / 32, cnt, d_changed, (const int64_t*)nullptr, (unsigned long long*)nullptr,
+                           (uint32_t*)nullptr);
+        timer.mark(TAG_APPLY);
+        if (more) {
+          hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(cnt)), dim3(dev::kBlock), 0, s, pa, (const V*)(d_vp + r0),
+                             (const uint32_t*)nullptr, xnext, xbits, cnt, desc.row_lo + r0);
+          int part[2] = {r0, cnt};
+          if (gm_graph_exchange(g, GM_XCHG_PART, xnext, (int64_t)sizeof(T), nullptr, part) != 0) fail("partial message exchange failed");
+          timer.mark(TAG_SEND);
+        }
+      };
+      int it = 0;
+      {
+        dev::ProgArg<P> pa = dev::make_prog_arg(gp);
+        timer.mark(TAG_START);
+        hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
+                           (const uint32_t*)nullptr, xcur, xbits, n_live, desc.row_lo);
+        if (gm_graph_exchange(g, GM_XCHG_MESSAGES, xcur, (int64_t)sizeof(T), xbits, nullptr) != 0) fail("message exchange callback failed");
+        timer.mark(TAG_SEND);
+      }
+      for (; it < iterations; it++) {
+        dev::ProgArg<P> pa = dev::make_prog_arg(gp);
+        const bool more = it + 1 < iterations;
+        timer.mark(TAG_START);
+        stage(pa, At, rs, n_live, more);
+        stage(pa, Ah, 0, rs, more);
+        if (more && gm_graph_exchange(g, GM_XCHG_WAIT, xnext, (int64_t)sizeof(T), nullptr, nullptr) != 0) fail("message exchange wait failed");
+        if (n_live < n) GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
+        gp->do_every_iteration(it);
+        T* t = xcur; xcur = xnext; xnext = t;
+      }
+      hipLaunchKernelGGL(dev::k_fill_u32, dim3(grid_for(nwords)), dim3(dev::kBlock), 0, s, d_active, (int64_t)nwords, 0xffffffffu);
+      GM_HIP_OK(hipStreamSynchronize(s));
+      aux.finish();
+      st.iterations = it;
+      timer.finish(&st);
+      gm_graph_record_stats(g, &st);
+      return it;
+    }
+  }
+
   int it = 0;
   tick("setup done", 0);
   while (true) {

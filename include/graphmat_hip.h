@@ -219,8 +219,30 @@ int gm_rmat_generate(int scale, uint64_t seed, int64_t first_edge, int64_t count
  * host int (1 = locally converged) to be AND-reduced in place.  Return 0 on success. */
 #define GM_XCHG_MESSAGES 0
 #define GM_XCHG_CONVERGED 1
+/* Overlapped form, used by fixed-count ALL_VERTICES programs when the caller has also adopted a
+ * second message buffer (workspace slot 9): the rows are processed in two stages -- first the
+ * many rows with few edges, then the few busy rows -- and each stage's part of the NEXT
+ * iteration's message vector is exchanged while the other stage computes.
+ * GM_XCHG_PART: d_ptr = base of the message buffer to fill (slot 1 or slot 9), h_flag[0] = first
+ * row of the part inside every shard's slice, h_flag[1] = number of rows; every shard's rows
+ * [h_flag[0], h_flag[0]+h_flag[1]) of its slice must reach all shards.  May return before the data
+ * has arrived.  GM_XCHG_WAIT: work enqueued afterwards on the library's stream must see all parts.
+ * No presence bits travel (every vertex sends). */
+#define GM_XCHG_PART 2
+#define GM_XCHG_WAIT 3
 typedef int (*gm_exchange_fn)(void* ctx, int kind, void* d_ptr, int64_t elt_bytes, uint32_t* d_bits, int* h_flag);
 int gm_graph_set_exchange(gm_graph_t* g, gm_exchange_fn fn, void* ctx);
+/* Two-stage schedule of a direction's rows: "head" = rows [0, *row_split) holding at least
+ * head_permille/1000 of the direction's edges (the degree-ranked device order puts the busy rows
+ * first), "tail" = the rest.  On entry *row_split = 0 asks the library to choose, a positive value
+ * (shards must agree on one split: the exchanged parts are the same rows of every slice) is
+ * used as given.  *row_split is a multiple of 64; *blk_split = first row-block holding
+ * a row >= *row_split (a straddling block belongs to the tail), *mid_split = first entry of
+ * mid_row >= *row_split.  All giant rows must lie in the head (else GM_ERR_INVALID). */
+int gm_graph_split(const gm_graph_t* g, int direction, int head_permille, int32_t* row_split, int32_t* blk_split,
+                   int32_t* mid_split);
+/* what a workspace slot currently holds (external = adopted from the caller) */
+int gm_graph_workspace_info(const gm_graph_t* g, int slot, void** d_ptr, size_t* bytes, int* external);
 
 /* ---- fixed-menu vertex programs ------------------------------------------------------
  * Vertex state arrays are DEVICE arrays over the shard's rows in device order

@@ -65,3 +65,42 @@ def test_exchange_world2_gloo():
     port = _free_port()
     mp.spawn(_worker, args=(2, port, nv, ranges, out), nprocs=2, join=True)
     assert out[0] == 1 and out[1] == 1
+
+
+def _worker_parts(rank, world, port, S, out):
+    """two-stage overlapped exchange (GM_XCHG_PART / GM_XCHG_WAIT): parts of a second buffer, started
+    asynchronously, complete at wait_parts()"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    elt = 4
+    nv = S * world
+    ranges = [(r * S, (r + 1) * S) for r in range(world)]
+    x = torch.zeros(nv * elt + 16, dtype=torch.uint8)
+    x2 = torch.zeros(nv * elt + 16, dtype=torch.uint8)
+    bits = torch.zeros((nv + 31) // 32 + 2, dtype=torch.int32)
+    live = S - 64  # the last 64 rows of every slice never travel
+    ex = MessageExchange(ranges, rank, x, bits, live_rows=live, x_bytes2=x2)
+    xv2 = x2[: nv * elt].view(torch.float32)
+    want = torch.zeros(nv, dtype=torch.float32)
+    split = 128
+    for r in range(world):
+        want[r * S: r * S + live] = torch.arange(r * S, r * S + live, dtype=torch.float32) * 2 + 1
+    lo = rank * S
+    # stage 1: tail rows [split, live) of the own slice, then stage 2: head rows [0, split)
+    xv2[lo + split: lo + live] = want[lo + split: lo + live]
+    ex.start_part(x2, split, live - split, elt)
+    xv2[lo: lo + split] = want[lo: lo + split]
+    ex.start_part(x2, 0, split, elt)
+    ex.wait_parts()
+    ok = bool((xv2 == want).all()) and ex.parts == 2 and not ex._pending
+    ok = ok and bool((x == 0).all())  # the first buffer was not touched
+    out[rank] = int(ok)
+    dist.destroy_process_group()
+
+
+def test_partial_exchange_world3_gloo():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_parts, args=(3, _free_port(), 64 * 6, out), nprocs=3, join=True)
+    assert out[0] == 1 and out[1] == 1 and out[2] == 1

@@ -31,9 +31,18 @@ def main():
     ex = attach_exchange(g)
     og = ob.OracleGraph(nv, s, d, v, ref_threads=2)
     ok = True
-    pr, deg, it = g.pagerank(8)
+    pr, deg, it = g.pagerank(8)  # fixed count, ALL_VERTICES: the overlapped two-stage schedule
     opr, oit, _ = og.pagerank(8)
     ok &= bool((deg == og.degree()).all()) and it == oit and bool((pr.view(np.uint32) == opr.view(np.uint32)).all())
+    staged = ex.parts
+    ok &= staged == 2 * 7  # two parts per iteration but the last
+    from graphmat_amd import _lib
+    _lib.lib().gm_set_option(b"debug_flags", 128)  # same run through the plain loop
+    pr_plain, _, _ = g.pagerank(8)
+    _lib.lib().gm_set_option(b"debug_flags", 0)
+    ok &= ex.parts == staged and bool((pr_plain.view(np.uint32) == opr.view(np.uint32)).all())
+    if not ok:
+        print("rank %d: fixed-count PageRank mismatch (parts=%d)" % (rank, ex.parts), flush=True)
     pr2, _, it2 = g.pagerank(-1)  # until convergence: exercises the flag all-reduce
     opr2, oit2, _ = og.pagerank(-1)
     ok &= it2 == oit2 and bool((pr2.view(np.uint32) == opr2.view(np.uint32)).all())
