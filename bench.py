@@ -252,7 +252,10 @@ def main():
     name = max(kern, key=lambda k: kern[k][0])
     ms, launches, alg_bytes = kern[name]
     if launches > 0 and ms > 0:
-        avg_ms = ms / launches
+        # the two-stage multi-GPU schedule launches every multiply kernel twice per iteration (tail rows,
+        # head rows): the algorithmic bytes are per iteration, so is the time they are divided by
+        per_step = max(1, round(launches / max(args.steps, 1)))
+        avg_ms = ms / launches * per_step
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -265,9 +268,10 @@ def main():
         roof = {"bound": "hbm", "kernel": name + "<PageRank>", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg_bytes,
-                "rowblock_avg_ms": round(stats["rowblock_ms"] / max(stats["rowblock_launches"], 1), 4),
-                "wave_avg_ms": round(stats["wave_ms"] / max(stats["wave_launches"], 1), 4),
-                "giant_avg_ms_overlapped": round(stats["giant_ms"] / max(stats["giant_launches"], 1), 4),
+                "launches_per_iteration": per_step,
+                "rowblock_avg_ms": round(stats["rowblock_ms"] / max(args.steps, 1), 4),
+                "wave_avg_ms": round(stats["wave_ms"] / max(args.steps, 1), 4),
+                "giant_avg_ms_overlapped": round(stats["giant_ms"] / max(args.steps, 1), 4),
                 "edges_rowblock_wave_giant": [e_short, e_mid, e_giant],
                 "send_avg_ms": round(stats["send_ms"] / args.steps, 4),
                 "apply_avg_ms": round(stats["apply_ms"] / args.steps, 4),

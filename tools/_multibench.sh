@@ -1,4 +1,2 @@
 export GM_BENCH_BACKEND=gloo
-for extra in "" "--no-overlap"; do
-python -m torch.distributed.run --nnodes=1 --nproc-per-node ${NP:-2} --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus ${NP:-2} --scale ${SCALE:-22} --steps 10 --warmup 2 $extra 2>&1 | grep -v "^$" | grep "summary\|Error\|error\|overlapped\|disagrees" | cut -c1-330
-done
+GRAPHMAT_VERBOSE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --scale ${SCALE:-24} --steps 3 --warmup 1 2>&1 | grep "two-stage" | sort | uniq -c
