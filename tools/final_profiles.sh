@@ -15,3 +15,11 @@ for sc in "$@"; do
   python bench.py --scale $sc --steps 20 --warmup 3 --cpu-scale 0 > $out/bench.json 2> $out/bench.err
   grep summary $out/bench.err; rm -f $out/*.db
 done
+# the other BASELINE configurations (text summaries)
+out=$R/gpurun_out/final_misc; mkdir -p $out
+python tools/bfs_bench.py --scale 26 2>&1 | grep "^BFS" > $out/bfs_scale26.txt
+python tools/sgd_bench.py --users 200000 --items 20000 2>&1 | grep "^SGD" > $out/sgd.txt
+python tools/sgd_bench.py 2>&1 | grep "^SGD" >> $out/sgd.txt
+python tools/sgd_bench.py --users 10000000 --items 1000000 --iters 3 2>&1 | grep "^SGD" >> $out/sgd.txt
+python tools/app_at_scale.py 20 2>&1 | grep "==" > $out/apps.txt
+python tools/app_at_scale.py 22 2>&1 | grep "==" >> $out/apps.txt
