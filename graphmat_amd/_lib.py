@@ -84,6 +84,8 @@ SIGNATURES = {
     "gm_graph_has_exchange": (C.c_int, [_P]),
     "gm_graph_timing_enabled": (C.c_int, [_P]),
     "gm_graph_split": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gm_graph_note_set": (C.c_int, [_P, C.c_int, C.c_int64]),
+    "gm_graph_note_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
     "gm_graph_workspace_info": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "gm_graph_run_resources": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "gm_graph_record_stats": (C.c_int, [_P, C.POINTER(RunStats)]),

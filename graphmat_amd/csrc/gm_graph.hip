@@ -682,6 +682,8 @@ int gm_graph_relayout_like(gm_graph_t* g, const gm_graph_t* like, gm_stream_t st
   if (vals) (void)hipFree(vals);
   gm::free_csr(&old_out);
   gm::free_csr(&old_in);
+  memset(g->split_memo, 0, sizeof(g->split_memo));  // answers about the old adjacency
+  memset(g->note_set, 0, sizeof(g->note_set));
   if (rc != GM_OK) return rc;
   if (g->rowbits_all && g->out.present && g->in.present) {
     const int nw = (g->desc.row_hi - g->desc.row_lo + 31) / 32 + 2;
@@ -756,6 +758,18 @@ int gm_graph_workspace(gm_graph_t* g, int slot, size_t bytes, void** d_ptr) {
   return GM_OK;
 }
 
+int gm_graph_note_set(gm_graph_t* g, int slot, int64_t value) {
+  if (!g || slot < 0 || slot >= GM_NOTE_SLOTS) { gm::set_error("gm_graph_note_set: invalid argument"); return GM_ERR_INVALID; }
+  g->note_val[slot] = value;
+  g->note_set[slot] = 1;
+  return GM_OK;
+}
+int gm_graph_note_get(const gm_graph_t* g, int slot, int64_t* value) {
+  if (!g || slot < 0 || slot >= GM_NOTE_SLOTS || !value || !g->note_set[slot]) return GM_ERR_INVALID;
+  *value = g->note_val[slot];
+  return GM_OK;
+}
+
 int gm_graph_workspace_info(const gm_graph_t* g, int slot, void** d_ptr, size_t* bytes, int* external) {
   if (!g || slot < 0 || slot >= GM_WS_SLOTS || !d_ptr || !bytes || !external) { gm::set_error("gm_graph_workspace_info: invalid argument"); return GM_ERR_INVALID; }
   *d_ptr = g->ws[slot];
@@ -770,6 +784,13 @@ int gm_graph_split(const gm_graph_t* g, int direction, int head_permille, int32_
   const gm::CsrOwned* c = direction == GM_DIR_OUT ? &g->out : direction == GM_DIR_IN ? &g->in : nullptr;
   if (!c || !c->present) { gm::set_error("gm_graph_split: direction %d not built", direction); return GM_ERR_INVALID; }
   const gm_csr_t& A = c->view;
+  gm_graph::SplitMemo* memo = const_cast<gm_graph::SplitMemo*>(g->split_memo[direction == GM_DIR_OUT ? 0 : 1]);
+  for (int k = 0; k < 2; k++)
+    if (memo[k].valid && memo[k].permille == head_permille && memo[k].asked == *row_split) {
+      *row_split = memo[k].rs; *blk_split = memo[k].bs; *mid_split = memo[k].ms;
+      return GM_OK;
+    }
+  const int32_t asked = *row_split;
   auto rd64 = [&](const int64_t* p, int64_t i, int64_t* out) { return hipMemcpy(out, p + i, 8, hipMemcpyDeviceToHost); };
   auto rd32 = [&](const int32_t* p, int64_t i, int32_t* out) { return hipMemcpy(out, p + i, 4, hipMemcpyDeviceToHost); };
   const int64_t target = (A.nnz * head_permille + 999) / 1000;
@@ -808,6 +829,8 @@ int gm_graph_split(const gm_graph_t* g, int direction, int head_permille, int32_
   *row_split = (int32_t)rs;
   *blk_split = (int32_t)bl;
   *mid_split = (int32_t)ml;
+  gm_graph::SplitMemo& m = memo[asked == 0 ? 0 : 1];
+  m.valid = 1; m.permille = head_permille; m.asked = asked; m.rs = (int32_t)rs; m.bs = (int32_t)bl; m.ms = (int32_t)ml;
   return GM_OK;
 }
 

@@ -73,4 +73,9 @@ struct gm_graph {
   hipStream_t aux_stream;
   hipEvent_t aux_fork, aux_join;
   void* pinned_flag;
+  // small per-graph memo for the header layer (gm_graph_note_*): e.g. the row split the shards agreed on
+  int64_t note_val[GM_NOTE_SLOTS];
+  int note_set[GM_NOTE_SLOTS];
+  // last answers of gm_graph_split per direction (the search costs ~70 small device reads)
+  struct SplitMemo { int valid, permille; int32_t asked, rs, bs, ms; } split_memo[2][2];
 };

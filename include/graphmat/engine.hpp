@@ -420,12 +420,19 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     bool staged = false;
     if (gm_graph_workspace_info(g, 9, &x2v, &x2_bytes, &x2_ext) == GM_OK && x2_ext && x2v != nullptr &&
         x2_bytes >= (size_t)desc.ndevice * sizeof(T)) {
-      int mine = (gm_graph_split(g, GM_DIR_OUT, 650, &rs, &bs, &ms) == GM_OK) ? -rs : 0;
-      gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &mine);  // MIN of -rs = -(largest rs)
-      rs = -mine;
-      int fine = (rs >= 64 && rs < n_live && gm_graph_split(g, GM_DIR_OUT, 650, &rs, &bs, &ms) == GM_OK) ? 1 : 0;
-      gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &fine);
-      staged = fine == 1;
+      int64_t agreed = 0;
+      if (gm_graph_note_get(g, 0, &agreed) == GM_OK) {  // note 0: the split the shards agreed on in an earlier run (0 = none)
+        rs = (int32_t)agreed;
+        staged = rs > 0 && gm_graph_split(g, GM_DIR_OUT, 650, &rs, &bs, &ms) == GM_OK;
+      } else {
+        int mine = (gm_graph_split(g, GM_DIR_OUT, 650, &rs, &bs, &ms) == GM_OK) ? -rs : 0;
+        gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &mine);  // MIN of -rs = -(largest rs)
+        rs = -mine;
+        int fine = (rs >= 64 && rs < n_live && gm_graph_split(g, GM_DIR_OUT, 650, &rs, &bs, &ms) == GM_OK) ? 1 : 0;
+        gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &fine);
+        staged = fine == 1;
+        gm_graph_note_set(g, 0, staged ? (int64_t)rs : 0);
+      }
     }
     if (staged) {
       if (verbose) printf("GraphMat(HIP): two-stage schedule, head rows [0,%d) tail rows [%d,%d)\n", rs, rs, n_live);

@@ -241,6 +241,12 @@ int gm_graph_set_exchange(gm_graph_t* g, gm_exchange_fn fn, void* ctx);
  * mid_row >= *row_split.  All giant rows must lie in the head (else GM_ERR_INVALID). */
 int gm_graph_split(const gm_graph_t* g, int direction, int head_permille, int32_t* row_split, int32_t* blk_split,
                    int32_t* mid_split);
+/* a few integers the header layer may park on a graph between runs (slot in [0, GM_NOTE_SLOTS));
+ * get returns GM_ERR_INVALID while a slot has never been set; rebuilding the adjacency
+ * (gm_graph_relayout_like) clears them */
+#define GM_NOTE_SLOTS 8
+int gm_graph_note_set(gm_graph_t* g, int slot, int64_t value);
+int gm_graph_note_get(const gm_graph_t* g, int slot, int64_t* value);
 /* what a workspace slot currently holds (external = adopted from the caller) */
 int gm_graph_workspace_info(const gm_graph_t* g, int slot, void** d_ptr, size_t* bytes, int* external);
 
