@@ -39,6 +39,12 @@ inline int& debug_flags() {
   return f;
 }
 
+// top-down steps are taken while the active set owns less than this many thousandths of the edges
+inline int& push_edge_permille() {
+  static int v = 50;
+  return v;
+}
+
 // HIP-event phase timer: every mark closes an interval that is charged to `tag`.
 enum { TAG_START = 0, TAG_SEND = 1, TAG_ROWBLOCK = 2, TAG_WAVE = 3, TAG_GIANT = 4, TAG_APPLY = 5 };
 struct PhaseTimer {
@@ -493,6 +499,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   tick("setup done", 0);
   while (true) {
     tick("iteration", it);
+    if (verbose && can_push) printf("GraphMat(HIP):   active set: %llu vertices, %llu out-edges (max %llu)\n", frontier_v, frontier_e, frontier_maxdeg);
     dev::ProgArg<P> pa = dev::make_prog_arg(gp);  // re-captured every iteration (do_every_iteration may change it)
     // Clear(&x) / Clear(&y) (:139-140): x presence words are fully rewritten by send.  With
     // every x entry present (ALL_VERTICES) y's presence is the static set of non-empty rows.
@@ -517,7 +524,8 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     const uint32_t* xb = dense_x ? nullptr : xbits;
     const uint32_t* apply_bits = ybits;
     // small frontiers only: few sources (compact list, bids) and few out-edges
-    const bool push = can_push && frontier_v > 0 && frontier_v <= 65536ull && frontier_e * 20ull < (unsigned long long)Aout.nnz;
+    const bool push = can_push && frontier_v > 0 && frontier_v <= 65536ull &&
+                      frontier_e * 1000ull < (unsigned long long)Aout.nnz * (unsigned long long)push_edge_permille();
     if (push) {
       {
         GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
@@ -525,7 +533,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
                            d_list, d_count);
         const unsigned pieces = (unsigned)((frontier_maxdeg + dev::kBlock * 4 - 1) / (dev::kBlock * 4));
         hipLaunchKernelGGL(dev::k_push_bid, dim3((unsigned)frontier_v, pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc,
-                           (const int32_t*)d_list, (int)frontier_v, native_of_dev, d_best);
+                           (const int32_t*)d_list, (int)frontier_v, native_of_dev, d_best, (const uint32_t*)d_want);
         if (use_vp)
           hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, true>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, Asrc,
                              (const T*)x, dev_of_native, (const V*)d_vp, d_best, y, ybits, n);

@@ -1107,7 +1107,8 @@ k_frontier_list(const uint32_t* __restrict__ active, int n, int32_t* __restrict_
 // bids: blockIdx.x = active source, blockIdx.y = 1024-edge piece of its out-edges
 __global__ void __launch_bounds__(kBlock)
 k_push_bid(gm_csr_t S /* rows = sources */, const int32_t* __restrict__ list, int nlist,
-           const int32_t* __restrict__ native_of_dev, unsigned long long* __restrict__ best) {
+           const int32_t* __restrict__ native_of_dev, unsigned long long* __restrict__ best,
+           const uint32_t* __restrict__ want /* row-filter bits of the destinations, or null */) {
   const int u = list[blockIdx.x];
   const int64_t e0 = S.rowptr[u] + (int64_t)blockIdx.y * (kBlock * 4), e1 = S.rowptr[u + 1];
   if (e0 >= e1) return;
@@ -1115,7 +1116,15 @@ k_push_bid(gm_csr_t S /* rows = sources */, const int32_t* __restrict__ list, in
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int64_t e = e0 + threadIdx.x + j * kBlock;
-    if (e < e1) atomicMax(&best[S.colidx[e]], hi | (unsigned long long)(uint32_t)e);
+    if (e < e1) {
+      const int c = S.colidx[e];
+      if (want != nullptr && !((want[c >> 5] >> (c & 31)) & 1u)) continue;  // destination ignores messages anyway
+      // bids only grow: a plain read that already shows a larger bid makes the atomic pointless (a
+      // stale, smaller value merely costs the atomic that decides anyway).  Hubs' neighbourhoods
+      // overlap heavily, so most bids are dropped here instead of serialising in the L2.
+      const unsigned long long key = hi | (unsigned long long)(uint32_t)e;
+      if (best[c] < key) atomicMax(&best[c], key);
+    }
   }
 }
 

@@ -9,8 +9,11 @@ import numpy as np, torch
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--scale", type=int, default=26)
     ap.add_argument("--debug-flags", type=int, default=0, help="ablation: 32 no push steps, 64 no grouped wave kernel")
+    ap.add_argument("--push-permille", type=int, default=-1, help="experiment: top-down while the active set owns < this many thousandths of the edges")
     args = ap.parse_args()
     from graphmat_amd import api, _lib
+    if args.push_permille >= 0:
+        _lib.lib().gm_set_option(b"push_edge_permille", args.push_permille)
     if args.debug_flags:
         _lib.lib().gm_set_option(b"debug_flags", args.debug_flags)
     nv, src, dst, _ = api.rmat_on_device(args.scale, 16, 1)
