@@ -569,6 +569,8 @@ int gm_graph_create(gm_graph_t** gout, const gm_graph_desc_t* desc, int64_t nnz,
   if (hipStreamSynchronize(s) != hipSuccess) { gm::set_error("graph build: stream sync failed"); gm_graph_destroy(g); return GM_ERR_HIP; }
   void* unused[4];
   if ((rc = gm_graph_run_resources(g, &unused[0], &unused[1], &unused[2], &unused[3])) != GM_OK) { gm_graph_destroy(g); return rc; }
+  void* flag = nullptr;
+  if (gm_graph_workspace(g, 0, 4096, &flag) == GM_OK) gm::warm_program_kernels(flag);
   *gout = g;
   return GM_OK;
 }

@@ -55,6 +55,8 @@ struct CsrOwned {
 
 }  // namespace gm
 
+namespace gm { void warm_program_kernels(void* d_scratch256); }
+
 struct gm_graph {
   gm_graph_desc_t desc;
   gm::CsrOwned out, in;

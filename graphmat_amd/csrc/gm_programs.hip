@@ -430,6 +430,17 @@ int run_fixed(P& prog, gm_graph_t* g, V* d_vp, uint32_t* d_active, int iteration
   return GM_OK;
 }
 
+// The HIP runtime resolves a code object's kernel table at the first launch of one of its
+// kernels (milliseconds for this translation unit's template instantiations): do it when the
+// first graph is created, not inside the first run.
+void warm_program_kernels(void* d_scratch256) {
+  static bool done = false;
+  if (done || !d_scratch256) return;
+  done = true;
+  hipLaunchKernelGGL(GraphMat::dev::k_fill_u32, dim3(1), dim3(GraphMat::dev::kBlock), 0, 0, (uint32_t*)d_scratch256, (int64_t)64, 0u);
+  (void)hipDeviceSynchronize();
+}
+
 }  // namespace gm
 
 extern "C" {
