@@ -23,7 +23,7 @@ def test_apps_compile_for_gfx950():
     build.build()
     import build_apps
     built = build_apps.build()
-    assert any(p.endswith("label_propagation") for p in built)
+    assert any(p.endswith("label_propagation") for p in built) and any(p.endswith("bfs_bottom_up") for p in built)
     if os.path.isdir("/root/reference/src"):
         for app in ("PageRank", "BFS", "SGD", "SSSP"):
             assert os.path.exists(os.path.join(REF_APPS, app))
@@ -114,6 +114,34 @@ def test_own_generic_program_label_propagation(golden_dir, tmp_path):
     for c in range(ncomp):
         members = np.where(ref_lab == c)[0]
         assert (lab[members] == members.min() + 1).all()
+
+
+@pytest.mark.gpu
+def test_own_bfs_with_row_filter_trait(golden_dir, ref):
+    """apps/bfs_bottom_up.cpp: a user-written BFS whose only extra is the program_row_filter trait (bottom-up
+    levels); the reduction strategy comes from the runtime's probe.  Golden depths/parents of G2, and the oracle
+    on an RMAT graph large enough to have row-blocks, wave rows and top-down steps."""
+    from graphmat_amd import generators as gen
+    from graphmat_amd.mtx import write_mtx_bin
+    from oracle import binding as ob
+    ob.build()
+    exe = _need(os.path.join(OWN_APPS, "bfs_bottom_up"))
+    g2 = ref["G2_bfs_test_bin_mtx"]
+    text = _run(exe, os.path.join(golden_dir, g2["file"]), g2["source"])
+    rows = re.findall(r"^vertex (\d+) depth (\d+) parent (-?\d+)$", text, flags=re.M)
+    assert [int(r[1]) for r in rows] == g2["depth"] and [int(r[2]) for r in rows] == g2["parent"]
+    assert "Completed %d iterations" % g2["iterations"] in text
+    nv, s, d, v = gen.rmat_edges(14, 16, seed=5)
+    path = "/tmp/bfs_bottom_up_rmat14.bin.mtx"
+    write_mtx_bin(path, nv, s, d, v)
+    text = _run(exe, path, 3)
+    got = {int(a): (int(b), int(c)) for a, b, c in re.findall(r"^vertex (\d+) depth (\d+) parent (-?\d+)$", text, flags=re.M)}
+    od, op, oit, _ = ob.OracleGraph(nv, s, d, v, ref_threads=1).bfs(3)
+    reached = np.where(od != 0xFFFFFFFF)[0]
+    assert len(got) == reached.size and "Completed %d iterations" % oit in text
+    for i in reached:
+        exp_parent = -1 if i + 1 == 3 else int(op[i])
+        assert got[i + 1] == (int(od[i]), exp_parent)
 
 
 @pytest.mark.gpu
