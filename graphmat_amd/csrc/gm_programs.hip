@@ -452,6 +452,7 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "rank_cap") && value >= 0) { gm::g_rank_cap = value; return GM_OK; }
   if (key && !strcmp(key, "rank_by") && value >= 0 && value <= 2) { gm::g_rank_by = value; return GM_OK; }
   if (key && !strcmp(key, "push_edge_permille") && value >= 0 && value <= 1000) { GraphMat::detail::push_edge_permille() = value; return GM_OK; }
+  if (key && !strcmp(key, "sparse_step_edges") && value >= 0) { GraphMat::detail::sparse_step_edges() = value; return GM_OK; }
   if (key && !strcmp(key, "debug_flags")) { GraphMat::detail::debug_flags() = value; return GM_OK; }
   gm::set_error("gm_set_option: unknown option");
   return GM_ERR_INVALID;

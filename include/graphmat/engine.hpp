@@ -45,6 +45,12 @@ inline int& push_edge_permille() {
   return v;
 }
 
+// ... and entirely on lists while it owns at most this many out-edges
+inline int& sparse_step_edges() {
+  static int v = 1 << 20;
+  return v;
+}
+
 // HIP-event phase timer: every mark closes an interval that is charged to `tag`.
 enum { TAG_START = 0, TAG_SEND = 1, TAG_ROWBLOCK = 2, TAG_WAVE = 3, TAG_GIANT = 4, TAG_APPLY = 5 };
 struct PhaseTimer {
@@ -350,12 +356,16 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   }
   unsigned long long* d_best = nullptr;
   int32_t* d_list = nullptr;
+  int32_t* d_touched = nullptr;
+  bool list_ready = false;  // d_list holds exactly the current active set
+  bool listed = false;      // the step just run wrote the list of its changed vertices
   unsigned long long* h_stats = nullptr;  // pinned: [0] changed flag (as int), [2],[3] frontier vertices / out-edges
 
   void* flag_v = nullptr;
   gm_graph_workspace(g, 0, 4096, &flag_v);
   int* d_changed = (int*)flag_v;  // words: [0] changed flag, [2] list counter, [4..9] frontier stats (3 x u64)
-  unsigned int* d_count = (unsigned int*)flag_v + 2;
+  unsigned int* d_count = (unsigned int*)flag_v + 2;   // entries of d_list (the active set, when it is small)
+  unsigned int* d_tcount = (unsigned int*)flag_v + 3;  // entries of d_touched (destinations bid for in a top-down step)
   unsigned long long* d_stats = (unsigned long long*)flag_v + 2;  // byte offset 16
   unsigned long long* d_striped = (unsigned long long*)flag_v + 64;  // byte offset 512: kStatSlots x 4 u64 (k_apply)
   const size_t striped_bytes = (size_t)dev::kStatSlots * 4 * sizeof(unsigned long long);
@@ -370,12 +380,14 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   unsigned long long frontier_v = 0, frontier_e = 0, frontier_maxdeg = 0;
   const int stats_grid = grid_for(n) < 2048 ? grid_for(n) : 2048;
   if (can_push) {
-    void *pb = nullptr, *pl = nullptr;
-    if (gm_graph_workspace(g, 6, (size_t)n * 8 + 64, &pb) != GM_OK || gm_graph_workspace(g, 7, (size_t)n * 4 + 64, &pl) != GM_OK) {
+    void *pb = nullptr, *pl = nullptr, *pt = nullptr;
+    if (gm_graph_workspace(g, 6, (size_t)n * 8 + 64, &pb) != GM_OK || gm_graph_workspace(g, 7, (size_t)n * 4 + 1024, &pl) != GM_OK ||
+        gm_graph_workspace(g, 10, (size_t)n * 4 + 1024, &pt) != GM_OK) {
       can_push = false;
     } else {
       d_best = (unsigned long long*)pb;
       d_list = (int32_t*)pl;
+      d_touched = (int32_t*)pt;
       GM_HIP_OK(hipMemsetAsync(d_best, 0, (size_t)n * 8, s));
       GM_HIP_OK(hipMemsetAsync(d_stats, 0, 24, s));
       hipLaunchKernelGGL(dev::k_frontier_stats, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active,
@@ -504,74 +516,123 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     // Clear(&x) / Clear(&y) (:139-140): x presence words are fully rewritten by send.  With
     // every x entry present (ALL_VERTICES) y's presence is the static set of non-empty rows.
     const bool static_bits = (act == ALL_VERTICES);
-    if (!static_bits) GM_HIP_OK(hipMemsetAsync(ybits, 0, (size_t)nwords * 4, s));
     GM_HIP_OK(hipMemsetAsync(d_changed, 0, sizeof(int), s));
     timer.mark(TAG_START);
-    // send (:145)
     const bool dense_x = (act == ALL_VERTICES);
-    // rows past n_live have no edge in either direction (degree-ranked order puts them at the
-    // tail): nobody reads their messages and they never receive one
-    hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
-                       dense_x ? (const uint32_t*)nullptr : (const uint32_t*)d_active, x, xbits, n_live, desc.row_lo);
-    if (multi) {
-      if (gm_graph_exchange(g, GM_XCHG_MESSAGES, x, (int64_t)sizeof(T), xbits, nullptr) != 0) {
-        printf("GraphMat(HIP): message exchange callback failed\n");
-        exit(1);
-      }
-    }
-    timer.mark(TAG_SEND);
-    // multiply + reduce (:160-176)
-    const uint32_t* xb = dense_x ? nullptr : xbits;
-    const uint32_t* apply_bits = ybits;
-    // small frontiers only: few sources (compact list, bids) and few out-edges
-    const bool push = can_push && frontier_v > 0 && frontier_v <= 65536ull &&
+    const bool want_stats = can_push && iterations <= 0;
+    // top-down step for small active sets only: few sources and few out-edges
+    const bool push = can_push && frontier_v > 0 && frontier_v <= (unsigned long long)dev::kSparseListCap &&
                       frontier_e * 1000ull < (unsigned long long)Aout.nnz * (unsigned long long)push_edge_permille();
-    if (push) {
-      {
+    // ... and among those, active sets with few out-edges run entirely on lists (nothing scans all vertices)
+    const bool sparse = push && frontier_e <= (unsigned long long)sparse_step_edges();
+    if (sparse) {
+      // ---- sparse top-down step ----
+      if (!list_ready) {
         GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
         hipLaunchKernelGGL(dev::k_frontier_list, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active, n,
                            d_list, d_count);
+      }
+      const int nf = (int)frontier_v;
+      hipLaunchKernelGGL((dev::k_send_list<P, T, V>), dim3(grid_for(nf)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
+                         (const int32_t*)d_list, nf, x, desc.row_lo);
+      timer.mark(TAG_SEND);
+      GM_HIP_OK(hipMemsetAsync(d_tcount, 0, 4, s));
+      const unsigned pieces = (unsigned)((frontier_maxdeg + dev::kBlock * 4 - 1) / (dev::kBlock * 4));
+      hipLaunchKernelGGL(dev::k_push_bid, dim3((unsigned)nf, pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc,
+                         (const int32_t*)d_list, nf, native_of_dev, d_best, (const uint32_t*)d_want, d_touched, d_tcount);
+      timer.mark(TAG_WAVE);
+      // the active set has been consumed: rewrite the active vector and the list for the next step
+      GM_HIP_OK(hipMemsetAsync(d_active, 0, (size_t)nwords * 4, s));
+      GM_HIP_OK(hipMemsetAsync(d_striped, 0, striped_bytes, s));
+      GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
+      const unsigned long long bound = frontier_e < (unsigned long long)n ? frontier_e : (unsigned long long)n;
+      if (bound > 0) {
+        if (use_vp)
+          hipLaunchKernelGGL((dev::k_push_finish<P, T, U, V, E, true>), dim3(grid_for((int64_t)bound)), dim3(dev::kBlock), 0, s, pa,
+                             Asrc, (const T*)x, dev_of_native, d_vp, d_best, (const int32_t*)d_touched, (const unsigned int*)d_tcount,
+                             d_active, d_changed, d_striped, d_want, d_list, d_count);
+        else
+          hipLaunchKernelGGL((dev::k_push_finish<P, T, U, V, E, false>), dim3(grid_for((int64_t)bound)), dim3(dev::kBlock), 0, s, pa,
+                             Asrc, (const T*)x, dev_of_native, d_vp, d_best, (const int32_t*)d_touched, (const unsigned int*)d_tcount,
+                             d_active, d_changed, d_striped, d_want, d_list, d_count);
+      }
+      st.spmv_launches += 2;
+      listed = true;
+      timer.mark(TAG_APPLY);
+    } else {
+      // Clear(&x) / Clear(&y) (:139-140): x presence words are fully rewritten by send.  With
+      // every x entry present (ALL_VERTICES) y's presence is the static set of non-empty rows.
+      if (!static_bits) GM_HIP_OK(hipMemsetAsync(ybits, 0, (size_t)nwords * 4, s));
+      // send (:145).  Rows past n_live have no edge in either direction (degree-ranked order puts
+      // them at the tail): nobody reads their messages and they never receive one
+      hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
+                         dense_x ? (const uint32_t*)nullptr : (const uint32_t*)d_active, x, xbits, n_live, desc.row_lo);
+      if (multi) {
+        if (gm_graph_exchange(g, GM_XCHG_MESSAGES, x, (int64_t)sizeof(T), xbits, nullptr) != 0) {
+          printf("GraphMat(HIP): message exchange callback failed\n");
+          exit(1);
+        }
+      }
+      timer.mark(TAG_SEND);
+      // multiply + reduce (:160-176)
+      const uint32_t* xb = dense_x ? nullptr : xbits;
+      const uint32_t* apply_bits = ybits;
+      if (push) {
+        // top-down step over a larger active set: bids, then one pass over all vertices picks the winners
+        if (!list_ready) {
+          GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
+          hipLaunchKernelGGL(dev::k_frontier_list, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active, n,
+                             d_list, d_count);
+        }
         const unsigned pieces = (unsigned)((frontier_maxdeg + dev::kBlock * 4 - 1) / (dev::kBlock * 4));
         hipLaunchKernelGGL(dev::k_push_bid, dim3((unsigned)frontier_v, pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc,
-                           (const int32_t*)d_list, (int)frontier_v, native_of_dev, d_best, (const uint32_t*)d_want);
+                           (const int32_t*)d_list, (int)frontier_v, native_of_dev, d_best, (const uint32_t*)d_want,
+                           (int32_t*)nullptr, (unsigned int*)nullptr);
         if (use_vp)
           hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, true>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, Asrc,
                              (const T*)x, dev_of_native, (const V*)d_vp, d_best, y, ybits, n);
         else
           hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, false>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, Asrc,
                              (const T*)x, dev_of_native, (const V*)d_vp, d_best, y, ybits, n);
-        st.spmv_launches += 3;
+        st.spmv_launches += 2;
         timer.mark(TAG_WAVE);
+      } else if (order == OUT_EDGES || order == ALL_EDGES) {
+        const int acc = static_bits ? dev::ACC_STATIC_BITS : 0;
+        if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
+        else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
+        if (static_bits) apply_bits = Aout.rowbits;
       }
-    } else if (order == OUT_EDGES || order == ALL_EDGES) {
-      const int acc = static_bits ? dev::ACC_STATIC_BITS : 0;
-      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
-      else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
-      if (static_bits) apply_bits = Aout.rowbits;
-    }
-    if (!push && (order == IN_EDGES || order == ALL_EDGES)) {
-      int acc = (order == ALL_EDGES) ? dev::ACC_READ_PREV : 0;
-      uint32_t* yb = ybits;
-      if (static_bits) {
-        acc |= dev::ACC_STATIC_BITS;
-        yb = const_cast<uint32_t*>(Aout.rowbits);  // only read (presence of the OUT pass's results)
-        apply_bits = Ain.rowbits;
-        if (order == ALL_EDGES && gm_graph_rowbits_all(g, &apply_bits) != GM_OK) { printf("%s\n", gm_last_error()); exit(1); }
+      if (!push && (order == IN_EDGES || order == ALL_EDGES)) {
+        int acc = (order == ALL_EDGES) ? dev::ACC_READ_PREV : 0;
+        uint32_t* yb = ybits;
+        if (static_bits) {
+          acc |= dev::ACC_STATIC_BITS;
+          yb = const_cast<uint32_t*>(Aout.rowbits);  // only read (presence of the OUT pass's results)
+          apply_bits = Ain.rowbits;
+          if (order == ALL_EDGES && gm_graph_rowbits_all(g, &apply_bits) != GM_OK) { printf("%s\n", gm_last_error()); exit(1); }
+        }
+        if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
+        else launch_spmv<P, T, U, V, E, false>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
       }
-      if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
-      else launch_spmv<P, T, U, V, E, false>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
+      // setAllInactive (:184) + apply (:195-225): the active vector is rewritten by k_apply
+      // (when top-down steps are possible the kernel also sizes and lists the next active set)
+      // the changed vertices are also listed when the next active set may be small (the current one is
+      // not huge); if that guess is wrong a k_frontier_list pass builds the list when it is needed
+      const bool build_list = want_stats && frontier_v <= 16ull * (unsigned long long)dev::kSparseListCap;
+      if (want_stats) {
+        GM_HIP_OK(hipMemsetAsync(d_striped, 0, striped_bytes, s));
+        GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
+      }
+      listed = build_list;
+      const int apply_grid = grid_for(n_live) < dev::kApplyMaxBlocks ? grid_for(n_live) : dev::kApplyMaxBlocks;
+      hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y,
+                         apply_bits, d_vp, d_active, n_live, d_changed, want_stats ? Asrc.rowptr : (const int64_t*)nullptr,
+                         want_stats ? d_striped : (unsigned long long*)nullptr, d_want, build_list ? d_list : (int32_t*)nullptr,
+                         build_list ? d_count : (unsigned int*)nullptr);
+      if (n_live < n)  // setAllInactive for the rows k_apply does not visit
+        GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
+      timer.mark(TAG_APPLY);
     }
-    // setAllInactive (:184) + apply (:195-225): the active vector is rewritten by k_apply
-    // (when top-down steps are possible the kernel also sizes the next active set)
-    const bool want_stats = can_push && iterations <= 0;
-    if (want_stats) GM_HIP_OK(hipMemsetAsync(d_striped, 0, striped_bytes, s));
-    const int apply_grid = grid_for(n_live) < dev::kApplyMaxBlocks ? grid_for(n_live) : dev::kApplyMaxBlocks;
-    hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y,
-                       apply_bits, d_vp, d_active, n_live, d_changed, want_stats ? Asrc.rowptr : (const int64_t*)nullptr,
-                       want_stats ? d_striped : (unsigned long long*)nullptr, d_want);
-    if (n_live < n)  // setAllInactive for the rows k_apply does not visit
-      GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
-    timer.mark(TAG_APPLY);
     int converged = 0;
     if (iterations <= 0) {  // the flag only matters when running until convergence (:257-259)
       if (can_push)  // size of the next active set (written by k_apply), fetched with the flag
@@ -585,6 +646,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
           frontier_e += h_striped[4 * k + 1];
           frontier_maxdeg = h_striped[4 * k + 2] > frontier_maxdeg ? h_striped[4 * k + 2] : frontier_maxdeg;
         }
+        list_ready = listed && frontier_v <= (unsigned long long)dev::kSparseListCap;  // k_apply / k_push_finish listed it
       }
       converged = (*h_changed == 0) ? 1 : 0;
       if (multi) gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &converged);  // :226 Allreduce(LAND)

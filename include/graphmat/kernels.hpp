@@ -136,6 +136,54 @@ k_send(ProgArg<P> pa, const V* __restrict__ vp, const uint32_t* __restrict__ act
 }
 
 // ------------------------------------------------------------------------------------
+// Building a compact list from a grid-stride loop.  Atomics with a result on ONE global counter cost
+// ~10 ns each on this chip, so a wave-level append of tens of thousands of entries takes
+// milliseconds.  A workgroup therefore collects its entries in LDS (LDS atomics) over all its loop
+// iterations and reserves global space once per kListBuf entries.  Every thread of the workgroup must
+// call add() the same number of times and finish() once.  `cap` > 0: the workgroup stops adding
+// once one of its reservations starts at or beyond `cap` entries (a list of at most `cap` entries
+// in total is always complete).
+constexpr int kListBuf = 1024;
+struct BlockList {
+  int32_t* buf;         // LDS, kListBuf entries
+  unsigned int* fill;   // LDS: [0] entries in buf, [1] global base of the last flush, [2] stopped
+  __device__ __forceinline__ void init() {
+    if (threadIdx.x == 0) { fill[0] = 0; fill[2] = 0; }
+    __syncthreads();
+  }
+  __device__ __forceinline__ void flush(int32_t* __restrict__ list, unsigned int* __restrict__ count, unsigned int cap) {
+    __syncthreads();
+    const unsigned int k = fill[0];
+    if (threadIdx.x == 0 && k) fill[1] = atomicAdd(count, k);
+    __syncthreads();
+    const unsigned int base = fill[1];
+    for (unsigned int j = threadIdx.x; j < k; j += kBlock) list[base + j] = buf[j];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      fill[0] = 0;
+      if (cap && k && base >= cap) fill[2] = 1;
+    }
+    __syncthreads();
+  }
+  __device__ __forceinline__ void add(bool mine, int value, int32_t* __restrict__ list, unsigned int* __restrict__ count, unsigned int cap) {
+    if (fill[0] + kBlock > kListBuf) flush(list, count, cap);  // block-uniform: room for one entry per thread
+    if (fill[2]) return;
+    const unsigned long long m = __ballot(mine);
+    if (m) {
+      const int lane = threadIdx.x & 63;
+      unsigned int start = 0;
+      if (lane == 0) start = atomicAdd(&fill[0], (unsigned int)__popcll(m));
+      start = (unsigned int)__shfl((int)start, 0, 64);
+      if (mine) buf[start + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = value;
+    }
+    __syncthreads();
+  }
+  __device__ __forceinline__ void finish(int32_t* __restrict__ list, unsigned int* __restrict__ count, unsigned int cap) {
+    flush(list, count, cap);
+  }
+};
+
+// ------------------------------------------------------------------------------------
 // apply on rows whose y bit is set; a changed vertex (V::operator!=) becomes active and
 // raises the changed flag (zeroed by the host before the launch).  The active vector is fully rewritten (the reference clears
 // it right before, GraphMatRuntime.h:184).
@@ -160,13 +208,20 @@ k_want_init(ProgArg<P> pa, const V* __restrict__ vp, int n, uint32_t* __restrict
 // set of atomics at the end, into one of kStatSlots counter triples that the host sums.
 constexpr int kStatSlots = 64;
 constexpr int kApplyMaxBlocks = 4096;
+constexpr int kSparseListCap = 65536;  // top-down steps are taken for active sets of at most this many vertices
 template <class P, class U, class V>
 __global__ void __launch_bounds__(kBlock)
 k_apply(ProgArg<P> pa, const U* __restrict__ y, const uint32_t* __restrict__ ybits, V* __restrict__ vp,
         uint32_t* __restrict__ active, int n, int* __restrict__ changed_flag, const int64_t* __restrict__ src_rowptr,
         unsigned long long* __restrict__ stats /* kStatSlots x {vertices, out-edges, max out-degree, -} or null */,
-        uint32_t* __restrict__ want /* row-filter bits to keep up to date, or null */) {
+        uint32_t* __restrict__ want /* row-filter bits to keep up to date, or null */,
+        int32_t* __restrict__ next_list = nullptr /* with stats: the changed vertices, while they are few */,
+        unsigned int* __restrict__ next_count = nullptr) {
   __shared__ unsigned long long s_c[kBlock / 64], s_e[kBlock / 64], s_m[kBlock / 64];
+  __shared__ int32_t s_lbuf[kListBuf];
+  __shared__ unsigned int s_lfill[4];
+  BlockList blist{s_lbuf, s_lfill};
+  if (next_list != nullptr) blist.init();
   unsigned long long cnt = 0, edges = 0, mx = 0;
   bool any = false;
   for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n; base += (int64_t)gridDim.x * kBlock) {
@@ -204,7 +259,10 @@ k_apply(ProgArg<P> pa, const U* __restrict__ y, const uint32_t* __restrict__ ybi
       edges += d;
       mx = d > mx ? d : mx;
     }
+    // compact list of the changed vertices for a following top-down step (while they are few)
+    if (next_list != nullptr) blist.add(changed, i, next_list, next_count, (unsigned int)kSparseListCap);
   }
+  if (next_list != nullptr) blist.finish(next_list, next_count, (unsigned int)kSparseListCap);
   if (any) *changed_flag = 1;
   if (stats == nullptr) return;
   for (int off = 32; off > 0; off >>= 1) {
@@ -1087,47 +1145,146 @@ k_frontier_stats(const uint32_t* __restrict__ active, const int64_t* __restrict_
   }
 }
 
-// compact list of the active vertices (order irrelevant); one atomic per wave that has any
+// compact list of the active vertices (order irrelevant)
 __global__ void __launch_bounds__(kBlock)
 k_frontier_list(const uint32_t* __restrict__ active, int n, int32_t* __restrict__ list, unsigned int* __restrict__ count) {
+  __shared__ int32_t s_lbuf[kListBuf];
+  __shared__ unsigned int s_lfill[4];
+  BlockList blist{s_lbuf, s_lfill};
+  blist.init();
   for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n; base += (int64_t)gridDim.x * kBlock) {
     const int i = (int)base + threadIdx.x;
-    const bool act = i < n && bit_get(active, i);
-    const unsigned long long m = __ballot(act);
-    if (m) {
-      const int lane = threadIdx.x & 63;
-      unsigned int start = 0;
-      if (lane == 0) start = atomicAdd(count, (unsigned int)__popcll(m));
-      start = (unsigned int)__shfl((int)start, 0, 64);
-      if (act) list[start + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = i;
-    }
+    blist.add(i < n && bit_get(active, i), i, list, count, 0u);
   }
+  blist.finish(list, count, 0u);
 }
 
-// bids: blockIdx.x = active source, blockIdx.y = 1024-edge piece of its out-edges
+// messages of the listed (active) vertices only
+template <class P, class T, class V>
+__global__ void __launch_bounds__(kBlock)
+k_send_list(ProgArg<P> pa, const V* __restrict__ vp, const int32_t* __restrict__ list, int nlist, T* __restrict__ x, int row_base) {
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nlist) return;
+  const int u = list[i];
+  T m;
+  p.P::send_message(vp[u], m);
+  x[(size_t)row_base + u] = m;
+}
+
+// bids: blockIdx.x = active source, blockIdx.y = 1024-edge piece of its out-edges.  The first bid
+// a destination receives also puts it on the `touched` list (its slot of `best` was 0 before).
 __global__ void __launch_bounds__(kBlock)
 k_push_bid(gm_csr_t S /* rows = sources */, const int32_t* __restrict__ list, int nlist,
            const int32_t* __restrict__ native_of_dev, unsigned long long* __restrict__ best,
-           const uint32_t* __restrict__ want /* row-filter bits of the destinations, or null */) {
+           const uint32_t* __restrict__ want /* row-filter bits of the destinations, or null */,
+           int32_t* __restrict__ touched, unsigned int* __restrict__ tcount) {
   const int u = list[blockIdx.x];
   const int64_t e0 = S.rowptr[u] + (int64_t)blockIdx.y * (kBlock * 4), e1 = S.rowptr[u + 1];
   if (e0 >= e1) return;
   const unsigned long long hi = (unsigned long long)((native_of_dev ? native_of_dev[u] : u) + 1) << 32;
+  const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int64_t e = e0 + threadIdx.x + j * kBlock;
+    bool first = false;
+    int c = 0;
     if (e < e1) {
-      const int c = S.colidx[e];
-      if (want != nullptr && !((want[c >> 5] >> (c & 31)) & 1u)) continue;  // destination ignores messages anyway
-      // bids only grow: a plain read that already shows a larger bid makes the atomic pointless (a
-      // stale, smaller value merely costs the atomic that decides anyway).  Hubs' neighbourhoods
-      // overlap heavily, so most bids are dropped here instead of serialising in the L2.
-      const unsigned long long key = hi | (unsigned long long)(uint32_t)e;
-      if (best[c] < key) atomicMax(&best[c], key);
+      c = S.colidx[e];
+      if (want == nullptr || ((want[c >> 5] >> (c & 31)) & 1u)) {  // else: destination ignores messages anyway
+        // bids only grow: a plain read that already shows a larger bid makes the atomic pointless (a
+        // stale, smaller value merely costs the atomic that decides anyway).  Hubs' neighbourhoods
+        // overlap heavily, so most bids are dropped here instead of serialising in the L2.
+        const unsigned long long key = hi | (unsigned long long)(uint32_t)e;
+        if (best[c] < key) first = atomicMax(&best[c], key) == 0ull;
+      }
+    }
+    const unsigned long long fm = touched != nullptr ? __ballot(first) : 0ull;
+    if (fm) {
+      unsigned int start = 0;
+      if (lane == 0) start = atomicAdd(tcount, (unsigned int)__popcll(fm));
+      start = (unsigned int)__shfl((int)start, 0, 64);
+      if (first) touched[start + (unsigned int)__popcll(fm & ((1ull << lane) - 1ull))] = c;
     }
   }
 }
 
+// the rest of a top-down step, one lane per touched destination: the winning bid's message is
+// evaluated and applied on the spot (a=b: exactly one message per destination, no y round trip);
+// changed vertices are activated, counted and listed for the next step.  The grid covers an
+// upper bound of the touched count (the active set's out-edges), the real count is read here.
+template <class P, class T, class U, class V, class E, bool USE_VP>
+__global__ void __launch_bounds__(kBlock)
+k_push_finish(ProgArg<P> pa, gm_csr_t S, const T* __restrict__ x, const int32_t* __restrict__ dev_of_native,
+              V* __restrict__ vp, unsigned long long* __restrict__ best, const int32_t* __restrict__ touched,
+              const unsigned int* __restrict__ tcount, uint32_t* __restrict__ active, int* __restrict__ changed_flag,
+              unsigned long long* __restrict__ stats, uint32_t* __restrict__ want, int32_t* __restrict__ next_list,
+              unsigned int* __restrict__ next_count) {
+  const unsigned int i = blockIdx.x * kBlock + threadIdx.x;
+  bool changed = false;
+  int v = 0;
+  if (i < *tcount) {
+    v = touched[i];
+    const unsigned long long key = best[v];
+    best[v] = 0ull;  // leave the scratch clean for the next step
+    ProgArg<P> local = pa;  // apply() is non-const in the API: give it a private copy
+    P& p = *reinterpret_cast<P*>(local.b);
+    V old_prop = vp[v];
+    bool wanted = true;
+    if constexpr (program_row_filter<P>::enabled) wanted = program_row_filter<P>::wants(p, old_prop);
+    if (wanted && key != 0ull) {
+      const int un = (int)(key >> 32) - 1;
+      const int64_t e = (int64_t)(uint32_t)key;
+      const int ud = dev_of_native ? dev_of_native[un] : un;
+      T m = x[ud];
+      U res;
+      V vprow;
+      if constexpr (USE_VP) vprow = old_prop;
+      p.P::process_message(m, edge_at<E>(S.vals, e), vprow, res);
+      V cur = old_prop;
+      p.P::apply(res, cur);
+      vp[v] = cur;
+      changed = old_prop != cur;
+      if (changed) atomicOr(&active[v >> 5], 1u << (v & 31));
+      if constexpr (program_row_filter<P>::enabled)
+        if (want != nullptr && !program_row_filter<P>::wants(p, cur)) atomicAnd(&want[v >> 5], ~(1u << (v & 31)));
+    }
+  }
+  // next active set: size (one set of atomics per workgroup) and, while it is small, its list
+  __shared__ unsigned long long s_c[kBlock / 64], s_e[kBlock / 64], s_m[kBlock / 64];
+  const unsigned long long m = __ballot(changed);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned long long deg = changed ? (unsigned long long)(S.rowptr[v + 1] - S.rowptr[v]) : 0ull, mx = deg;
+  for (int off = 32; off > 0; off >>= 1) {
+    deg += __shfl_down(deg, off, 64);
+    const unsigned long long o = __shfl_down(mx, off, 64);
+    mx = o > mx ? o : mx;
+  }
+  if (lane == 0) { s_c[wv] = (unsigned long long)__popcll(m); s_e[wv] = deg; s_m[wv] = mx; }
+  if (m != 0ull) {
+    unsigned int start = 0;
+    if (lane == 0) start = atomicAdd(next_count, (unsigned int)__popcll(m));
+    start = (unsigned int)__shfl((int)start, 0, 64);
+    // entries beyond the cap are never read (the host takes a top-down step only for small sets)
+    if (changed && start < (unsigned int)kSparseListCap + 64u) next_list[start + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long c = 0, e = 0, x2 = 0;
+    for (int w = 0; w < kBlock / 64; w++) { c += s_c[w]; e += s_e[w]; x2 = s_m[w] > x2 ? s_m[w] : x2; }
+    if (c) {
+      *changed_flag = 1;
+      unsigned long long* slot = stats + 4 * (blockIdx.x % kStatSlots);
+      atomicAdd(&slot[0], c);
+      atomicAdd(&slot[1], e);
+      atomicMax(&slot[2], x2);
+    }
+  }
+}
+
+// The same for a top-down step whose active set has many out-edges: no touched list (building one
+// costs an atomic with a result per 64 destinations), all vertices are looked at instead, and the
+// ordinary k_apply follows.
 template <class P, class T, class U, class V, class E, bool USE_VP>
 __global__ void __launch_bounds__(kBlock)
 k_push_resolve(ProgArg<P> pa, gm_csr_t S, const T* __restrict__ x, const int32_t* __restrict__ dev_of_native,
