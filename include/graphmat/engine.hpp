@@ -418,7 +418,8 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     if (gm_graph_workspace(g, 8, ((size_t)(n + 31) / 32 + 2) * 4, &pw) == GM_OK) {
       d_want = (uint32_t*)pw;
       dev::ProgArg<P> pa0 = dev::make_prog_arg(gp);
-      hipLaunchKernelGGL((dev::k_want_init<P, V>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa0, (const V*)d_vp, n, d_want);
+      // (rows past n_live have no edges: no kernel ever looks at their bit)
+      hipLaunchKernelGGL((dev::k_want_init<P, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa0, (const V*)d_vp, n_live, d_want);
     }
   }
   const bool grouped_waves = !(debug_flags() & dev::DBG_NO_GROUPED);
