@@ -245,6 +245,28 @@ def test_edge_cases(env):
     assert it == 1 and (pr == np.float32(0.3)).all() and (deg == 0).all()
 
 
+@pytest.mark.parametrize("width", [1000, 65536, 65537, 200000])
+def test_bfs_active_set_sizes_around_the_top_down_limits(env, width):
+    """source -> `width` middle vertices -> one leaf each (plus a few cross edges): the active set of
+    level 2 has exactly `width` vertices, i.e. below, at and above the list capacity of the top-down
+    steps (65536), and the middle vertices arrive in 64..1024-entry batches of the LDS list builder."""
+    api, ob = env
+    rng = np.random.default_rng(width)
+    mid = np.arange(2, 2 + width, dtype=np.int32)
+    leaf = mid + width
+    extra_s = rng.choice(mid, 500).astype(np.int32)
+    extra_d = rng.choice(leaf, 500).astype(np.int32)
+    s = np.concatenate([np.full(width, 1, np.int32), mid, extra_s])
+    d = np.concatenate([mid, leaf, extra_d])
+    nv = 1 + 2 * width
+    for threads in (1, 2):
+        g = api.Graph(nv, s, d, None, ref_threads=threads)
+        depth, parent, it = g.bfs(1)
+        od, op, oit, _ = ob.OracleGraph(nv, s, d, None, ref_threads=threads).bfs(1)
+        assert it == oit and np.array_equal(depth, od) and np.array_equal(parent, op)
+        assert depth.max() == 2 and (depth == 1).sum() == width
+
+
 def test_fullscale_property_checker_agrees_with_oracle_regime():
     """The independent torch property checks used at RMAT-26 (tools/fullscale_checks.py) pass at a
     scale where the oracle parity is also tested (they must agree on what 'correct' means)."""
