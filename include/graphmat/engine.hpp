@@ -256,17 +256,12 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
     if (timer) timer->mark(TAG_ROWBLOCK);
   }
   if (A.nmid > 0) {
-    bool launched = false;
-    if constexpr (program_row_filter<P>::enabled) {
-      if (grouped && want != nullptr) {  // few rows still wanted: 64 list entries per wave
-        const int groups = (A.nmid + 63) / 64;
-        hipLaunchKernelGGL((dev::k_spmv_wave_grouped<P, T, U, V, E, USE_VP, RK>), dim3((groups + WPB - 1) / WPB),
-                           dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
-                           debug_flags(), want);
-        launched = true;
-      }
-    }
-    if (!launched)
+    if (grouped && want != nullptr) {  // a row bitmap governs: 64 list entries per wave, only the wanted rows are worked on
+      const int groups = (A.nmid + 63) / 64;
+      hipLaunchKernelGGL((dev::k_spmv_wave_grouped<P, T, U, V, E, USE_VP, RK>), dim3((groups + WPB - 1) / WPB),
+                         dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
+                         debug_flags(), want);
+    } else
       hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, RK>), dim3((A.nmid + WPB - 1) / WPB),
                          dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
                          debug_flags(), want);
@@ -339,9 +334,12 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   const bool multi = gm_graph_has_exchange(g) != 0;
   const int n_live = (desc.xchg_rows > 0 && desc.xchg_rows < n && (desc.xchg_rows & 63) == 0) ? desc.xchg_rows : n;
 
-  // top-down push steps for tiny active sets (kernels.hpp: k_push_*): REDUCE_LAST programs over
+  // top-down steps for small active sets (kernels.hpp: k_push_*): REDUCE_LAST programs over
   // OUT_EDGES, running until convergence (the host already syncs once per iteration), unsharded,
-  // when the by-source adjacency is available
+  // when the by-source adjacency is available.  (A frontier-guided pull for the other reduction
+  // kinds -- mark the rows that have an active in-neighbour, multiply only those -- was tried and
+  // dropped: on RMAT graphs an active set of any size reaches most busy rows, and the extra passes
+  // plus the per-iteration statistics made SSSP 7.0 -> 13 ms on RMAT-22.)
   bool can_push = false;
   gm_csr_t Asrc;
   memset(&Asrc, 0, sizeof(Asrc));
@@ -349,14 +347,14 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   const int rk = reduce_kind_of<P, U>(gp);
   tick("reduce_function probed", rk);
   if (verbose) printf("GraphMat(HIP): reduce strategy %d (0 ordered, 1 commutative, 2 last, 3 float add)\n", rk);
-  if (rk == REDUCE_LAST) {
-    can_push = order == OUT_EDGES && act == ACTIVE_ONLY && iterations <= 0 && !multi && !(debug_flags() & dev::DBG_NO_PUSH) &&
-               gm_graph_csr(g, GM_DIR_IN, &Asrc) == GM_OK && desc.row_lo == 0 && desc.row_hi == desc.ndevice;
-    if (can_push) gm_graph_maps(g, &dev_of_native, &native_of_dev);
-  }
+  can_push = rk == REDUCE_LAST && order == OUT_EDGES && act == ACTIVE_ONLY && iterations <= 0 && !multi &&
+             !(debug_flags() & dev::DBG_NO_PUSH) && gm_graph_csr(g, GM_DIR_IN, &Asrc) == GM_OK && desc.row_lo == 0 &&
+             desc.row_hi == desc.ndevice;
+  if (can_push) gm_graph_maps(g, &dev_of_native, &native_of_dev);
   unsigned long long* d_best = nullptr;
   int32_t* d_list = nullptr;
   int32_t* d_touched = nullptr;
+  unsigned int* d_off = nullptr;
   bool list_ready = false;  // d_list holds exactly the current active set
   bool listed = false;      // the step just run wrote the list of its changed vertices
   unsigned long long* h_stats = nullptr;  // pinned: [0] changed flag (as int), [2],[3] frontier vertices / out-edges
@@ -381,12 +379,13 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   const int stats_grid = grid_for(n) < 2048 ? grid_for(n) : 2048;
   if (can_push) {
     void *pb = nullptr, *pl = nullptr, *pt = nullptr;
-    if (gm_graph_workspace(g, 6, (size_t)n * 8 + 64, &pb) != GM_OK || gm_graph_workspace(g, 7, (size_t)n * 4 + 1024, &pl) != GM_OK ||
-        gm_graph_workspace(g, 10, (size_t)n * 4 + 1024, &pt) != GM_OK) {
+    if (gm_graph_workspace(g, 7, (size_t)n * 4 + 1024 + ((size_t)dev::kSparseListCap + 64) * 4, &pl) != GM_OK ||
+        gm_graph_workspace(g, 6, (size_t)n * 8 + 64, &pb) != GM_OK || gm_graph_workspace(g, 10, (size_t)n * 4 + 1024, &pt) != GM_OK) {
       can_push = false;
     } else {
       d_best = (unsigned long long*)pb;
       d_list = (int32_t*)pl;
+      d_off = (unsigned int*)((char*)pl + ((size_t)n * 4 + 1024) / 256 * 256);  // piece offsets of the listed sources
       d_touched = (int32_t*)pt;
       GM_HIP_OK(hipMemsetAsync(d_best, 0, (size_t)n * 8, s));
       GM_HIP_OK(hipMemsetAsync(d_stats, 0, 24, s));
@@ -526,6 +525,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
                       frontier_e * 1000ull < (unsigned long long)Aout.nnz * (unsigned long long)push_edge_permille();
     // ... and among those, active sets with few out-edges run entirely on lists (nothing scans all vertices)
     const bool sparse = push && frontier_e <= (unsigned long long)sparse_step_edges();
+    const bool dense_push = push && !sparse;
     if (sparse) {
       // ---- sparse top-down step ----
       if (!list_ready) {
@@ -538,9 +538,11 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
                          (const int32_t*)d_list, nf, x, desc.row_lo);
       timer.mark(TAG_SEND);
       GM_HIP_OK(hipMemsetAsync(d_tcount, 0, 4, s));
-      const unsigned pieces = (unsigned)((frontier_maxdeg + dev::kBlock * 4 - 1) / (dev::kBlock * 4));
-      hipLaunchKernelGGL(dev::k_push_bid, dim3((unsigned)nf, pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc,
-                         (const int32_t*)d_list, nf, native_of_dev, d_best, (const uint32_t*)d_want, d_touched, d_tcount);
+      const unsigned pieces = (unsigned)(frontier_e / dev::kPieceEdges + frontier_v);  // upper bound of the pieces
+      hipLaunchKernelGGL(dev::k_piece_offsets, dim3(1), dim3(dev::kBlock), 0, s, Asrc, (const int32_t*)d_list, nf, d_off);
+      hipLaunchKernelGGL(dev::k_push_bid, dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc,
+                         (const int32_t*)d_list, nf, (const unsigned int*)d_off, native_of_dev, d_best, (const uint32_t*)d_want, d_touched,
+                         d_tcount);
       timer.mark(TAG_WAVE);
       // the active set has been consumed: rewrite the active vector and the list for the next step
       GM_HIP_OK(hipMemsetAsync(d_active, 0, (size_t)nwords * 4, s));
@@ -578,17 +580,19 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       // multiply + reduce (:160-176)
       const uint32_t* xb = dense_x ? nullptr : xbits;
       const uint32_t* apply_bits = ybits;
-      if (push) {
+      const uint32_t* row_bits = d_want;  // which rows the multiply works on
+      if (dense_push) {
         // top-down step over a larger active set: bids, then one pass over all vertices picks the winners
         if (!list_ready) {
           GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
           hipLaunchKernelGGL(dev::k_frontier_list, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active, n,
                              d_list, d_count);
         }
-        const unsigned pieces = (unsigned)((frontier_maxdeg + dev::kBlock * 4 - 1) / (dev::kBlock * 4));
-        hipLaunchKernelGGL(dev::k_push_bid, dim3((unsigned)frontier_v, pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc,
-                           (const int32_t*)d_list, (int)frontier_v, native_of_dev, d_best, (const uint32_t*)d_want,
-                           (int32_t*)nullptr, (unsigned int*)nullptr);
+        const unsigned pieces = (unsigned)(frontier_e / dev::kPieceEdges + frontier_v);
+        hipLaunchKernelGGL(dev::k_piece_offsets, dim3(1), dim3(dev::kBlock), 0, s, Asrc, (const int32_t*)d_list, (int)frontier_v, d_off);
+        hipLaunchKernelGGL(dev::k_push_bid, dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc,
+                           (const int32_t*)d_list, (int)frontier_v, (const unsigned int*)d_off, native_of_dev, d_best,
+                           (const uint32_t*)d_want, (int32_t*)nullptr, (unsigned int*)nullptr);
         if (use_vp)
           hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, true>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, Asrc,
                              (const T*)x, dev_of_native, (const V*)d_vp, d_best, y, ybits, n);
@@ -599,11 +603,11 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         timer.mark(TAG_WAVE);
       } else if (order == OUT_EDGES || order == ALL_EDGES) {
         const int acc = static_bits ? dev::ACC_STATIC_BITS : 0;
-        if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
-        else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
+        if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves);
+        else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves);
         if (static_bits) apply_bits = Aout.rowbits;
       }
-      if (!push && (order == IN_EDGES || order == ALL_EDGES)) {
+      if (!dense_push && (order == IN_EDGES || order == ALL_EDGES)) {
         int acc = (order == ALL_EDGES) ? dev::ACC_READ_PREV : 0;
         uint32_t* yb = ybits;
         if (static_bits) {

@@ -62,17 +62,14 @@ struct program_row_filter {
 
 namespace dev {
 
-// Row filter lookup (program_row_filter).  The engine keeps one bit per row, "this row still wants
-// messages" (k_want_init / k_apply), so the multiply kernels test a bit of an L2-resident bitmap
-// instead of fetching the row's vertex property; `want` == nullptr evaluates the filter directly.
+// Which rows a multiply pass works on.  `want` is a bitmap over the rows: the program's row filter
+// (program_row_filter; the engine keeps it as one bit per row, k_want_init / k_apply).
+// `want` == nullptr evaluates the program's filter directly (every row if it has none).
 template <class P, class V>
 __device__ __forceinline__ bool row_wanted(const P& p, const V* __restrict__ vp, const uint32_t* __restrict__ want, int row) {
-  if constexpr (program_row_filter<P>::enabled) {
-    if (want != nullptr) return (want[row >> 5] >> (row & 31)) & 1u;
-    return program_row_filter<P>::wants(p, vp[row]);
-  } else {
-    return true;
-  }
+  if (want != nullptr) return (want[row >> 5] >> (row & 31)) & 1u;
+  if constexpr (program_row_filter<P>::enabled) return program_row_filter<P>::wants(p, vp[row]);
+  return true;
 }
 
 
@@ -410,7 +407,7 @@ k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32
   if (n == 0 || n > kStage) return;  // cannot happen for a row-block (see gm_csr_t)
   constexpr bool dense = DENSE;  // every x entry present (xbits == nullptr)
   bool wanted = true;
-  if constexpr (program_row_filter<P>::enabled) {
+  if (program_row_filter<P>::enabled || want != nullptr) {  // (uniform over the launch)
     wanted = row < r1 && rp1 > rp0 && row_wanted(p, vp, want, row);
     if (!__syncthreads_or(wanted)) return;  // no row of this block would use a message
   }
@@ -1159,6 +1156,58 @@ k_frontier_list(const uint32_t* __restrict__ active, int n, int32_t* __restrict_
   blist.finish(list, count, 0u);
 }
 
+// Work decomposition of the kernels that walk the out-edges of a listed active set: source i owns
+// ceil(deg_i / kPieceEdges) pieces; off[i] = pieces before source i (off[nlist] = total).  One
+// workgroup scans the (at most kSparseListCap) list entries.  The edge kernels are launched with
+// an upper bound of the total (out-edges / kPieceEdges + sources) and find their source by
+// bisection -- a grid of sources x max-pieces would be almost entirely empty workgroups as soon as
+// one hub is active (2.7 K sources x 837 pieces = 2.2 M launches for 18 K useful ones).
+constexpr int kPieceEdges = kBlock * 4;
+__global__ void __launch_bounds__(kBlock)
+k_piece_offsets(gm_csr_t S, const int32_t* __restrict__ list, int nlist, unsigned int* __restrict__ off) {
+  __shared__ unsigned int s_w[kBlock / 64];
+  __shared__ unsigned int s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int base = 0; base < nlist; base += kBlock) {
+    const int i = base + threadIdx.x;
+    unsigned int v = 0;
+    if (i < nlist) {
+      const int u = list[i];
+      v = (unsigned int)((S.rowptr[u + 1] - S.rowptr[u] + kPieceEdges - 1) / kPieceEdges);
+    }
+    unsigned int inc = v;  // inclusive scan inside the wave
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned int o = (unsigned int)__shfl_up((int)inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    unsigned int before = s_carry;
+    for (int w = 0; w < wv; w++) before += s_w[w];
+    if (i < nlist) off[i] = before + inc - v;
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) s_carry = before + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) off[nlist] = s_carry;
+}
+// (source index, first edge, end edge) of workgroup b; false when b is past the last piece
+__device__ __forceinline__ bool piece_of_block(const gm_csr_t& S, const int32_t* __restrict__ list, int nlist,
+                                               const unsigned int* __restrict__ off, unsigned int b, int* u, int64_t* e0, int64_t* e1) {
+  if (b >= off[nlist]) return false;
+  int lo = 0, hi = nlist - 1;  // largest i with off[i] <= b
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (off[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  *u = list[lo];
+  *e0 = S.rowptr[*u] + (int64_t)(b - off[lo]) * kPieceEdges;
+  *e1 = S.rowptr[*u + 1];
+  return *e0 < *e1;
+}
+
 // messages of the listed (active) vertices only
 template <class P, class T, class V>
 __global__ void __launch_bounds__(kBlock)
@@ -1172,16 +1221,17 @@ k_send_list(ProgArg<P> pa, const V* __restrict__ vp, const int32_t* __restrict__
   x[(size_t)row_base + u] = m;
 }
 
-// bids: blockIdx.x = active source, blockIdx.y = 1024-edge piece of its out-edges.  The first bid
+// bids: one workgroup per 1024-edge piece of an active source's out-edges.  The first bid
 // a destination receives also puts it on the `touched` list (its slot of `best` was 0 before).
 __global__ void __launch_bounds__(kBlock)
 k_push_bid(gm_csr_t S /* rows = sources */, const int32_t* __restrict__ list, int nlist,
-           const int32_t* __restrict__ native_of_dev, unsigned long long* __restrict__ best,
+           const unsigned int* __restrict__ off, const int32_t* __restrict__ native_of_dev,
+           unsigned long long* __restrict__ best,
            const uint32_t* __restrict__ want /* row-filter bits of the destinations, or null */,
            int32_t* __restrict__ touched, unsigned int* __restrict__ tcount) {
-  const int u = list[blockIdx.x];
-  const int64_t e0 = S.rowptr[u] + (int64_t)blockIdx.y * (kBlock * 4), e1 = S.rowptr[u + 1];
-  if (e0 >= e1) return;
+  int u;
+  int64_t e0, e1;
+  if (!piece_of_block(S, list, nlist, off, blockIdx.x, &u, &e0, &e1)) return;
   const unsigned long long hi = (unsigned long long)((native_of_dev ? native_of_dev[u] : u) + 1) << 32;
   const int lane = threadIdx.x & 63;
 #pragma unroll
