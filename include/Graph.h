@@ -67,6 +67,30 @@ void AddFn(const T& a, const T& b, T* c, void* vsp) {
   *c = a + b;
 }
 
+// Host mirrors live in pinned memory: an application typically touches every vertex on the host
+// between runs (src/BFS.cpp:114-119 of the reference), so each run starts with a full upload,
+// which from pageable memory costs more than the traversal itself (100 MB at RMAT-22: 2.5-7 ms).
+template <class T>
+struct PinnedAllocator {
+  typedef T value_type;
+  PinnedAllocator() {}
+  template <class O>
+  PinnedAllocator(const PinnedAllocator<O>&) {}
+  T* allocate(size_t n) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, n * sizeof(T) > 0 ? n * sizeof(T) : 1, hipHostMallocDefault) != hipSuccess || !p) {
+      printf("GraphMat(HIP): could not allocate %zu bytes of pinned host memory\n", n * sizeof(T));
+      exit(1);
+    }
+    return static_cast<T*>(p);
+  }
+  void deallocate(T* p, size_t) { (void)hipHostFree(p); }
+  template <class O>
+  bool operator==(const PinnedAllocator<O>&) const { return true; }
+  template <class O>
+  bool operator!=(const PinnedAllocator<O>&) const { return false; }
+};
+
 // ---- device vector with the reference's "dense segment" semantics ---------------------
 // value[capacity] + presence bits (bit i&31 of word i>>5), cf. the reference's
 // include/GMDP/vectors/DenseSegment.h:423-640; here both live in HBM, with an
@@ -81,8 +105,8 @@ class DenseSegment {
   uint32_t* bit_vector;  // device
   bool owns_device;
   bool mirrored;
-  std::vector<store_t> hvalue;
-  std::vector<uint32_t> hbits;
+  std::vector<store_t, PinnedAllocator<store_t> > hvalue;
+  std::vector<uint32_t, PinnedAllocator<uint32_t> > hbits;
   bool host_valid, dev_valid;
 
   DenseSegment(int n, bool with_values)
@@ -499,7 +523,7 @@ template <class T>
 void Graph<V, E>::applyReduceAllVertices(T* val, void (*ApplyFn)(V*, T*, void*),
                                          void (*ReduceFn)(const T&, const T&, T*, void*), void* param) {
   vertexproperty->segment->need_host();
-  std::vector<V>& h = vertexproperty->segment->hvalue;
+  auto& h = vertexproperty->segment->hvalue;
   const int n = (int)h.size();
   const int nthreads = num_threads;  // chunking of reduce.h:57-66
   const int per = (n + nthreads - 1) / nthreads;
@@ -520,7 +544,7 @@ void Graph<V, E>::applyReduceAllVertices(T* val, void (*ApplyFn)(V*, T*, void*),
 template <class V, class E>
 void Graph<V, E>::applyToAllEdges(void (*ApplyFn)(E*, const V&, const V&, void*), void* param) {
   vertexproperty->segment->need_host();
-  const std::vector<V>& h = vertexproperty->segment->hvalue;
+  const auto& h = vertexproperty->segment->hvalue;
   for (int dir : {GM_DIR_OUT, GM_DIR_IN}) {
     gm_csr_t c;
     if (gm_graph_csr(A, dir, &c) != GM_OK) continue;
