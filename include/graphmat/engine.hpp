@@ -621,15 +621,18 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       }
       // setAllInactive (:184) + apply (:195-225): the active vector is rewritten by k_apply
       // (when top-down steps are possible the kernel also sizes and lists the next active set)
-      // the changed vertices are also listed when the next active set may be small (the current one is
-      // not huge); if that guess is wrong a k_frontier_list pass builds the list when it is needed
-      const bool build_list = want_stats && frontier_v <= 16ull * (unsigned long long)dev::kSparseListCap;
+      // the changed vertices are also listed when the next active set is bound to be small: it cannot
+      // have more vertices than the current one has out-edges.  (If it turns out small without having
+      // been listed, a k_frontier_list pass builds the list when it is needed.)
+      const bool build_list = want_stats && frontier_e <= 64ull * (unsigned long long)dev::kSparseListCap;
       if (want_stats) {
         GM_HIP_OK(hipMemsetAsync(d_striped, 0, striped_bytes, s));
         GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
       }
       listed = build_list;
-      const int apply_grid = grid_for(n_live) < dev::kApplyMaxBlocks ? grid_for(n_live) : dev::kApplyMaxBlocks;
+      // (a workgroup that lists changed vertices ends with one global atomic: fewer, longer-running workgroups then)
+      const int apply_cap = build_list ? dev::kApplyMaxBlocks / 4 : dev::kApplyMaxBlocks;
+      const int apply_grid = grid_for(n_live) < apply_cap ? grid_for(n_live) : apply_cap;
       hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y,
                          apply_bits, d_vp, d_active, n_live, d_changed, want_stats ? Asrc.rowptr : (const int64_t*)nullptr,
                          want_stats ? d_striped : (unsigned long long*)nullptr, d_want, build_list ? d_list : (int32_t*)nullptr,
