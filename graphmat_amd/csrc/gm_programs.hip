@@ -166,7 +166,7 @@ namespace gm {
 // to the generic kernels'; only the mapping to the machine differs:
 //   * x (the message vector = a copy of the latent vectors) is laid out with a row stride of K
 //     floats (512 B for K = 128), without the sqerr field, so a row is one aligned burst;
-//   * one wave per row, 32 edges at a time, their x rows fetched once as coalesced bursts into an
+//   * one wave per row, 16 edges at a time, their x rows fetched once as coalesced bursts into an
 //     LDS tile (next tile in flight meanwhile): phase A gives every lane one edge and walks its x
 //     row sequentially against the row's own vector (the ordered dot product); phase B gives
 //     every lane K/64 components and walks the edges in order, accumulating error-scaled messages.
@@ -199,14 +199,14 @@ static int sgd_exchange(gm_graph_t* g, float* x, int K) {
 }
 
 // MODE 0: SGD messages into y (row stride K);  MODE 1: RMSE, squared errors summed into y1[row]
-// One wave per row, kSgdTile edges per step.  The step's x rows are fetched exactly once, as
+// One wave per row, kSgdTile (16) edges per step.  The step's x rows are fetched exactly once, as
 // whole coalesced bursts (each load instruction covers 64/(K/4) complete rows), and parked in the
 // wave's LDS tile; the next step's rows are already in flight while this step computes:
 //   phase A  lane = edge: the ordered K-term dot product of its x row (LDS) with the row's own
 //            vector (LDS, broadcast), then err = rating - estimate;
 //   phase B  lane = K/64 components: the tile's edges in stored order, y += x_row * err, x from LDS.
-constexpr int kSgdMulBlock = 128;  // 2 waves: 2 x (32 x (K+4) + K) floats of LDS = 34.8 KB at K = 128
-constexpr int kSgdTile = 32;
+constexpr int kSgdMulBlock = 128;  // 2 waves: 2 x (16 x (K+4) + K) floats of LDS = 17.9 KB at K = 128
+constexpr int kSgdTile = 16;       // measured on 2e8 ratings: tile 8 / 16 / 32 / 64 -> 41.0 / 31.6 / 34.6 / 50.3 ms per iteration
 
 template <int K, int MODE>
 __global__ void __launch_bounds__(kSgdMulBlock)
