@@ -347,7 +347,10 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   const int rk = reduce_kind_of<P, U>(gp);
   tick("reduce_function probed", rk);
   if (verbose) printf("GraphMat(HIP): reduce strategy %d (0 ordered, 1 commutative, 2 last, 3 float add)\n", rk);
-  can_push = rk == REDUCE_LAST && order == OUT_EDGES && act == ACTIVE_ONLY && iterations <= 0 && !multi &&
+  // (REDUCE_COMMUTATIVE programs with a 4-byte reduction type take the list-based steps too, folding with
+  // compare-and-swap: k_push_combine)
+  const bool comm_push = rk == REDUCE_COMMUTATIVE && sizeof(U) == 4 && std::is_trivially_copyable<U>::value;
+  can_push = (rk == REDUCE_LAST || comm_push) && order == OUT_EDGES && act == ACTIVE_ONLY && iterations <= 0 && !multi &&
              !(debug_flags() & dev::DBG_NO_PUSH) && gm_graph_csr(g, GM_DIR_IN, &Asrc) == GM_OK && desc.row_lo == 0 &&
              desc.row_hi == desc.ndevice;
   if (can_push) gm_graph_maps(g, &dev_of_native, &native_of_dev);
@@ -379,7 +382,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   const int stats_grid = grid_for(n) < 2048 ? grid_for(n) : 2048;
   if (can_push) {
     void *pb = nullptr, *pl = nullptr, *pt = nullptr;
-    if (gm_graph_workspace(g, 7, (size_t)n * 4 + 1024 + ((size_t)dev::kSparseListCap + 64) * 4, &pl) != GM_OK ||
+    if (gm_graph_workspace(g, 7, (size_t)n * 4 + 1024 + ((size_t)dev::kSparseListCap + 64 + dev::kSparseListCap / dev::kBlock + 64) * 4, &pl) != GM_OK ||
         gm_graph_workspace(g, 6, (size_t)n * 8 + 64, &pb) != GM_OK || gm_graph_workspace(g, 10, (size_t)n * 4 + 1024, &pt) != GM_OK) {
       can_push = false;
     } else {
@@ -507,6 +510,16 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     }
   }
 
+  // piece offsets of the listed sources (kernels.hpp: k_piece_*); the per-workgroup bases live behind them
+  auto piece_offsets = [&](int nf) {
+    const int nb = grid_for(nf);
+    unsigned int* d_base = d_off + dev::kSparseListCap + 64;
+    hipLaunchKernelGGL(dev::k_piece_count, dim3(nb), dim3(dev::kBlock), 0, s, Asrc, (const int32_t*)d_list, nf, d_base);
+    hipLaunchKernelGGL(dev::k_piece_block_scan, dim3(1), dim3(dev::kBlock), 0, s, d_base, nb);
+    hipLaunchKernelGGL(dev::k_piece_offsets, dim3(nb), dim3(dev::kBlock), 0, s, Asrc, (const int32_t*)d_list, nf,
+                       (const unsigned int*)d_base, d_off);
+  };
+
   int it = 0;
   tick("setup done", 0);
   while (true) {
@@ -525,7 +538,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
                       frontier_e * 1000ull < (unsigned long long)Aout.nnz * (unsigned long long)push_edge_permille();
     // ... and among those, active sets with few out-edges run entirely on lists (nothing scans all vertices)
     const bool sparse = push && frontier_e <= (unsigned long long)sparse_step_edges();
-    const bool dense_push = push && !sparse;
+    const bool dense_push = push && !sparse && rk == REDUCE_LAST;
     if (sparse) {
       // ---- sparse top-down step ----
       if (!list_ready) {
@@ -539,10 +552,23 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       timer.mark(TAG_SEND);
       GM_HIP_OK(hipMemsetAsync(d_tcount, 0, 4, s));
       const unsigned pieces = (unsigned)(frontier_e / dev::kPieceEdges + frontier_v);  // upper bound of the pieces
-      hipLaunchKernelGGL(dev::k_piece_offsets, dim3(1), dim3(dev::kBlock), 0, s, Asrc, (const int32_t*)d_list, nf, d_off);
-      hipLaunchKernelGGL(dev::k_push_bid, dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc,
-                         (const int32_t*)d_list, nf, (const unsigned int*)d_off, native_of_dev, d_best, (const uint32_t*)d_want, d_touched,
-                         d_tcount);
+      piece_offsets(nf);
+      if (rk == REDUCE_LAST) {
+        hipLaunchKernelGGL(dev::k_push_bid, dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc,
+                           (const int32_t*)d_list, nf, (const unsigned int*)d_off, native_of_dev, d_best, (const uint32_t*)d_want,
+                           d_touched, d_tcount);
+      } else {
+        if constexpr (sizeof(U) == 4 && std::is_trivially_copyable<U>::value) {
+          if (use_vp)
+            hipLaunchKernelGGL((dev::k_push_combine<P, T, U, V, E, true>), dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, pa,
+                               Asrc, (const int32_t*)d_list, nf, (const unsigned int*)d_off, (const T*)x, (const V*)d_vp, d_best,
+                               (const uint32_t*)d_want, d_touched, d_tcount);
+          else
+            hipLaunchKernelGGL((dev::k_push_combine<P, T, U, V, E, false>), dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, pa,
+                               Asrc, (const int32_t*)d_list, nf, (const unsigned int*)d_off, (const T*)x, (const V*)d_vp, d_best,
+                               (const uint32_t*)d_want, d_touched, d_tcount);
+        }
+      }
       timer.mark(TAG_WAVE);
       // the active set has been consumed: rewrite the active vector and the list for the next step
       GM_HIP_OK(hipMemsetAsync(d_active, 0, (size_t)nwords * 4, s));
@@ -550,14 +576,17 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
       const unsigned long long bound = frontier_e < (unsigned long long)n ? frontier_e : (unsigned long long)n;
       if (bound > 0) {
-        if (use_vp)
-          hipLaunchKernelGGL((dev::k_push_finish<P, T, U, V, E, true>), dim3(grid_for((int64_t)bound)), dim3(dev::kBlock), 0, s, pa,
-                             Asrc, (const T*)x, dev_of_native, d_vp, d_best, (const int32_t*)d_touched, (const unsigned int*)d_tcount,
-                             d_active, d_changed, d_striped, d_want, d_list, d_count);
-        else
-          hipLaunchKernelGGL((dev::k_push_finish<P, T, U, V, E, false>), dim3(grid_for((int64_t)bound)), dim3(dev::kBlock), 0, s, pa,
-                             Asrc, (const T*)x, dev_of_native, d_vp, d_best, (const int32_t*)d_touched, (const unsigned int*)d_tcount,
-                             d_active, d_changed, d_striped, d_want, d_list, d_count);
+        auto finish = [&](auto use_vp_c, auto combined_c) {
+          hipLaunchKernelGGL((dev::k_push_finish<P, T, U, V, E, decltype(use_vp_c)::value, decltype(combined_c)::value>),
+                             dim3(grid_for((int64_t)bound)), dim3(dev::kBlock), 0, s, pa, Asrc, (const T*)x, dev_of_native, d_vp, d_best,
+                             (const int32_t*)d_touched, (const unsigned int*)d_tcount, d_active, d_changed, d_striped, d_want, d_list,
+                             d_count);
+        };
+        if (rk == REDUCE_LAST) {
+          if (use_vp) finish(std::true_type(), std::false_type()); else finish(std::false_type(), std::false_type());
+        } else {
+          if (use_vp) finish(std::true_type(), std::true_type()); else finish(std::false_type(), std::true_type());
+        }
       }
       st.spmv_launches += 2;
       listed = true;
@@ -589,7 +618,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
                              d_list, d_count);
         }
         const unsigned pieces = (unsigned)(frontier_e / dev::kPieceEdges + frontier_v);
-        hipLaunchKernelGGL(dev::k_piece_offsets, dim3(1), dim3(dev::kBlock), 0, s, Asrc, (const int32_t*)d_list, (int)frontier_v, d_off);
+        piece_offsets((int)frontier_v);
         hipLaunchKernelGGL(dev::k_push_bid, dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc,
                            (const int32_t*)d_list, (int)frontier_v, (const unsigned int*)d_off, native_of_dev, d_best,
                            (const uint32_t*)d_want, (int32_t*)nullptr, (unsigned int*)nullptr);
@@ -624,7 +653,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       // the changed vertices are also listed when the next active set is bound to be small: it cannot
       // have more vertices than the current one has out-edges.  (If it turns out small without having
       // been listed, a k_frontier_list pass builds the list when it is needed.)
-      const bool build_list = want_stats && frontier_e <= 64ull * (unsigned long long)dev::kSparseListCap;
+      const bool build_list = want_stats && frontier_e <= (4ull << 20);
       if (want_stats) {
         GM_HIP_OK(hipMemsetAsync(d_striped, 0, striped_bytes, s));
         GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));

@@ -205,7 +205,7 @@ k_want_init(ProgArg<P> pa, const V* __restrict__ vp, int n, uint32_t* __restrict
 // set of atomics at the end, into one of kStatSlots counter triples that the host sums.
 constexpr int kStatSlots = 64;
 constexpr int kApplyMaxBlocks = 4096;
-constexpr int kSparseListCap = 65536;  // top-down steps are taken for active sets of at most this many vertices
+constexpr int kSparseListCap = 65536;  // top-down steps are taken for active sets of at most this many vertices (2^20: slower, the list kernels live on global atomics)
 template <class P, class U, class V>
 __global__ void __launch_bounds__(kBlock)
 k_apply(ProgArg<P> pa, const U* __restrict__ y, const uint32_t* __restrict__ ybits, V* __restrict__ vp,
@@ -1157,41 +1157,65 @@ k_frontier_list(const uint32_t* __restrict__ active, int n, int32_t* __restrict_
 }
 
 // Work decomposition of the kernels that walk the out-edges of a listed active set: source i owns
-// ceil(deg_i / kPieceEdges) pieces; off[i] = pieces before source i (off[nlist] = total).  One
-// workgroup scans the (at most kSparseListCap) list entries.  The edge kernels are launched with
+// ceil(deg_i / kPieceEdges) pieces; off[i] = pieces before source i (off[nlist] = total).
+// The edge kernels are launched with
 // an upper bound of the total (out-edges / kPieceEdges + sources) and find their source by
 // bisection -- a grid of sources x max-pieces would be almost entirely empty workgroups as soon as
 // one hub is active (2.7 K sources x 837 pieces = 2.2 M launches for 18 K useful ones).
 constexpr int kPieceEdges = kBlock * 4;
-__global__ void __launch_bounds__(kBlock)
-k_piece_offsets(gm_csr_t S, const int32_t* __restrict__ list, int nlist, unsigned int* __restrict__ off) {
-  __shared__ unsigned int s_w[kBlock / 64];
-  __shared__ unsigned int s_carry;
-  if (threadIdx.x == 0) s_carry = 0;
-  __syncthreads();
+// exclusive scan of the piece counts in three small launches: per-workgroup totals, a one-workgroup
+// scan of those (at most kSparseListCap / kBlock of them), per-workgroup scan plus its base
+__device__ __forceinline__ unsigned int pieces_of(const gm_csr_t& S, int u) {
+  return (unsigned int)((S.rowptr[u + 1] - S.rowptr[u] + kPieceEdges - 1) / kPieceEdges);
+}
+// inclusive scan of one value per thread over the workgroup; returns the inclusive value, *total = workgroup sum
+__device__ __forceinline__ unsigned int block_scan_inclusive(unsigned int v, unsigned int* s_w /* kBlock/64 */, unsigned int* total) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int base = 0; base < nlist; base += kBlock) {
-    const int i = base + threadIdx.x;
-    unsigned int v = 0;
-    if (i < nlist) {
-      const int u = list[i];
-      v = (unsigned int)((S.rowptr[u + 1] - S.rowptr[u] + kPieceEdges - 1) / kPieceEdges);
-    }
-    unsigned int inc = v;  // inclusive scan inside the wave
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned int o = (unsigned int)__shfl_up((int)inc, d, 64);
-      if (lane >= d) inc += o;
-    }
-    if (lane == 63) s_w[wv] = inc;
-    __syncthreads();
-    unsigned int before = s_carry;
-    for (int w = 0; w < wv; w++) before += s_w[w];
-    if (i < nlist) off[i] = before + inc - v;
-    __syncthreads();
-    if (threadIdx.x == kBlock - 1) s_carry = before + inc;
-    __syncthreads();
+  unsigned int inc = v;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned int o = (unsigned int)__shfl_up((int)inc, d, 64);
+    if (lane >= d) inc += o;
   }
-  if (threadIdx.x == 0) off[nlist] = s_carry;
+  __syncthreads();  // s_w may still be read from a previous call
+  if (lane == 63) s_w[wv] = inc;
+  __syncthreads();
+  unsigned int before = 0, all = 0;
+  for (int w = 0; w < kBlock / 64; w++) { if (w < wv) before += s_w[w]; all += s_w[w]; }
+  *total = all;
+  return before + inc;
+}
+__global__ void __launch_bounds__(kBlock)
+k_piece_count(gm_csr_t S, const int32_t* __restrict__ list, int nlist, unsigned int* __restrict__ block_sum) {
+  __shared__ unsigned int s_w[kBlock / 64];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  unsigned int total;
+  (void)block_scan_inclusive(i < nlist ? pieces_of(S, list[i]) : 0u, s_w, &total);
+  if (threadIdx.x == 0) block_sum[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(kBlock)
+k_piece_block_scan(unsigned int* __restrict__ block_sum, int nblocks) {  // in place: exclusive; [nblocks] = grand total
+  __shared__ unsigned int s_w[kBlock / 64];
+  unsigned int carry = 0;
+  for (int base = 0; base < nblocks; base += kBlock) {
+    const int i = base + threadIdx.x;
+    const unsigned int v = i < nblocks ? block_sum[i] : 0u;
+    unsigned int total;
+    const unsigned int inc = block_scan_inclusive(v, s_w, &total);
+    if (i < nblocks) block_sum[i] = carry + inc - v;
+    carry += total;
+  }
+  if (threadIdx.x == 0) block_sum[nblocks] = carry;
+}
+__global__ void __launch_bounds__(kBlock)
+k_piece_offsets(gm_csr_t S, const int32_t* __restrict__ list, int nlist, const unsigned int* __restrict__ block_base,
+                unsigned int* __restrict__ off) {
+  __shared__ unsigned int s_w[kBlock / 64];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const unsigned int v = i < nlist ? pieces_of(S, list[i]) : 0u;
+  unsigned int total;
+  const unsigned int inc = block_scan_inclusive(v, s_w, &total);
+  if (i < nlist) off[i] = block_base[blockIdx.x] + inc - v;
+  if (i == nlist - 1) off[nlist] = block_base[blockIdx.x] + inc;
 }
 // (source index, first edge, end edge) of workgroup b; false when b is past the last piece
 __device__ __forceinline__ bool piece_of_block(const gm_csr_t& S, const int32_t* __restrict__ list, int nlist,
@@ -1259,11 +1283,70 @@ k_push_bid(gm_csr_t S /* rows = sources */, const int32_t* __restrict__ list, in
   }
 }
 
+// Top-down step of a REDUCE_COMMUTATIVE program with a 4-byte reduction type (SSSP distances,
+// labels, counts): every out-edge of the active set evaluates its message and folds it into the
+// destination's slot of `acc` -- (1 << 32 | value bits), 0 = empty, because there is no additive
+// identity: the first message assigns -- with a compare-and-swap loop around the user's
+// reduce_function.  Any order is fine for such programs, so the result is the pull's.
+template <class P, class T, class U, class V, class E, bool USE_VP>
+__global__ void __launch_bounds__(kBlock)
+k_push_combine(ProgArg<P> pa, gm_csr_t S /* rows = sources */, const int32_t* __restrict__ list, int nlist,
+               const unsigned int* __restrict__ off, const T* __restrict__ x, const V* __restrict__ vp,
+               unsigned long long* __restrict__ acc, const uint32_t* __restrict__ want, int32_t* __restrict__ touched,
+               unsigned int* __restrict__ tcount) {
+  static_assert(sizeof(U) == 4, "packed (flag, value) slots need a 4-byte reduction type");
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  int u;
+  int64_t e0, e1;
+  if (!piece_of_block(S, list, nlist, off, blockIdx.x, &u, &e0, &e1)) return;
+  const T m = x[u];
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int64_t e = e0 + threadIdx.x + j * kBlock;
+    bool first = false;
+    int c = 0;
+    if (e < e1) {
+      c = S.colidx[e];
+      if (want == nullptr || ((want[c >> 5] >> (c & 31)) & 1u)) {
+        V vprow;
+        if constexpr (USE_VP) vprow = vp[c];
+        U res;
+        p.P::process_message(m, edge_at<E>(S.vals, e), vprow, res);
+        unsigned long long old = acc[c];
+        while (true) {
+          U folded = res;
+          if (old != 0ull) {
+            const uint32_t ob = (uint32_t)old;
+            memcpy(&folded, &ob, 4);
+            p.P::reduce_function(folded, res);
+          }
+          uint32_t fb;
+          memcpy(&fb, &folded, 4);
+          const unsigned long long neu = (1ull << 32) | (unsigned long long)fb;
+          if (neu == old) break;  // the message changes nothing
+          const unsigned long long seen = atomicCAS(&acc[c], old, neu);
+          if (seen == old) { first = old == 0ull; break; }
+          old = seen;
+        }
+      }
+    }
+    const unsigned long long fm = __ballot(first);
+    if (fm) {
+      unsigned int start = 0;
+      if (lane == 0) start = atomicAdd(tcount, (unsigned int)__popcll(fm));
+      start = (unsigned int)__shfl((int)start, 0, 64);
+      if (first) touched[start + (unsigned int)__popcll(fm & ((1ull << lane) - 1ull))] = c;
+    }
+  }
+}
+
 // the rest of a top-down step, one lane per touched destination: the winning bid's message is
 // evaluated and applied on the spot (a=b: exactly one message per destination, no y round trip);
 // changed vertices are activated, counted and listed for the next step.  The grid covers an
 // upper bound of the touched count (the active set's out-edges), the real count is read here.
-template <class P, class T, class U, class V, class E, bool USE_VP>
+// COMBINED: the slot holds the already folded value (k_push_combine) instead of a bid (k_push_bid).
+template <class P, class T, class U, class V, class E, bool USE_VP, bool COMBINED>
 __global__ void __launch_bounds__(kBlock)
 k_push_finish(ProgArg<P> pa, gm_csr_t S, const T* __restrict__ x, const int32_t* __restrict__ dev_of_native,
               V* __restrict__ vp, unsigned long long* __restrict__ best, const int32_t* __restrict__ touched,
@@ -1283,14 +1366,19 @@ k_push_finish(ProgArg<P> pa, gm_csr_t S, const T* __restrict__ x, const int32_t*
     bool wanted = true;
     if constexpr (program_row_filter<P>::enabled) wanted = program_row_filter<P>::wants(p, old_prop);
     if (wanted && key != 0ull) {
-      const int un = (int)(key >> 32) - 1;
-      const int64_t e = (int64_t)(uint32_t)key;
-      const int ud = dev_of_native ? dev_of_native[un] : un;
-      T m = x[ud];
       U res;
-      V vprow;
-      if constexpr (USE_VP) vprow = old_prop;
-      p.P::process_message(m, edge_at<E>(S.vals, e), vprow, res);
+      if constexpr (COMBINED) {
+        const uint32_t rb = (uint32_t)key;
+        memcpy(&res, &rb, sizeof(U) < 4 ? sizeof(U) : 4);
+      } else {
+        const int un = (int)(key >> 32) - 1;
+        const int64_t e = (int64_t)(uint32_t)key;
+        const int ud = dev_of_native ? dev_of_native[un] : un;
+        T m = x[ud];
+        V vprow;
+        if constexpr (USE_VP) vprow = old_prop;
+        p.P::process_message(m, edge_at<E>(S.vals, e), vprow, res);
+      }
       V cur = old_prop;
       p.P::apply(res, cur);
       vp[v] = cur;
