@@ -158,6 +158,28 @@ def test_sssp_bit_exact(env, golden_dir):
     assert it == oit and (dist == odist).all()
 
 
+def test_sssp_small_active_sets_with_colliding_relaxations(env):
+    """Layered weighted graph whose active sets stay tiny, so every level is a list-based top-down step
+    (k_push_combine): many sources relax the same destination in one step (compare-and-swap fold of min),
+    duplicate edges included."""
+    api, ob = env
+    rng = np.random.default_rng(42)
+    layers = [np.array([1])] + [np.arange(a, b) for a, b in ((2, 52), (52, 252), (252, 1252), (1252, 1300))]
+    s, d = [], []
+    for up, down in zip(layers[:-1], layers[1:]):
+        for v in down:
+            for u in rng.choice(up, size=min(len(up), 6), replace=True):  # duplicates on purpose
+                s.append(int(u)); d.append(int(v))
+    s, d = np.array(s, np.int32), np.array(d, np.int32)
+    w = rng.integers(1, 100, len(s)).astype(np.int32)
+    nv = 1400  # the last 100 vertices are unreachable
+    for threads in (1, 3):
+        dist, it = api.Graph(nv, s, d, w, ref_threads=threads).sssp(1)
+        odist, oit = ob.OracleGraph(nv, s, d, w, threads).sssp(1)
+        assert it == oit and np.array_equal(dist, odist)
+    assert (dist[1300:] == 0xFFFFFFFF).all() and dist[0] == 0 and (dist[1:1299] < 0xFFFFFFFF).all()
+
+
 @pytest.mark.parametrize("n", [100, 500])
 def test_bfs_depths_closed_form(env, n):
     """The reference's own BFS tests (test/test_bfs.cpp:97-236) against the HIP path."""
