@@ -46,23 +46,25 @@ def build_one(name):
     return out
 
 
-def build(verbose=False):
-    built = []
+def build(verbose=False, jobs=None):
+    """Compile every application (a few at a time: each hipcc run is single-threaded)."""
+    from concurrent.futures import ThreadPoolExecutor
+    work = []
     appdir = os.path.join(ROOT, "apps")
     outdir = os.path.join(ROOT, "build", "apps")
     os.makedirs(outdir, exist_ok=True)
     for f in sorted(os.listdir(appdir)):
         if f.endswith(".cpp"):
-            out = os.path.join(outdir, f[:-4])
-            _compile(os.path.join(appdir, f), out, "$ORIGIN/../../graphmat_amd")
-            built.append(out)
+            work.append((os.path.join(appdir, f), os.path.join(outdir, f[:-4])))
     if os.path.isdir(os.path.join(REF, "src")):
         outdir = os.path.join(ROOT, "build", "ref_apps")
         os.makedirs(outdir, exist_ok=True)
         for app in ("PageRank", "BFS", "SGD", "SSSP", "IncrementalPageRank", "TopologicalSort", "DeltaStepping"):
-            out = os.path.join(outdir, app)
-            _compile(os.path.join(REF, "src", app + ".cpp"), out, "$ORIGIN/../../graphmat_amd")
-            built.append(out)
+            work.append((os.path.join(REF, "src", app + ".cpp"), os.path.join(outdir, app)))
+    jobs = jobs or max(1, min(6, (os.cpu_count() or 2) - 1))
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        list(pool.map(lambda w: _compile(w[0], w[1], "$ORIGIN/../../graphmat_amd"), work))
+    built = [w[1] for w in work]
     if verbose:
         print("\n".join(built))
     return built
