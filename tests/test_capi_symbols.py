@@ -97,3 +97,29 @@ def test_error_convention_invalid_arguments(lib):
     assert lib.gm_run_sgd(None, None, 20, 8, 0.0, 0.0, 1, None, None) != 0
     assert lib.gm_set_option(b"no_such_option", 1) == 1
     assert lib.gm_graph_destroy(None) == 0
+
+
+def test_error_convention_of_the_service_entry_points(lib, tmp_path):
+    """The entry points the header layer and the multi-GPU glue use reject bad arguments with a status
+    code (no GPU needed), and the edge-list reader reports unreadable / inconsistent files."""
+    import ctypes as C
+    i32, i64, vp, sz = C.c_int32(), C.c_int64(), C.c_void_p(), C.c_size_t()
+    assert lib.gm_graph_split(None, 1, 650, C.byref(i32), C.byref(i32), C.byref(i32)) == 1
+    assert lib.gm_graph_note_set(None, 0, 1) == 1 and lib.gm_graph_note_get(None, 0, C.byref(i64)) == 1
+    assert lib.gm_graph_workspace_info(None, 0, C.byref(vp), C.byref(sz), C.byref(C.c_int())) == 1
+    assert lib.gm_graph_run_resources(None, C.byref(vp), C.byref(vp), C.byref(vp), C.byref(vp)) == 1
+    assert lib.gm_graph_workspace(None, 0, 16, C.byref(vp)) == 1
+    assert lib.gm_graph_adopt_workspace(None, 1, None, 0) == 1
+    m, n = C.c_int(), C.c_int()
+    ps, pd, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    args = (C.byref(m), C.byref(n), C.byref(i64), C.byref(ps), C.byref(pd), C.byref(pv))
+    assert lib.gm_edgelist_read(str(tmp_path / "nope").encode(), 1, 1, 1, 1, *args) != 0
+    assert b"Could not open" in lib.gm_last_error()
+    assert lib.gm_edgelist_read(b"x", 1, 1, 1, 99, *args) == 1           # unknown value kind
+    assert lib.gm_edgelist_read(b"x", 0, 1, 1, 0x100 + 12, *args) == 1   # opaque values need a binary file
+    short = tmp_path / "short.bin"
+    short.write_bytes(b"\x05\x00\x00\x00\x05\x00\x00\x00\x03\x00\x00\x00" + b"\x01\x00\x00\x00\x02\x00\x00\x00\x07\x00\x00\x00")
+    assert lib.gm_edgelist_read(str(short).encode(), 1, 1, 1, 1, *args) != 0
+    assert b"header says 3 edges" in lib.gm_last_error()
+    assert lib.gm_edgelist_write(None, 1, 1, 1, 1, 3, 3, 0, None, None, None) == 1
+    assert lib.gm_set_option(b"push_edge_permille", 2000) == 1 and lib.gm_set_option(b"push_edge_permille", 50) == 0
