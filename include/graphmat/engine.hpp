@@ -468,7 +468,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         else launch_spmv<P, T, U, V, E, false>(g, pa, A, xcur, nullptr, d_vp, y, ybits, dev::ACC_STATIC_BITS, s, &st.spmv_launches, &timer, &aux, rk);
         const int cnt = r1 - r0;
         const int ag = grid_for(cnt) < dev::kApplyMaxBlocks ? grid_for(cnt) : dev::kApplyMaxBlocks;
-        hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(ag), dim3(dev::kBlock), 0, s, pa, (const U*)(y + r0), Aout.rowbits + r0 / 32,
+        hipLaunchKernelGGL((dev::k_apply<P, U, V, false>), dim3(ag), dim3(dev::kBlock), 0, s, pa, (const U*)(y + r0), Aout.rowbits + r0 / 32,
                            d_vp + r0, d_active + r0 / 32, cnt, d_changed, (const int64_t*)nullptr, (unsigned long long*)nullptr,
                            (uint32_t*)nullptr);
         timer.mark(TAG_APPLY);
@@ -662,10 +662,14 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       // (a workgroup that lists changed vertices ends with one global atomic: fewer, longer-running workgroups then)
       const int apply_cap = build_list ? dev::kApplyMaxBlocks / 4 : dev::kApplyMaxBlocks;
       const int apply_grid = grid_for(n_live) < apply_cap ? grid_for(n_live) : apply_cap;
-      hipLaunchKernelGGL((dev::k_apply<P, U, V>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y,
-                         apply_bits, d_vp, d_active, n_live, d_changed, want_stats ? Asrc.rowptr : (const int64_t*)nullptr,
-                         want_stats ? d_striped : (unsigned long long*)nullptr, d_want, build_list ? d_list : (int32_t*)nullptr,
-                         build_list ? d_count : (unsigned int*)nullptr);
+      if (want_stats)
+        hipLaunchKernelGGL((dev::k_apply<P, U, V, true>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y, apply_bits,
+                           d_vp, d_active, n_live, d_changed, Asrc.rowptr, d_striped, d_want, build_list ? d_list : (int32_t*)nullptr,
+                           build_list ? d_count : (unsigned int*)nullptr);
+      else
+        hipLaunchKernelGGL((dev::k_apply<P, U, V, false>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y, apply_bits,
+                           d_vp, d_active, n_live, d_changed, (const int64_t*)nullptr, (unsigned long long*)nullptr, d_want,
+                           (int32_t*)nullptr, (unsigned int*)nullptr);
       if (n_live < n)  // setAllInactive for the rows k_apply does not visit
         GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
       timer.mark(TAG_APPLY);

@@ -206,7 +206,9 @@ k_want_init(ProgArg<P> pa, const V* __restrict__ vp, int n, uint32_t* __restrict
 constexpr int kStatSlots = 64;
 constexpr int kApplyMaxBlocks = 4096;
 constexpr int kSparseListCap = 65536;  // top-down steps are taken for active sets of at most this many vertices (2^20: slower, the list kernels live on global atomics)
-template <class P, class U, class V>
+// STEER: the variant used by programs that may take top-down steps (statistics, list, LDS buffer);
+// plain fixed-count programs (PageRank) run the lean one.
+template <class P, class U, class V, bool STEER>
 __global__ void __launch_bounds__(kBlock)
 k_apply(ProgArg<P> pa, const U* __restrict__ y, const uint32_t* __restrict__ ybits, V* __restrict__ vp,
         uint32_t* __restrict__ active, int n, int* __restrict__ changed_flag, const int64_t* __restrict__ src_rowptr,
@@ -214,10 +216,11 @@ k_apply(ProgArg<P> pa, const U* __restrict__ y, const uint32_t* __restrict__ ybi
         uint32_t* __restrict__ want /* row-filter bits to keep up to date, or null */,
         int32_t* __restrict__ next_list = nullptr /* with stats: the changed vertices, while they are few */,
         unsigned int* __restrict__ next_count = nullptr) {
-  __shared__ unsigned long long s_c[kBlock / 64], s_e[kBlock / 64], s_m[kBlock / 64];
-  __shared__ int32_t s_lbuf[kListBuf];
+  __shared__ unsigned long long s_c[STEER ? kBlock / 64 : 1], s_e[STEER ? kBlock / 64 : 1], s_m[STEER ? kBlock / 64 : 1];
+  __shared__ int32_t s_lbuf[STEER ? kListBuf : 1];
   __shared__ unsigned int s_lfill[4];
   BlockList blist{s_lbuf, s_lfill};
+  if constexpr (!STEER) { stats = nullptr; next_list = nullptr; }
   if (next_list != nullptr) blist.init();
   unsigned long long cnt = 0, edges = 0, mx = 0;
   bool any = false;
