@@ -354,6 +354,13 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
              !(debug_flags() & dev::DBG_NO_PUSH) && gm_graph_csr(g, GM_DIR_IN, &Asrc) == GM_OK && desc.row_lo == 0 &&
              desc.row_hi == desc.ndevice;
   if (can_push) gm_graph_maps(g, &dev_of_native, &native_of_dev);
+  // a=b programs consume one message per row: unsharded, they evaluate it on demand from the sender's
+  // vertex property (kernels.hpp: message_of) and the send pass disappears; the presence bits of x
+  // are the active bits themselves
+  const bool lazy_send = rk == REDUCE_LAST && sizeof(U) <= 8 && std::is_trivially_copyable<U>::value && !multi &&
+                         act == ACTIVE_ONLY && order == OUT_EDGES && desc.row_lo == 0 && desc.row_hi == desc.ndevice &&
+                         !(debug_flags() & dev::DBG_NO_LAZY_SEND);
+  if (verbose && lazy_send) printf("GraphMat(HIP): messages are evaluated on demand (no send pass)\n");
   unsigned long long* d_best = nullptr;
   int32_t* d_list = nullptr;
   int32_t* d_touched = nullptr;
@@ -529,6 +536,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     // Clear(&x) / Clear(&y) (:139-140): x presence words are fully rewritten by send.  With
     // every x entry present (ALL_VERTICES) y's presence is the static set of non-empty rows.
     const bool static_bits = (act == ALL_VERTICES);
+    const T* xq = lazy_send ? (const T*)nullptr : (const T*)x;  // what the multiply side reads messages from
     GM_HIP_OK(hipMemsetAsync(d_changed, 0, sizeof(int), s));
     timer.mark(TAG_START);
     const bool dense_x = (act == ALL_VERTICES);
@@ -547,8 +555,9 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
                            d_list, d_count);
       }
       const int nf = (int)frontier_v;
-      hipLaunchKernelGGL((dev::k_send_list<P, T, V>), dim3(grid_for(nf)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
-                         (const int32_t*)d_list, nf, x, desc.row_lo);
+      if (!lazy_send)
+        hipLaunchKernelGGL((dev::k_send_list<P, T, V>), dim3(grid_for(nf)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
+                           (const int32_t*)d_list, nf, x, desc.row_lo);
       timer.mark(TAG_SEND);
       GM_HIP_OK(hipMemsetAsync(d_tcount, 0, 4, s));
       const unsigned pieces = (unsigned)(frontier_e / dev::kPieceEdges + frontier_v);  // upper bound of the pieces
@@ -578,7 +587,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       if (bound > 0) {
         auto finish = [&](auto use_vp_c, auto combined_c) {
           hipLaunchKernelGGL((dev::k_push_finish<P, T, U, V, E, decltype(use_vp_c)::value, decltype(combined_c)::value>),
-                             dim3(grid_for((int64_t)bound)), dim3(dev::kBlock), 0, s, pa, Asrc, (const T*)x, dev_of_native, d_vp, d_best,
+                             dim3(grid_for((int64_t)bound)), dim3(dev::kBlock), 0, s, pa, Asrc, xq, dev_of_native, d_vp, d_best,
                              (const int32_t*)d_touched, (const unsigned int*)d_tcount, d_active, d_changed, d_striped, d_want, d_list,
                              d_count);
         };
@@ -597,8 +606,9 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       if (!static_bits) GM_HIP_OK(hipMemsetAsync(ybits, 0, (size_t)nwords * 4, s));
       // send (:145).  Rows past n_live have no edge in either direction (degree-ranked order puts
       // them at the tail): nobody reads their messages and they never receive one
-      hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
-                         dense_x ? (const uint32_t*)nullptr : (const uint32_t*)d_active, x, xbits, n_live, desc.row_lo);
+      if (!lazy_send)
+        hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
+                           dense_x ? (const uint32_t*)nullptr : (const uint32_t*)d_active, x, xbits, n_live, desc.row_lo);
       if (multi) {
         if (gm_graph_exchange(g, GM_XCHG_MESSAGES, x, (int64_t)sizeof(T), xbits, nullptr) != 0) {
           printf("GraphMat(HIP): message exchange callback failed\n");
@@ -607,7 +617,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       }
       timer.mark(TAG_SEND);
       // multiply + reduce (:160-176)
-      const uint32_t* xb = dense_x ? nullptr : xbits;
+      const uint32_t* xb = dense_x ? nullptr : (lazy_send ? (const uint32_t*)d_active : (const uint32_t*)xbits);
       const uint32_t* apply_bits = ybits;
       const uint32_t* row_bits = d_want;  // which rows the multiply works on
       if (dense_push) {
@@ -624,16 +634,16 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
                            (const uint32_t*)d_want, (int32_t*)nullptr, (unsigned int*)nullptr);
         if (use_vp)
           hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, true>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, Asrc,
-                             (const T*)x, dev_of_native, (const V*)d_vp, d_best, y, ybits, n);
+                             xq, dev_of_native, (const V*)d_vp, d_best, y, ybits, n);
         else
           hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, false>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, Asrc,
-                             (const T*)x, dev_of_native, (const V*)d_vp, d_best, y, ybits, n);
+                             xq, dev_of_native, (const V*)d_vp, d_best, y, ybits, n);
         st.spmv_launches += 2;
         timer.mark(TAG_WAVE);
       } else if (order == OUT_EDGES || order == ALL_EDGES) {
         const int acc = static_bits ? dev::ACC_STATIC_BITS : 0;
-        if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves);
-        else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, x, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves);
+        if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves);
+        else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves);
         if (static_bits) apply_bits = Aout.rowbits;
       }
       if (!dense_push && (order == IN_EDGES || order == ALL_EDGES)) {

@@ -73,6 +73,18 @@ __device__ __forceinline__ bool row_wanted(const P& p, const V* __restrict__ vp,
 }
 
 
+// The message of vertex c.  a=b programs consume one message per row, so (unsharded) they do
+// not need the send pass at all: with x == nullptr the message is evaluated on demand from the
+// sender's vertex property -- send_message is const and vertex properties do not change between
+// the send and the multiply phase, so this is the value k_send would have stored.
+template <class P, class T, class V>
+__device__ __forceinline__ T message_of(const P& p, const T* __restrict__ x, const V* __restrict__ vp, int c) {
+  if (x != nullptr) return x[c];
+  T m;
+  p.P::send_message(vp[c], m);
+  return m;
+}
+
 // [0] chunks accepted by the exact fp32 replay, [1] chunks folded serially (long rows)
 static __device__ unsigned long long g_longrow_counters[4];
 
@@ -310,7 +322,7 @@ __device__ __forceinline__ E edge_at(const void* __restrict__ vals, int64_t k) {
 // earlier pass (their presence is read from ybits); ACC_STATIC_BITS = do not write presence
 // bits (every x entry is present, so y's presence equals the graph's static row bits)
 enum { ACC_READ_PREV = 1, ACC_STATIC_BITS = 2 };
-enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64, DBG_NO_PIPELINE = 128 };
+enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64, DBG_NO_PIPELINE = 128, DBG_NO_LAZY_SEND = 256 };
 
 // presence bits of a wave's 64 consecutive rows: one atomicOr per 32-row word (not per row:
 // same-word atomics from 32 lanes serialise in the L2); nothing when the bits are static
@@ -364,7 +376,7 @@ k_spmv_short_last(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint
       if (cc >= 0 && !(dbg & DBG_SKIP_FOLD)) {
         V vprow;
         if constexpr (USE_VP) vprow = vp[row];
-        T m = x[cc];
+        T m = message_of(p, x, vp, cc);
         U res;
         p.P::process_message(m, edge_at<E>(A.vals, kk), vprow, res);
         y[row] = res;
@@ -596,7 +608,7 @@ __device__ __forceinline__ void wave_row(const P& p, const gm_csr_t& A, const in
         if (mask) {
           if (lane == 63 - __clzll(mask)) {
             const int64_t k = hi - 64 * (u + 1) + lane;
-            T m = x[c[u]];
+            T m = message_of(p, x, vp, c[u]);
             U res;
             p.P::process_message(m, edge_at<E>(A.vals, k), vprow, res);
             y[row] = res;
@@ -925,7 +937,7 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
       if (f >= 0) {
         if (tid == 0) {
           int64_t k = lo + f;
-          T m = x[A.colidx[k]];
+          T m = message_of(p, x, vp, A.colidx[k]);
           U res;
           p.P::process_message(m, edge_at<E>(A.vals, k), vprow, res);
           y[row] = res;
@@ -1377,7 +1389,7 @@ k_push_finish(ProgArg<P> pa, gm_csr_t S, const T* __restrict__ x, const int32_t*
         const int un = (int)(key >> 32) - 1;
         const int64_t e = (int64_t)(uint32_t)key;
         const int ud = dev_of_native ? dev_of_native[un] : un;
-        T m = x[ud];
+        T m = message_of(p, x, (const V*)vp, ud);
         V vprow;
         if constexpr (USE_VP) vprow = old_prop;
         p.P::process_message(m, edge_at<E>(S.vals, e), vprow, res);
@@ -1444,7 +1456,7 @@ k_push_resolve(ProgArg<P> pa, gm_csr_t S, const T* __restrict__ x, const int32_t
         const int un = (int)(key >> 32) - 1;
         const int64_t e = (int64_t)(uint32_t)key;
         const int ud = dev_of_native ? dev_of_native[un] : un;
-        T m = x[ud];
+        T m = message_of(p, x, vp, ud);
         V vprow;
         if constexpr (USE_VP) vprow = vp[v];
         U res;
