@@ -399,13 +399,15 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       d_touched = (int32_t*)pt;
       GM_HIP_OK(hipMemsetAsync(d_best, 0, (size_t)n * 8, s));
       GM_HIP_OK(hipMemsetAsync(d_stats, 0, 24, s));
+      GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
       hipLaunchKernelGGL(dev::k_frontier_stats, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active,
-                         Asrc.rowptr, n, d_stats);
+                         Asrc.rowptr, n, d_stats, d_list, d_count);
       GM_HIP_OK(hipMemcpyAsync(h_stats + 2, d_stats, 24, hipMemcpyDeviceToHost, s));
       GM_HIP_OK(hipStreamSynchronize(s));
       frontier_v = h_stats[2];
       frontier_e = h_stats[3];
       frontier_maxdeg = h_stats[4];
+      list_ready = frontier_v <= (unsigned long long)dev::kSparseListCap;  // listed by the same pass
     }
   }
 

@@ -1127,17 +1127,27 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
 // Grid-stride with one set of atomics per workgroup (launch <= 2048 workgroups).
 __global__ void __launch_bounds__(kBlock)
 k_frontier_stats(const uint32_t* __restrict__ active, const int64_t* __restrict__ src_rowptr, int n,
-                 unsigned long long* __restrict__ stats /* [0] vertices, [1] out-edges, [2] max out-degree */) {
+                 unsigned long long* __restrict__ stats /* [0] vertices, [1] out-edges, [2] max out-degree */,
+                 int32_t* __restrict__ list /* also list the active vertices while they are few, or null */,
+                 unsigned int* __restrict__ count) {
   __shared__ unsigned long long s_c[kBlock / 64], s_e[kBlock / 64], s_m[kBlock / 64];
+  __shared__ int32_t s_lbuf[kListBuf];
+  __shared__ unsigned int s_lfill[4];
+  BlockList blist{s_lbuf, s_lfill};
+  if (list != nullptr) blist.init();
   unsigned long long cnt = 0, edges = 0, mx = 0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    if (bit_get(active, (int)i)) {
+  for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n; base += (int64_t)gridDim.x * kBlock) {
+    const int64_t i = base + threadIdx.x;
+    const bool act = i < n && bit_get(active, (int)i);
+    if (act) {
       unsigned long long d = (unsigned long long)(src_rowptr[i + 1] - src_rowptr[i]);
       cnt++;
       edges += d;
       mx = d > mx ? d : mx;
     }
+    if (list != nullptr) blist.add(act, (int)i, list, count, (unsigned int)kSparseListCap);
   }
+  if (list != nullptr) blist.finish(list, count, (unsigned int)kSparseListCap);
   for (int off = 32; off > 0; off >>= 1) {
     cnt += __shfl_down(cnt, off, 64);
     edges += __shfl_down(edges, off, 64);
