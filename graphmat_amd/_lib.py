@@ -29,7 +29,7 @@ class Csr(C.Structure):
                 ("seg_row", C.c_void_p), ("nseg", C.c_int32), ("blk_seg", C.c_void_p), ("nblk", C.c_int32),
                 ("mid_row", C.c_void_p), ("nmid", C.c_int32), ("giant_row", C.c_void_p), ("ngiant", C.c_int32),
                 ("gchunk_row", C.c_void_p), ("gchunk_edge", C.c_void_p), ("gterm_off", C.c_void_p),
-                ("ngchunk", C.c_int32), ("giant_edges", C.c_int64), ("short_row", C.c_int32)]
+                ("ngchunk", C.c_int32), ("giant_edges", C.c_int64), ("short_row", C.c_int32), ("nmid_long", C.c_int32)]
 
 
 class RunStats(C.Structure):

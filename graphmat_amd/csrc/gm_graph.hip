@@ -185,6 +185,15 @@ k_or_words(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint3
   if (i < n) o[i] = a[i] | b[i];
 }
 
+// one past the last entry of the wave-row list whose row has more than `limit` edges
+__global__ void __launch_bounds__(kT)
+k_last_long(const int32_t* __restrict__ mid_row, int nmid, const int64_t* __restrict__ rowptr, int64_t limit, int* __restrict__ out) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= nmid) return;
+  const int r = mid_row[i];
+  if (rowptr[r + 1] - rowptr[r] > limit) atomicMax(out, i + 1);
+}
+
 __global__ void __launch_bounds__(kT)
 k_giant_extent(const int32_t* __restrict__ giant_row, int ngiant, const int64_t* __restrict__ rowptr,
                int64_t* __restrict__ ext) {
@@ -345,6 +354,16 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
     if ((rc = blkl.alloc(16))) return rc;
   }
 
+  // wave rows: where the long ones (more than GM_LONG_MID edges) end in the list
+  int nmid_long = 0;
+  if (nmid > 0) {
+    GM_TRY_HIP(hipMemsetAsync(cnt.p, 0, 4, s));
+    hipLaunchKernelGGL(k_last_long, dim3(grid_for(nmid)), dim3(kT), 0, s, mid.as<int32_t>(), (int)nmid, rowptr.as<int64_t>(),
+                       (int64_t)GM_LONG_MID, cnt.as<int>());
+    GM_TRY_HIP(hipMemcpyAsync(&nmid_long, cnt.p, 4, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+  }
+
   // pieces of the giant rows for the parallel products pass
   DevBuf gcr, gce, gto;
   std::vector<int32_t> h_gcr;
@@ -409,6 +428,7 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   v.ngchunk = (int32_t)h_gcr.size();
   v.giant_edges = h_gto.back();
   v.short_row = g_short_row;
+  v.nmid_long = nmid_long;
   return GM_OK;
 }
 

@@ -186,6 +186,13 @@ int reduce_kind_of(const P* gp) {
   else return probe_reduce_kind<P, U>(gp);
 }
 
+// which programs the 16-rows-per-wave ordered kernel takes
+template <class U, bool USE_VP, int RK>
+constexpr bool wave16_ok() {
+  return !USE_VP && (RK == REDUCE_ORDERED || RK == REDUCE_F32_ADD) && std::is_trivially_copyable<U>::value &&
+         (sizeof(U) == 4 || sizeof(U) == 8);
+}
+
 // one multiply+reduce pass over one direction of the adjacency, strategy RK
 template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
 void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits,
@@ -261,6 +268,20 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
       hipLaunchKernelGGL((dev::k_spmv_wave_grouped<P, T, U, V, E, USE_VP, RK>), dim3((groups + WPB - 1) / WPB),
                          dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
                          debug_flags(), want);
+    } else if (wave16_ok<U, USE_VP, RK>() && !(debug_flags() & dev::DBG_NO_WAVE16)) {
+      if constexpr (wave16_ok<U, USE_VP, RK>()) {
+        // ordered folds: the long rows at the head of the list get a wave each, the rest are folded 16 to a wave
+        const int nlong = A.nmid_long < A.nmid ? A.nmid_long : A.nmid;
+        if (nlong > 0)
+          hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, RK>), dim3((nlong + WPB - 1) / WPB), dim3(dev::kBlock), 0, s,
+                             pa, A, A.mid_row, nlong, x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
+        const int rest = A.nmid - nlong;
+        if (rest > 0) {
+          const int groups = (rest + dev::kWaveRows - 1) / dev::kWaveRows;
+          hipLaunchKernelGGL((dev::k_spmv_wave16<P, T, U, V, E>), dim3((groups + WPB - 1) / WPB), dim3(dev::kBlock), 0, s, pa, A,
+                             A.mid_row + nlong, rest, x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
+        }
+      }
     } else
       hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, RK>), dim3((A.nmid + WPB - 1) / WPB),
                          dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,

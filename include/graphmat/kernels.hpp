@@ -322,7 +322,7 @@ __device__ __forceinline__ E edge_at(const void* __restrict__ vals, int64_t k) {
 // earlier pass (their presence is read from ybits); ACC_STATIC_BITS = do not write presence
 // bits (every x entry is present, so y's presence equals the graph's static row bits)
 enum { ACC_READ_PREV = 1, ACC_STATIC_BITS = 2 };
-enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64, DBG_NO_PIPELINE = 128, DBG_NO_LAZY_SEND = 256 };
+enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64, DBG_NO_PIPELINE = 128, DBG_NO_LAZY_SEND = 256, DBG_NO_WAVE16 = 512 };
 
 // presence bits of a wave's 64 consecutive rows: one atomicOr per 32-row word (not per row:
 // same-word atomics from 32 lanes serialise in the L2); nothing when the bits are static
@@ -725,6 +725,104 @@ k_spmv_wave(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nli
   if (!row_wanted(p, vp, want, row)) return;
   wave_row<P, T, U, V, E, USE_VP, RK>(p, A, row, A.rowptr[row], A.rowptr[row + 1], threadIdx.x & 63, x, xbits, vp, y, ybits,
                                       accumulate, dbg);
+}
+
+// Ordered folds of wave rows without paying 64 serial broadcasts per 64 edges: a wave takes kWaveRows
+// (16) consecutive entries of the row list at once.  Per step it fetches the next 64-edge chunk of
+// each of them (16 coalesced index loads and 16 gathers per lane in flight, the next step's already
+// issued), writes the 16 x 64 products to its LDS tile, and then lanes 0..15 fold one row each,
+// in stored order, straight out of LDS -- 16 folds run side by side instead of every lane carrying
+// the same running value.  The list is in device (degree-ranked) order, so the 16 rows have
+// similar lengths.  2-operand programs with a reduction type of 4 or 8 bytes; the others keep
+// k_spmv_wave.
+constexpr int kWaveRows = 16;
+template <class P, class T, class U, class V, class E>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_wave16(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nlist, const T* __restrict__ x,
+              const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
+              uint32_t* __restrict__ ybits, int accumulate, int dbg, const uint32_t* __restrict__ want) {
+  static_assert(sizeof(U) == 4 || sizeof(U) == 8, "LDS tile of 4- or 8-byte products");
+  constexpr int G = kWaveRows;
+  constexpr int kStride = 64 + 16 / (int)sizeof(U);  // padded row of the tile (keeps 16-byte alignment, staggers banks)
+  __shared__ __attribute__((aligned(16))) U s_t[kBlock / 64][G][kStride];
+  __shared__ unsigned long long s_mask[kBlock / 64][G];
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int first = (blockIdx.x * (kBlock / 64) + wv) * G;
+  if (first >= nlist) return;
+  const bool dense = (xbits == nullptr);
+  // lane r < G owns list entry first + r
+  int my_row = -1;
+  int64_t my_e0 = 0, my_e1 = 0;
+  if (lane < G && first + lane < nlist) {
+    my_row = rows[first + lane];
+    if (row_wanted(p, vp, want, my_row)) { my_e0 = A.rowptr[my_row]; my_e1 = A.rowptr[my_row + 1]; }
+  }
+  int64_t longest = my_e1 - my_e0;
+  for (int off = 8; off > 0; off >>= 1) {
+    const int64_t o = __shfl_xor(longest, off, 64);
+    longest = o > longest ? o : longest;
+  }
+  longest = __shfl(longest, 0, 64);
+  const int nsteps = (int)((longest + 63) / 64);
+  bool has = false;
+  U acc;
+  if (lane < G && my_row >= 0 && (accumulate & ACC_READ_PREV) && bit_get(ybits, my_row)) { acc = y[my_row]; has = true; }
+  V no_vp;  // 2-operand programs ignore the vertex property argument
+
+  int c[G];
+  T m[G];
+  auto fetch = [&](int step) {  // column ids and messages of chunk `step` of every row
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+      const int64_t k = wave_bcast(my_e0, r) + (int64_t)step * 64 + lane;
+      c[r] = (k < wave_bcast(my_e1, r)) ? stream_load(&A.colidx[k]) : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+      if (c[r] >= 0 && !dense && !bit_get(xbits, c[r])) c[r] = -1;
+      if (c[r] >= 0) m[r] = x[c[r]];
+    }
+  };
+  if (nsteps > 0) fetch(0);
+  for (int step = 0; step < nsteps; step++) {
+    // products of this step into the tile
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+      const bool pres = c[r] >= 0;
+      U term;
+      if (pres) {
+        const int64_t k = wave_bcast(my_e0, r) + (int64_t)step * 64 + lane;
+        p.P::process_message(m[r], edge_at<E>(A.vals, k), no_vp, term);
+        s_t[wv][r][lane] = term;
+      }
+      const unsigned long long mask = __ballot(pres);
+      if (lane == 0) s_mask[wv][r] = mask;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (step + 1 < nsteps) fetch(step + 1);  // in flight during the folds below
+    if (lane < G && !(dbg & DBG_SKIP_FOLD)) {
+      unsigned long long mask = s_mask[wv][lane];
+      const U* t = s_t[wv][lane];
+      if (mask == ~0ull) {
+        int k = 0;
+        if (!has) { acc = t[0]; has = true; k = 1; }
+        for (; k < 64; k++) { U v = t[k]; p.P::reduce_function(acc, v); }
+      } else {
+        while (mask) {
+          const int k = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          U v = t[k];
+          if (has) p.P::reduce_function(acc, v); else { acc = v; has = true; }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane < G && my_row >= 0 && has) {
+    y[my_row] = acc;
+    if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[my_row >> 5], 1u << (my_row & 31));
+  }
 }
 
 // The same for programs with a row filter once most rows have dropped out: a wave takes 64

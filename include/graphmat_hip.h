@@ -164,11 +164,15 @@ typedef struct {
   int32_t ngchunk;
   int64_t giant_edges;        /* = gterm_off[ngiant]                                          */
   int32_t short_row;          /* rows of up to this many edges are in row-blocks, longer ones in mid/giant_row */
+  int32_t nmid_long;          /* mid_row[0, nmid_long) holds every wave row of more than GM_LONG_MID edges (the list is
+                                 in degree-ranked order, so this is a short prefix): one wave each; the rest are folded
+                                 16 to a wave */
 } gm_csr_t;
 
 #define GM_GIANT_CHUNK 4096 /* edges per piece of the parallel giant-row pass */
 
 #define GM_BLOCK_NNZ 1024   /* a row-block holds < 2*GM_BLOCK_NNZ edges and <= 256 rows     */
+#define GM_LONG_MID 1024    /* see gm_csr_t.nmid_long */
 #define GM_SHORT_ROW 64     /* rows up to this many edges are folded one lane per row        */
 #define GM_GIANT_ROW 32768  /* rows above this get a workgroup of their own; chosen per graph and
                                direction (smallest power of two >= 4096 leaving <= 1024 such rows):
