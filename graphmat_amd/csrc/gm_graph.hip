@@ -358,8 +358,11 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   int nmid_long = 0;
   if (nmid > 0) {
     GM_TRY_HIP(hipMemsetAsync(cnt.p, 0, 4, s));
+    // (with a million wave rows there are plenty of 16-row groups to keep the chip busy, and rows of up to
+    // 4096 edges can be grouped too: RMAT-26 8.02 -> 7.87 ms; on RMAT-22 that limit costs 17 %)
+    const int64_t long_limit = nmid >= (1u << 20) ? 4 * (int64_t)GM_LONG_MID : (int64_t)GM_LONG_MID;
     hipLaunchKernelGGL(k_last_long, dim3(grid_for(nmid)), dim3(kT), 0, s, mid.as<int32_t>(), (int)nmid, rowptr.as<int64_t>(),
-                       (int64_t)GM_LONG_MID, cnt.as<int>());
+                       long_limit, cnt.as<int>());
     GM_TRY_HIP(hipMemcpyAsync(&nmid_long, cnt.p, 4, hipMemcpyDeviceToHost, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
   }

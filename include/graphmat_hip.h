@@ -164,7 +164,8 @@ typedef struct {
   int32_t ngchunk;
   int64_t giant_edges;        /* = gterm_off[ngiant]                                          */
   int32_t short_row;          /* rows of up to this many edges are in row-blocks, longer ones in mid/giant_row */
-  int32_t nmid_long;          /* mid_row[0, nmid_long) holds every wave row of more than GM_LONG_MID edges (the list is
+  int32_t nmid_long;          /* mid_row[0, nmid_long) holds every wave row of more than GM_LONG_MID edges (4x that
+                                 when there are over 2^20 wave rows) (the list is
                                  in degree-ranked order, so this is a short prefix): one wave each; the rest are folded
                                  16 to a wave */
 } gm_csr_t;
