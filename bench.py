@@ -264,7 +264,8 @@ def main():
     e_short = int(c_out.nnz) - e_long
     # per-kernel algorithmic bytes per launch:
     #   row-block: 4 B column id per edge + per row 8 (rowptr) + 4 (y) ; x counted once per iteration in the wave line
-    #   wave:      4 B per edge + per row 4 (row id) + 16 (rowptr pair) + 4 (y)
+    #   wave:      4 B per edge + per row 4 (row id) + 16 (rowptr pair) + 4 (y); the wave rows are handled by a pair of
+    #              launches timed as one: k_spmv_wave (the few long rows) and k_spmv_wave16 (the rest, 16 rows to a wave)
     kern = {
         "k_spmv_rowblock": (stats["rowblock_ms"], stats["rowblock_launches"], 4 * e_short + 12 * rows0),
         "k_spmv_wave": (stats["wave_ms"], stats["wave_launches"], 4 * e_mid + 24 * int(c_out.nmid)),
@@ -283,10 +284,13 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get("scale%d" % args.scale, {}).get(name + "_bytes_per_launch")
+                per = tj.get("scale%d" % args.scale, {})
+                traffic = per.get(name + "_bytes_per_launch")
+                if name == "k_spmv_wave" and traffic is not None:
+                    traffic += per.get("k_spmv_wave16_bytes_per_launch", 0)
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "kernel": name + "<PageRank>", "achieved": round(ach, 1),
+        roof = {"bound": "hbm", "kernel": ("k_spmv_wave16+k_spmv_wave" if name == "k_spmv_wave" else name) + "<PageRank>", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg_bytes,
                 "launches_per_iteration": per_step,
