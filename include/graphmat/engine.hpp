@@ -491,7 +491,9 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       T* xnext = (T*)x2v;
       gm_csr_t At = Aout, Ah = Aout;
       At.blk_seg += bs; At.nblk -= bs; At.mid_row += ms; At.nmid -= ms; At.ngiant = 0; At.ngchunk = 0;
+      At.nmid_long = Aout.nmid_long > ms ? Aout.nmid_long - ms : 0;
       Ah.nblk = bs; Ah.nmid = ms;
+      Ah.nmid_long = Aout.nmid_long < ms ? Aout.nmid_long : ms;
       auto fail = [&](const char* what) { printf("GraphMat(HIP): %s\n", what); exit(1); };
       auto stage = [&](const dev::ProgArg<P>& pa, const gm_csr_t& A, int r0, int r1, bool more) {
         if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, A, xcur, nullptr, d_vp, y, ybits, dev::ACC_STATIC_BITS, s, &st.spmv_launches, &timer, &aux, rk);
