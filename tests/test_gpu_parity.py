@@ -158,6 +158,31 @@ def test_sssp_bit_exact(env, golden_dir):
     assert it == oit and (dist == odist).all()
 
 
+@pytest.mark.parametrize("degrees", [(65, 127, 128, 129, 200), (64, 65, 1024, 1025, 4096, 4097, 70, 300, 90, 91, 92, 93, 94, 95, 96, 97, 98, 99, 100),
+                                     tuple(range(65, 65 + 40))])
+def test_pagerank_rows_around_the_wave_kernels_boundaries(env, degrees):
+    """in-degrees at the chunk (64), group (16 rows per wave) and long-row (1024 / 4096 edges) boundaries of the
+    ordered wave kernels, a partial last group, duplicates: fp32 sums bit-exact against the oracle"""
+    api, ob = env
+    rng = np.random.default_rng(len(degrees))
+    nsrc = 6000
+    s, d = [], []
+    for i, deg in enumerate(degrees):
+        t = nsrc + 1 + i
+        srcs = rng.integers(1, nsrc + 1, deg)  # with repetitions
+        s.extend(srcs.tolist()); d.extend([t] * deg)
+    # give the sources out-edges among themselves so that their ranks differ
+    a = rng.integers(1, nsrc + 1, 20000); b = rng.integers(1, nsrc + 1, 20000)
+    s.extend(a.tolist()); d.extend(b.tolist())
+    s, d = np.array(s, np.int32), np.array(d, np.int32)
+    nv = nsrc + len(degrees) + 5
+    for threads, layout in ((1, 1), (2, 0)):
+        g = api.Graph(nv, s, d, None, ref_threads=threads, layout=layout)
+        pr, deg_out, it = g.pagerank(6)
+        opr, oit, _ = ob.OracleGraph(nv, s, d, None, threads).pagerank(6)
+        assert it == oit == 6 and np.array_equal(f32bits(pr), f32bits(opr))
+
+
 def test_sssp_small_active_sets_with_colliding_relaxations(env):
     """Layered weighted graph whose active sets stay tiny, so every level is a list-based top-down step
     (k_push_combine): many sources relax the same destination in one step (compare-and-swap fold of min),
