@@ -197,7 +197,7 @@ constexpr bool wave16_ok() {
 template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
 void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits,
                     const V* vp, U* y, uint32_t* ybits, int accumulate, hipStream_t s, int* launches, PhaseTimer* timer,
-                    AuxStream* aux, const uint32_t* want = nullptr, bool grouped = false) {
+                    AuxStream* aux, const uint32_t* want = nullptr, bool grouped = false, const uint32_t* xsum = nullptr) {
   constexpr int WPB = dev::kBlock / 64;  // rows (waves) per workgroup of k_spmv_wave
   if (A.nnz == 0) return;
   const bool overlap = aux != nullptr && aux->s != nullptr && A.ngiant > 0 && (A.nblk > 0 || A.nmid > 0);
@@ -248,7 +248,7 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
     // a=b: one lane per row over the whole row range (short rows pick themselves by their length)
     if constexpr (RK == REDUCE_LAST) {
       hipLaunchKernelGGL((dev::k_spmv_short_last<P, T, U, V, E, USE_VP>), dim3(grid_for(A.nrows)), dim3(dev::kBlock), 0, s,
-                         pa, A, x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
+                         pa, A, x, xbits, vp, y, ybits, accumulate, debug_flags(), want, xsum);
       (*launches)++;
       if (timer) timer->mark(TAG_ROWBLOCK);
     }
@@ -297,28 +297,28 @@ template <class P, class T, class U, class V, class E, bool USE_VP>
 void launch_spmv(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits,
                  const V* vp, U* y, uint32_t* ybits, int accumulate, hipStream_t s, int* launches,
                  PhaseTimer* timer = nullptr, AuxStream* aux = nullptr, int rk = REDUCE_ORDERED, const uint32_t* want = nullptr,
-                 bool grouped = false) {
+                 bool grouped = false, const uint32_t* xsum = nullptr) {
   if constexpr ((int)program_traits<P>::reduce != (int)REDUCE_AUTO) {
     launch_spmv_rk<P, T, U, V, E, USE_VP, (int)program_traits<P>::reduce>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s,
-                                                                          launches, timer, aux, want, grouped);
+                                                                          launches, timer, aux, want, grouped, xsum);
   } else {
     if constexpr (std::is_same<U, float>::value) {
       if (rk == REDUCE_F32_ADD) {
-        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_F32_ADD>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped);
+        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_F32_ADD>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped, xsum);
         return;
       }
     }
     if constexpr (std::is_trivially_copyable<U>::value && sizeof(U) <= 8) {
       if (rk == REDUCE_LAST) {
-        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_LAST>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped);
+        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_LAST>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped, xsum);
         return;
       }
       if (rk == REDUCE_COMMUTATIVE) {
-        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_COMMUTATIVE>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped);
+        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_COMMUTATIVE>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped, xsum);
         return;
       }
     }
-    launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_ORDERED>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped);
+    launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_ORDERED>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped, xsum);
   }
 }
 
@@ -667,8 +667,18 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         timer.mark(TAG_WAVE);
       } else if (order == OUT_EDGES || order == ALL_EDGES) {
         const int acc = static_bits ? dev::ACC_STATIC_BITS : 0;
-        if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves);
-        else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves);
+        // sparse active set of an a=b program: a 64:1 summary of the presence bits for the short-row kernel
+        const uint32_t* xsum = nullptr;
+        if (want_stats && rk == REDUCE_LAST && xb != nullptr && frontier_v * 512ull < (unsigned long long)n_live) {
+          void* ps = nullptr;
+          const int nsum = (nwords / 2 + 31) / 32 + 1;
+          if (gm_graph_workspace(g, 11, (size_t)nsum * 4 + 64, &ps) == GM_OK) {
+            hipLaunchKernelGGL(dev::k_bits_summary, dim3(grid_for(nsum)), dim3(dev::kBlock), 0, s, xb, nwords, (uint32_t*)ps, nsum);
+            xsum = (const uint32_t*)ps;
+          }
+        }
+        if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves, xsum);
+        else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves, xsum);
         if (static_bits) apply_bits = Aout.rowbits;
       }
       if (!dense_push && (order == IN_EDGES || order == ALL_EDGES)) {

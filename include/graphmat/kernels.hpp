@@ -351,7 +351,8 @@ template <class P, class T, class U, class V, class E, bool USE_VP>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_short_last(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
                   const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg,
-                  const uint32_t* __restrict__ want) {
+                  const uint32_t* __restrict__ want,
+                  const uint32_t* __restrict__ xsum /* 1 bit per 64 x entries "any present", or null (k_bits_summary) */) {
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int row = blockIdx.x * kBlock + threadIdx.x;
   const bool dense = (xbits == nullptr);
@@ -368,7 +369,9 @@ k_spmv_short_last(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint
         for (int j = 0; j < B; j++) c[j] = (hi - 1 - j >= rp0) ? A.colidx[hi - 1 - j] : -1;
         bool pr[B];
 #pragma unroll
-        for (int j = 0; j < B; j++) pr[j] = c[j] >= 0 && (dense || ((dbg & DBG_SKIP_GATHER) ? (c[j] == 0x7fffffff) : bit_get(xbits, c[j])));
+        for (int j = 0; j < B; j++)
+          pr[j] = c[j] >= 0 && (dense || ((dbg & DBG_SKIP_GATHER) ? (c[j] == 0x7fffffff)
+                                                                   : ((xsum == nullptr || bit_get(xsum, c[j] >> 6)) && bit_get(xbits, c[j]))));
 #pragma unroll
         for (int j = B - 1; j >= 0; j--)
           if (pr[j]) { cc = c[j]; kk = hi - 1 - j; }  // ends with the smallest j = the edge nearest the row's end
@@ -1589,6 +1592,25 @@ k_push_resolve(ProgArg<P> pa, gm_csr_t S, const T* __restrict__ x, const int32_t
     if ((uint32_t)bm) ybits[v >> 5] = (uint32_t)bm;
     if ((uint32_t)(bm >> 32)) ybits[(v >> 5) + 1] = (uint32_t)(bm >> 32);
   }
+}
+
+// 64:1 summary of a presence bit vector: bit j of the result = "some bit of entries [64j, 64j+64) is set".
+// While the active set is small the bottom-up kernels test this 128 KB table first: most of their
+// presence tests then never touch the 8 MB vector (level 1 of BFS RMAT-26: half of the short-row
+// kernel's time was those gathers).
+__global__ void __launch_bounds__(kBlock)
+k_bits_summary(const uint32_t* __restrict__ bits, int nwords, uint32_t* __restrict__ sum, int nsum) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= nsum) return;
+  uint32_t out = 0;
+  for (int b = 0; b < 32; b++) {
+    const int w = (t * 32 + b) * 2;
+    uint32_t any = 0;
+    if (w < nwords) any |= bits[w];
+    if (w + 1 < nwords) any |= bits[w + 1];
+    if (any) out |= 1u << b;
+  }
+  sum[t] = out;
 }
 
 // ------------------------------------------------------------------------------------

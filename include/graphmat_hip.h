@@ -305,7 +305,7 @@ int gm_graph_last_stats(const gm_graph_t* g, gm_run_stats_t* out);
  * Device scratch owned by the graph, grown on demand and reused across runs (the
  * reference allocates x/y per run_graph_program call, GraphMatRuntime.h:110-120).
  * slot in [0, GM_WS_SLOTS). */
-#define GM_WS_SLOTS 11
+#define GM_WS_SLOTS 12
 int gm_graph_workspace(gm_graph_t* g, int slot, size_t bytes, void** d_ptr);
 /* Let the caller provide a scratch slot (e.g. a torch tensor it also hands to its collective
  * library): slot 1 = message values x (nvertices * elt bytes), slot 2 = x presence bits
