@@ -192,6 +192,42 @@ struct BlockList {
   }
 };
 
+// The same per wave, without workgroup barriers: right when only a few waves will have anything
+// to add (k_apply lists the changed vertices only when the next active set is bound to be small), so
+// the number of global reservations stays small although every wave makes its own.
+constexpr int kWaveListBuf = 256;
+struct WaveList {
+  int32_t* buf;       // this wave's LDS buffer, kWaveListBuf entries
+  unsigned int fill;  // wave-uniform
+  bool stopped;       // wave-uniform
+  __device__ __forceinline__ void init(int32_t* lds_of_block) {
+    buf = lds_of_block + (threadIdx.x >> 6) * kWaveListBuf;
+    fill = 0;
+    stopped = false;
+  }
+  __device__ __forceinline__ void flush(int32_t* __restrict__ list, unsigned int* __restrict__ count, unsigned int cap) {
+    if (fill == 0) return;
+    const int lane = threadIdx.x & 63;
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(count, fill);
+    base = (unsigned int)__shfl((int)base, 0, 64);
+    for (unsigned int j = lane; j < fill; j += 64) list[base + j] = buf[j];
+    if (cap && base >= cap) stopped = true;
+    fill = 0;
+  }
+  __device__ __forceinline__ void add(bool mine, int value, int32_t* __restrict__ list, unsigned int* __restrict__ count, unsigned int cap) {
+    if (stopped) return;
+    const unsigned long long m = __ballot(mine);
+    if (m == 0ull) return;
+    const unsigned int k = (unsigned int)__popcll(m);
+    if (fill + k > (unsigned int)kWaveListBuf) flush(list, count, cap);
+    if (stopped) return;
+    const int lane = threadIdx.x & 63;
+    if (mine) buf[fill + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = value;
+    fill += k;
+  }
+};
+
 // ------------------------------------------------------------------------------------
 // apply on rows whose y bit is set; a changed vertex (V::operator!=) becomes active and
 // raises the changed flag (zeroed by the host before the launch).  The active vector is fully rewritten (the reference clears
@@ -229,11 +265,10 @@ k_apply(ProgArg<P> pa, const U* __restrict__ y, const uint32_t* __restrict__ ybi
         int32_t* __restrict__ next_list = nullptr /* with stats: the changed vertices, while they are few */,
         unsigned int* __restrict__ next_count = nullptr) {
   __shared__ unsigned long long s_c[STEER ? kBlock / 64 : 1], s_e[STEER ? kBlock / 64 : 1], s_m[STEER ? kBlock / 64 : 1];
-  __shared__ int32_t s_lbuf[STEER ? kListBuf : 1];
-  __shared__ unsigned int s_lfill[4];
-  BlockList blist{s_lbuf, s_lfill};
+  __shared__ int32_t s_lbuf[STEER ? (kBlock / 64) * kWaveListBuf : 1];
+  WaveList wlist;
+  wlist.init(s_lbuf);
   if constexpr (!STEER) { stats = nullptr; next_list = nullptr; }
-  if (next_list != nullptr) blist.init();
   unsigned long long cnt = 0, edges = 0, mx = 0;
   bool any = false;
   for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n; base += (int64_t)gridDim.x * kBlock) {
@@ -272,9 +307,9 @@ k_apply(ProgArg<P> pa, const U* __restrict__ y, const uint32_t* __restrict__ ybi
       mx = d > mx ? d : mx;
     }
     // compact list of the changed vertices for a following top-down step (while they are few)
-    if (next_list != nullptr) blist.add(changed, i, next_list, next_count, (unsigned int)kSparseListCap);
+    if (next_list != nullptr) wlist.add(changed, i, next_list, next_count, (unsigned int)kSparseListCap);
   }
-  if (next_list != nullptr) blist.finish(next_list, next_count, (unsigned int)kSparseListCap);
+  if (next_list != nullptr) wlist.flush(next_list, next_count, (unsigned int)kSparseListCap);
   if (any) *changed_flag = 1;
   if (stats == nullptr) return;
   for (int off = 32; off > 0; off >>= 1) {
