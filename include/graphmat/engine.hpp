@@ -278,7 +278,8 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
         const int rest = A.nmid - nlong;
         if (rest > 0) {
           const int groups = (rest + dev::kWaveRows - 1) / dev::kWaveRows;
-          hipLaunchKernelGGL((dev::k_spmv_wave16<P, T, U, V, E>), dim3((groups + WPB - 1) / WPB), dim3(dev::kBlock), 0, s, pa, A,
+          constexpr int W16 = dev::kWave16Block / 64;
+          hipLaunchKernelGGL((dev::k_spmv_wave16<P, T, U, V, E>), dim3((groups + W16 - 1) / W16), dim3(dev::kWave16Block), 0, s, pa, A,
                              A.mid_row + nlong, rest, x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
         }
       }

@@ -775,16 +775,17 @@ k_spmv_wave(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nli
 // k_spmv_wave.
 constexpr int kWaveRows = 16;
 constexpr int kHotEntries = 8192;
+constexpr int kWave16Block = 256;  // (512 threads sharing one hot set: no difference; 1024: slower)
 template <class P, class T, class U, class V, class E>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kWave16Block)
 k_spmv_wave16(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nlist, const T* __restrict__ x,
               const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
               uint32_t* __restrict__ ybits, int accumulate, int dbg, const uint32_t* __restrict__ want) {
   static_assert(sizeof(U) == 4 || sizeof(U) == 8, "LDS tile of 4- or 8-byte products");
   constexpr int G = kWaveRows;
   constexpr int kStride = 64 + 16 / (int)sizeof(U);  // padded row of the tile (keeps 16-byte alignment, staggers banks)
-  __shared__ __attribute__((aligned(16))) U s_t[kBlock / 64][G][kStride];
-  __shared__ unsigned long long s_mask[kBlock / 64][G];
+  __shared__ __attribute__((aligned(16))) U s_t[kWave16Block / 64][G][kStride];
+  __shared__ unsigned long long s_mask[kWave16Block / 64][G];
   // the hottest x entries (device order is degree-ranked: they are the first ones) live in LDS: at
   // RMAT-26 the first 8192 vertices are the source of 14 % of the edges (34 % at RMAT-22), and a gather
   // served from LDS is one request less for the L2 (RMAT-26 wave rows 6.10 -> 5.87 ms; 4096 / 8192 /
@@ -792,11 +793,11 @@ k_spmv_wave16(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int n
   constexpr int kHot = sizeof(T) == 4 ? kHotEntries : 1;
   __shared__ T s_hot[kHot];
   const int nhot = kHot > 1 ? (A.ncols < kHot ? A.ncols : kHot) : 0;
-  for (int i = threadIdx.x; i < nhot; i += kBlock) s_hot[i] = x[i];
+  for (int i = threadIdx.x; i < nhot; i += kWave16Block) s_hot[i] = x[i];
   __syncthreads();
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int first = (blockIdx.x * (kBlock / 64) + wv) * G;
+  const int first = (blockIdx.x * (kWave16Block / 64) + wv) * G;
   if (first >= nlist) return;
   const bool dense = (xbits == nullptr);
   // lane r < G owns list entry first + r
