@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--rank-by", type=int, default=0, help="experiment: device order ranked by 0 total, 1 out-, 2 in-degree")
     ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: plain exchange between send and multiply (no two-stage overlap)")
     ap.add_argument("--native-layout", action="store_true", help="device order = native order (single GPU; for A/B)")
+    ap.add_argument("--tile-min-row", type=int, default=0, help="experiment: rows of more than this many edges are tiled")
+    ap.add_argument("--col-tiles", type=int, default=-1, help="column tiles of the OUT adjacency (-1 = default for the scale, 1 = none)")
     ap.add_argument("--debug-flags", type=int, default=0, help="ablation only (results become invalid): 1 skip fold, 2 skip gathers")
     args = ap.parse_args()
 
@@ -129,6 +131,8 @@ def main():
         _lib.check(L.gm_set_option(b"rank_cap", args.rank_cap))
     if args.rank_by:
         _lib.check(L.gm_set_option(b"rank_by", args.rank_by))
+    if args.tile_min_row:
+        _lib.check(L.gm_set_option(b"tile_min_row", args.tile_min_row))
     # ---- synthetic input, generated in HBM ------------------------------------------------
     t0 = time.time()
     nv, src, dst, _ = api.rmat_on_device(args.scale, args.edge_factor, args.seed, weights=False, device=local_rank)
@@ -136,7 +140,8 @@ def main():
     nparts = args.ref_threads * 16
     # device order chosen by the library: degree-ranked, dealt over the `world` shards
     g = api.Graph(nv, src, dst, None, ref_threads=args.ref_threads, device=local_rank, keep_values=False,
-                  layout=(_lib.GM_LAYOUT_NATIVE if args.native_layout else _lib.GM_LAYOUT_DEGREE), nshards=world, shard=rank)
+                  layout=(_lib.GM_LAYOUT_NATIVE if args.native_layout else _lib.GM_LAYOUT_DEGREE), nshards=world, shard=rank,
+                  col_tiles=(args.col_tiles if args.col_tiles >= 0 else 0))
     S = g.row_hi - g.row_lo
     ranges = [(r * S, (r + 1) * S) for r in range(world)] if world > 1 else [(0, g.ndevice)]
     del src, dst
@@ -313,6 +318,7 @@ def main():
                    "V": nv, "E": E, "parallelism": "1d-rows x%d" % world, "exchange": ("two-stage overlapped all-gather" if overlapped else
                                                                              ("all-gather between send and multiply" if world > 1 else "none")), "id_layout_nparts": nparts,
                    "device_order": "native" if args.native_layout else "degree-ranked, dealt over shards",
+                   "col_tiles": int(g.col_tiles),
                    "rows_per_shard": S, "exchanged_rows_per_shard": int(g.xchg_rows),
                    "max_in_degree_rank0": max_deg,
                    "giant_row_groups_replayed": int(cnt64[0]), "giant_row_groups_serial": int(cnt64[1])},

@@ -20,7 +20,7 @@ class GraphDesc(C.Structure):
     _fields_ = [("nvertices", C.c_int32), ("nparts", C.c_int32), ("row_lo", C.c_int32), ("row_hi", C.c_int32),
                 ("directions", C.c_int32), ("val_bytes", C.c_int32), ("ids_on_device", C.c_int32),
                 ("ids_are_native", C.c_int32), ("layout", C.c_int32), ("nshards", C.c_int32), ("shard", C.c_int32),
-                ("ndevice", C.c_int32), ("xchg_rows", C.c_int32)]
+                ("ndevice", C.c_int32), ("xchg_rows", C.c_int32), ("col_tiles", C.c_int32)]
 
 
 class Csr(C.Structure):
@@ -29,7 +29,9 @@ class Csr(C.Structure):
                 ("seg_row", C.c_void_p), ("nseg", C.c_int32), ("blk_seg", C.c_void_p), ("nblk", C.c_int32),
                 ("mid_row", C.c_void_p), ("nmid", C.c_int32), ("giant_row", C.c_void_p), ("ngiant", C.c_int32),
                 ("gchunk_row", C.c_void_p), ("gchunk_edge", C.c_void_p), ("gterm_off", C.c_void_p),
-                ("ngchunk", C.c_int32), ("giant_edges", C.c_int64), ("short_row", C.c_int32), ("nmid_long", C.c_int32)]
+                ("ngchunk", C.c_int32), ("giant_edges", C.c_int64), ("short_row", C.c_int32), ("nmid_long", C.c_int32),
+                ("umid_row", C.c_void_p), ("numid", C.c_int32), ("numid_long", C.c_int32), ("tile_min_row", C.c_int32),
+                ("hot_base", C.c_int32), ("hot_len", C.c_int32)]
 
 
 class RunStats(C.Structure):
@@ -61,6 +63,8 @@ SIGNATURES = {
     "gm_graph_desc": (C.c_int, [_P, C.POINTER(GraphDesc)]),
     "gm_graph_csr": (C.c_int, [_P, C.c_int, C.POINTER(Csr)]),
     "gm_graph_rowbits_all": (C.c_int, [_P, C.POINTER(_P)]),
+    "gm_graph_tiles": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
+    "gm_graph_tile": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(Csr), C.POINTER(_P)]),
     "gm_graph_csr_to_host": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "gm_graph_relayout_like": (C.c_int, [_P, _P, _P]),
     "gm_graph_maps": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),

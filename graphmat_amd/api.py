@@ -35,12 +35,15 @@ def _stream():
 
 class Graph:
     def __init__(self, nv, src, dst, val=None, ref_threads=1, directions=GM_DIR_OUT | GM_DIR_IN, device=0,
-                 row_range=None, keep_values=True, nranks_layout=1, layout=GM_LAYOUT_DEGREE, nshards=1, shard=0):
+                 row_range=None, keep_values=True, nranks_layout=1, layout=GM_LAYOUT_DEGREE, nshards=1, shard=0,
+                 col_tiles=0):
         """src/dst: 1-based ids, numpy (host) or torch.cuda int32 tensors (device).
 
         layout GM_LAYOUT_DEGREE (default): the library picks the device order (degree-ranked,
         dealt over `nshards`); GM_LAYOUT_NATIVE: device order = native order, optional
-        row_range=(lo,hi) shard.  Results are identical in both."""
+        row_range=(lo,hi) shard.  Results are identical in both.
+        col_tiles: column tiles of the OUT adjacency (graphmat_hip.h gm_graph_tile): 0 = library
+        default, 1 = none, N = that many; results are identical for every value."""
         if not torch.cuda.is_available():
             raise RuntimeError("graphmat_amd needs a GPU (no CPU fallback)")
         self.L = _lib.lib()
@@ -70,13 +73,14 @@ class Graph:
             nnz = src.size
         self.nnz_input = int(nnz)
         d = _lib.GraphDesc(self.nv, self.nparts, int(lo), int(hi), directions, 4 if vp else 0,
-                           1 if on_dev else 0, 0, layout, nshards, shard, 0, 0)
+                           1 if on_dev else 0, 0, layout, nshards, shard, 0, 0, int(col_tiles))
         h = C.c_void_p()
         check(self.L.gm_graph_create(C.byref(h), C.byref(d), nnz, sp, dp, vp, _stream()))
         self.h = h
         check(self.L.gm_graph_desc(self.h, C.byref(d)))
         self.row_lo, self.row_hi, self.ndevice = d.row_lo, d.row_hi, d.ndevice
         self.xchg_rows = d.xchg_rows
+        self.col_tiles = d.col_tiles
         self.rows = self.row_hi - self.row_lo
         self.layout, self.nshards, self.shard = layout, nshards, shard
         self._dov = None
@@ -133,6 +137,13 @@ class Graph:
         c = _lib.Csr()
         check(self.L.gm_graph_csr(self.h, direction, C.byref(c)))
         return c
+
+    def tile(self, direction, t):
+        """(Csr view of column tile t, device pointer of the presence bits of rows already started)."""
+        c = _lib.Csr()
+        prev = C.c_void_p()
+        check(self.L.gm_graph_tile(self.h, direction, t, C.byref(c), C.byref(prev)))
+        return c, prev.value
 
     def csr_to_host(self, direction):
         c = self.csr(direction)
@@ -239,6 +250,23 @@ class Graph:
         check(fn(st.data_ptr() + K * st.element_size(), self.rows, K + 1, C.byref(out), _stream()))
         sq = self.to_vertex_order(st)[:, K].cpu().numpy()
         return out.value, sq
+
+
+_hip = None
+
+
+def copy_from_device(host_array, dev_ptr):
+    """hipMemcpy of host_array.nbytes bytes from a raw device pointer (tests look at library-owned arrays)."""
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipMemcpy.restype = C.c_int
+    if host_array.nbytes == 0:
+        return
+    rc = _hip.hipMemcpy(host_array.ctypes.data, dev_ptr, host_array.nbytes, 2)  # hipMemcpyDeviceToHost
+    if rc != 0:
+        raise RuntimeError("hipMemcpy failed: %d" % rc)
 
 
 def rmat_on_device(scale, edge_factor=16, seed=1, weights=False, device=0):

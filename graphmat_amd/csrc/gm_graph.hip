@@ -27,6 +27,8 @@ int g_short_row = GM_SHORT_ROW;   // tunable through gm_set_option (experiments)
 int g_giant_row = 0;  // 0 = choose per graph (see pick_giant_threshold)
 int g_rank_cap = 0;   // experiment: > 0 ranks only vertices of total degree >= cap; the others keep native order behind them
 int g_rank_by = 0;    // experiment: 0 rank vertices by total degree, 1 by out-degree, 2 by in-degree
+int g_tile_min_row = GM_TILE_MIN_ROW;  // rows of more than this many edges are tiled
+int g_col_tiles = 0;  // default number of column tiles for graphs whose descriptor says 0 (0 = environment GRAPHMAT_COL_TILES, else none)
 
 constexpr int kT = 256;
 inline int grid_for(int64_t n) { return (int)((n + kT - 1) / kT); }
@@ -60,6 +62,21 @@ k_rank_keys(const uint32_t* __restrict__ deg, int nv, uint32_t* __restrict__ key
   if (cap > 0 && d > 0 && d < cap) d = 1;
   keys[v] = 0xffffffffu - d;  // ascending sort => descending degree; stable => ties by native id
   ids[v] = v;
+}
+
+__global__ void __launch_bounds__(kT)
+k_live_flags(const uint32_t* __restrict__ deg, int nv, uint32_t* __restrict__ live) {
+  int v = blockIdx.x * kT + threadIdx.x;
+  if (v < nv) live[v] = deg[v] ? 1u : 0u;
+}
+// tile of the k-th ranked vertex: (live vertices before it in NATIVE order) / tile size; 255 = no edges
+__global__ void __launch_bounds__(kT)
+k_tile_of_ranked(const int32_t* __restrict__ order, int nv, const uint32_t* __restrict__ deg, const uint32_t* __restrict__ live_before,
+                 int tile_size, uint8_t* __restrict__ tile) {
+  int k = blockIdx.x * kT + threadIdx.x;
+  if (k >= nv) return;
+  const int v = order[k];
+  tile[k] = deg[v] ? (uint8_t)(live_before[v] / (uint32_t)tile_size) : (uint8_t)255;
 }
 
 // rank k -> device id (k % nshards) * S + k / nshards
@@ -195,6 +212,18 @@ k_last_long(const int32_t* __restrict__ mid_row, int nmid, const int64_t* __rest
 }
 
 __global__ void __launch_bounds__(kT)
+k_mid_long_flags(const int32_t* __restrict__ mid_row, int nmid, const int64_t* __restrict__ rowptr, int64_t limit, int64_t max_len,
+                 unsigned char* __restrict__ is_long, unsigned char* __restrict__ is_rest) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= nmid) return;
+  const int r = mid_row[i];
+  const int64_t len = rowptr[r + 1] - rowptr[r];
+  const bool keep = len <= max_len, lg = len > limit;
+  is_long[i] = (keep && lg) ? 1 : 0;
+  is_rest[i] = (keep && !lg) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(kT)
 k_giant_extent(const int32_t* __restrict__ giant_row, int ngiant, const int64_t* __restrict__ rowptr,
                int64_t* __restrict__ ext) {
   int i = blockIdx.x * kT + threadIdx.x;
@@ -235,6 +264,37 @@ static int bits_for(uint32_t maxval) {
   return b;
 }
 
+// out = [entries of mid_row whose row has more than long_limit edges][the others], both in list order,
+// keeping only rows of at most max_len edges; *n_long / *n_total = sizes
+static int partition_mid(const int32_t* mid_row, int nmid, const int64_t* rowptr, int64_t long_limit, int64_t max_len,
+                         int32_t* out, int* n_long, unsigned int* n_total, hipStream_t s) {
+  DevBuf fl, fs, tmp, cnt;
+  int rc;
+  if ((rc = fl.alloc((size_t)nmid)) || (rc = fs.alloc((size_t)nmid)) || (rc = cnt.alloc(16))) return rc;
+  hipLaunchKernelGGL(k_mid_long_flags, dim3(grid_for(nmid)), dim3(kT), 0, s, mid_row, nmid, rowptr, long_limit, max_len,
+                     fl.as<unsigned char>(), fs.as<unsigned char>());
+  size_t tb = 0;
+  GM_TRY_HIP(rocprim::select(nullptr, tb, mid_row, fl.as<unsigned char>(), out, cnt.as<unsigned int>(), (size_t)nmid, s));
+  if ((rc = tmp.alloc(tb + 256))) return rc;
+  GM_TRY_HIP(rocprim::select(tmp.p, tb, mid_row, fl.as<unsigned char>(), out, cnt.as<unsigned int>(), (size_t)nmid, s));
+  unsigned int nl = 0, ns = 0;
+  GM_TRY_HIP(hipMemcpyAsync(&nl, cnt.p, 4, hipMemcpyDeviceToHost, s));
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  GM_TRY_HIP(rocprim::select(tmp.p, tb, mid_row, fs.as<unsigned char>(), out + nl, cnt.as<unsigned int>() + 1, (size_t)nmid, s));
+  GM_TRY_HIP(hipMemcpyAsync(&ns, cnt.as<unsigned int>() + 1, 4, hipMemcpyDeviceToHost, s));
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  *n_long = (int)nl;
+  *n_total = nl + ns;
+  return GM_OK;
+}
+
+static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* idx_sorted, unsigned long long kept,
+                      const void* d_val, hipStream_t s, CsrOwned* out, int tile_split = 0);
+static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* idx_sorted, unsigned long long kept,
+                       const void* d_val, hipStream_t s, const CsrOwned* whole);
+
+// Sorts the edges of one direction into the reference's reduction order and builds its CSR
+// (and, for GM_DIR_OUT of a tiled graph, the per-tile CSRs from the same sorted keys).
 static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* d_src, const int32_t* d_dst,
                            const void* d_val, hipStream_t s, CsrOwned* out) {
   const gm_graph_desc_t& D = g->desc;
@@ -266,18 +326,32 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   keys_in.alloc(0);
   idx_in.alloc(0);
   tmp.alloc(0);
+  const bool tiled = by_dst && g->ntiles > 1;
+  if ((rc = finish_csr(g, keys_out.as<uint64_t>(), idx_out.as<uint32_t>(), kept, d_val, s, out, tiled ? g_tile_min_row : 0))) return rc;
+  if (tiled) rc = build_tiles(g, keys_out.as<uint64_t>(), idx_out.as<uint32_t>(), kept, d_val, s, out);
+  return rc;
+}
 
+// CSR arrays and work decomposition from `kept` sorted keys (row << 32 | native col) and, for the
+// edge values, the input position of every sorted edge.
+// tile_split > 0 (whole-graph CSR of a tiled graph): also list the wave rows of at most tile_split edges.
+static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* idx_sorted, unsigned long long kept,
+                      const void* d_val, hipStream_t s, CsrOwned* out, int tile_split) {
+  const gm_graph_desc_t& D = g->desc;
+  const int nrows = D.row_hi - D.row_lo;
+  int rc;
+  DevBuf tmp;
   DevBuf rowptr, colidx, vals, cnt;
   if ((rc = rowptr.alloc((size_t)(nrows + 1) * 8))) return rc;
   if ((rc = colidx.alloc((size_t)kept * 4))) return rc;
   const bool keep_vals = D.val_bytes > 0 && d_val != nullptr;
   if (keep_vals && (rc = vals.alloc((size_t)kept * D.val_bytes))) return rc;
   if (kept > 0) {
-    hipLaunchKernelGGL(k_unpack, dim3(grid_for((int64_t)kept)), dim3(kT), 0, s, keys_out.as<uint64_t>(),
-                       idx_out.as<uint32_t>(), (int64_t)kept, d_val, D.val_bytes, (const int32_t*)g->dev_of_native,
+    hipLaunchKernelGGL(k_unpack, dim3(grid_for((int64_t)kept)), dim3(kT), 0, s, keys_sorted,
+                       idx_sorted, (int64_t)kept, d_val, D.val_bytes, (const int32_t*)g->dev_of_native,
                        colidx.as<int32_t>(), keep_vals ? vals.p : nullptr);
   }
-  hipLaunchKernelGGL(k_rowptr, dim3(grid_for(nrows + 1)), dim3(kT), 0, s, keys_out.as<uint64_t>(), (int64_t)kept,
+  hipLaunchKernelGGL(k_rowptr, dim3(grid_for(nrows + 1)), dim3(kT), 0, s, keys_sorted, (int64_t)kept,
                      nrows, rowptr.as<int64_t>());
   GM_TRY_HIP(hipGetLastError());
 
@@ -355,16 +429,34 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   }
 
   // wave rows: where the long ones (more than GM_LONG_MID edges) end in the list
-  int nmid_long = 0;
+  int nmid_long = 0, numid_long = 0;
+  unsigned int numid = 0;
+  DevBuf umid;
   if (nmid > 0) {
     GM_TRY_HIP(hipMemsetAsync(cnt.p, 0, 4, s));
     // (with a million wave rows there are plenty of 16-row groups to keep the chip busy, and rows of up to
     // 4096 edges can be grouped too: RMAT-26 8.02 -> 7.87 ms; on RMAT-22 that limit costs 17 %)
     const int64_t long_limit = nmid >= (1u << 20) ? 4 * (int64_t)GM_LONG_MID : (int64_t)GM_LONG_MID;
-    hipLaunchKernelGGL(k_last_long, dim3(grid_for(nmid)), dim3(kT), 0, s, mid.as<int32_t>(), (int)nmid, rowptr.as<int64_t>(),
-                       long_limit, cnt.as<int>());
-    GM_TRY_HIP(hipMemcpyAsync(&nmid_long, cnt.p, 4, hipMemcpyDeviceToHost, s));
-    GM_TRY_HIP(hipStreamSynchronize(s));
+    if (g->ntiles > 1) {
+      // tiled device order = (tile, degree rank): the long rows are no prefix of the row-ordered list,
+      // so the list is partitioned instead: [long rows][the rest], each part in row order
+      DevBuf mid2;
+      if ((rc = mid2.alloc((size_t)(nrows + 1) * 4))) return rc;
+      unsigned int n_all = 0;
+      if ((rc = partition_mid(mid.as<int32_t>(), (int)nmid, rowptr.as<int64_t>(), long_limit, (int64_t)1 << 62, mid2.as<int32_t>(), &nmid_long, &n_all, s))) return rc;
+      if (tile_split > 0) {  // the wave rows that stay untiled, same layout
+        if ((rc = umid.alloc((size_t)(nmid + 1) * 4))) return rc;
+        if ((rc = partition_mid(mid.as<int32_t>(), (int)nmid, rowptr.as<int64_t>(), long_limit, (int64_t)tile_split, umid.as<int32_t>(), &numid_long, &numid, s))) return rc;
+      }
+      void* old = mid.release();
+      mid.p = mid2.release();
+      (void)hipFree(old);
+    } else {
+      hipLaunchKernelGGL(k_last_long, dim3(grid_for(nmid)), dim3(kT), 0, s, mid.as<int32_t>(), (int)nmid, rowptr.as<int64_t>(),
+                         long_limit, cnt.as<int>());
+      GM_TRY_HIP(hipMemcpyAsync(&nmid_long, cnt.p, 4, hipMemcpyDeviceToHost, s));
+      GM_TRY_HIP(hipStreamSynchronize(s));
+    }
   }
 
   // pieces of the giant rows for the parallel products pass
@@ -406,6 +498,7 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   out->gchunk_row = (int32_t*)gcr.release();
   out->gchunk_edge = (int64_t*)gce.release();
   out->gterm_off = (int64_t*)gto.release();
+  out->umid_row = numid > 0 ? (int32_t*)umid.release() : nullptr;
   out->present = true;
   gm_csr_t& v = out->view;
   v.nnz = (int64_t)kept;
@@ -432,6 +525,108 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   v.giant_edges = h_gto.back();
   v.short_row = g_short_row;
   v.nmid_long = nmid_long;
+  v.umid_row = out->umid_row;
+  v.numid = (int32_t)numid;
+  v.numid_long = numid_long;
+  v.tile_min_row = tile_split;
+  v.hot_base = 0;
+  v.hot_len = D.ndevice;
+  return GM_OK;
+}
+
+// ---- column tiles (graphmat_hip.h: gm_graph_tile) ------------------------------------------------
+// tile of every sorted edge: device id of its column / tile_size; 255 = not tiled (short row)
+__global__ void __launch_bounds__(kT)
+k_tile_keys(const uint64_t* __restrict__ keys, int64_t n, const int64_t* __restrict__ rowptr, int short_row,
+            const int32_t* __restrict__ dev_of_native, int tile_size, uint8_t* __restrict__ tkey, uint32_t* __restrict__ pos) {
+  const int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (k >= n) return;
+  const uint64_t key = keys[k];
+  const int row = (int)(key >> 32);
+  const int cn = (int)(uint32_t)key;
+  const bool tiled = rowptr[row + 1] - rowptr[row] > short_row;
+  tkey[k] = tiled ? (uint8_t)(dev_of_native[cn] / tile_size) : (uint8_t)255;
+  pos[k] = (uint32_t)k;
+}
+// first position of every tile in the tile-sorted key array (lower bounds of 0..ntiles)
+__global__ void k_tile_bounds(const uint8_t* __restrict__ tkey, int64_t n, int ntiles, int64_t* __restrict__ out) {
+  const int t = threadIdx.x;
+  if (t > ntiles) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int)tkey[mid] < t) lo = mid + 1; else hi = mid;
+  }
+  out[t] = lo;
+}
+__global__ void __launch_bounds__(kT)
+k_tile_gather(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ pos, int64_t n,
+              uint64_t* __restrict__ keys_t, uint32_t* __restrict__ idx_t) {
+  const int64_t j = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t p = pos[j];
+  keys_t[j] = keys[p];
+  idx_t[j] = idx[p];
+}
+
+static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* idx_sorted, unsigned long long kept,
+                       const void* d_val, hipStream_t s, const CsrOwned* whole) {
+  const int T = g->ntiles;
+  const int nrows = g->desc.row_hi - g->desc.row_lo;
+  const int nw = (nrows + 31) / 32 + 2;
+  int rc;
+  g->out_tiles = new CsrOwned[T];
+  g->out_tile_prev = new uint32_t*[T];
+  for (int t = 0; t < T; t++) g->out_tile_prev[t] = nullptr;
+  DevBuf tk_in, tk_out, pos_in, pos_out, tmp, bounds;
+  if ((rc = tk_in.alloc((size_t)kept)) || (rc = tk_out.alloc((size_t)kept)) || (rc = pos_in.alloc((size_t)kept * 4)) ||
+      (rc = pos_out.alloc((size_t)kept * 4)) || (rc = bounds.alloc((size_t)(GM_MAX_TILES + 2) * 8)))
+    return rc;
+  std::vector<int64_t> h_bounds((size_t)T + 1, 0);
+  if (kept > 0) {
+    hipLaunchKernelGGL(k_tile_keys, dim3(grid_for((int64_t)kept)), dim3(kT), 0, s, keys_sorted, (int64_t)kept,
+                       (const int64_t*)whole->rowptr, whole->view.tile_min_row, (const int32_t*)g->dev_of_native, (int)g->tile_size,
+                       tk_in.as<uint8_t>(), pos_in.as<uint32_t>());
+    GM_TRY_HIP(hipGetLastError());
+    size_t tb = 0;  // stable: inside a tile the edges keep their (row, native col) order
+    GM_TRY_HIP(rocprim::radix_sort_pairs(nullptr, tb, tk_in.as<uint8_t>(), tk_out.as<uint8_t>(), pos_in.as<uint32_t>(),
+                                         pos_out.as<uint32_t>(), (size_t)kept, 0u, 8u, s));
+    if ((rc = tmp.alloc(tb))) return rc;
+    GM_TRY_HIP(rocprim::radix_sort_pairs(tmp.p, tb, tk_in.as<uint8_t>(), tk_out.as<uint8_t>(), pos_in.as<uint32_t>(),
+                                         pos_out.as<uint32_t>(), (size_t)kept, 0u, 8u, s));
+    hipLaunchKernelGGL(k_tile_bounds, dim3(1), dim3(128), 0, s, (const uint8_t*)tk_out.p, (int64_t)kept, T, bounds.as<int64_t>());
+    GM_TRY_HIP(hipMemcpyAsync(h_bounds.data(), bounds.p, (size_t)(T + 1) * 8, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+  }
+  tk_in.alloc(0);
+  pos_in.alloc(0);
+  tmp.alloc(0);
+  int64_t largest = 0;
+  for (int t = 0; t < T; t++) largest = std::max(largest, h_bounds[t + 1] - h_bounds[t]);
+  DevBuf keys_t, idx_t;
+  if ((rc = keys_t.alloc((size_t)largest * 8)) || (rc = idx_t.alloc((size_t)largest * 4))) return rc;
+  uint32_t* prev = nullptr;
+  GM_TRY_HIP(hipMalloc((void**)&prev, (size_t)nw * 4));
+  GM_TRY_HIP(hipMemsetAsync(prev, 0, (size_t)nw * 4, s));
+  g->out_tile_prev[0] = prev;
+  for (int t = 0; t < T; t++) {
+    const int64_t n = h_bounds[t + 1] - h_bounds[t];
+    if (n > 0)
+      hipLaunchKernelGGL(k_tile_gather, dim3(grid_for(n)), dim3(kT), 0, s, keys_sorted, idx_sorted,
+                         (const uint32_t*)pos_out.as<uint32_t>() + h_bounds[t], n, keys_t.as<uint64_t>(), idx_t.as<uint32_t>());
+    if ((rc = finish_csr(g, keys_t.as<uint64_t>(), idx_t.as<uint32_t>(), (unsigned long long)n, d_val, s, &g->out_tiles[t]))) return rc;
+    gm_csr_t& v = g->out_tiles[t].view;
+    v.hot_base = t * g->tile_size;
+    v.hot_len = std::min(g->tile_size, g->nlive - v.hot_base);
+    if (t + 1 < T) {
+      uint32_t* nxt = nullptr;
+      GM_TRY_HIP(hipMalloc((void**)&nxt, (size_t)nw * 4));
+      hipLaunchKernelGGL(k_or_words, dim3(grid_for(nw)), dim3(kT), 0, s, (const uint32_t*)g->out_tile_prev[t],
+                         (const uint32_t*)g->out_tiles[t].rowbits, nxt, nw);
+      g->out_tile_prev[t + 1] = nxt;
+    }
+  }
+  GM_TRY_HIP(hipStreamSynchronize(s));
   return GM_OK;
 }
 
@@ -461,9 +656,6 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
   if ((rc = tmp.alloc(tb))) return rc;
   GM_TRY_HIP(rocprim::radix_sort_pairs(tmp.p, tb, keys_in.as<uint32_t>(), keys_out.as<uint32_t>(), ids_in.as<int32_t>(),
                                        order.as<int32_t>(), (size_t)nv, 0u, 32u, s));
-  hipLaunchKernelGGL(k_deal, dim3(grid_for(nv)), dim3(kT), 0, s, order.as<int32_t>(), nv, G, S, don.as<int32_t>(),
-                     nod.as<int32_t>());
-  GM_TRY_HIP(hipGetLastError());
   // vertices with at least one edge come first in every slice: the rest is never gathered
   DevBuf nzd;
   if ((rc = nzd.alloc(8))) return rc;
@@ -472,6 +664,47 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
                      nzd.as<unsigned long long>());
   unsigned long long nz = 0;
   GM_TRY_HIP(hipMemcpyAsync(&nz, nzd.p, 8, hipMemcpyDeviceToHost, s));
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  g->nlive = (int32_t)nz;
+  // column tiles: contiguous NATIVE ranges holding equally many live vertices; the device order
+  // becomes (tile, degree rank inside the tile), vertices without edges last.  A stable sort of the
+  // ranked list by tile does it.
+  int T = D.col_tiles;
+  if (T == 0) T = g_col_tiles;
+  if (T == 0) { const char* e = getenv("GRAPHMAT_COL_TILES"); if (e) T = atoi(e); }
+  if (T < 1 || G > 1 || nz < 2) T = 1;
+  if (T > GM_MAX_TILES) T = GM_MAX_TILES;
+  if (T > 1) {
+    int tsize = (int)((nz + T - 1) / T);
+    tsize = (tsize + 63) / 64 * 64;
+    T = (int)((nz + tsize - 1) / tsize);
+    if (T > 1) {
+      DevBuf live, lpre, tk_in, tk_out, order2;
+      if ((rc = live.alloc((size_t)nv * 4)) || (rc = lpre.alloc((size_t)nv * 4)) || (rc = tk_in.alloc((size_t)nv)) ||
+          (rc = tk_out.alloc((size_t)nv)) || (rc = order2.alloc((size_t)nv * 4)))
+        return rc;
+      hipLaunchKernelGGL(k_live_flags, dim3(grid_for(nv)), dim3(kT), 0, s, deg.as<uint32_t>(), nv, live.as<uint32_t>());
+      size_t sb = 0;
+      GM_TRY_HIP(rocprim::exclusive_scan(nullptr, sb, live.as<uint32_t>(), lpre.as<uint32_t>(), 0u, (size_t)nv, rocprim::plus<uint32_t>(), s));
+      if ((rc = tmp.alloc(sb))) return rc;
+      GM_TRY_HIP(rocprim::exclusive_scan(tmp.p, sb, live.as<uint32_t>(), lpre.as<uint32_t>(), 0u, (size_t)nv, rocprim::plus<uint32_t>(), s));
+      hipLaunchKernelGGL(k_tile_of_ranked, dim3(grid_for(nv)), dim3(kT), 0, s, order.as<int32_t>(), nv, deg.as<uint32_t>(),
+                         lpre.as<uint32_t>(), tsize, tk_in.as<uint8_t>());
+      sb = 0;
+      GM_TRY_HIP(rocprim::radix_sort_pairs(nullptr, sb, tk_in.as<uint8_t>(), tk_out.as<uint8_t>(), order.as<int32_t>(),
+                                           order2.as<int32_t>(), (size_t)nv, 0u, 8u, s));
+      if ((rc = tmp.alloc(sb))) return rc;
+      GM_TRY_HIP(rocprim::radix_sort_pairs(tmp.p, sb, tk_in.as<uint8_t>(), tk_out.as<uint8_t>(), order.as<int32_t>(),
+                                           order2.as<int32_t>(), (size_t)nv, 0u, 8u, s));
+      GM_TRY_HIP(hipMemcpyAsync(order.p, order2.p, (size_t)nv * 4, hipMemcpyDeviceToDevice, s));
+      g->tile_size = tsize;
+    }
+  }
+  g->ntiles = T;
+  D.col_tiles = T;
+  hipLaunchKernelGGL(k_deal, dim3(grid_for(nv)), dim3(kT), 0, s, order.as<int32_t>(), nv, G, S, don.as<int32_t>(),
+                     nod.as<int32_t>());
+  GM_TRY_HIP(hipGetLastError());
   GM_TRY_HIP(hipStreamSynchronize(s));
   {
     long long per = ((long long)nz + G - 1) / G;
@@ -517,12 +750,44 @@ static void free_csr(CsrOwned* c) {
   if (c->gchunk_row) (void)hipFree(c->gchunk_row);
   if (c->gchunk_edge) (void)hipFree(c->gchunk_edge);
   if (c->gterm_off) (void)hipFree(c->gterm_off);
+  if (c->umid_row) (void)hipFree(c->umid_row);
   *c = CsrOwned();
+}
+
+static void free_tiles(gm_graph* g) {
+  if (g->out_tiles) {
+    for (int t = 0; t < g->ntiles; t++) free_csr(&g->out_tiles[t]);
+    delete[] g->out_tiles;
+    g->out_tiles = nullptr;
+  }
+  if (g->out_tile_prev) {
+    for (int t = 0; t < g->ntiles; t++)
+      if (g->out_tile_prev[t]) (void)hipFree(g->out_tile_prev[t]);
+    delete[] g->out_tile_prev;
+    g->out_tile_prev = nullptr;
+  }
 }
 
 }  // namespace gm
 
 extern "C" {
+
+int gm_graph_tiles(const gm_graph_t* g, int direction, int* ntiles) {
+  if (!g || !ntiles) { gm::set_error("gm_graph_tiles: null argument"); return GM_ERR_INVALID; }
+  *ntiles = (direction == GM_DIR_OUT && g->out_tiles && g->ntiles > 1) ? g->ntiles : 1;
+  return GM_OK;
+}
+
+int gm_graph_tile(const gm_graph_t* g, int direction, int tile, gm_csr_t* out, const uint32_t** d_prev_bits) {
+  if (!g || !out) { gm::set_error("gm_graph_tile: null argument"); return GM_ERR_INVALID; }
+  if (direction != GM_DIR_OUT || !g->out_tiles || tile < 0 || tile >= g->ntiles) {
+    gm::set_error("gm_graph_tile: no tile %d in direction %d", tile, direction);
+    return GM_ERR_INVALID;
+  }
+  *out = g->out_tiles[tile].view;
+  if (d_prev_bits) *d_prev_bits = g->out_tile_prev[tile];
+  return GM_OK;
+}
 
 int gm_graph_create(gm_graph_t** gout, const gm_graph_desc_t* desc, int64_t nnz, const int32_t* src,
                     const int32_t* dst, const void* val, gm_stream_t stream) {
@@ -578,7 +843,9 @@ int gm_graph_create(gm_graph_t** gout, const gm_graph_desc_t* desc, int64_t nnz,
   }
   g->desc.ndevice = desc->nvertices;
   g->desc.xchg_rows = desc->row_hi - desc->row_lo;
+  g->ntiles = 1;
   if (desc->layout == GM_LAYOUT_DEGREE) rc = gm::build_degree_layout(g, nnz, d_src, d_dst, s);
+  else g->desc.col_tiles = 1;
   if (rc != GM_OK) { gm_graph_destroy(g); return rc; }
   if (desc->directions & GM_DIR_OUT) rc = gm::build_direction(g, 1, nnz, d_src, d_dst, d_val, s, &g->out);
   if (rc == GM_OK && (desc->directions & GM_DIR_IN)) rc = gm::build_direction(g, 0, nnz, d_src, d_dst, d_val, s, &g->in);
@@ -628,6 +895,7 @@ int gm_graph_destroy(gm_graph_t* g) {
   if (g->dev_of_native) (void)hipFree(g->dev_of_native);
   if (g->native_of_dev) (void)hipFree(g->native_of_dev);
   if (g->rowbits_all) (void)hipFree(g->rowbits_all);
+  gm::free_tiles(g);
   for (int i = 0; i < GM_WS_SLOTS; i++)
     if (g->ws[i] && !g->ws_external[i]) (void)hipFree(g->ws[i]);
   if (g->aux_stream) {
@@ -694,6 +962,12 @@ int gm_graph_relayout_like(gm_graph_t* g, const gm_graph_t* like, gm_stream_t st
     GM_TRY_HIP(hipMemcpyAsync(g->native_of_dev, like->native_of_dev, (size_t)b.ndevice * 4, hipMemcpyDeviceToDevice, s));
   }
   g->desc.layout = b.layout;
+  // ... and its column tiles (the tile of a column is a function of its device id)
+  gm::free_tiles(g);
+  g->ntiles = like->ntiles > 1 ? like->ntiles : 1;
+  g->tile_size = like->tile_size;
+  g->nlive = like->nlive;
+  g->desc.col_tiles = g->ntiles;
   // the other graph's order ranks ITS edges: this graph's vertices with edges may sit anywhere in it
   g->desc.xchg_rows = b.row_hi - b.row_lo;
   const int saved_native = g->desc.ids_are_native, saved_vb = g->desc.val_bytes;

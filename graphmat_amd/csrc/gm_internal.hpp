@@ -50,6 +50,7 @@ struct CsrOwned {
   int32_t* gchunk_row = nullptr;
   int64_t* gchunk_edge = nullptr;
   int64_t* gterm_off = nullptr;
+  int32_t* umid_row = nullptr;
   bool present = false;
 };
 
@@ -80,4 +81,10 @@ struct gm_graph {
   int note_set[GM_NOTE_SLOTS];
   // last answers of gm_graph_split per direction (the search costs ~70 small device reads)
   struct SplitMemo { int valid, permille; int32_t asked, rs, bs, ms; } split_memo[2][2];
+  // column tiles of the GM_DIR_OUT adjacency (gm_graph_tile); ntiles <= 1: none
+  int ntiles;
+  int32_t tile_size;            // device ids [t * tile_size, (t+1) * tile_size) belong to tile t (the last one ends at nlive)
+  int32_t nlive;                // vertices with at least one edge (they come first in the device order)
+  gm::CsrOwned* out_tiles;      // [ntiles]
+  uint32_t** out_tile_prev;     // [ntiles] presence bits of the rows with an edge in an earlier tile
 };

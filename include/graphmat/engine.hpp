@@ -678,8 +678,32 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
             xsum = (const uint32_t*)ps;
           }
         }
-        if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves, xsum);
-        else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves, xsum);
+        // Column tiles (graphmat_hip.h: gm_graph_tile): with every x entry present and an ordered or
+        // commutative fold, the rows of more than GM_SHORT_ROW edges are multiplied tile by tile -- each
+        // pass gathers from one slice of x and continues the row's fold from the value y holds -- and
+        // only the short rows take the untiled row-blocks.  Same fold order, same bits.
+        int ntile = 1;
+        if (dense_x && !multi && row_bits == nullptr && rk != REDUCE_LAST && !(debug_flags() & dev::DBG_NO_TILES))
+          gm_graph_tiles(g, GM_DIR_OUT, &ntile);
+        if (ntile > 1) {
+          gm_csr_t As = Aout;  // the rows that are not tiled: row-blocks and the shorter wave rows
+          As.mid_row = Aout.umid_row; As.nmid = Aout.numid; As.nmid_long = Aout.numid_long; As.ngiant = 0; As.ngchunk = 0;
+          if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, As, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk);
+          else launch_spmv<P, T, U, V, E, false>(g, pa, As, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk);
+          for (int t = 0; t < ntile; t++) {
+            gm_csr_t At;
+            const uint32_t* prev = nullptr;
+            if (gm_graph_tile(g, GM_DIR_OUT, t, &At, &prev) != GM_OK) { printf("GraphMat(HIP): %s\n", gm_last_error()); exit(1); }
+            // y's presence bits are static (dense x): `prev` says which rows already carry a value
+            uint32_t* pb = const_cast<uint32_t*>(prev);
+            const int tacc = dev::ACC_STATIC_BITS | dev::ACC_READ_PREV;
+            if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, At, xq, xb, d_vp, y, pb, tacc, s, &st.spmv_launches, &timer, &aux, rk);
+            else launch_spmv<P, T, U, V, E, false>(g, pa, At, xq, xb, d_vp, y, pb, tacc, s, &st.spmv_launches, &timer, &aux, rk);
+          }
+        } else {
+          if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves, xsum);
+          else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves, xsum);
+        }
         if (static_bits) apply_bits = Aout.rowbits;
       }
       if (!dense_push && (order == IN_EDGES || order == ALL_EDGES)) {

@@ -357,7 +357,7 @@ __device__ __forceinline__ E edge_at(const void* __restrict__ vals, int64_t k) {
 // earlier pass (their presence is read from ybits); ACC_STATIC_BITS = do not write presence
 // bits (every x entry is present, so y's presence equals the graph's static row bits)
 enum { ACC_READ_PREV = 1, ACC_STATIC_BITS = 2 };
-enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64, DBG_NO_PIPELINE = 128, DBG_NO_LAZY_SEND = 256, DBG_NO_WAVE16 = 512 };
+enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64, DBG_NO_PIPELINE = 128, DBG_NO_LAZY_SEND = 256, DBG_NO_WAVE16 = 512, DBG_NO_TILES = 1024 };
 
 // presence bits of a wave's 64 consecutive rows: one atomicOr per 32-row word (not per row:
 // same-word atomics from 32 lanes serialise in the L2); nothing when the bits are static
@@ -792,8 +792,10 @@ k_spmv_wave16(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int n
   // 12288 / 16384 entries: 5.94 / 5.87 / 5.90 / 7.52 ms -- the last leaves one workgroup per CU)
   constexpr int kHot = sizeof(T) == 4 ? kHotEntries : 1;
   __shared__ T s_hot[kHot];
-  const int nhot = kHot > 1 ? (A.ncols < kHot ? A.ncols : kHot) : 0;
-  for (int i = threadIdx.x; i < nhot; i += kWave16Block) s_hot[i] = x[i];
+  // (a column tile's columns are a slice [hot_base, hot_base + hot_len) of the device order, busiest first)
+  const int nhot = kHot > 1 ? (A.hot_len < kHot ? A.hot_len : kHot) : 0;
+  const T* __restrict__ xhot = x + A.hot_base;
+  for (int i = threadIdx.x; i < nhot; i += kWave16Block) s_hot[i] = xhot[i];
   __syncthreads();
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -830,7 +832,10 @@ k_spmv_wave16(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int n
 #pragma unroll
     for (int r = 0; r < G; r++) {
       if (c[r] >= 0 && !dense && !bit_get(xbits, c[r])) c[r] = -1;
-      if (c[r] >= 0) m[r] = c[r] < nhot ? s_hot[c[r]] : x[c[r]];
+      if (c[r] >= 0) {
+        const unsigned rel = (unsigned)(c[r] - A.hot_base);
+        m[r] = rel < (unsigned)nhot ? s_hot[rel] : x[c[r]];
+      }
     }
   };
   if (nsteps > 0) fetch(0);

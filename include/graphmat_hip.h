@@ -129,6 +129,10 @@ typedef struct {
                             x (and their presence words) are ever read by other shards: with
                             GM_LAYOUT_DEGREE the vertices without any edge sit at the tail of
                             each slice.  Multiple of 64; = slice size for GM_LAYOUT_NATIVE.   */
+  int32_t col_tiles;     /* column tiles of the GM_DIR_OUT adjacency (see gm_graph_tile): 0 = library default
+                            (gm_set_option("col_tiles"), else environment GRAPHMAT_COL_TILES, else none),
+                            1 = none, 2..GM_MAX_TILES = that many.  GM_LAYOUT_DEGREE with one shard only
+                            (ignored otherwise).  Output: the number of tiles built (1 = none).             */
 } gm_graph_desc_t;
 
 /* One direction of the adjacency as laid out in HBM (see DESIGN.md "data layout"). */
@@ -168,6 +172,13 @@ typedef struct {
                                  when there are over 2^20 wave rows) (the list is
                                  in degree-ranked order, so this is a short prefix): one wave each; the rest are folded
                                  16 to a wave */
+  const int32_t* umid_row;    /* tiled graphs, whole-graph CSR only: the wave rows that are NOT tiled (more than      */
+  int32_t numid;              /*   GM_SHORT_ROW and at most tile_min_row edges), laid out like mid_row: the first    */
+  int32_t numid_long;         /*   numid_long entries are the long ones                                              */
+  int32_t tile_min_row;       /* rows of more than this many edges are multiplied tile by tile (0: not tiled)        */
+  int32_t hot_base;           /* the columns of this adjacency lie in device ids [hot_base, hot_base + hot_len) and   */
+  int32_t hot_len;            /*   the busiest come first: the kernels keep x[hot_base ...] in LDS.  Whole graph:
+                                 0 / ncols; a column tile: its slice of the device order                              */
 } gm_csr_t;
 
 #define GM_GIANT_CHUNK 4096 /* edges per piece of the parallel giant-row pass */
@@ -188,6 +199,26 @@ int gm_graph_create(gm_graph_t** g, const gm_graph_desc_t* desc, int64_t nnz, co
 int gm_graph_destroy(gm_graph_t* g);
 int gm_graph_desc(const gm_graph_t* g, gm_graph_desc_t* out);
 int gm_graph_csr(const gm_graph_t* g, int direction, gm_csr_t* out);
+/* ---- column tiles of a direction's adjacency ------------------------------------------------
+ * The gathers of x are what bounds the multiply on large graphs (one 4-byte gather per edge; at
+ * RMAT-26 x is 268 MB and 28 % of the gathers miss the 4 MB L2s).  With col_tiles = T > 1 the
+ * library cuts the NATIVE id space into T contiguous ranges holding equally many vertices with
+ * edges, lays the device order out as (tile, degree rank inside the tile) -- a tile's slice of x
+ * is contiguous with its busiest entries first -- and keeps, for the rows of more than
+ * GM_SHORT_ROW edges, one CSR per tile (only the edges whose column lies in the tile; same row
+ * ids, columns still in ascending native order).  Because the tiles are native ranges, folding a
+ * row's tile-0 edges, then its tile-1 edges, ... carrying the running value in y, is exactly the
+ * reference's ascending-native-column fold: results do not change, but every pass gathers from
+ * an x slice T times smaller (L2-resident hot part, LDS-resident hottest entries).
+ * Only rows of more than tile_min_row edges (gm_set_option("tile_min_row"), default
+ * GM_TILE_MIN_ROW) are tiled -- their per-tile pieces stay long enough for the wave kernels; the
+ * shorter rows keep the untiled kernels (gm_csr_t.umid_row lists the untiled wave rows).
+ * *d_prev_bits = presence bits of the rows that have an edge in an earlier tile (the rows whose
+ * running value y already holds when tile `tile` is multiplied). */
+#define GM_MAX_TILES 64
+#define GM_TILE_MIN_ROW 1024
+int gm_graph_tiles(const gm_graph_t* g, int direction, int* ntiles); /* *ntiles = 1: not tiled */
+int gm_graph_tile(const gm_graph_t* g, int direction, int tile, gm_csr_t* out, const uint32_t** d_prev_bits);
 /* rowbits of GM_DIR_OUT | rowbits of GM_DIR_IN (graphs built with both directions; ALL_EDGES programs) */
 int gm_graph_rowbits_all(const gm_graph_t* g, const uint32_t** d_bits);
 /* Rebuild g's adjacency in the device order of `like` (same vertex count and nparts, single

@@ -1,0 +1,137 @@
+"""Column tiles (graphmat_hip.h gm_graph_tile): the tiled multiply must give the untiled bits.
+
+A tile holds the edges whose column lies in one contiguous NATIVE range, so folding a row's tiles
+one after the other, carrying the running value in y, is the reference's ascending-native-column
+fold (include/GMDP/singlenode/spmspv.h:49-81 over the DCSC order of matrices/DCSCTile.h:41-58).
+Needs an MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from graphmat_amd import generators as gen
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from graphmat_amd import build
+    build.build()
+    from graphmat_amd import api
+    from oracle import binding as ob
+    return api, ob
+
+
+def f32bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture
+def tile_min(env):
+    """sets the tiling threshold for one test (rows of more edges are tiled), restores the default"""
+    api, _ = env
+
+    def set_(v):
+        api._lib.check(api._lib.lib().gm_set_option(b"tile_min_row", v))
+    yield set_
+    set_(1024)
+
+
+@pytest.mark.parametrize("tiles,threads,minrow", [(2, 1, 64), (5, 3, 64), (8, 1, 200), (64, 2, 64)])
+def test_tile_structure(env, tile_min, tiles, threads, minrow):
+    """device order = (tile, degree rank); every tile CSR holds exactly the edges of the long rows
+    whose column lies in the tile's slice, in the untiled order."""
+    api, _ = env
+    tile_min(minrow)
+    nv, s, d, v = gen.rmat_edges(12, 16, 3, weights="hash")
+    g = api.Graph(nv, s, d, v, ref_threads=threads, col_tiles=tiles)
+    T = g.col_tiles
+    assert 1 < T <= tiles
+    don, nod = g.maps_to_host()
+    nat = api.native_index(nv, threads * 16)
+    sn, dn = nat[s - 1], nat[d - 1]
+    deg = np.bincount(sn, minlength=nv) + np.bincount(dn, minlength=nv)
+    nlive = int((deg > 0).sum())
+    assert (deg[nod[:nlive]] > 0).all() and (deg[nod[nlive:]] == 0).all()
+    rp, ci, vv = g.csr_to_host(api.GM_DIR_OUT)
+    rowlen = np.diff(rp)
+    import torch
+    seen = 0
+    prev_rows = np.zeros(nv, bool)
+    for t in range(T):
+        c, prev = g.tile(api.GM_DIR_OUT, t)
+        lo, hi = c.hot_base, c.hot_base + c.hot_len
+        assert lo == (0 if t == 0 else last_hi) and hi <= nlive
+        last_hi = hi
+        # the slice is a contiguous native range, busiest first
+        natives = nod[lo:hi]
+        if t > 0:
+            assert natives.min() > prev_native_max
+        prev_native_max = natives.max()
+        assert (np.diff(deg[natives]) <= 0).all()
+        # expected content: long rows' edges with column in [lo, hi), untiled order
+        trp = np.zeros(c.nrows + 1, np.int64)
+        tci = np.zeros(max(c.nnz, 1), np.int32)
+        tvv = np.zeros(max(c.nnz, 1), np.int32)
+        api.copy_from_device(trp, c.rowptr)
+        if c.nnz:
+            api.copy_from_device(tci[: c.nnz], c.colidx)
+            api.copy_from_device(tvv[: c.nnz], c.vals)
+        rows_of_edge = np.repeat(np.arange(nv), rowlen)
+        keep = (rowlen[rows_of_edge] > minrow) & (ci >= lo) & (ci < hi)
+        assert c.nnz == int(keep.sum())
+        assert (tci[: c.nnz] == ci[keep]).all() and (tvv[: c.nnz] == vv[keep]).all()
+        assert (np.diff(trp) == np.bincount(rows_of_edge[keep], minlength=nv)).all()
+        bits = np.zeros((nv + 31) // 32 + 2, np.uint32)
+        api.copy_from_device(bits, prev)
+        got = ((bits[np.arange(nv) >> 5] >> (np.arange(nv) & 31)) & 1).astype(bool)
+        assert (got == prev_rows).all()
+        prev_rows |= np.diff(trp) > 0
+        seen += c.nnz
+    assert last_hi == nlive
+    assert seen == int(rowlen[rowlen > minrow].sum())
+    # the wave rows that stay untiled: more than 64 and at most minrow edges, long ones first
+    c = g.csr(api.GM_DIR_OUT)
+    assert c.tile_min_row == minrow
+    um = np.zeros(c.numid, np.int32)
+    api.copy_from_device(um, c.umid_row)
+    want = np.nonzero((rowlen > 64) & (rowlen <= minrow))[0]
+    assert sorted(um.tolist()) == want.tolist()
+    assert (rowlen[um[: c.numid_long]] > 1024).all() and (rowlen[um[c.numid_long:]] <= 1024).all()
+
+
+@pytest.mark.parametrize("scale,threads,tiles,minrow", [(10, 1, 2, 64), (12, 4, 3, 64), (14, 1, 8, 100), (16, 2, 4, 64),
+                                                         (16, 1, 16, 1024), (18, 1, 4, 1024)])
+def test_pagerank_tiled_bit_exact(env, tile_min, scale, threads, tiles, minrow):
+    api, ob = env
+    tile_min(minrow)
+    nv, s, d, v = gen.rmat_edges(scale, 16, seed=scale)
+    og = ob.OracleGraph(nv, s, d, v, threads)
+    g = api.Graph(nv, s, d, v, ref_threads=threads, col_tiles=tiles)
+    assert g.col_tiles > 1
+    opr, oit, _ = og.pagerank(10)
+    for force in (0, 1):
+        api._lib.lib().gm_set_option(b"force_ordered", force)
+        pr, deg, it = g.pagerank(10)
+        assert (deg == og.degree()).all() and it == oit == 10
+        assert (f32bits(pr) == f32bits(opr)).all(), "tiled pagerank bits differ (force_ordered=%d)" % force
+    api._lib.lib().gm_set_option(b"force_ordered", 0)
+    pr, _, it = g.pagerank(-1)
+    opr, oit, _ = og.pagerank(-1)
+    assert it == oit and (f32bits(pr) == f32bits(opr)).all()
+
+
+def test_other_programs_on_a_tiled_graph(env, tile_min):
+    """BFS / SSSP / SGD do not use the tiles but run on the tiled device order."""
+    api, ob = env
+    tile_min(64)
+    nv, s, d, v = gen.rmat_edges(13, 16, seed=77, weights="hash")
+    og = ob.OracleGraph(nv, s, d, v, 2)
+    g = api.Graph(nv, s, d, v, ref_threads=2, col_tiles=4)
+    depth, parent, it = g.bfs(1)
+    od, op, oit, _ = og.bfs(1)
+    assert it == oit and (depth == od).all() and (parent == op).all()
+    dist, it = g.sssp(1)
+    odist, oit = og.sssp(1)
+    assert it == oit and (dist == odist).all()
