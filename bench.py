@@ -20,6 +20,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# the cpu_baseline leg (OpenMP) follows the reference's README.md:30-39: threads spread over the cores and
+# pinned, memory interleaved over the NUMA nodes (set_mempolicy below).  libgomp reads these when it is
+# loaded, which `import torch` does.
+os.environ.setdefault("OMP_PROC_BIND", "spread")
+os.environ.setdefault("OMP_PLACES", "cores")
+
 import numpy as np
 import torch
 
@@ -31,6 +37,26 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def interleave_memory(on):
+    """set_mempolicy(MPOL_INTERLEAVE over all online NUMA nodes) for this process, or back to the default."""
+    try:
+        nodes = 0
+        for part in open("/sys/devices/system/node/online").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            nodes = max(nodes, int(hi or lo) + 1)
+        if nodes < 2:
+            return False
+        libc = C.CDLL(None, use_errno=True)
+        mask = (C.c_ulong * 16)()
+        for n in range(nodes):
+            mask[n // 64] |= 1 << (n % 64)
+        MPOL_DEFAULT, MPOL_INTERLEAVE, SYS_set_mempolicy = 0, 3, 238  # x86_64
+        rc = libc.syscall(SYS_set_mempolicy, MPOL_INTERLEAVE if on else MPOL_DEFAULT, mask if on else None, 1024 if on else 0)
+        return rc == 0 and on
+    except Exception:
+        return False
+
+
 def cpu_baseline(scale, iters, rank):
     """The oracle (CPU restatement of the reference algorithm, OpenMP over the reference's row
     partitions: 16 per layout thread) timed on this box's host cores on a bounded sample
@@ -40,6 +66,7 @@ def cpu_baseline(scale, iters, rank):
     from graphmat_amd import api
     from oracle import binding as ob
     cores = os.cpu_count() or 1
+    interleaved = interleave_memory(True)   # what `numactl -i all` does (the reference's README.md:30-39)
     nv, s, d, _ = api.rmat_on_device(scale, 16, 1)
     s = s.cpu().numpy()
     d = d.cpu().numpy()
@@ -65,9 +92,91 @@ def cpu_baseline(scale, iters, rank):
     og.pagerank(iters, degree=deg)
     dt = time.time() - t0
     log(rank, "cpu_baseline: RMAT-%d, %d iterations %.2fs on %d threads" % (scale, iters, dt, t))
-    return {"value": round(len(s) * iters / dt / 1e9, 4), "unit": "GTEPS", "cores": t, "kind": "port",
+    interleave_memory(False)
+    return {"numa": "OMP_PROC_BIND=%s OMP_PLACES=%s, memory %s" % (os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"),
+                                                                  "interleaved over all NUMA nodes" if interleaved else "default policy"),
+            "value": round(len(s) * iters / dt / 1e9, 4), "unit": "GTEPS", "cores": t, "kind": "port",
             "sample": "oracle (oracle/gm_oracle.hpp, OpenMP, %d of %d host cores, layout threads=%d) PageRank, %d iterations on "
                       "RMAT-%d (V=%d, E=%d), graph build excluded" % (t, cores, t, iters, scale, nv, len(s))}
+
+
+def kernels_fingerprint():
+    """sha256 (16 hex digits) of the sources the multiply kernels are built from: a committed PMC traffic figure
+    is only quoted while it was measured on exactly these kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("include/graphmat/kernels.hpp", "include/graphmat/engine.hpp", "graphmat_amd/csrc/gm_graph.hip",
+                "graphmat_amd/csrc/gm_programs.hip"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def extra_bfs(scale, edge_factor, seed, ref_threads, local_rank, rank):
+    """BASELINE config 3: BFS on RMAT-<scale>, whole gm_run_bfs call per source (host syncs included), with the
+    independent torch check of depth and parent (tools/fullscale_checks.py: max-native-id parent rule)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from fullscale_checks import check_bfs
+    from graphmat_amd import api
+    dev = torch.device("cuda", local_rank)
+    nv, src, dst, _ = api.rmat_on_device(scale, edge_factor, seed, weights=False, device=local_rank)
+    g = api.Graph(nv, src, dst, None, ref_threads=ref_threads, device=local_rank, keep_values=False)
+    nat = torch.from_numpy(api.native_index(nv, ref_threads * 16)).to(dev)
+    g.bfs(1)  # warm: kernels, scratch
+    runs = []
+    for source in (1, 12345, 777):
+        r = check_bfs(g, nv, src, dst, nat, source, dev)
+        # SURVEY 8d: 4 B per traversable edge + per vertex (8 rowptr + 24 read + 24 written) + 2 bit vectors per level
+        r["alg_bytes"] = 4 * r["traversable_edges"] + nv * 56 + 2 * (nv // 8) * r["levels"]
+        r["gteps"] = round(r["traversable_edges"] / r["wall_ms"] / 1e6, 2)
+        r["hbm_gbps"] = round(r["alg_bytes"] / r["wall_ms"] / 1e6, 1)
+        r["hbm_frac"] = round(r["alg_bytes"] / r["wall_ms"] / 1e6 / HBM_PEAK_GBPS, 4)
+        r["wall_ms"] = round(r["wall_ms"], 3)
+        log(rank, "extra bfs: source %d: %d levels, %.2f ms, %.1f GTEPS, parents %s" % (source, r["levels"], r["wall_ms"], r["gteps"], "OK" if r["ok"] else "WRONG"))
+        runs.append(r)
+    g.close()
+    del src, dst, nat
+    torch.cuda.empty_cache()
+    return {"workload": "BFS (src/BFS.cpp program) on RMAT scale-%d, whole gm_run_bfs call per source" % scale,
+            "parents_bit_exact_vs_max_native_rule": all(r["ok"] for r in runs),
+            "median_wall_ms": sorted(r["wall_ms"] for r in runs)[1], "median_gteps": sorted(r["gteps"] for r in runs)[1],
+            "runs": runs}
+
+
+def extra_sgd(users, items, per_user, iters, local_rank, rank):
+    """BASELINE config 5 shape on one GPU: SGD/CF, K=128 fp32 latent vectors, one ALL_EDGES iteration."""
+    from graphmat_amd import _lib, api
+    L = _lib.lib()
+    dev = torch.device("cuda", local_rank)
+    K = 128
+    nv = users + items
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    src = torch.arange(1, users + 1, dtype=torch.int32, device=dev).repeat_interleave(per_user)
+    dst = (users + 1 + torch.randint(0, items, (src.numel(),), generator=gen, device=dev)).to(torch.int32)
+    val = torch.randint(1, 6, (src.numel(),), generator=gen, device=dev).to(torch.int32)
+    E = src.numel()
+    g = api.Graph(nv, src, dst, val, device=local_rank, keep_values=True)
+    del src, dst, val
+    lat = torch.rand((g.rows, K + 1), generator=gen, device=dev, dtype=torch.float32)
+    it = C.c_int(0)
+    _lib.check(L.gm_run_sgd(g.h, lat.data_ptr(), K, 4, 0.001, 1e-5, 1, C.byref(it), None))  # warm
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _lib.check(L.gm_run_sgd(g.h, lat.data_ptr(), K, 4, 0.001, 1e-5, iters, C.byref(it), None))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    finite = bool(torch.isfinite(lat).all())
+    balg = 2 * E * 8 + nv * K * 4 * 4          # SURVEY 8d: index + rating per edge direction, x/vp read+write per vertex
+    flops = 2 * E * 4 * K + 3 * K * nv
+    g.close()
+    del lat
+    torch.cuda.empty_cache()
+    log(rank, "extra sgd: %d x %d, %d ratings: %.2f ms/iteration" % (users, items, E, dt * 1e3))
+    return {"workload": "SGD/CF (src/SGD.cpp program, K=128 fp32) on synthetic %d users x %d items, %d ratings, one ALL_EDGES iteration"
+                        % (users, items, E), "ms_per_iteration": round(dt * 1e3, 3), "iterations_timed": iters,
+            "edge_visits_per_s_e9": round(2 * E / dt / 1e9, 3), "alg_bytes": balg, "hbm_gbps": round(balg / dt / 1e9, 1),
+            "hbm_frac": round(balg / dt / 1e9 / HBM_PEAK_GBPS, 4), "gather_inclusive_gbps": round(2 * E * K * 4 / dt / 1e9, 1),
+            "tflops": round(flops / dt / 1e12, 2), "result_finite": finite}
 
 
 def main():
@@ -81,6 +190,9 @@ def main():
     ap.add_argument("--ref-threads", type=int, default=1, help="layout parameter of the id permutation (oracle config)")
     ap.add_argument("--cpu-scale", type=int, default=22, help="RMAT scale of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=300, help="iterations of the cpu_baseline sample (~10-15 s of CPU work)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the BFS (config 3) and SGD (config 5) legs of the JSON line")
+    ap.add_argument("--sgd-users", type=int, default=10_000_000)
+    ap.add_argument("--sgd-items", type=int, default=1_000_000)
     ap.add_argument("--no-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--short-row", type=int, default=0, help="experiment: rows up to this many edges go to row-blocks")
     ap.add_argument("--giant-row", type=int, default=0, help="experiment: rows above this many edges get a workgroup")
@@ -285,18 +397,25 @@ def main():
         avg_ms = ms / launches * per_step
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
+        # HBM/fabric bytes per launch from the committed rocprofv3 PMC passes -- quoted only while they were taken on
+        # exactly the kernels that just ran (fingerprint of the kernel sources); otherwise null
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        traffic_note = "no PMC pass on record for these kernels"
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 per = tj.get("scale%d" % args.scale, {})
-                traffic = per.get(name + "_bytes_per_launch")
-                if name == "k_spmv_wave" and traffic is not None:
-                    traffic += per.get("k_spmv_wave16_bytes_per_launch", 0)
+                if tj.get("kernels_fingerprint") == kernels_fingerprint() and int(g.col_tiles) <= 1:
+                    traffic = per.get(name + "_bytes_per_launch")
+                    if name == "k_spmv_wave" and traffic is not None:
+                        traffic += per.get("k_spmv_wave16_bytes_per_launch", 0)
+                    traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernels (profiles/pmc_traffic.json)"
+                else:
+                    traffic_note = "profiles/pmc_traffic.json was measured on other kernel sources: not quoted"
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "kernel": ("k_spmv_wave16+k_spmv_wave" if name == "k_spmv_wave" else name) + "<PageRank>", "achieved": round(ach, 1),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg_bytes,
                 "launches_per_iteration": per_step,
                 "rowblock_avg_ms": round(stats["rowblock_ms"] / max(args.steps, 1), 4),
@@ -332,6 +451,21 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.cpu_scale, args.cpu_iters, rank)
     elif rank == 0:
         out["cpu_baseline"] = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        # the other single-GPU configurations of BASELINE.json, measured by the same run
+        g.close()
+        del st
+        torch.cuda.empty_cache()
+        extra = {}
+        try:
+            extra["bfs_rmat%d" % args.scale] = extra_bfs(args.scale, args.edge_factor, args.seed, args.ref_threads, local_rank, rank)
+        except Exception as e:  # pragma: no cover
+            extra["bfs_rmat%d" % args.scale] = {"error": repr(e)}
+        try:
+            extra["sgd_k128"] = extra_sgd(args.sgd_users, args.sgd_items, 100, 3, local_rank, rank)
+        except Exception as e:  # pragma: no cover
+            extra["sgd_k128"] = {"error": repr(e)}
+        out["extra"] = extra
     if rank == 0:
         r = roof or {}
         log(rank, "summary scale=%d gpus=%d dbg=%d ms/step=%.3f GTEPS=%.1f rowblock=%.3fms wave=%.3fms giant=%.3fms send=%.3f "

@@ -33,6 +33,24 @@ int g_col_tiles = 0;  // default number of column tiles for graphs whose descrip
 constexpr int kT = 256;
 inline int grid_for(int64_t n) { return (int)((n + kT - 1) / kT); }
 
+// edge ids outside [lo, hi] (the reference only asserts this in __DEBUG builds, edgelist.h; here an
+// out-of-range id would index device arrays out of bounds, so it is checked before anything else)
+__global__ void __launch_bounds__(kT)
+k_validate_ids(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t nnz, int lo, int hi,
+               unsigned long long* __restrict__ bad /* [0] count, [1] first offending edge + 1 */) {
+  const int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x;
+  bool b = false;
+  if (e < nnz) {
+    const int s = src[e], d = dst[e];
+    b = s < lo || s > hi || d < lo || d > hi;
+  }
+  const unsigned long long m = __ballot(b);
+  if (m && (threadIdx.x & 63) == __ffsll((long long)m) - 1) {
+    atomicAdd(&bad[0], (unsigned long long)__popcll(m));
+    atomicMin(&bad[1], (unsigned long long)e + 1ull);
+  }
+}
+
 // total degree (in + out) per native vertex, for the GM_LAYOUT_DEGREE ranking
 __global__ void __launch_bounds__(kT)
 k_degree(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t nnz, int nparts, int nv,
@@ -839,6 +857,26 @@ int gm_graph_create(gm_graph_t** gout, const gm_graph_desc_t* desc, int64_t nnz,
         gm::set_error("edge value upload failed"); delete g; return GM_ERR_HIP;
       }
       d_val = uval.p;
+    }
+  }
+  if (nnz > 0) {  // every id must name a vertex: 1..nvertices (0..nvertices-1 when ids_are_native)
+    gm::DevBuf badc;
+    if ((rc = badc.alloc(16))) { delete g; return rc; }
+    const unsigned long long init[2] = {0ull, ~0ull};
+    const int lo = desc->ids_are_native ? 0 : 1, hi = desc->ids_are_native ? desc->nvertices - 1 : desc->nvertices;
+    unsigned long long bad[2] = {0ull, 0ull};
+    if (hipMemcpyAsync(badc.p, init, 16, hipMemcpyHostToDevice, s) != hipSuccess) { gm::set_error("edge id check: upload failed"); delete g; return GM_ERR_HIP; }
+    hipLaunchKernelGGL(gm::k_validate_ids, dim3(gm::grid_for(nnz)), dim3(gm::kT), 0, s, d_src, d_dst, nnz, lo, hi, badc.as<unsigned long long>());
+    if (hipMemcpyAsync(bad, badc.p, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+      gm::set_error("edge id check failed: %s", hipGetErrorString(hipGetLastError()));
+      delete g;
+      return GM_ERR_HIP;
+    }
+    if (bad[0] != 0) {
+      gm::set_error("gm_graph_create: %llu edge(s) name a vertex outside [%d, %d] (first: edge %llu); ids are %s", bad[0], lo, hi,
+                    bad[1] - 1ull, desc->ids_are_native ? "0-based native ids" : "1-based vertex ids as in the .mtx file");
+      delete g;
+      return GM_ERR_INVALID;
     }
   }
   g->desc.ndevice = desc->nvertices;

@@ -16,12 +16,20 @@
 //      OBJECT symbol on the host is refreshed with hipMemcpy.
 // Limits: single translation unit applications; uncompressed offload
 // bundles (hipcc's default); the executable must keep its symbol table (not stripped).
+// When the image cannot be parsed (stripped executable, --offload-compress bundle, anchor not
+// found) the device copies would silently stay zero -- MAX_DIST = 0 in the reference's BFS --
+// so that case is FATAL: message + exit(1), the reference's error convention
+// (GRAPHMAT_ALLOW_UNMIRRORED_GLOBALS=1 turns it into a warning for applications that are known
+// not to read host globals in their vertex programs).  Variables that are HIP device variables
+// in their own right (`__device__ int v;`: hipGetSymbolAddress resolves their host shadow) are
+// left alone -- their host shadow holds no value.
 #pragma once
 #include <elf.h>
 #include <hip/hip_runtime.h>
 #include <link.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -104,12 +112,25 @@ inline std::vector<MirroredGlobal>& mirrored_globals() {
   done = true;
   (void)&gm_anchor_touch;
   void* anchor_dev = nullptr;
-  if (hipGetSymbolAddress(&anchor_dev, HIP_SYMBOL(gm_code_object_anchor)) != hipSuccess || !anchor_dev) return list;
+  auto cannot = [&](const char* why) -> std::vector<MirroredGlobal>& {
+    const char* allow = getenv("GRAPHMAT_ALLOW_UNMIRRORED_GLOBALS");
+    const bool fatal = !(allow && allow[0] == '1');
+    printf("GraphMat(HIP): %s: cannot mirror host namespace-scope variables into the device code (%s).\n"
+           "GraphMat(HIP): vertex programs that read such variables (e.g. MAX_DIST of BFS/SSSP) would see zeros. Build the\n"
+           "GraphMat(HIP): application unstripped, as one translation unit, without --offload-compress%s\n",
+           fatal ? "error" : "warning", why, fatal ? "; or set GRAPHMAT_ALLOW_UNMIRRORED_GLOBALS=1 if it reads none." : ".");
+    if (fatal) exit(1);
+    return list;
+  };
+  if (hipGetSymbolAddress(&anchor_dev, HIP_SYMBOL(gm_code_object_anchor)) != hipSuccess || !anchor_dev) {
+    (void)hipGetLastError();
+    return cannot("the anchor variable of this translation unit has no device address");
+  }
   std::vector<unsigned char> exe;
-  if (!read_file("/proc/self/exe", exe)) return list;
+  if (!read_file("/proc/self/exe", exe)) return cannot("/proc/self/exe is not readable");
   std::vector<ElfSym> host;
   elf_objects(exe.data(), exe.size(), host);
-  if (host.empty()) return list;  // stripped
+  if (host.empty()) return cannot("the executable has no symbol table (stripped)");
   uint64_t base = 0;
   dl_iterate_phdr(phdr_cb, &base);
   static const char magic[] = "__CLANG_OFFLOAD_BUNDLE__";
@@ -146,6 +167,10 @@ inline std::vector<MirroredGlobal>& mirrored_globals() {
           continue;
         for (const ElfSym& h : host) {
           if (h.name == s.name && h.size == s.size && (h.sec_flags & SHF_ALLOC)) {
+            // a HIP device variable of the application (its host symbol is the registration shadow): not ours
+            void* registered = nullptr;
+            if (hipGetSymbolAddress(&registered, (const void*)(base + h.value)) == hipSuccess && registered != nullptr) break;
+            (void)hipGetLastError();
             MirroredGlobal m;
             m.dev = (void*)(bias + s.value);
             m.host = (const void*)(base + h.value);
@@ -159,7 +184,10 @@ inline std::vector<MirroredGlobal>& mirrored_globals() {
       return list;  // the code object holding this translation unit's anchor has been handled
     }
   }
-  return list;
+  static const char ccob[] = "CCOB";
+  if (memmem(exe.data(), exe.size(), ccob, 4) != nullptr && memmem(exe.data(), exe.size(), magic, mlen) == nullptr)
+    return cannot("the offload bundle is compressed (--offload-compress)");
+  return cannot("no gfx950 code object of the executable holds this translation unit's anchor");
 }
 
 // Called when a graph is constructed: loads this translation unit's code object (done lazily by

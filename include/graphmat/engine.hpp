@@ -581,9 +581,13 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
                            d_list, d_count);
       }
       const int nf = (int)frontier_v;
-      if (!lazy_send)
-        hipLaunchKernelGGL((dev::k_send_list<P, T, V>), dim3(grid_for(nf)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
-                           (const int32_t*)d_list, nf, x, desc.row_lo);
+      // The messages of the listed vertices are always materialised here, also for programs that
+      // otherwise evaluate them on demand: k_push_finish applies while other lanes still fetch
+      // messages, so an on-demand send_message(vp[u]) could read a vertex property that this very
+      // step is rewriting (any a=b program whose active vertices can change again).  The list is
+      // small (<= kSparseListCap vertices), so this costs microseconds.
+      hipLaunchKernelGGL((dev::k_send_list<P, T, V>), dim3(grid_for(nf)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
+                         (const int32_t*)d_list, nf, x, desc.row_lo);
       timer.mark(TAG_SEND);
       GM_HIP_OK(hipMemsetAsync(d_tcount, 0, 4, s));
       const unsigned pieces = (unsigned)(frontier_e / dev::kPieceEdges + frontier_v);  // upper bound of the pieces
@@ -613,7 +617,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       if (bound > 0) {
         auto finish = [&](auto use_vp_c, auto combined_c) {
           hipLaunchKernelGGL((dev::k_push_finish<P, T, U, V, E, decltype(use_vp_c)::value, decltype(combined_c)::value>),
-                             dim3(grid_for((int64_t)bound)), dim3(dev::kBlock), 0, s, pa, Asrc, xq, dev_of_native, d_vp, d_best,
+                             dim3(grid_for((int64_t)bound)), dim3(dev::kBlock), 0, s, pa, Asrc, (const T*)x, dev_of_native, d_vp, d_best,
                              (const int32_t*)d_touched, (const unsigned int*)d_tcount, d_active, d_changed, d_striped, d_want, d_list,
                              d_count);
         };

@@ -232,3 +232,31 @@ def test_sparse_float_sum_exactness_app():
     wave and short rows all equal a host fold in native order, bit for bit."""
     text = _run(_need(os.path.join(OWN_APPS, "active_float_sum")))
     assert "FLOATSUM PASS" in text, text[-1500:]
+
+
+@pytest.mark.gpu
+def test_last_writer_program_with_changing_senders():
+    """apps/last_writer.cpp: an a=b program whose active vertices are rewritten in the step they send in
+    (list-based top-down steps must use the messages of BEFORE the step); equals a host restatement."""
+    text = _run(_need(os.path.join(OWN_APPS, "last_writer")))
+    assert "LASTWRITER PASS" in text, text[-1500:]
+
+
+@pytest.mark.gpu
+def test_unmirrorable_globals_are_fatal(tmp_path):
+    """include/graphmat/device_globals.hpp: an application whose image cannot be parsed (here: a stripped copy
+    of the reference-style BFS) must not run with zeroed device copies of its host globals: message + exit(1);
+    GRAPHMAT_ALLOW_UNMIRRORED_GLOBALS=1 downgrades that to a warning."""
+    import shutil
+    src = _need(os.path.join(OWN_APPS, "bfs_bottom_up"))
+    exe = str(tmp_path / "bfs_stripped")
+    shutil.copy(src, exe)
+    if subprocess.run(["strip", exe]).returncode != 0:
+        pytest.skip("strip is not available")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "graphmat_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    fixture = os.path.join(ROOT, "tests", "golden", "test.bin.mtx")
+    out = subprocess.run([exe, fixture, "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, env=env)
+    assert out.returncode == 1 and b"cannot mirror host namespace-scope variables" in out.stdout, out.stdout[-800:]
+    env["GRAPHMAT_ALLOW_UNMIRRORED_GLOBALS"] = "1"
+    out = subprocess.run([exe, fixture, "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, env=env)
+    assert b"warning" in out.stdout

@@ -405,3 +405,30 @@ def test_sgd_with_giant_rows(env):
     e, sq = g.rmse_sum(lv2)
     oe, osq = og.rmse_sum(olv2)
     np.testing.assert_allclose(sq, osq, rtol=1e-6, atol=0)
+
+
+def test_edge_ids_are_validated(env):
+    """ids outside 1..nvertices would index device arrays out of bounds: GM_ERR_INVALID with a message
+    (the reference asserts this only in __DEBUG builds, include/GMDP/utils/edgelist.h)."""
+    api, _ = env
+    for s, d in (([0, 1, 2], [1, 2, 3]), ([1, 2, 3], [2, 3, 9]), ([1, -4, 3], [2, 3, 1])):
+        with pytest.raises(RuntimeError, match="outside"):
+            api.Graph(8, np.array(s, np.int32), np.array(d, np.int32), None)
+    g = api.Graph(8, np.array([1, 8], np.int32), np.array([8, 1], np.int32), None)  # the extremes are fine
+    assert g.nnz_input == 2
+
+
+@pytest.mark.timeout(900)
+def test_fullscale_bfs_parents_rmat26():
+    """BASELINE config 3 at its full size: BFS on RMAT-26 (1.07 G edges); depth and EVERY parent are checked
+    against the defining properties of the reference's result (BFS levels; parent = the previous-level
+    in-neighbour with the largest native id), evaluated independently with torch on the edge list
+    (tools/fullscale_checks.py), together with PageRank's degree pass and run-to-run reproducibility."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fullscale_checks.py"), "--scale", "26"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=850)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "ALL PASS" in text, text[-3000:]
+    assert text.count("=> PASS") >= 3

@@ -27,6 +27,42 @@ import numpy as np
 import torch
 
 
+def check_bfs(g, nv, src, dst, nat, source, dev):
+    """Runs gm_run_bfs from `source` and checks depth + parent against the defining properties, evaluated with
+    torch on the edge list.  Returns a dict (ok, levels, reached, traversable_edges, wall_ms, the violation counts)."""
+    torch.cuda.synchronize()
+    depth, parent, it = g.bfs(source)
+    wall_ms = g.last_wall_ms
+    d = torch.from_numpy(depth.astype(np.int64)).to(dev)
+    par = torch.from_numpy(parent.astype(np.int64)).to(dev)
+    INF = 0xFFFFFFFF
+    si = (src - 1).long()
+    di = (dst - 1).long()
+    du = d[si]
+    dv = d[di]
+    reach_u = du != INF
+    bad_skip = int(((dv > du + 1) & reach_u).sum())  # (i) no edge skips a level
+    on_tree = reach_u & (dv == du + 1)               # (ii)+(parent): among edges from the previous level, the largest native source id
+    del du, dv
+    cand = torch.full((nv,), -1, dtype=torch.int64, device=dev)
+    cand.scatter_reduce_(0, di[on_tree], nat[si[on_tree]], reduce="amax", include_self=True)
+    e_reach = int(reach_u.sum())
+    del on_tree, reach_u, si, di
+    reached = d != INF
+    nonsrc = reached.clone()
+    nonsrc[source - 1] = False
+    miss_parent = int((nonsrc & ~(cand >= 0)).sum())
+    par_nat = torch.full((nv,), -1, dtype=torch.int64, device=dev)  # parent ids are vertex ids (1-based); compare in native space
+    par_nat[nonsrc] = nat[(par[nonsrc] - 1)]
+    wrong_parent = int((nonsrc & (par_nat != cand)).sum())
+    src_ok = int(d[source - 1]) == 0 and int(par[source - 1]) == -1
+    unreached_ok = int(((~reached) & (par != -1)).sum()) == 0
+    ok = bad_skip == 0 and miss_parent == 0 and wrong_parent == 0 and src_ok and unreached_ok
+    return {"ok": bool(ok), "source": source, "levels": int(it), "reached": int(reached.sum()), "traversable_edges": e_reach,
+            "wall_ms": float(wall_ms), "level_skip_edges": bad_skip, "no_previous_level_neighbour": miss_parent,
+            "parents_not_max_native": wrong_parent, "source_ok": bool(src_ok), "unreached_untouched": bool(unreached_ok)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=int, default=26)
@@ -44,43 +80,16 @@ def main():
 
     # ---------------- BFS ----------------
     for source in (1, 12345):
-        torch.cuda.synchronize()
         t0 = time.time()
-        depth, parent, it = g.bfs(source)
+        r = check_bfs(g, nv, src, dst, nat, source, dev)
         dt = time.time() - t0
-        d = torch.from_numpy(depth.astype(np.int64)).to(dev)
-        par = torch.from_numpy(parent.astype(np.int64)).to(dev)
-        INF = 0xFFFFFFFF
-        du = d[(src - 1).long()]
-        dv = d[(dst - 1).long()]
-        reach_u = du != INF
-        # (i) no edge skips a level
-        bad_skip = int(((dv > du + 1) & reach_u).sum())
-        # (ii)+(parent): among edges from the previous level, the largest native source id
-        on_tree = reach_u & (dv == du + 1)
-        cand = torch.full((nv,), -1, dtype=torch.int64, device=dev)
-        cand.scatter_reduce_(0, (dst - 1).long()[on_tree], nat[(src - 1).long()[on_tree]], reduce="amax", include_self=True)
-        reached = d != INF
-        nonsrc = reached.clone()
-        nonsrc[source - 1] = False
-        have = cand >= 0
-        miss_parent = int((nonsrc & ~have).sum())
-        # parent ids are vertex ids (1-based); compare in native space
-        par_nat = torch.full((nv,), -1, dtype=torch.int64, device=dev)
-        par_nat[nonsrc] = nat[(par[nonsrc] - 1)]
-        wrong_parent = int((nonsrc & (par_nat != cand)).sum())
-        src_ok = int(d[source - 1]) == 0 and int(par[source - 1]) == -1
-        unreached_ok = int(((~reached) & (par != -1)).sum()) == 0
-        nreach = int(reached.sum())
-        e_reach = int(reach_u.sum())
-        this_ok = bad_skip == 0 and miss_parent == 0 and wrong_parent == 0 and src_ok and unreached_ok
-        ok &= this_ok
-        print("BFS source=%d: %d levels, %d reachable, %.1f ms wall (incl. state setup/readback), "
+        ok &= r["ok"]
+        print("BFS source=%d: %d levels, %d reachable, gm_run_bfs %.2f ms wall (%.1f s with the torch evaluation of the properties), "
               "edges from reached sources=%d | level-skip edges=%d, vertices without a previous-level in-neighbour=%d, "
               "parents != max-native rule=%d, source ok=%s, unreached untouched=%s => %s"
-              % (source, it, nreach, dt * 1e3, e_reach, bad_skip, miss_parent, wrong_parent, src_ok, unreached_ok,
-                 "PASS" if this_ok else "FAIL"))
-        del d, par, du, dv, reach_u, on_tree, cand, reached, nonsrc, have, par_nat
+              % (source, r["levels"], r["reached"], r["wall_ms"], dt, r["traversable_edges"], r["level_skip_edges"],
+                 r["no_previous_level_neighbour"], r["parents_not_max_native"], r["source_ok"], r["unreached_untouched"],
+                 "PASS" if r["ok"] else "FAIL"))
 
     # ---------------- PageRank ----------------
     st = g.new_pr_state()

@@ -27,6 +27,9 @@ def main():
                     "--no-timing` (one counter set per run, kernel-trace only): (FETCH_SIZE + WRITE_SIZE) * 1024. No x2 correction "
                     "is applied: FETCH_SIZE / TCC_MISS = 63.5-64 B per miss, i.e. these are 64-byte random fetches, not wide "
                     "streaming reads (MI355X_MICROARCH.md HBM section). tools/final_profiles.sh + tools/pmc_to_json.py.")
+    sys.path.insert(0, ROOT)
+    import bench
+    doc["kernels_fingerprint"] = bench.kernels_fingerprint()
     for sc in scales:
         f = per_dispatch(os.path.join(ROOT, "profiles", "%s_scale%s_pmc_FETCH_SIZE.md" % (tag, sc)), "FETCH_SIZE")
         w = per_dispatch(os.path.join(ROOT, "profiles", "%s_scale%s_pmc_WRITE_SIZE.md" % (tag, sc)), "WRITE_SIZE")
