@@ -265,6 +265,11 @@ def main():
         args.scale, nv, E, build_s, ranges[rank][0], ranges[rank][1], c_out.nnz, c_out.nblk, c_out.nmid, c_out.ngiant))
 
     ex = None
+    # N > 1.  The message buffers are torch tensors adopted by the library, so either exchange
+    # implementation can serve them: the library's native RCCL exchange (gm_dist.hip: no Python per
+    # iteration) or the torch.distributed callback (graphmat_amd/dist.py; the only one gloo can use, and
+    # the cross-check of the native one below).  GM_BENCH_EXCHANGE=python forces the callback.
+    native = False
     if world > 1:
         x_bytes = torch.zeros(g.ndevice * 4 + 64, dtype=torch.uint8, device=dev)
         x_bits = torch.zeros((g.ndevice + 31) // 32 + 2, dtype=torch.int32, device=dev)
@@ -280,6 +285,32 @@ def main():
         cb = ex.callback()
         g._cb = cb
         _lib.check(L.gm_graph_set_exchange(g.h, cb, None))
+        if backend == "nccl" and os.environ.get("GM_BENCH_EXCHANGE", "rccl") == "rccl":
+            from graphmat_amd import dist as gdist
+            ok = 1
+            try:
+                gdist.init_native_rccl(device=dev)
+                # the two implementations must produce the same bits: a few iterations each from the same state
+                st_a = g.new_pr_state()
+                g.run_degree(st_a)
+                st_b = st_a.clone()
+                g.run_pagerank(st_b, 3)                      # callback exchange
+                _lib.check(L.gm_graph_use_rccl(g.h))
+                g.run_pagerank(st_a, 3)                      # native exchange
+                ok = 1 if bool(torch.equal(st_a, st_b)) else 0
+                del st_a, st_b
+            except Exception as e:  # pragma: no cover
+                log(rank, "native RCCL exchange unavailable: %r" % (e,))
+                ok = 0
+            okt = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            native = int(okt.item()) == 1
+            if native:
+                log(rank, "native RCCL exchange verified against the torch.distributed callback (3 iterations, same bits)")
+            else:
+                log(rank, "native RCCL exchange NOT used (unavailable or disagreeing): torch.distributed callback instead")
+                _lib.check(L.gm_graph_set_exchange(g.h, cb, None))
+                ex.parts = 0
 
     # edges handled by the long-row kernel (for per-kernel algorithmic bytes):
     # pull rowptr to the host once (8 bytes/row) and compute degrees
@@ -302,6 +333,11 @@ def main():
     st = g.new_pr_state()
     g.run_degree(st)
     overlapped = False
+
+    def parts_started():
+        if native:
+            return gdist.exchange_counters(g)[1]
+        return ex.parts if ex is not None else 0
     if world > 1 and ex is not None and ex.x_bytes2 is not None:
         # the overlapped schedule must give the plain loop's bits; if it does not (or cannot run
         # here), say so and time the plain loop
@@ -323,7 +359,7 @@ def main():
         try:
             a, b = st.clone(), st.clone()
             timed(a, 0, 2)           # first use of each path (staging buffers, kernels)
-            overlapped = ex.parts > 0
+            overlapped = parts_started() > 0
             timed(b, 128, 2)
             t_two = timed(a, 0)
             t_plain = timed(b, 128)
@@ -434,7 +470,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "PageRank (alpha=0.3, fp32, fixed iteration count) on RMAT scale-%d, a/b/c=.57/.19/.19, "
                                "edge factor %d, seed %d, duplicates and self loops kept" % (args.scale, args.edge_factor, args.seed),
-                   "V": nv, "E": E, "parallelism": "1d-rows x%d" % world, "exchange": ("two-stage overlapped all-gather" if overlapped else
+                   "V": nv, "E": E, "parallelism": "1d-rows x%d" % world, "exchange": (("native RCCL (gm_dist.hip), " if native else "torch.distributed callback, ") if world > 1 else "") +
+                                                                            ("two-stage overlapped all-gather" if overlapped else
                                                                              ("all-gather between send and multiply" if world > 1 else "none")), "id_layout_nparts": nparts,
                    "device_order": "native" if args.native_layout else "degree-ranked, dealt over shards",
                    "col_tiles": int(g.col_tiles),

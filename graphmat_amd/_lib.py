@@ -12,6 +12,10 @@ GM_XCHG_MESSAGES = 0
 GM_XCHG_CONVERGED = 1
 GM_XCHG_PART = 2
 GM_XCHG_WAIT = 3
+GM_XCHG_STATE = 4
+GM_XCHG_GATHER = 5
+GM_XCAP_SPARSE = 1
+GM_WS_GATHER = 12
 GM_LAYOUT_NATIVE = 0
 GM_LAYOUT_DEGREE = 1
 
@@ -38,7 +42,7 @@ class RunStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("send_ms", C.c_float), ("spmv_ms", C.c_float), ("apply_ms", C.c_float),
                 ("total_ms", C.c_float), ("spmv_launches", C.c_int32), ("rowblock_ms", C.c_float),
                 ("wave_ms", C.c_float), ("giant_ms", C.c_float), ("rowblock_launches", C.c_int32),
-                ("wave_launches", C.c_int32), ("giant_launches", C.c_int32)]
+                ("wave_launches", C.c_int32), ("giant_launches", C.c_int32), ("sparse_exchanges", C.c_int32)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int))
@@ -72,6 +76,16 @@ SIGNATURES = {
     "gm_graph_set_vals": (C.c_int, [_P, C.c_int, _P]),
     "gm_rmat_generate": (C.c_int, [C.c_int, C.c_uint64, C.c_int64, C.c_int64, _P, _P, _P, C.c_int, _P]),
     "gm_graph_set_exchange": (C.c_int, [_P, EXCHANGE_FN, _P]),
+    "gm_graph_set_exchange_caps": (C.c_int, [_P, C.c_int]),
+    "gm_graph_exchange_caps": (C.c_int, [_P]),
+    "gm_dist_unique_id": (C.c_int, [_P, C.c_size_t]),
+    "gm_dist_init": (C.c_int, [C.c_int, C.c_int, _P, C.c_size_t]),
+    "gm_dist_finalize": (C.c_int, []),
+    "gm_dist_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gm_graph_use_rccl": (C.c_int, [_P]),
+    "gm_graph_exchange_is_native": (C.c_int, [_P]),
+    "gm_graph_exchange_counters": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "gm_graph_set_run_stream": (C.c_int, [_P, _P]),
     "gm_run_degree": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int), _P]),
     "gm_run_pagerank": (C.c_int, [_P, _P, C.c_float, C.c_int, C.POINTER(C.c_int), _P]),
     "gm_run_bfs": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_int), _P]),

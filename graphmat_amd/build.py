@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libgraphmat_hip.so")
-SOURCES = ["gm_core.hip", "gm_graph.hip", "gm_programs.hip"]
+SOURCES = ["gm_core.hip", "gm_graph.hip", "gm_programs.hip", "gm_dist.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-DGRAPHMAT_NO_MPI"]
 
@@ -44,7 +44,7 @@ def build(force=False, verbose=False):
         elif verbose and out:
             sys.stderr.write(out.decode())
     if procs or not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(o) for o in objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

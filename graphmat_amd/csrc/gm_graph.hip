@@ -934,6 +934,7 @@ int gm_graph_destroy(gm_graph_t* g) {
   if (g->native_of_dev) (void)hipFree(g->native_of_dev);
   if (g->rowbits_all) (void)hipFree(g->rowbits_all);
   gm::free_tiles(g);
+  gm::free_native_exchange(g);
   for (int i = 0; i < GM_WS_SLOTS; i++)
     if (g->ws[i] && !g->ws_external[i]) (void)hipFree(g->ws[i]);
   if (g->aux_stream) {
@@ -1184,8 +1185,15 @@ int gm_graph_set_exchange(gm_graph_t* g, gm_exchange_fn fn, void* ctx) {
   if (!g) { gm::set_error("gm_graph_set_exchange: null graph"); return GM_ERR_INVALID; }
   g->xfn = fn;
   g->xctx = ctx;
+  g->xcaps = 0;
   return GM_OK;
 }
+int gm_graph_set_exchange_caps(gm_graph_t* g, int caps) {
+  if (!g) { gm::set_error("gm_graph_set_exchange_caps: null graph"); return GM_ERR_INVALID; }
+  g->xcaps = caps;
+  return GM_OK;
+}
+int gm_graph_exchange_caps(const gm_graph_t* g) { return (g && g->xfn) ? g->xcaps : 0; }
 int gm_graph_has_exchange(const gm_graph_t* g) { return (g && g->xfn) ? 1 : 0; }
 int gm_graph_exchange(gm_graph_t* g, int kind, void* d_ptr, int64_t elt_bytes, uint32_t* d_bits, int* h_flag) {
   if (!g || !g->xfn) return GM_OK;

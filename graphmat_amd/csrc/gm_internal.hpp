@@ -87,4 +87,9 @@ struct gm_graph {
   int32_t nlive;                // vertices with at least one edge (they come first in the device order)
   gm::CsrOwned* out_tiles;      // [ntiles]
   uint32_t** out_tile_prev;     // [ntiles] presence bits of the rows with an edge in an earlier tile
+  // native RCCL exchange (gm_dist.hip): state behind xfn/xctx when gm_graph_use_rccl installed it
+  int xcaps;                    // GM_XCAP_* of the installed exchange
+  void* native_xchg;
+  hipStream_t run_stream;       // the stream of the run in progress (gm_graph_set_run_stream): collectives are enqueued on it
 };
+namespace gm { void free_native_exchange(gm_graph* g); }

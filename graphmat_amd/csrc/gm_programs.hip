@@ -186,8 +186,9 @@ k_sgd_send(const float* __restrict__ vp, float* __restrict__ x, int n) {  // x[v
 // x holds every shard's slice (ndevice rows); ours was just written, the others arrive through the
 // exchange callback (an all-gather of K*4-byte elements).  The presence words travel with it
 // (the callback's contract) but all vertices send, so nobody reads them.
-static int sgd_exchange(gm_graph_t* g, float* x, int K) {
+static int sgd_exchange(gm_graph_t* g, float* x, int K, hipStream_t s) {
   if (!g->xfn) return GM_OK;
+  g->run_stream = s;
   void* bits = nullptr;
   int rc;
   if ((rc = gm_graph_workspace(g, 2, ((size_t)(g->desc.ndevice + 31) / 32 + 2) * 4, &bits))) return rc;
@@ -347,7 +348,7 @@ int run_sgd_wide(gm_graph_t* g, float* d_latent, float lambda, float step, int i
   for (int it = 0; it < iterations; it++) {
     hipLaunchKernelGGL((k_sgd_send<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)d_latent,
                        (float*)px + (size_t)d.row_lo * K, n);
-    if ((rc = sgd_exchange(g, (float*)px, K))) return rc;
+    if ((rc = sgd_exchange(g, (float*)px, K, s))) return rc;
     hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3(wgrid), dim3(kSgdMulBlock), 0, s, g->out.view, (const float*)px,
                        (const float*)d_latent, (float*)py, (const uint32_t*)nullptr, 0);
     hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3(wgrid), dim3(kSgdMulBlock), 0, s, g->in.view, (const float*)px,
@@ -377,7 +378,7 @@ int run_rmse_wide(gm_graph_t* g, float* d_latent, hipStream_t s) {
   const int egrid = (int)(((int64_t)n * K + kSgdBlock - 1) / kSgdBlock);
   hipLaunchKernelGGL((k_sgd_send<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)d_latent,
                      (float*)px + (size_t)d.row_lo * K, n);
-  if ((rc = sgd_exchange(g, (float*)px, K))) return rc;
+  if ((rc = sgd_exchange(g, (float*)px, K, s))) return rc;
   hipLaunchKernelGGL((k_sgd_multiply<K, 1>), dim3(wgrid), dim3(kSgdMulBlock), 0, s, g->in.view, (const float*)px,
                      (const float*)d_latent, (float*)py, (const uint32_t*)nullptr, 0);
   hipLaunchKernelGGL(k_rmse_apply, dim3((n + kSgdBlock - 1) / kSgdBlock), dim3(kSgdBlock), 0, s, (const float*)py,

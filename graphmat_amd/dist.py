@@ -68,6 +68,9 @@ class MessageExchange:
         self.parts = 0
         self._pending = []       # (work handle, deferred copy or None)
         self._part_stage = None
+        self.gather_buf = None   # adopted as workspace slot GM_WS_GATHER: blocks of (device id, message) entries
+        self.sparse_gathers = 0
+        self.sparse_bytes = 0
 
     def _buffer_of(self, d_ptr):
         if d_ptr == self.x_bytes.data_ptr():
@@ -170,6 +173,30 @@ class MessageExchange:
         dist.all_reduce(self.flag, op=dist.ReduceOp.MIN, group=self.group)
         return int(self.flag.item())
 
+    def exchange_state(self, converged, count):
+        """convergence flag (AND) and active-set sizes (max, sum) over the shards: one all-gather of two ints"""
+        n = len(self.ranges)
+        mine = torch.tensor([converged, count], dtype=torch.int32, device=self.flag.device)
+        parts = [torch.empty_like(mine) for _ in range(n)]
+        dist.all_gather(parts, mine, group=self.group)
+        allv = torch.stack(parts).cpu()
+        conv = int(bool((allv[:, 0] != 0).all()))
+        return conv, int(allv[:, 1].max()), min(int(allv[:, 1].to(torch.int64).sum()), 0x7FFFFFFF)
+
+    def gather_blocks(self, block_bytes):
+        """in-place all-gather of equal blocks of the adopted gather buffer (sparse message exchange)"""
+        n = len(self.ranges)
+        buf = self.gather_buf
+        self.sparse_gathers += 1
+        self.sparse_bytes += block_bytes
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(buf[: n * block_bytes], buf[self.rank * block_bytes: (self.rank + 1) * block_bytes],
+                                        group=self.group)
+            return
+        hs = [dist.broadcast(buf[r * block_bytes: (r + 1) * block_bytes], src=r, group=self.group, async_op=True) for r in range(n)]
+        for h in hs:
+            h.wait()
+
     def callback(self):
         def fn(ctx, kind, d_ptr, elt_bytes, d_bits, h_flag):
             try:
@@ -185,13 +212,66 @@ class MessageExchange:
                     self.start_part(buf, int(h_flag[0]), int(h_flag[1]), int(elt_bytes))
                 elif kind == _lib.GM_XCHG_WAIT:
                     self.wait_parts()
-                else:
+                elif kind == _lib.GM_XCHG_CONVERGED:
                     h_flag[0] = self.all_reduce_converged(h_flag[0])
+                elif kind == _lib.GM_XCHG_STATE:
+                    conv, mx, total = self.exchange_state(int(h_flag[0]), int(h_flag[1]))
+                    h_flag[0], h_flag[1], h_flag[2] = conv, mx, total
+                elif kind == _lib.GM_XCHG_GATHER:
+                    if self.gather_buf is None or d_ptr != self.gather_buf.data_ptr():
+                        return 2
+                    self.gather_blocks(int(h_flag[0]) * int(elt_bytes))
+                else:
+                    return 3
                 return 0
             except Exception as e:  # never let an exception cross the C boundary
                 print("graphmat_amd.dist: exchange failed:", repr(e), flush=True)
                 return 1
         return _lib.EXCHANGE_FN(fn)
+
+
+def init_native_rccl(group=None, device=None):
+    """Create the library's own RCCL communicator (graphmat_hip.h gm_dist_init) over the ranks of `group`:
+    rank 0 draws the unique id, torch.distributed carries the 128 bytes to the others (any backend)."""
+    import ctypes as C
+    L = _lib.lib()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    raw = (C.c_ubyte * 128)()
+    if rank == 0:
+        _lib.check(L.gm_dist_unique_id(raw, 128))
+    if world > 1:
+        on_gpu = dist.get_backend(group) == "nccl"
+        t = torch.tensor(list(raw), dtype=torch.uint8, device=(device if on_gpu else "cpu"))
+        dist.broadcast(t, src=0, group=group)
+        raw = (C.c_ubyte * 128)(*t.cpu().tolist())
+    _lib.check(L.gm_dist_init(rank, world, raw, 128))
+    return rank, world
+
+
+def attach_native_exchange(g, group=None):
+    """Sharded api.Graph over the library's native RCCL exchange (no Python per iteration).
+    init_native_rccl() must have been called.  Installs the result-gather function like attach_exchange."""
+    L = _lib.lib()
+    _lib.check(L.gm_graph_use_rccl(g.h))
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def gather(t_rows):
+        if world == 1:
+            return t_rows
+        parts = [torch.empty_like(t_rows) for _ in range(world)]
+        dist.all_gather(parts, t_rows, group=group)
+        return torch.cat(parts, 0)
+
+    g.gather_fn = gather
+
+
+def exchange_counters(g):
+    """(exchange calls, overlapped parts started, bytes this rank contributed) of a native exchange."""
+    import ctypes as C
+    out = (C.c_int64 * 4)()
+    _lib.check(_lib.lib().gm_graph_exchange_counters(g.h, out))
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def attach_exchange(g, group=None, max_elt_bytes=8, overlap=True):
@@ -219,6 +299,11 @@ def attach_exchange(g, group=None, max_elt_bytes=8, overlap=True):
     cb = ex.callback()
     g._cb = (cb, ex)  # keep alive
     _lib.check(L.gm_graph_set_exchange(g.h, cb, None))
+    if max_elt_bytes <= 8:
+        # sparse exchange of small active sets: world blocks of up to 65536 entries of (4 + 8) bytes
+        ex.gather_buf = torch.zeros(world * 65536 * 12 + 256, dtype=torch.uint8, device=g.device)
+        _lib.check(L.gm_graph_adopt_workspace(g.h, _lib.GM_WS_GATHER, ex.gather_buf.data_ptr(), ex.gather_buf.numel()))
+        _lib.check(L.gm_graph_set_exchange_caps(g.h, _lib.GM_XCAP_SPARSE))
 
     def gather(t_rows):
         parts = [torch.empty_like(t_rows) for _ in range(world)]

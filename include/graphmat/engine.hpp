@@ -354,6 +354,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   const int n = desc.row_hi - desc.row_lo;
   const int nwords = (n + 31) / 32;
   const bool multi = gm_graph_has_exchange(g) != 0;
+  gm_graph_set_run_stream(g, (gm_stream_t)s);  // a native (RCCL) exchange enqueues its collectives here
   const int n_live = (desc.xchg_rows > 0 && desc.xchg_rows < n && (desc.xchg_rows & 63) == 0) ? desc.xchg_rows : n;
 
   // top-down steps for small active sets (kernels.hpp: k_push_*): REDUCE_LAST programs over
@@ -376,6 +377,16 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
              !(debug_flags() & dev::DBG_NO_PUSH) && gm_graph_csr(g, GM_DIR_IN, &Asrc) == GM_OK && desc.row_lo == 0 &&
              desc.row_hi == desc.ndevice;
   if (can_push) gm_graph_maps(g, &dev_of_native, &native_of_dev);
+  // Sharded ACTIVE_ONLY programs running until convergence exchange a SMALL active set as (device id,
+  // message) lists instead of all-gathering the whole dense x (graphmat_hip.h: GM_XCHG_STATE / GM_XCHG_GATHER;
+  // the reference compresses sparse segments before sending them, DenseSegment.h:532-538,665-700)
+  constexpr bool kSparseT = std::is_trivially_copyable<T>::value && sizeof(T) <= 8;
+  bool xsparse_ok = kSparseT && multi && act == ACTIVE_ONLY && iterations <= 0 && (gm_graph_exchange_caps(g) & GM_XCAP_SPARSE) &&
+                    !(debug_flags() & dev::DBG_NO_SPARSE_XCHG);
+  if (xsparse_ok && Asrc.rowptr == nullptr) (void)gm_graph_csr(g, GM_DIR_IN, &Asrc);  // out-degrees for the statistics, when available
+  typedef dev::sparse_entry<typename std::conditional<kSparseT, T, int>::type> xentry_t;
+  xentry_t* d_gather = nullptr;
+  int xs_max = 0, xs_total = 0;  // largest / total number of active vertices per shard (from the last GM_XCHG_STATE)
   // a=b programs consume one message per row: unsharded, they evaluate it on demand from the sender's
   // vertex property (kernels.hpp: message_of) and the send pass disappears; the presence bits of x
   // are the active bits themselves
@@ -409,17 +420,23 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   unsigned long long* h_striped = (unsigned long long*)res_pinned + 64;
   unsigned long long frontier_v = 0, frontier_e = 0, frontier_maxdeg = 0;
   const int stats_grid = grid_for(n) < 2048 ? grid_for(n) : 2048;
-  if (can_push) {
+  if (xsparse_ok) {
+    void* pg = nullptr;
+    if (gm_graph_workspace(g, GM_WS_GATHER, (size_t)desc.nshards * dev::kSparseListCap * sizeof(xentry_t) + 256, &pg) == GM_OK) d_gather = (xentry_t*)pg;
+    else xsparse_ok = false;  // (an adopted buffer that is too small: dense exchanges only)
+  }
+  if (can_push || xsparse_ok) {
     void *pb = nullptr, *pl = nullptr, *pt = nullptr;
     if (gm_graph_workspace(g, 7, (size_t)n * 4 + 1024 + ((size_t)dev::kSparseListCap + 64 + dev::kSparseListCap / dev::kBlock + 64) * 4, &pl) != GM_OK ||
-        gm_graph_workspace(g, 6, (size_t)n * 8 + 64, &pb) != GM_OK || gm_graph_workspace(g, 10, (size_t)n * 4 + 1024, &pt) != GM_OK) {
+        (can_push && (gm_graph_workspace(g, 6, (size_t)n * 8 + 64, &pb) != GM_OK || gm_graph_workspace(g, 10, (size_t)n * 4 + 1024, &pt) != GM_OK))) {
       can_push = false;
+      xsparse_ok = false;
     } else {
       d_best = (unsigned long long*)pb;
       d_list = (int32_t*)pl;
       d_off = (unsigned int*)((char*)pl + ((size_t)n * 4 + 1024) / 256 * 256);  // piece offsets of the listed sources
       d_touched = (int32_t*)pt;
-      GM_HIP_OK(hipMemsetAsync(d_best, 0, (size_t)n * 8, s));
+      if (can_push) GM_HIP_OK(hipMemsetAsync(d_best, 0, (size_t)n * 8, s));
       GM_HIP_OK(hipMemsetAsync(d_stats, 0, 24, s));
       GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
       hipLaunchKernelGGL(dev::k_frontier_stats, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active,
@@ -431,6 +448,20 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       frontier_maxdeg = h_stats[4];
       list_ready = frontier_v <= (unsigned long long)dev::kSparseListCap;  // listed by the same pass
     }
+  }
+  auto exchange_state = [&](int* converged) {  // flag AND + active-set sizes over the shards
+    int hf[4] = {*converged, frontier_v > 0x7fffffffull ? 0x7fffffff : (int)frontier_v, 0, 0};
+    if (gm_graph_exchange(g, GM_XCHG_STATE, nullptr, 0, nullptr, hf) != 0) {
+      printf("GraphMat(HIP): state exchange failed\n");
+      exit(1);
+    }
+    *converged = hf[0];
+    xs_max = hf[1];
+    xs_total = hf[2];
+  };
+  if (xsparse_ok) {
+    int dummy = 0;
+    exchange_state(&dummy);
   }
 
   if (act == ALL_VERTICES) {  // GraphMatRuntime.h:121-123 g.setAllActive()
@@ -470,8 +501,13 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     // every shard must use the same split (the parts are the same rows of every slice): take the
     // largest of the shards' own choices, then check that it suits everybody
     bool staged = false;
-    if (gm_graph_workspace_info(g, 9, &x2v, &x2_bytes, &x2_ext) == GM_OK && x2_ext && x2v != nullptr &&
-        x2_bytes >= (size_t)desc.ndevice * sizeof(T)) {
+    // the second message buffer: adopted from the caller (callback exchange: the collective library must know
+    // it), or simply the library's own when the exchange is native
+    bool have_x2 = gm_graph_workspace_info(g, 9, &x2v, &x2_bytes, &x2_ext) == GM_OK && x2_ext && x2v != nullptr &&
+                   x2_bytes >= (size_t)desc.ndevice * sizeof(T);
+    if (!have_x2 && gm_graph_exchange_is_native(g))
+      have_x2 = gm_graph_workspace(g, 9, (size_t)desc.ndevice * sizeof(T) + 64, &x2v) == GM_OK && x2v != nullptr;
+    if (have_x2) {
       int64_t agreed = 0;
       if (gm_graph_note_get(g, 0, &agreed) == GM_OK) {  // note 0: the split the shards agreed on in an earlier run (0 = none)
         rs = (int32_t)agreed;
@@ -566,7 +602,11 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     GM_HIP_OK(hipMemsetAsync(d_changed, 0, sizeof(int), s));
     timer.mark(TAG_START);
     const bool dense_x = (act == ALL_VERTICES);
-    const bool want_stats = can_push && iterations <= 0;
+    const bool want_stats = (can_push || xsparse_ok) && iterations <= 0;
+    // this iteration's x travels as lists when every shard's active set is small: fewer bytes than the dense
+    // slices (entry = id + message against one message per live row) and within the list capacity
+    const bool xsp = xsparse_ok && xs_max <= dev::kSparseListCap &&
+                     (unsigned long long)xs_max * sizeof(xentry_t) * 2ull < (unsigned long long)n_live * sizeof(T);
     // top-down step for small active sets only: few sources and few out-edges
     const bool push = can_push && frontier_v > 0 && frontier_v <= (unsigned long long)dev::kSparseListCap &&
                       frontier_e * 1000ull < (unsigned long long)Aout.nnz * (unsigned long long)push_edge_permille();
@@ -636,13 +676,42 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       if (!static_bits) GM_HIP_OK(hipMemsetAsync(ybits, 0, (size_t)nwords * 4, s));
       // send (:145).  Rows past n_live have no edge in either direction (degree-ranked order puts
       // them at the tail): nobody reads their messages and they never receive one
-      if (!lazy_send)
-        hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
-                           dense_x ? (const uint32_t*)nullptr : (const uint32_t*)d_active, x, xbits, n_live, desc.row_lo);
-      if (multi) {
-        if (gm_graph_exchange(g, GM_XCHG_MESSAGES, x, (int64_t)sizeof(T), xbits, nullptr) != 0) {
-          printf("GraphMat(HIP): message exchange callback failed\n");
-          exit(1);
+      if (xsp) {
+        if constexpr (kSparseT) {
+          // sparse exchange: messages of the listed active vertices only, as (device id, message) entries
+          if (!list_ready) {
+            GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
+            hipLaunchKernelGGL(dev::k_frontier_list, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active, n,
+                               d_list, d_count);
+          }
+          const int nf = (int)frontier_v;
+          const int cap = xs_max > 0 ? (xs_max + 63) / 64 * 64 : 64;
+          GM_HIP_OK(hipMemsetAsync(xbits, 0, ((size_t)(desc.ndevice + 31) / 32) * 4, s));
+          if (nf > 0)
+            hipLaunchKernelGGL((dev::k_send_list<P, T, V>), dim3(grid_for(nf)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
+                               (const int32_t*)d_list, nf, x, desc.row_lo);
+          hipLaunchKernelGGL((dev::k_pack_frontier<T>), dim3(grid_for(cap)), dim3(dev::kBlock), 0, s, (const int32_t*)d_list, nf,
+                             (const T*)x, desc.row_lo, d_gather + (size_t)desc.shard * cap, cap);
+          int hf[2] = {cap, 0};
+          if (gm_graph_exchange(g, GM_XCHG_GATHER, d_gather, (int64_t)sizeof(xentry_t), nullptr, hf) != 0) {
+            printf("GraphMat(HIP): sparse message exchange failed\n");
+            exit(1);
+          }
+          const int64_t nall = (int64_t)desc.nshards * cap;
+          hipLaunchKernelGGL((dev::k_unpack_frontier<T>), dim3(grid_for(nall)), dim3(dev::kBlock), 0, s, (const xentry_t*)d_gather, nall, x, xbits);
+          if (verbose) printf("GraphMat(HIP):   sparse exchange: %d active here, at most %d per shard, %zu bytes sent instead of %zu\n", nf, xs_max,
+                              (size_t)cap * sizeof(xentry_t), (size_t)n_live * sizeof(T) + (size_t)n_live / 8);
+          st.sparse_exchanges++;
+        }
+      } else {
+        if (!lazy_send)
+          hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
+                             dense_x ? (const uint32_t*)nullptr : (const uint32_t*)d_active, x, xbits, n_live, desc.row_lo);
+        if (multi) {
+          if (gm_graph_exchange(g, GM_XCHG_MESSAGES, x, (int64_t)sizeof(T), xbits, nullptr) != 0) {
+            printf("GraphMat(HIP): message exchange callback failed\n");
+            exit(1);
+          }
         }
       }
       timer.mark(TAG_SEND);
@@ -674,11 +743,13 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         const int acc = static_bits ? dev::ACC_STATIC_BITS : 0;
         // sparse active set of an a=b program: a 64:1 summary of the presence bits for the short-row kernel
         const uint32_t* xsum = nullptr;
-        if (want_stats && rk == REDUCE_LAST && xb != nullptr && frontier_v * 512ull < (unsigned long long)n_live) {
+        const unsigned long long present_x = xsparse_ok ? (unsigned long long)xs_total : frontier_v;  // entries of x that are present
+        if (want_stats && rk == REDUCE_LAST && xb != nullptr && present_x * 512ull < (unsigned long long)n_live * (unsigned long long)desc.nshards) {
           void* ps = nullptr;
-          const int nsum = (nwords / 2 + 31) / 32 + 1;
+          const int xwords = (desc.ndevice + 31) / 32;  // x (and its presence bits) cover every shard's rows
+          const int nsum = (xwords / 2 + 31) / 32 + 1;
           if (gm_graph_workspace(g, 11, (size_t)nsum * 4 + 64, &ps) == GM_OK) {
-            hipLaunchKernelGGL(dev::k_bits_summary, dim3(grid_for(nsum)), dim3(dev::kBlock), 0, s, xb, nwords, (uint32_t*)ps, nsum);
+            hipLaunchKernelGGL(dev::k_bits_summary, dim3(grid_for(nsum)), dim3(dev::kBlock), 0, s, xb, xwords, (uint32_t*)ps, nsum);
             xsum = (const uint32_t*)ps;
           }
         }
@@ -750,11 +821,11 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     }
     int converged = 0;
     if (iterations <= 0) {  // the flag only matters when running until convergence (:257-259)
-      if (can_push)  // size of the next active set (written by k_apply), fetched with the flag
+      if (want_stats)  // size of the next active set (written by k_apply), fetched with the flag
         GM_HIP_OK(hipMemcpyAsync(h_striped, d_striped, striped_bytes, hipMemcpyDeviceToHost, s));
       GM_HIP_OK(hipMemcpyAsync(h_changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, s));
       GM_HIP_OK(hipStreamSynchronize(s));
-      if (can_push) {
+      if (want_stats) {
         frontier_v = frontier_e = frontier_maxdeg = 0;
         for (int k = 0; k < dev::kStatSlots; k++) {
           frontier_v += h_striped[4 * k];
@@ -764,7 +835,8 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         list_ready = listed && frontier_v <= (unsigned long long)dev::kSparseListCap;  // k_apply / k_push_finish listed it
       }
       converged = (*h_changed == 0) ? 1 : 0;
-      if (multi) gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &converged);  // :226 Allreduce(LAND)
+      if (xsparse_ok) exchange_state(&converged);  // the flag and the shards' active-set sizes in one step
+      else if (multi) gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &converged);  // :226 Allreduce(LAND)
     }
     gp->do_every_iteration(it);  // :236
     if (act == ALL_VERTICES && iterations > 0 && it + 1 == iterations) {

@@ -301,7 +301,7 @@ k_apply(ProgArg<P> pa, const U* __restrict__ y, const uint32_t* __restrict__ ybi
       if (m) any = true;
     }
     if (stats != nullptr && changed) {
-      const unsigned long long d = (unsigned long long)(src_rowptr[i + 1] - src_rowptr[i]);
+      const unsigned long long d = src_rowptr ? (unsigned long long)(src_rowptr[i + 1] - src_rowptr[i]) : 0ull;
       cnt++;
       edges += d;
       mx = d > mx ? d : mx;
@@ -357,7 +357,7 @@ __device__ __forceinline__ E edge_at(const void* __restrict__ vals, int64_t k) {
 // earlier pass (their presence is read from ybits); ACC_STATIC_BITS = do not write presence
 // bits (every x entry is present, so y's presence equals the graph's static row bits)
 enum { ACC_READ_PREV = 1, ACC_STATIC_BITS = 2 };
-enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64, DBG_NO_PIPELINE = 128, DBG_NO_LAZY_SEND = 256, DBG_NO_WAVE16 = 512, DBG_NO_TILES = 1024 };
+enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64, DBG_NO_PIPELINE = 128, DBG_NO_LAZY_SEND = 256, DBG_NO_WAVE16 = 512, DBG_NO_TILES = 1024, DBG_NO_SPARSE_XCHG = 2048 };
 
 // presence bits of a wave's 64 consecutive rows: one atomicOr per 32-row word (not per row:
 // same-word atomics from 32 lanes serialise in the L2); nothing when the bits are static
@@ -1292,7 +1292,7 @@ k_frontier_stats(const uint32_t* __restrict__ active, const int64_t* __restrict_
     const int64_t i = base + threadIdx.x;
     const bool act = i < n && bit_get(active, (int)i);
     if (act) {
-      unsigned long long d = (unsigned long long)(src_rowptr[i + 1] - src_rowptr[i]);
+      unsigned long long d = src_rowptr ? (unsigned long long)(src_rowptr[i + 1] - src_rowptr[i]) : 0ull;
       cnt++;
       edges += d;
       mx = d > mx ? d : mx;
@@ -1652,6 +1652,47 @@ k_bits_summary(const uint32_t* __restrict__ bits, int nwords, uint32_t* __restri
     if (any) out |= 1u << b;
   }
   sum[t] = out;
+}
+
+// ------------------------------------------------------------------------------------
+// Sparse exchange of the message vector between shards (ACTIVE_ONLY programs with a small active set; the
+// reference compresses a segment the same way before sending it when few entries are set,
+// include/GMDP/vectors/DenseSegment.h:532-538,665-700).  A shard packs the messages of its listed active
+// vertices as (global device id, message) entries into its block of the gather buffer -- `cap` entries per
+// shard, unused ones marked with id -1 --, the blocks are all-gathered, and every shard scatters all
+// entries into x and sets their presence bits (cleared beforehand).
+template <class T>
+struct alignas(4) sparse_entry {
+  int32_t idx;
+  unsigned char msg[(sizeof(T) + 3) / 4 * 4];
+};
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_pack_frontier(const int32_t* __restrict__ list, int nlist, const T* __restrict__ x, int row_base, sparse_entry<T>* __restrict__ block, int cap) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= cap) return;
+  sparse_entry<T> e;
+  memset(&e, 0, sizeof(e));
+  e.idx = -1;
+  if (i < nlist) {
+    const int u = list[i];
+    e.idx = row_base + u;
+    const T m = x[(size_t)row_base + u];
+    memcpy(e.msg, &m, sizeof(T));
+  }
+  block[i] = e;
+}
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+k_unpack_frontier(const sparse_entry<T>* __restrict__ all, int64_t n, T* __restrict__ x, uint32_t* __restrict__ xbits) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const sparse_entry<T> e = all[i];
+  if (e.idx < 0) return;
+  T m;
+  memcpy(&m, e.msg, sizeof(T));
+  x[e.idx] = m;
+  atomicOr(&xbits[e.idx >> 5], 1u << (e.idx & 31));
 }
 
 // ------------------------------------------------------------------------------------

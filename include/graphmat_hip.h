@@ -266,8 +266,48 @@ int gm_rmat_generate(int scale, uint64_t seed, int64_t first_edge, int64_t count
  * No presence bits travel (every vertex sends). */
 #define GM_XCHG_PART 2
 #define GM_XCHG_WAIT 3
+/* Sparse exchange for ACTIVE_ONLY programs with a small active set (the reference compresses a segment
+ * before sending it when few entries are set, include/GMDP/vectors/DenseSegment.h:532-538,665-700):
+ * GM_XCHG_STATE: the convergence flag and the size of the local active set in one step.  In: h_flag[0] =
+ *   locally converged (0/1), h_flag[1] = vertices in this shard's next active set.  Out: h_flag[0] = AND
+ *   over shards, h_flag[1] = largest such count over the shards, h_flag[2] = their sum (clamped to INT_MAX).
+ * GM_XCHG_GATHER: in-place all-gather of equal blocks: d_ptr = a buffer of nshards blocks of
+ *   h_flag[0] entries of elt_bytes bytes (workspace slot GM_WS_GATHER), this shard's block filled; afterwards
+ *   every shard holds all blocks.  The library packs (device id, message) entries into it and scatters them
+ *   into x itself.
+ * An exchange implementation announces that it handles these with gm_graph_set_exchange_caps. */
+#define GM_XCHG_STATE 4
+#define GM_XCHG_GATHER 5
+#define GM_XCAP_SPARSE 1 /* GM_XCHG_STATE and GM_XCHG_GATHER are implemented */
+#define GM_WS_GATHER 12  /* workspace slot of the gather buffer (adopt it when the collective library must know the buffer) */
 typedef int (*gm_exchange_fn)(void* ctx, int kind, void* d_ptr, int64_t elt_bytes, uint32_t* d_bits, int* h_flag);
 int gm_graph_set_exchange(gm_graph_t* g, gm_exchange_fn fn, void* ctx);
+int gm_graph_set_exchange_caps(gm_graph_t* g, int caps); /* GM_XCAP_*; gm_graph_set_exchange resets them to 0 */
+int gm_graph_exchange_caps(const gm_graph_t* g);
+
+/* ---- the same exchange, natively on RCCL (graphmat_amd/csrc/gm_dist.hip) ---------------------------
+ * Replaces the reference's MPI transport of the multi-rank SpMSpV (include/GMDP/multinode/spmspv.h:62-116)
+ * and its convergence Allreduce (include/GraphMatRuntime.h:226): one process per GPU, shard r of a
+ * GM_LAYOUT_DEGREE graph on rank r.  The library implements GM_XCHG_MESSAGES / PART / WAIT / CONVERGED
+ * itself with ncclAllGather / ncclAllReduce on HIP streams (the overlapped parts on a side stream,
+ * ordered with events): nothing but the convergence flag crosses to the host per iteration.
+ *   rank 0:     gm_dist_unique_id(id, 128); hand `id` to the other ranks (launcher's job: MPI_Bcast,
+ *               torch.distributed broadcast, a file ...)
+ *   every rank: gm_set_device(local gpu); gm_dist_init(rank, nranks, id, 128);
+ *               gm_graph_create(... nshards = nranks, shard = rank ...); gm_graph_use_rccl(g);
+ * RCCL (librccl.so.1) is loaded by gm_dist_init, not at library load. */
+#define GM_DIST_ID_BYTES 128
+int gm_dist_unique_id(void* out, size_t bytes);
+int gm_dist_init(int rank, int nranks, const void* unique_id, size_t bytes);
+int gm_dist_finalize(void);
+int gm_dist_info(int* rank, int* nranks); /* *nranks = 0 before gm_dist_init */
+int gm_graph_use_rccl(gm_graph_t* g);
+int gm_graph_exchange_is_native(const gm_graph_t* g);
+/* out[0] exchange calls, out[1] overlapped parts started, out[2] bytes this rank contributed to all-gathers,
+ * out[3] sparse (GM_XCHG_GATHER) exchanges */
+int gm_graph_exchange_counters(const gm_graph_t* g, int64_t out[4]);
+/* the stream the current run enqueues on (the header layer tells the library before it asks for exchanges) */
+int gm_graph_set_run_stream(gm_graph_t* g, gm_stream_t stream);
 /* Two-stage schedule of a direction's rows: "head" = rows [0, *row_split) holding at least
  * head_permille/1000 of the direction's edges (the degree-ranked device order puts the busy rows
  * first), "tail" = the rest.  On entry *row_split = 0 asks the library to choose, a positive value
@@ -328,6 +368,7 @@ typedef struct {
   int32_t spmv_launches;
   float rowblock_ms, wave_ms, giant_ms;       /* the three multiply+reduce kernels, separately */
   int32_t rowblock_launches, wave_launches, giant_launches;
+  int32_t sparse_exchanges;                   /* iterations whose messages travelled as lists (GM_XCHG_GATHER) */
 } gm_run_stats_t;
 int gm_graph_enable_timing(gm_graph_t* g, int on);
 int gm_graph_last_stats(const gm_graph_t* g, gm_run_stats_t* out);
@@ -336,7 +377,7 @@ int gm_graph_last_stats(const gm_graph_t* g, gm_run_stats_t* out);
  * Device scratch owned by the graph, grown on demand and reused across runs (the
  * reference allocates x/y per run_graph_program call, GraphMatRuntime.h:110-120).
  * slot in [0, GM_WS_SLOTS). */
-#define GM_WS_SLOTS 12
+#define GM_WS_SLOTS 14
 int gm_graph_workspace(gm_graph_t* g, int slot, size_t bytes, void** d_ptr);
 /* Let the caller provide a scratch slot (e.g. a torch tensor it also hands to its collective
  * library): slot 1 = message values x (nvertices * elt bytes), slot 2 = x presence bits

@@ -104,3 +104,47 @@ def test_partial_exchange_world3_gloo():
     out = mgr.dict()
     mp.spawn(_worker_parts, args=(3, _free_port(), 64 * 6, out), nprocs=3, join=True)
     assert out[0] == 1 and out[1] == 1 and out[2] == 1
+
+
+def _worker_sparse(rank, world, port, out):
+    """sparse exchange of small active sets (GM_XCHG_STATE / GM_XCHG_GATHER): the fused flag + sizes
+    all-gather and the in-place all-gather of equal blocks of (device id, message) entries"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S = 256
+    nv = S * world
+    ranges = [(r * S, (r + 1) * S) for r in range(world)]
+    ex = MessageExchange(ranges, rank, torch.zeros(nv * 8 + 16, dtype=torch.uint8), torch.zeros(nv // 32 + 2, dtype=torch.int32))
+    # flag AND, sizes max / sum
+    conv, mx, total = ex.exchange_state(1 if rank != 1 else 0, 10 * (rank + 1))
+    ok = conv == 0 and mx == 10 * world and total == 10 * world * (world + 1) // 2
+    conv, mx, total = ex.exchange_state(1, 0)
+    ok = ok and conv == 1 and mx == 0 and total == 0
+    # blocks of 64 entries of 12 bytes (int32 id + 8 message bytes): every rank fills its own block
+    entry = np.dtype([("idx", np.int32), ("msg", np.uint64)], align=False)
+    assert entry.itemsize == 12
+    cap = 64
+    ex.gather_buf = torch.zeros(world * cap * 12 + 64, dtype=torch.uint8)
+    mine = np.zeros(cap, entry)
+    mine["idx"] = -1
+    k = 5 + rank
+    mine["idx"][:k] = rank * S + np.arange(k) * 3
+    mine["msg"][:k] = 1000 * (rank + 1) + np.arange(k)
+    ex.gather_buf[rank * cap * 12: (rank + 1) * cap * 12] = torch.from_numpy(mine.view(np.uint8).copy())
+    ex.gather_blocks(cap * 12)
+    allv = ex.gather_buf[: world * cap * 12].numpy().view(entry).reshape(world, cap)
+    for r in range(world):
+        kr = 5 + r
+        ok = ok and (allv[r]["idx"][:kr] == r * S + np.arange(kr) * 3).all() and (allv[r]["idx"][kr:] == -1).all()
+        ok = ok and (allv[r]["msg"][:kr] == 1000 * (r + 1) + np.arange(kr)).all()
+    ok = ok and ex.sparse_gathers == 1 and ex.sparse_bytes == cap * 12
+    out[rank] = int(bool(ok))
+    dist.destroy_process_group()
+
+
+def test_sparse_exchange_world3_gloo():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_sparse, args=(3, _free_port(), out), nprocs=3, join=True)
+    assert out[0] == 1 and out[1] == 1 and out[2] == 1

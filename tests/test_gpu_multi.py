@@ -31,3 +31,20 @@ def test_sharded_runs_match_oracle(world):
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env, cwd=ROOT)
     text = out.stdout.decode()
     assert out.returncode == 0 and "MULTI_OK" in text, text[-3000:]
+
+
+def test_native_rccl_exchange_single_rank():
+    """The library's own RCCL exchange (gm_dist.hip: ncclAllGather / ncclAllReduce on HIP streams, overlapped
+    parts on a side stream).  RCCL wants one rank per GPU, so on this 1-GPU box the world has one rank: the
+    communicator, the staged live-prefix gather, the two-stage PART/WAIT schedule, the flag all-reduce and
+    the 512-byte-row SGD exchange all run for real, and every result must equal the oracle's."""
+    from graphmat_amd import build
+    build.build()
+    from oracle import binding
+    binding.build()
+    env = dict(os.environ, GM_BACKEND="gloo", GM_SCALE="13", GM_EXCHANGE="native")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "multi_check.py")]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env, cwd=ROOT)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "MULTI_OK" in text and "native-rccl" in text, text[-3000:]

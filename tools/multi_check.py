@@ -4,7 +4,10 @@
 Launched by tests/test_gpu_multi.py as
   python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 ... tools/multi_check.py
 On a 1-GPU box every rank uses cuda:0 and the collectives run over gloo (NCCL refuses two ranks
-on one device); on an N-GPU node set GM_BACKEND=nccl.  Prints MULTI_OK on rank 0."""
+on one device); on an N-GPU node set GM_BACKEND=nccl.  GM_EXCHANGE=native uses the library's own RCCL
+exchange (gm_dist.hip) instead of the torch.distributed callback -- one rank per GPU, so on a 1-GPU box
+that is a world of 1 (every code path of the exchange runs, with a single participant).
+Prints MULTI_OK on rank 0."""
 import os
 import sys
 
@@ -23,12 +26,33 @@ def main():
     torch.cuda.set_device(device)
     dist.init_process_group(backend, rank=rank, world_size=world)
     from graphmat_amd import api, generators
-    from graphmat_amd.dist import attach_exchange
+    from graphmat_amd.dist import attach_exchange, attach_native_exchange, exchange_counters, init_native_rccl
+    native = os.environ.get("GM_EXCHANGE", "callback") == "native"
+    if native:
+        init_native_rccl(device=torch.device("cuda", device))
+
+    class NativeCounters:  # same read-outs as MessageExchange
+        def __init__(self, g):
+            self.g = g
+
+        @property
+        def parts(self):
+            return exchange_counters(self.g)[1]
+
+        @property
+        def calls(self):
+            return exchange_counters(self.g)[0]
+
+    def attach(g, **kw):
+        if native:
+            attach_native_exchange(g)
+            return NativeCounters(g)
+        return attach_exchange(g, **kw)
     from oracle import binding as ob
     scale = int(os.environ.get("GM_SCALE", "14"))
     nv, s, d, v = generators.rmat_edges(scale, 16, seed=21, weights="hash")
     g = api.Graph(nv, s, d, v, ref_threads=2, device=device, layout=api.GM_LAYOUT_DEGREE, nshards=world, shard=rank)
-    ex = attach_exchange(g)
+    ex = attach(g)
     og = ob.OracleGraph(nv, s, d, v, ref_threads=2)
     ok = True
     pr, deg, it = g.pagerank(8)  # fixed count, ALL_VERTICES: the overlapped two-stage schedule
@@ -46,13 +70,33 @@ def main():
     pr2, _, it2 = g.pagerank(-1)  # until convergence: exercises the flag all-reduce
     opr2, oit2, _ = og.pagerank(-1)
     ok &= it2 == oit2 and bool((pr2.view(np.uint32) == opr2.view(np.uint32)).all())
+    sparse_levels = 0
     for src in (1, 7):
         depth, parent, itb = g.bfs(src)
         od, op, oitb, _ = og.bfs(src)
-        ok &= itb == oitb and bool((depth == od).all()) and bool((parent == op).all())
+        this = itb == oitb and bool((depth == od).all()) and bool((parent == op).all())
+        if not this:
+            print("rank %d: BFS from %d differs from the oracle (%d vs %d levels, %d depth / %d parent mismatches)" % (
+                rank, src, itb, oitb, int((depth != od).sum()), int((parent != op).sum())), flush=True)
+        ok &= this
+        sparse_levels += g.last_stats()["sparse_exchanges"]
+    # the first and last levels of a traversal have small active sets: their messages travel as lists
+    if sparse_levels < 2:
+        print("rank %d: BFS never used the sparse exchange (%d levels)" % (rank, sparse_levels), flush=True)
+        ok = False
+    _lib.lib().gm_set_option(b"debug_flags", 2048)  # same traversal with dense exchanges only
+    depth2, parent2, itb2 = g.bfs(7)
+    _lib.lib().gm_set_option(b"debug_flags", 0)
+    this = itb2 == itb and g.last_stats()["sparse_exchanges"] == 0 and bool((depth2 == depth).all()) and bool((parent2 == parent).all())
+    if not this:
+        print("rank %d: dense-only BFS differs (%d levels, %d sparse exchanges)" % (rank, itb2, g.last_stats()["sparse_exchanges"]), flush=True)
+    ok &= this
     dist_, its = g.sssp(1)
     odist, oits = og.sssp(1)
-    ok &= its == oits and bool((dist_ == odist).all())
+    this = its == oits and bool((dist_ == odist).all())
+    if not this:
+        print("rank %d: SSSP differs from the oracle (%d vs %d iterations, %d mismatches)" % (rank, its, oits, int((dist_ != odist).sum())), flush=True)
+    ok &= this
     # SGD / RMSE with K=128 fp32 latent vectors (BASELINE config 5 shape) on a sharded bipartite
     # ratings graph: the dedicated kernels exchange 512-byte x rows; bit-exact against the oracle
     rng = np.random.default_rng(7)
@@ -62,7 +106,7 @@ def main():
     rv = rng.integers(1, 6, nr).astype(np.int32)
     lv = rng.random((nu + ni, K)).astype(np.float32)
     g2 = api.Graph(nu + ni, rs, rd, rv, ref_threads=1, device=device, layout=api.GM_LAYOUT_DEGREE, nshards=world, shard=rank)
-    ex2 = attach_exchange(g2, max_elt_bytes=K * 4)
+    ex2 = attach(g2, max_elt_bytes=K * 4)
     og2 = ob.OracleGraph(nu + ni, rs, rd, rv, 1)
     _, sq = g2.rmse_sum(lv)
     _, osq = og2.rmse_sum(lv)
@@ -77,7 +121,8 @@ def main():
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
-        print("MULTI_OK" if int(flag) == 1 else "MULTI_FAIL", "world=%d exchanges=%d rows/shard=%d" % (world, ex.calls, g.rows), flush=True)
+        print("MULTI_OK" if int(flag) == 1 else "MULTI_FAIL", "world=%d exchange=%s exchanges=%d rows/shard=%d" % (
+            world, "native-rccl" if native else "callback", ex.calls, g.rows), flush=True)
     dist.destroy_process_group()
     sys.exit(0 if int(flag) == 1 else 1)
 
