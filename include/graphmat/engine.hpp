@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <sys/time.h>
 
+#include <limits>
 #include <type_traits>
 #include <vector>
 
@@ -134,30 +135,16 @@ template <class P, class U>
 int probe_reduce_kind(const P* gp) {
   const char* off = getenv("GRAPHMAT_NO_PROBE");
   if (off && off[0] == '1') return REDUCE_ORDERED;
-  if constexpr (!std::is_trivially_copyable<U>::value || sizeof(U) > 8) {
+  // arithmetic reduction types only: the function is called on the host with synthetic operands, which is
+  // harmless for numbers and not for pointers or structures with invariants
+  if constexpr (!std::is_arithmetic<U>::value || std::is_same<U, bool>::value || sizeof(U) > 8) {
     return REDUCE_ORDERED;
   } else {
     unsigned long long st = 0x9E3779B97F4A7C15ull;
     auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
     bool is_last = true, is_fadd = std::is_same<U, float>::value, is_iadd = std::is_integral<U>::value,
          is_min = std::is_integral<U>::value, is_max = std::is_integral<U>::value;
-    for (int k = 0; k < 96; k++) {
-      U a, b;
-      if constexpr (std::is_same<U, float>::value) {
-        // magnitudes over many binades, both signs, a few ties-prone small integers
-        const int ea = (int)(next() % 40) - 20, eb = (int)(next() % 40) - 20;
-        a = (float)((double)(next() % 16777216) * (1.0 / 16777216.0)) * (float)(1ull << 20) * ((next() & 1) ? 1.f : -1.f);
-        b = (float)((double)(next() % 16777216) * (1.0 / 16777216.0)) * (float)(1ull << 20) * ((next() & 1) ? 1.f : -1.f);
-        a = ea >= 0 ? a * (float)(1 << ea) : a / (float)(1 << -ea);
-        b = eb >= 0 ? b * (float)(1 << eb) : b / (float)(1 << -eb);
-        if (k % 7 == 0) { a = (float)(next() % 9); b = (float)(next() % 9) + 0.5f; }
-      } else {
-        unsigned long long ra = next(), rb = next();
-        if (k % 5 == 0) { ra &= 0xff; rb &= 0xff; }
-        memcpy(&a, &ra, sizeof(U));
-        memcpy(&b, &rb, sizeof(U));
-        if constexpr (std::is_floating_point<U>::value) { a = (U)(double)(long long)(ra % 1000003); b = (U)(double)(long long)(rb % 1000003) / (U)7; }
-      }
+    auto test = [&](U a, U b) {
       U c = a;
       gp->P::reduce_function(c, b);
       if (memcmp(&c, &b, sizeof(U)) != 0) is_last = false;
@@ -172,6 +159,50 @@ int probe_reduce_kind(const P* gp) {
         if (c != add) is_iadd = false;
         if (c != mn) is_min = false;
         if (c != mx) is_max = false;
+      }
+    };
+    if constexpr (std::is_floating_point<U>::value) {
+      // every pairing of a list of edge values (zeros of both signs, the extremes of the format, powers of
+      // two around 1, thresholds a clamping or saturating function might use) ...
+      const U fmaxv = std::numeric_limits<U>::max(), fminv = std::numeric_limits<U>::min(), den = std::numeric_limits<U>::denorm_min();
+      const U edge[] = {(U)0, -(U)0, (U)1, -(U)1, (U)2, (U)0.5, (U)3, (U)1e-30, (U)1e30, -(U)1e30, (U)3e38 < fmaxv ? (U)3e38 : fmaxv, fmaxv, -fmaxv, fminv,
+                        den, (U)16777216, (U)16777217, (U)1e10, (U)65504, (U)1e-10};
+      for (U a : edge)
+        for (U b : edge) test(a, b);
+      // ... and pseudo-random pairs with independent exponents over the whole range (sums that overflow,
+      // underflow, cancel, or round at every distance), both signs, plus same-binade pairs rich in ties
+      for (int k = 0; k < 4096; k++) {
+        U a, b;
+        if constexpr (std::is_same<U, float>::value) {
+          uint32_t ba = (uint32_t)next(), bb = (uint32_t)next();
+          if (((ba >> 23) & 0xff) == 0xff) ba ^= 0x00800000u;  // no inf / nan
+          if (((bb >> 23) & 0xff) == 0xff) bb ^= 0x00800000u;
+          if (k % 4 == 0) bb = (bb & 0x807fffffu) | (ba & 0x7f800000u);             // same binade
+          if (k % 8 == 1) { ba &= 0xfffff000u; bb = (bb & 0x807ff800u) | (ba & 0x7f800000u) | 0x800u; }  // ties
+          memcpy(&a, &ba, 4);
+          memcpy(&b, &bb, 4);
+        } else {
+          unsigned long long ba = next(), bb = next();
+          if (((ba >> 52) & 0x7ff) == 0x7ff) ba ^= 1ull << 52;
+          if (((bb >> 52) & 0x7ff) == 0x7ff) bb ^= 1ull << 52;
+          memcpy(&a, &ba, sizeof(U));
+          memcpy(&b, &bb, sizeof(U));
+        }
+        test(a, b);
+      }
+    } else {
+      const U lo = std::numeric_limits<U>::min(), hi = std::numeric_limits<U>::max();
+      const U edge[] = {(U)0, (U)1, (U)2, (U)-1, lo, hi, (U)(hi - 1), (U)(lo + 1), (U)(hi / 2), (U)(hi / 2 + 1), (U)255, (U)256, (U)65535, (U)65536};
+      for (U a : edge)
+        for (U b : edge) test(a, b);
+      for (int k = 0; k < 4096; k++) {
+        unsigned long long ra = next(), rb = next();
+        if (k % 5 == 0) { ra &= 0xff; rb &= 0xff; }
+        if (k % 7 == 0) { ra >>= (next() % 64); rb >>= (next() % 64); }
+        U a, b;
+        memcpy(&a, &ra, sizeof(U));
+        memcpy(&b, &rb, sizeof(U));
+        test(a, b);
       }
     }
     if (is_last) return REDUCE_LAST;
@@ -367,7 +398,10 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   gm_csr_t Asrc;
   memset(&Asrc, 0, sizeof(Asrc));
   const int32_t *dev_of_native = nullptr, *native_of_dev = nullptr;
-  const int rk = reduce_kind_of<P, U>(gp);
+  int rk = reduce_kind_of<P, U>(gp);
+  // a strategy the program did not declare but the probe inferred is cross-checked on the device against the
+  // ordered fold the first time a pull multiply runs (k_check_rows); a disagreement falls back to the ordered fold
+  bool rk_unverified = (int)program_traits<P>::reduce == (int)REDUCE_AUTO && rk != REDUCE_ORDERED && !getenv("GRAPHMAT_NO_PROBE_CHECK");
   tick("reduce_function probed", rk);
   if (verbose) printf("GraphMat(HIP): reduce strategy %d (0 ordered, 1 commutative, 2 last, 3 float add)\n", rk);
   // (REDUCE_COMMUTATIVE programs with a 4-byte reduction type take the list-based steps too, folding with
@@ -390,7 +424,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   // a=b programs consume one message per row: unsharded, they evaluate it on demand from the sender's
   // vertex property (kernels.hpp: message_of) and the send pass disappears; the presence bits of x
   // are the active bits themselves
-  const bool lazy_send = rk == REDUCE_LAST && sizeof(U) <= 8 && std::is_trivially_copyable<U>::value && !multi &&
+  bool lazy_send = rk == REDUCE_LAST && sizeof(U) <= 8 && std::is_trivially_copyable<U>::value && !multi &&
                          act == ACTIVE_ONLY && order == OUT_EDGES && desc.row_lo == 0 && desc.row_hi == desc.ndevice &&
                          !(debug_flags() & dev::DBG_NO_LAZY_SEND);
   if (verbose && lazy_send) printf("GraphMat(HIP): messages are evaluated on demand (no send pass)\n");
@@ -598,7 +632,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     // Clear(&x) / Clear(&y) (:139-140): x presence words are fully rewritten by send.  With
     // every x entry present (ALL_VERTICES) y's presence is the static set of non-empty rows.
     const bool static_bits = (act == ALL_VERTICES);
-    const T* xq = lazy_send ? (const T*)nullptr : (const T*)x;  // what the multiply side reads messages from
+    const T* xq = lazy_send ? (const T*)nullptr : (const T*)x;  // what the multiply side reads messages from (may change below)
     GM_HIP_OK(hipMemsetAsync(d_changed, 0, sizeof(int), s));
     timer.mark(TAG_START);
     const bool dense_x = (act == ALL_VERTICES);
@@ -716,8 +750,58 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       }
       timer.mark(TAG_SEND);
       // multiply + reduce (:160-176)
-      const uint32_t* xb = dense_x ? nullptr : (lazy_send ? (const uint32_t*)d_active : (const uint32_t*)xbits);
+      const uint32_t* xb = dense_x ? nullptr : (lazy_send ? (const uint32_t*)d_active : (const uint32_t*)xbits);  // (may change below)
       const uint32_t* apply_bits = ybits;
+      // Cross-check of a probed strategy after the first pass of a pull multiply over adjacency A whose results
+      // (presence bits yb) are in y: giant rows, the first wave rows and a strided sample of all rows are folded
+      // again in order.  On a mismatch the pass is redone with the ordered fold, which also governs the rest of the run.
+      auto check_probed = [&](const gm_csr_t& A, const uint32_t* yb, const uint32_t* rowfilter, int acc_flags, uint32_t* yb_write) {
+        if (!rk_unverified || (acc_flags & dev::ACC_READ_PREV)) return;
+        rk_unverified = false;
+        unsigned int* d_mis = (unsigned int*)flag_v + 700;
+        GM_HIP_OK(hipMemsetAsync(d_mis, 0, 4, s));
+        const T* xc = xq;
+        const uint32_t* xbc = xb;
+        if (lazy_send) {  // the ordered fold reads materialised messages: write them once for the check
+          hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
+                             dense_x ? (const uint32_t*)nullptr : (const uint32_t*)d_active, x, xbits, n_live, desc.row_lo);
+          xc = x;
+          xbc = dense_x ? nullptr : (const uint32_t*)xbits;
+        }
+        auto sample = [&](const int32_t* rows, int cnt, int stride) {
+          if (cnt <= 0) return;
+          const int grid = (cnt + dev::kBlock / 64 - 1) / (dev::kBlock / 64);
+          if constexpr ((int)program_traits<P>::reduce != (int)REDUCE_AUTO) return;  // (declared strategies are never checked)
+          else if (use_vp)
+            hipLaunchKernelGGL((dev::k_check_rows<P, T, U, V, E, true>), dim3(grid), dim3(dev::kBlock), 0, s, pa, A, rows, cnt, stride, xc, xbc,
+                               (const V*)d_vp, (const U*)y, yb, rowfilter, d_mis);
+          else
+            hipLaunchKernelGGL((dev::k_check_rows<P, T, U, V, E, false>), dim3(grid), dim3(dev::kBlock), 0, s, pa, A, rows, cnt, stride, xc, xbc,
+                               (const V*)d_vp, (const U*)y, yb, rowfilter, d_mis);
+        };
+        sample(A.giant_row, A.ngiant, 0);
+        sample(A.mid_row, A.nmid < 2048 ? A.nmid : 2048, 0);
+        const int live_rows = n_live < A.nrows ? n_live : A.nrows;
+        const int stride = live_rows > 2048 ? live_rows / 2048 : 1;
+        sample(nullptr, live_rows / stride, stride);
+        unsigned int mis = 0;
+        GM_HIP_OK(hipMemcpyAsync(&mis, d_mis, 4, hipMemcpyDeviceToHost, s));
+        GM_HIP_OK(hipStreamSynchronize(s));
+        if (verbose) printf("GraphMat(HIP):   probed reduce strategy %d cross-checked against the ordered fold: %u mismatching rows\n", rk, mis);
+        if (mis == 0) return;
+        printf("GraphMat(HIP): warning: reduce_function matched strategy %d on the probe's operands but not on this run's data (%u sampled "
+               "rows differ from the ordered fold); using the ordered fold.  Declare GraphMat::program_traits<YourProgram>::reduce to choose explicitly.\n", rk, mis);
+        rk = REDUCE_ORDERED;
+        can_push = false;
+        if (lazy_send) {  // the ordered kernels read materialised messages (written above for the check)
+          lazy_send = false;
+          xq = x;
+          xb = dense_x ? nullptr : (const uint32_t*)xbits;
+        }
+        if (!(acc_flags & dev::ACC_STATIC_BITS)) GM_HIP_OK(hipMemsetAsync(yb_write, 0, (size_t)nwords * 4, s));
+        if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, A, xq, xb, d_vp, y, yb_write, acc_flags, s, &st.spmv_launches, &timer, &aux, rk, rowfilter);
+        else launch_spmv<P, T, U, V, E, false>(g, pa, A, xq, xb, d_vp, y, yb_write, acc_flags, s, &st.spmv_launches, &timer, &aux, rk, rowfilter);
+      };
       const uint32_t* row_bits = d_want;  // which rows the multiply works on
       if (dense_push) {
         // top-down step over a larger active set: bids, then one pass over all vertices picks the winners
@@ -778,6 +862,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         } else {
           if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves, xsum);
           else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves, xsum);
+          check_probed(Aout, static_bits ? Aout.rowbits : (const uint32_t*)ybits, row_bits, acc, ybits);
         }
         if (static_bits) apply_bits = Aout.rowbits;
       }
@@ -792,6 +877,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         }
         if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
         else launch_spmv<P, T, U, V, E, false>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
+        if (order == IN_EDGES) check_probed(Ain, static_bits ? Ain.rowbits : (const uint32_t*)ybits, d_want, acc, ybits);
       }
       // setAllInactive (:184) + apply (:195-225): the active vector is rewritten by k_apply
       // (when top-down steps are possible the kernel also sizes and lists the next active set)

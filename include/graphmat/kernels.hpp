@@ -617,7 +617,8 @@ template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
 __device__ __forceinline__ void wave_row(const P& p, const gm_csr_t& A, const int row, const int64_t e0, const int64_t e1,
                                          const int lane, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
                                          const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits,
-                                         const int accumulate, const int dbg) {
+                                         const int accumulate, const int dbg, U* out_acc = nullptr, bool* out_has = nullptr) {
+  // (out_acc / out_has, ordered kind only: hand the result back instead of storing it -- k_check_rows)
   const bool dense = (xbits == nullptr);
   V vprow;
   if constexpr (USE_VP) vprow = vp[row];
@@ -743,10 +744,45 @@ __device__ __forceinline__ void wave_row(const P& p, const gm_csr_t& A, const in
         cn[u] = load_col(cb + 64 * 2 * D + lane);
       }
     }
-    if (lane == 0 && has) {
+    if (out_acc != nullptr) {
+      if (has) *out_acc = acc;
+      *out_has = has;
+    } else if (lane == 0 && has) {
       y[row] = acc;
       if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
     }
+  }
+}
+
+// Cross-check of a reduction strategy that was chosen by PROBING the program's reduce_function (engine.hpp:
+// probe_reduce_kind): a sample of rows is folded again, strictly in order with the program's own functions,
+// and compared bit for bit with what the fast strategy left in y.  One wave per sampled row; rows come from
+// a list or, with rows == nullptr, are every `stride`-th row.
+template <class P, class T, class U, class V, class E, bool USE_VP>
+__global__ void __launch_bounds__(kBlock)
+k_check_rows(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nlist, int stride, const T* __restrict__ x,
+             const uint32_t* __restrict__ xbits, const V* __restrict__ vp, const U* __restrict__ y, const uint32_t* __restrict__ ybits,
+             const uint32_t* __restrict__ want, unsigned int* __restrict__ mismatches) {
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (w >= nlist) return;
+  const int row = rows ? rows[w] : w * stride;
+  if (row >= A.nrows || !row_wanted(p, vp, want, row)) return;
+  const int64_t e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
+  if (e1 == e0) return;
+  U acc;
+  bool has = false;
+  wave_row<P, T, U, V, E, USE_VP, REDUCE_ORDERED>(p, A, row, e0, e1, threadIdx.x & 63, x, xbits, vp, (U*)nullptr, (uint32_t*)nullptr, 0, 0,
+                                                  &acc, &has);
+  if ((threadIdx.x & 63) == 0) {
+    const bool present = bit_get(ybits, row);
+    bool bad = has != present;
+    if (!bad && has) {
+      const U got = y[row];
+      const unsigned char *pa_ = reinterpret_cast<const unsigned char*>(&got), *pb_ = reinterpret_cast<const unsigned char*>(&acc);
+      for (size_t i = 0; i < sizeof(U); i++) bad |= pa_[i] != pb_[i];
+    }
+    if (bad) atomicAdd(mismatches, 1u);
   }
 }
 

@@ -260,3 +260,20 @@ def test_unmirrorable_globals_are_fatal(tmp_path):
     env["GRAPHMAT_ALLOW_UNMIRRORED_GLOBALS"] = "1"
     out = subprocess.run([exe, fixture, "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, env=env)
     assert b"warning" in out.stdout
+
+
+@pytest.mark.gpu
+def test_probed_reduce_strategies_are_cross_checked():
+    """apps/reduce_probe_cases.cpp: unannotated programs whose reduce_function is not float a+b (saturating add,
+    float max, a+b with a quirk at one value) must end up with the ordered fold -- by the probe's adversarial
+    operands or by the device-side cross-check -- and every result must equal a host fold with the program's function."""
+    exe = _need(os.path.join(OWN_APPS, "reduce_probe_cases"))
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=dict(os.environ, GRAPHMAT_VERBOSE="1"))
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "PROBECASES PASS" in text, text[-3000:]
+    sect = {name: body for name, body in re.findall(r"== (\w+)\n(.*?)(?=\n== |\nPROBECASES)", text, flags=re.S)}
+    assert "reduce strategy 3" in sect["PlainAdd"] and "0 mismatching rows" in sect["PlainAdd"]
+    assert "reduce strategy 0" in sect["SatAdd"] and "reduce strategy 0" in sect["FloatMax"]
+    assert "reduce strategy 3" in sect["QuirkAdd"] and "using the ordered fold" in sect["QuirkAdd"]
+    for name in sect:
+        assert "results-ok" in sect[name], name
