@@ -103,6 +103,32 @@ int main(int argc, char** argv) {
       ok &= (out.edges[i].val == (10 * out.edges[i].src + 1) + s * (10 * out.edges[i].dst + 1));
     CHECK(ok);
     out.clear();
+    // ---- the same three operations on the device (functor forms): no host mirror involved ----
+    {
+      GraphMat::Graph<IntProp> H;
+      H.ReadEdgelist(E);
+      for (int v = 1; v <= n; v++) { IntProp p; p.v = 10 * v; H.setVertexproperty(v, p); }
+      H.applyToAllVertices([](const IntProp& in, IntProp* out) { out->v = in.v + 1; });
+      long long dsum = 5;  // combined with the caller's value, like the reference
+      H.applyReduceAllVertices(&dsum, [](const IntProp& p, long long* out) { *out = p.v; });
+      CHECK(dsum == 5 + 10LL * n * (n + 1) / 2 + n);
+      int dmax = -1;
+      H.applyReduceAllVertices(&dmax, [](const IntProp& p, int* out) { *out = p.v; },
+                               [](const int& a, const int& b, int* c) { *c = a > b ? a : b; });
+      CHECK(dmax == 10 * n + 1);
+      const int s2 = 1000;
+      H.applyToAllEdges([s2](int* e, const IntProp& src, const IntProp& dst) { *e = src.v + s2 * dst.v; });
+      GraphMat::edgelist_t<int> out2;
+      H.getEdgelist(out2);
+      ok = out2.nnz == (int)ed.size();
+      for (int i = 0; i < out2.nnz; i++)
+        ok &= (out2.edges[i].val == (10 * out2.edges[i].src + 1) + s2 * (10 * out2.edges[i].dst + 1));
+      CHECK(ok);
+      out2.clear();
+      ok = true;
+      for (int v = 1; v <= n; v++) ok &= (H.getVertexproperty(v).v == 10 * v + 1);  // device result seen through the host API
+      CHECK(ok);
+    }
     // ---- activity bookkeeping ----
     G.setAllInactive();
     CHECK(G.active->getNNZ() == 0);

@@ -1074,6 +1074,7 @@ int gm_graph_set_vals(gm_graph_t* g, int direction, const void* h_vals) {
   if (!g || !h_vals) { gm::set_error("gm_graph_set_vals: null argument"); return GM_ERR_INVALID; }
   gm::CsrOwned* c = direction == GM_DIR_OUT ? &g->out : direction == GM_DIR_IN ? &g->in : nullptr;
   if (!c || !c->present || !c->vals) { gm::set_error("gm_graph_set_vals: direction %d has no edge values", direction); return GM_ERR_INVALID; }
+  if (g->ntiles > 1) { gm::set_error("gm_graph_set_vals: not supported on a graph with column tiles (the tiles hold copies of the edge values)"); return GM_ERR_UNSUPPORTED; }
   if (c->view.nnz) GM_TRY_HIP(hipMemcpy(c->vals, h_vals, (size_t)c->view.nnz * c->view.val_bytes, hipMemcpyHostToDevice));
   return GM_OK;
 }

@@ -25,6 +25,7 @@
 #include <iostream>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #if !defined(GRAPHMAT_NO_MPI) && defined(__has_include)
@@ -258,6 +259,25 @@ class Graph {
   void applyReduceAllVertices(T* val, void (*ApplyFn)(V*, T*, void*),
                               void (*ReduceFn)(const T&, const T&, T*, void*) = AddFn<T>, void* param = nullptr);
   void applyToAllEdges(void (*ApplyFn)(E*, const V&, const V&, void*), void* param = nullptr);
+  // The same three operations ON THE DEVICE, for callables the compiler can see (function objects / lambdas
+  // compiled with --hipstdpar; captures take the place of the void* parameter): vertex state and edge values
+  // stay in HBM, nothing is copied to the host mirror.  The function-pointer forms above necessarily run on the
+  // host mirror -- a host function pointer cannot be called from a kernel -- like the reference's OpenMP loops
+  // (include/GMDP/singlenode/apply.h, reduce.h:51-99, applyedges.h:38-78).
+  //   applyToAllVertices(f)              f(const V& in, V* out)
+  //   applyReduceAllVertices(&t, map)    map(const V& v, T* out), summed with operator+ (AddFn)
+  //   applyReduceAllVertices(&t, map, r) r(const T& a, const T& b, T* c): must be associative and commutative
+  //                                      (blocks are combined in a tree, not in the reference's chunk order)
+  //   applyToAllEdges(f)                 f(E* value, const V& src, const V& dst)
+  template <class F, class = decltype(std::declval<F&>()(std::declval<const V&>(), (V*)nullptr))>
+  void applyToAllVertices(F f);
+  template <class T, class Map, class = decltype(std::declval<Map&>()(std::declval<const V&>(), (T*)nullptr))>
+  void applyReduceAllVertices(T* val, Map map);
+  template <class T, class Map, class Reduce, class = decltype(std::declval<Map&>()(std::declval<const V&>(), (T*)nullptr)),
+            class = decltype(std::declval<Reduce&>()(std::declval<const T&>(), std::declval<const T&>(), (T*)nullptr))>
+  void applyReduceAllVertices(T* val, Map map, Reduce reduce);
+  template <class F, class = decltype(std::declval<F&>()((E*)nullptr, std::declval<const V&>(), std::declval<const V&>()))>
+  void applyToAllEdges(F f);
   ~Graph();
 
   int vertexToNative(int vertex, int nsegments, int len) const {
@@ -560,6 +580,137 @@ void Graph<V, E>::applyToAllEdges(void (*ApplyFn)(E*, const V&, const V&, void*)
       }
     gm_graph_set_vals(A, dir, vv.data());
   }
+}
+
+// ---- device forms (functors) -------------------------------------------------------------------
+namespace dev {
+template <class V, class F>
+__global__ void __launch_bounds__(kBlock) k_vertices_apply(V* __restrict__ vp, const uint32_t* __restrict__ bits, int n, F f) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n || !bit_get(bits, i)) return;
+  const V in = vp[i];
+  V out = in;
+  f(in, &out);
+  vp[i] = out;
+}
+// map + reduce over the present vertices: private folds (grid-stride), then a tree per workgroup in LDS;
+// one partial (and "has" flag) per workgroup, finished on the host
+template <class V, class T, class Map, class Reduce>
+__global__ void __launch_bounds__(kBlock) k_vertices_reduce(const V* __restrict__ vp, const uint32_t* __restrict__ bits, int n, Map map,
+                                                            Reduce reduce, T* __restrict__ partial, int* __restrict__ partial_has) {
+  static_assert(sizeof(T) <= 128, "applyReduceAllVertices on the device: reduction type of at most 128 bytes");
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[kBlock * sizeof(T)];
+  __shared__ int s_has[kBlock];
+  T* s_val = reinterpret_cast<T*>(s_raw);
+  T acc;
+  bool has = false;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    if (!bit_get(bits, (int)i)) continue;
+    T t;
+    map(vp[i], &t);
+    if (has) { T a = acc; reduce(a, t, &acc); } else { acc = t; has = true; }
+  }
+  s_has[threadIdx.x] = has;
+  if (has) s_val[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s && s_has[threadIdx.x + s]) {
+      if (s_has[threadIdx.x]) { T a = s_val[threadIdx.x]; reduce(a, s_val[threadIdx.x + s], &s_val[threadIdx.x]); }
+      else { s_val[threadIdx.x] = s_val[threadIdx.x + s]; s_has[threadIdx.x] = 1; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial_has[blockIdx.x] = s_has[0];
+    if (s_has[0]) partial[blockIdx.x] = s_val[0];
+  }
+}
+// one wave per row of one direction's CSR; rows_are_dst: row = destination, column = source
+template <class V, class E, class F>
+__global__ void __launch_bounds__(kBlock) k_edges_apply(gm_csr_t A, E* __restrict__ vals, const V* __restrict__ vp, int rows_are_dst, F f) {
+  const int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= A.nrows) return;
+  const V vr = vp[row];
+  for (int64_t e = A.rowptr[row] + (threadIdx.x & 63); e < A.rowptr[row + 1]; e += 64) {
+    const V vc = vp[A.colidx[e]];
+    E v = vals[e];
+    if (rows_are_dst) f(&v, vc, vr); else f(&v, vr, vc);
+    vals[e] = v;
+  }
+}
+}  // namespace dev
+
+template <class V, class E>
+template <class F, class>
+void Graph<V, E>::applyToAllVertices(F f) {
+  auto* seg = vertexproperty->segment;
+  seg->need_device();
+  const int n = seg->capacity;
+  if (n > 0) hipLaunchKernelGGL((dev::k_vertices_apply<V, F>), dim3(detail::grid_for(n)), dim3(dev::kBlock), 0, 0, (V*)seg->value, (const uint32_t*)seg->bit_vector, n, f);
+  GM_HIP_OK(hipDeviceSynchronize());
+  seg->device_modified();
+}
+
+namespace detail {
+template <class T>
+struct device_add {
+  __host__ __device__ void operator()(const T& a, const T& b, T* c) const { *c = a + b; }
+};
+}  // namespace detail
+
+template <class V, class E>
+template <class T, class Map, class>
+void Graph<V, E>::applyReduceAllVertices(T* val, Map map) {
+  applyReduceAllVertices(val, map, detail::device_add<T>());
+}
+
+template <class V, class E>
+template <class T, class Map, class Reduce, class, class>
+void Graph<V, E>::applyReduceAllVertices(T* val, Map map, Reduce reduce) {
+  auto* seg = vertexproperty->segment;
+  seg->need_device();
+  const int n = seg->capacity;
+  if (n <= 0) return;
+  const int grid = detail::grid_for(n) < 1024 ? detail::grid_for(n) : 1024;
+  T* d_partial = nullptr;
+  int* d_has = nullptr;
+  GM_HIP_OK(hipMalloc((void**)&d_partial, (size_t)grid * sizeof(T)));
+  GM_HIP_OK(hipMalloc((void**)&d_has, (size_t)grid * sizeof(int)));
+  hipLaunchKernelGGL((dev::k_vertices_reduce<V, T, Map, Reduce>), dim3(grid), dim3(dev::kBlock), 0, 0, (const V*)seg->value,
+                     (const uint32_t*)seg->bit_vector, n, map, reduce, d_partial, d_has);
+  std::vector<unsigned char> raw((size_t)grid * sizeof(T));
+  std::vector<int> has((size_t)grid);
+  GM_HIP_OK(hipMemcpy(raw.data(), d_partial, raw.size(), hipMemcpyDeviceToHost));
+  GM_HIP_OK(hipMemcpy(has.data(), d_has, (size_t)grid * sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(d_partial);
+  (void)hipFree(d_has);
+  bool first = false;
+  T total;
+  for (int b = 0; b < grid; b++) {
+    if (!has[b]) continue;
+    T t;
+    memcpy((void*)&t, raw.data() + (size_t)b * sizeof(T), sizeof(T));
+    if (first) { T a = total; reduce(a, t, &total); } else { total = t; first = true; }
+  }
+  if (first) { T a = *val; reduce(a, total, val); }  // like reduce.h:93-96: combined with the caller's value
+}
+
+template <class V, class E>
+template <class F, class>
+void Graph<V, E>::applyToAllEdges(F f) {
+  auto* seg = vertexproperty->segment;
+  seg->need_device();
+  int ntile = 1;
+  gm_graph_tiles(A, GM_DIR_OUT, &ntile);
+  if (ntile > 1) { printf("GraphMat(HIP): applyToAllEdges on a graph with column tiles is not supported (the tiles hold copies of the edge values)\n"); exit(1); }
+  for (int dir : {GM_DIR_OUT, GM_DIR_IN}) {
+    gm_csr_t c;
+    if (gm_graph_csr(A, dir, &c) != GM_OK || c.vals == nullptr || c.nrows == 0) continue;
+    hipLaunchKernelGGL((dev::k_edges_apply<V, E, F>), dim3((c.nrows + dev::kBlock / 64 - 1) / (dev::kBlock / 64)), dim3(dev::kBlock), 0, 0, c,
+                       (E*)const_cast<void*>(c.vals) /* library-owned edge values, rewritten in place */, (const V*)seg->value,
+                       dir == GM_DIR_OUT ? 1 : 0, f);
+  }
+  GM_HIP_OK(hipDeviceSynchronize());
 }
 
 template <class V, class E>
