@@ -42,6 +42,8 @@ def lib():
         f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
         L.gmo_sgd_f64.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, f64p]
         L.gmo_sgd_f32.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, f32p]
+        L.gmo_mapreduce_double_sum.restype = C.c_int
+        L.gmo_mapreduce_double_sum.argtypes = [i32p, np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.c_int, C.c_int, C.c_int]
         L.gmo_rmse_f64.restype = C.c_double
         L.gmo_rmse_f64.argtypes = [C.c_void_p, C.c_int, f64p, C.c_void_p]
         L.gmo_rmse_f32.restype = C.c_double
@@ -134,3 +136,10 @@ def vertex_to_native(v1, nparts, n):
 
 def native_to_vertex(v1, nparts, n):
     return lib().gmo_native_to_vertex(int(v1), int(nparts), int(n))
+
+
+def mapreduce_double_sum(values, present, nthreads=1, init=0):
+    """test/test_reduce.cpp's MapReduce (map 2a, reduce a+b) over the present entries of an int vector."""
+    v = np.ascontiguousarray(values, np.int32)
+    m = np.ascontiguousarray(present, np.uint8)
+    return int(lib().gmo_mapreduce_double_sum(v, m, len(v), int(nthreads), int(init)))

@@ -363,4 +363,24 @@ void map_reduce(const std::vector<V>& vp, R* res, Map op_map, int nthreads) {
   }
 }
 
+// the same over a dense segment with presence bits: only the present entries take part
+// (include/GMDP/singlenode/reduce.h:51-99 walks the set bits of the segment)
+template <class V, class R, class Map>
+void map_reduce_present(const std::vector<V>& vals, const std::vector<unsigned char>& present, R* res, Map op_map, int nthreads) {
+  int n = (int)vals.size();
+  int per = (n + nthreads - 1) / nthreads;
+  for (int p = 0; p < nthreads; p++) {
+    int s = std::min(per * p, n), e = std::min(per * (p + 1), n);
+    bool first = false;
+    R local = R();
+    for (int i = s; i < e; i++) {
+      if (!present[i]) continue;
+      R t;
+      op_map(vals[i], &t);
+      if (first) local = local + t; else { local = t; first = true; }
+    }
+    if (first) *res = *res + local;
+  }
+}
+
 }  // namespace gmo

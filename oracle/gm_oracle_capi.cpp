@@ -366,4 +366,13 @@ void gmo_spmv_f64(void* gv, int transpose, const double* x, const unsigned char*
   }
 }
 
+
+// MapReduce of test/test_reduce.cpp:37-38 (map: 2a, reduce: a+b) over an int vector with presence flags
+int gmo_mapreduce_double_sum(const int* values, const unsigned char* present, int n, int nthreads, int init) {
+  std::vector<int> v(values, values + n);
+  std::vector<unsigned char> m(present, present + n);
+  int res = init;
+  map_reduce_present(v, m, &res, [](const int& a, int* b) { *b = 2 * a; }, nthreads > 0 ? nthreads : 1);
+  return res;
+}
 }  // extern "C"

@@ -277,3 +277,14 @@ def test_probed_reduce_strategies_are_cross_checked():
     assert "reduce strategy 3" in sect["QuirkAdd"] and "using the ordered fold" in sect["QuirkAdd"]
     for name in sect:
         assert "results-ok" in sect[name], name
+
+
+@pytest.mark.gpu
+def test_reference_unit_test_closed_forms_on_the_device():
+    """apps/closed_forms.cpp: the closed forms of the reference's unit tests for this path (test/test_reduce.cpp:39-65
+    MapReduce = 2000, test/test_apply_edges.cpp:39-112 val = src + s*dst on identity and random graphs,
+    test/test_graph_basics.cpp:56-81 set/get through the permutation), function-pointer and device-functor forms."""
+    text = _run(_need(os.path.join(OWN_APPS, "closed_forms")))
+    assert "CLOSEDFORMS PASS" in text, text[-2000:]
+    lines = re.findall(r"^CLOSED (\w+) (\w+)$", text, flags=re.M)
+    assert len(lines) == 10 and all(v == "ok" for _, v in lines), lines

@@ -432,3 +432,25 @@ def test_fullscale_bfs_parents_rmat26():
     text = out.stdout.decode()
     assert out.returncode == 0 and "ALL PASS" in text, text[-3000:]
     assert text.count("=> PASS") >= 3
+
+
+def test_mapreduce_closed_forms_device(env):
+    """test/test_reduce.cpp:39-65 on the C-ABI reductions (the device side of MapReduce, include/GMDP/singlenode/
+    reduce.h:51-99): 1000 doubled ones sum to 2000; a segment with entries 1, 10, 200, 300 set has 4 present entries."""
+    import ctypes as C
+    import torch
+    api, _ = env
+    L = api._lib.lib()
+    x = torch.full((1000,), 2.0, dtype=torch.float32, device="cuda")
+    out = C.c_double(0)
+    api._lib.check(L.gm_reduce_sum_f32(x.data_ptr(), 1000, 1, C.byref(out), None))
+    assert out.value == 2000.0
+    xd = torch.full((1000, 3), 2.0, dtype=torch.float64, device="cuda")  # strided: one field of a wider record
+    api._lib.check(L.gm_reduce_sum_f64(xd.data_ptr(), 1000, 3, C.byref(out), None))
+    assert out.value == 2000.0
+    bits = torch.zeros(34, dtype=torch.int32, device="cuda")
+    for i in (0, 9, 199, 299):
+        bits[i >> 5] |= 1 << (i & 31)
+    cnt = C.c_int64(0)
+    api._lib.check(L.gm_popcount_bits(bits.data_ptr(), 1000, C.byref(cnt), None))
+    assert cnt.value == 4

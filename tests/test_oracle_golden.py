@@ -168,3 +168,14 @@ def test_sssp_upper_triangle(golden_dir):
                 heapq.heappush(pq, (du + w, b))
     exp = np.array([best.get(i, 0xFFFFFFFF) for i in range(1, nv + 1)], np.uint32)
     assert (dist == exp).all()
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_mapreduce_closed_forms(threads):
+    """test/test_reduce.cpp:39-65: 1000 ones -> 2000; entries 1, 10, 200, 300 set -> 8; nothing set -> the initial value."""
+    ones = np.ones(1000, np.int32)
+    assert ob.mapreduce_double_sum(ones, np.ones(1000, np.uint8), threads) == 2000
+    m = np.zeros(1000, np.uint8)
+    m[[0, 9, 199, 299]] = 1
+    assert ob.mapreduce_double_sum(ones, m, threads) == 8
+    assert ob.mapreduce_double_sum(ones, np.zeros(1000, np.uint8), threads, init=7) == 7
