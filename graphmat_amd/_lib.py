@@ -81,6 +81,9 @@ SIGNATURES = {
     "gm_dist_unique_id": (C.c_int, [_P, C.c_size_t]),
     "gm_dist_init": (C.c_int, [C.c_int, C.c_int, _P, C.c_size_t]),
     "gm_dist_finalize": (C.c_int, []),
+    "gm_dist_init_from_env": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gm_dist_barrier": (C.c_int, []),
+    "gm_dist_allgatherv_host": (C.c_int, [_P, C.c_int64, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "gm_dist_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gm_graph_use_rccl": (C.c_int, [_P]),
     "gm_graph_exchange_is_native": (C.c_int, [_P]),

@@ -44,7 +44,7 @@ def build(force=False, verbose=False):
         elif verbose and out:
             sys.stderr.write(out.decode())
     if procs or not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(o) for o in objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl"]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl", "-lrt"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -164,7 +164,8 @@ int val_kind_bytes(int kind) {
   if (kind > 0x100 && kind <= 0x100 + 4096) return kind - 0x100;
   return -1;
 }
-void store_one(void* dst, int kind) {  // the value an unweighted edge gets: (T)1
+void store_one(void* dst, int kind) {  // the value an unweighted edge gets: (T)1; opaque kinds: zero bytes (the C++ layer constructs T(1) over them)
+  if (kind > 0x100) { memset(dst, 0, (size_t)(kind - 0x100)); return; }
   if (kind == GM_VAL_I32) { int32_t v = 1; memcpy(dst, &v, 4); }
   else if (kind == GM_VAL_U32) { uint32_t v = 1; memcpy(dst, &v, 4); }
   else if (kind == GM_VAL_F32) { float v = 1.f; memcpy(dst, &v, 4); }
@@ -198,7 +199,7 @@ int gm_edgelist_read(const char* path, int binary, int header, int weights, int 
                      int32_t** h_src, int32_t** h_dst, void** h_val) {
   const int vb = val_kind_bytes(val_kind);
   if (!path || !m || !n || !nnz || !h_src || !h_dst || !h_val || vb <= 0) { gm::set_error("gm_edgelist_read: invalid argument"); return GM_ERR_INVALID; }
-  if (!binary && val_kind > 0x100) { gm::set_error("gm_edgelist_read: opaque values need a binary file"); return GM_ERR_INVALID; }
+  if (!binary && weights && val_kind > 0x100) { gm::set_error("gm_edgelist_read: opaque values need a binary file"); return GM_ERR_INVALID; }
   FILE* fp = fopen(path, binary ? "rb" : "r");
   if (!fp) { gm::set_error("Could not open file: %s", path); return GM_ERR_IO; }
   fseek(fp, 0, SEEK_END);

@@ -11,7 +11,16 @@
 // RCCL is bound when gm_dist_init is called (dlopen of librccl.so.1), so single-GPU processes never map
 // the 570 MB library.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <string>
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -35,8 +44,112 @@ static RcclApi g_rccl;
 static ncclComm_t g_comm = nullptr;
 static int g_rank = 0, g_nranks = 1;
 
+// ---- host shared-memory transport (GRAPHMAT_DIST_TRANSPORT=shm) ---------------------------------------
+// RCCL wants one rank per GPU, so a multi-rank run cannot be tried on a 1-GPU box with it.  This transport
+// has the same four entry points but moves the bytes through a POSIX shared-memory segment (device -> host
+// -> barrier -> device, blocking): slow and for tests only, like gloo is for the Python callback path.
+struct ShmHeader {
+  std::atomic<int> count;
+  std::atomic<int> generation;
+  char pad[56];
+};
+struct ShmState {
+  ShmHeader* hdr = nullptr;
+  char* data = nullptr;
+  size_t data_bytes = 0;
+  int rank = 0, nranks = 1;
+  std::string name;
+};
+static ShmState g_shm;
+static void shm_barrier() {
+  ShmHeader* h = g_shm.hdr;
+  const int gen = h->generation.load(std::memory_order_acquire);
+  if (h->count.fetch_add(1, std::memory_order_acq_rel) == g_shm.nranks - 1) {
+    h->count.store(0, std::memory_order_relaxed);
+    h->generation.store(gen + 1, std::memory_order_release);
+  } else {
+    while (h->generation.load(std::memory_order_acquire) == gen) usleep(20);
+  }
+}
+static size_t nccl_type_bytes(ncclDataType_t t) { return (t == ncclChar || t == ncclUint8) ? 1 : (t == ncclInt64 || t == ncclUint64 || t == ncclFloat64) ? 8 : 4; }
+static ncclResult_t shm_get_unique_id(ncclUniqueId* id) {
+  memset(id, 0, sizeof(*id));
+  snprintf(id->internal, sizeof(id->internal), "/graphmat_shm_%d_%ld", (int)getpid(), (long)time(nullptr));
+  return ncclSuccess;
+}
+static ncclResult_t shm_comm_init(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank) {
+  const char* mb = getenv("GRAPHMAT_SHM_MB");
+  const size_t bytes = sizeof(ShmHeader) + (size_t)(mb ? atoi(mb) : 64) * 1024 * 1024;
+  int fd = shm_open(id.internal, O_CREAT | O_RDWR, 0600);
+  if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) return ncclSystemError;
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return ncclSystemError;
+  g_shm.hdr = (ShmHeader*)p;  // a fresh segment is zero-filled: counters start at 0
+  g_shm.data = (char*)p + sizeof(ShmHeader);
+  g_shm.data_bytes = bytes - sizeof(ShmHeader);
+  g_shm.rank = rank;
+  g_shm.nranks = nranks;
+  g_shm.name = id.internal;
+  *comm = (ncclComm_t)&g_shm;
+  shm_barrier();
+  return ncclSuccess;
+}
+static ncclResult_t shm_comm_destroy(ncclComm_t) {
+  if (g_shm.hdr) {
+    shm_barrier();
+    munmap((void*)g_shm.hdr, g_shm.data_bytes + sizeof(ShmHeader));
+    if (g_shm.rank == 0) shm_unlink(g_shm.name.c_str());
+    g_shm.hdr = nullptr;
+  }
+  return ncclSuccess;
+}
+static ncclResult_t shm_all_gather(const void* send, void* recv, size_t count, ncclDataType_t t, ncclComm_t, hipStream_t s) {
+  const size_t bytes = count * nccl_type_bytes(t);
+  const int n = g_shm.nranks, r = g_shm.rank;
+  if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
+  const size_t chunk = (g_shm.data_bytes / (size_t)n) & ~(size_t)63;
+  for (size_t off = 0; off < bytes; off += chunk) {
+    const size_t len = bytes - off < chunk ? bytes - off : chunk;
+    if (hipMemcpy(g_shm.data + (size_t)r * chunk, (const char*)send + off, len, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    shm_barrier();
+    for (int q = 0; q < n; q++)
+      if (hipMemcpy((char*)recv + (size_t)q * bytes + off, g_shm.data + (size_t)q * chunk, len, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    shm_barrier();
+  }
+  return ncclSuccess;
+}
+static ncclResult_t shm_all_reduce(const void* send, void* recv, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t, hipStream_t s) {
+  if (t != ncclInt32 || count != 1 || (op != ncclMin && op != ncclMax && op != ncclSum)) return ncclInvalidArgument;
+  if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
+  int v = 0;
+  if (hipMemcpy(&v, send, 4, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+  ((int*)g_shm.data)[g_shm.rank] = v;
+  shm_barrier();
+  int acc = ((int*)g_shm.data)[0];
+  for (int q = 1; q < g_shm.nranks; q++) {
+    const int o = ((int*)g_shm.data)[q];
+    acc = op == ncclMin ? (o < acc ? o : acc) : op == ncclMax ? (o > acc ? o : acc) : acc + o;
+  }
+  shm_barrier();
+  if (hipMemcpy(recv, &acc, 4, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+  return ncclSuccess;
+}
+static const char* shm_error_string(ncclResult_t r) { return r == ncclSuccess ? "ok" : "shared-memory transport error"; }
+
 static int bind_rccl() {
   if (g_rccl.handle) return GM_OK;
+  const char* tr = getenv("GRAPHMAT_DIST_TRANSPORT");
+  if (tr && !strcmp(tr, "shm")) {  // test transport: same entry points over host shared memory
+    g_rccl.GetUniqueId = shm_get_unique_id;
+    g_rccl.CommInitRank = shm_comm_init;
+    g_rccl.CommDestroy = shm_comm_destroy;
+    g_rccl.AllGather = shm_all_gather;
+    g_rccl.AllReduce = shm_all_reduce;
+    g_rccl.GetErrorString = shm_error_string;
+    g_rccl.handle = (void*)&g_shm;
+    return GM_OK;
+  }
   void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!h) { set_error("gm_dist: cannot load librccl.so.1: %s", dlerror()); return GM_ERR_UNSUPPORTED; }
@@ -329,6 +442,108 @@ int gm_graph_exchange_counters(const gm_graph_t* g, int64_t out[4]) {
   out[1] = X ? X->parts : 0;
   out[2] = X ? (int64_t)X->bytes_sent : 0;
   out[3] = X ? X->sparse_gathers : 0;
+  return GM_OK;
+}
+
+// rank / size / local device from the launcher's environment, the unique id through a rendezvous file
+int gm_dist_init_from_env(int* rank_out, int* nranks_out) {
+  auto env_int = [](const char* const* names, int dflt) {
+    for (int i = 0; names[i]; i++) { const char* v = getenv(names[i]); if (v && *v) return atoi(v); }
+    return dflt;
+  };
+  static const char* const rk[] = {"GRAPHMAT_RANK", "RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "SLURM_PROCID", nullptr};
+  static const char* const sz[] = {"GRAPHMAT_NRANKS", "WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS", nullptr};
+  static const char* const lr[] = {"GRAPHMAT_LOCAL_RANK", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID", nullptr};
+  const int nranks = env_int(sz, 1), rank = env_int(rk, 0);
+  if (rank_out) *rank_out = rank;
+  if (nranks_out) *nranks_out = nranks;
+  if (nranks <= 1) return GM_OK;  // single process: nothing to set up
+  if (gm::g_comm) return GM_OK;
+  if (rank < 0 || rank >= nranks) { gm::set_error("gm_dist_init_from_env: rank %d of %d", rank, nranks); return GM_ERR_INVALID; }
+  int ndev = 0;
+  GM_TRY_HIP(hipGetDeviceCount(&ndev));
+  if (ndev < 1) { gm::set_error("gm_dist_init_from_env: no GPU"); return GM_ERR_HIP; }
+  GM_TRY_HIP(hipSetDevice(env_int(lr, rank) % ndev));
+  // rendezvous file: GRAPHMAT_RENDEZVOUS, else /tmp/graphmat_rdv_<MASTER_PORT or parent pid>
+  std::string path;
+  if (const char* e = getenv("GRAPHMAT_RENDEZVOUS")) path = e;
+  else {
+    const char* port = getenv("MASTER_PORT");
+    path = std::string("/tmp/graphmat_rdv_") + (port && *port ? std::string(port) : std::to_string((long)getppid()));
+  }
+  char id[GM_DIST_ID_BYTES];
+  if (rank == 0) {
+    int rc = gm_dist_unique_id(id, sizeof(id));
+    if (rc) return rc;
+    const std::string tmp = path + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) { if (f) fclose(f); gm::set_error("gm_dist_init_from_env: cannot write %s", tmp.c_str()); return GM_ERR_IO; }
+    fclose(f);
+    if (rename(tmp.c_str(), path.c_str()) != 0) { gm::set_error("gm_dist_init_from_env: cannot publish %s", path.c_str()); return GM_ERR_IO; }
+  } else {
+    bool got = false;
+    for (int tries = 0; tries < 60000 && !got; tries++) {  // up to ~60 s
+      FILE* f = fopen(path.c_str(), "rb");
+      if (f) { got = fread(id, 1, sizeof(id), f) == sizeof(id); fclose(f); }
+      if (!got) usleep(1000);
+    }
+    if (!got) { gm::set_error("gm_dist_init_from_env: rank 0 never published %s", path.c_str()); return GM_ERR_IO; }
+  }
+  int rc = gm_dist_init(rank, nranks, id, sizeof(id));
+  if (rc) return rc;
+  rc = gm_dist_barrier();  // everybody has read the file
+  if (rank == 0) (void)remove(path.c_str());
+  return rc;
+}
+
+int gm_dist_barrier(void) {
+  if (!gm::g_comm || gm::g_nranks <= 1) return GM_OK;
+  static int* d = nullptr;
+  if (!d) { GM_TRY_HIP(hipMalloc((void**)&d, 64)); GM_TRY_HIP(hipMemset(d, 0, 64)); }
+  GM_TRY_NCCL(gm::g_rccl.AllReduce(d, d, 1, ncclInt32, ncclMax, gm::g_comm, (hipStream_t)0));
+  GM_TRY_HIP(hipStreamSynchronize((hipStream_t)0));
+  return GM_OK;
+}
+
+// all-gather of host buffers of different sizes: *all = malloc'ed concatenation in rank order (gm_host_free),
+// counts[r] = bytes of rank r.  (Edge lists read per rank, per-rank partial results of a map-reduce.)
+int gm_dist_allgatherv_host(const void* mine, int64_t my_bytes, void** all, int64_t* counts) {
+  if (!all || !counts || my_bytes < 0 || (my_bytes && !mine)) { gm::set_error("gm_dist_allgatherv_host: invalid argument"); return GM_ERR_INVALID; }
+  const int n = gm::g_comm ? gm::g_nranks : 1, r = gm::g_comm ? gm::g_rank : 0;
+  if (n == 1) {
+    counts[0] = my_bytes;
+    *all = malloc((size_t)(my_bytes > 0 ? my_bytes : 1));
+    if (my_bytes) memcpy(*all, mine, (size_t)my_bytes);
+    return GM_OK;
+  }
+  // sizes first (as two int32 halves per rank), then the payload padded to the largest size
+  int* d_sz = nullptr;
+  GM_TRY_HIP(hipMalloc((void**)&d_sz, (size_t)n * 8));
+  const int half[2] = {(int)(my_bytes & 0x7fffffff), (int)(my_bytes >> 31)};
+  GM_TRY_HIP(hipMemcpy(d_sz + 2 * r, half, 8, hipMemcpyHostToDevice));
+  GM_TRY_NCCL(gm::g_rccl.AllGather(d_sz + 2 * r, d_sz, 2, ncclInt32, gm::g_comm, (hipStream_t)0));
+  std::vector<int> h((size_t)2 * n);
+  GM_TRY_HIP(hipMemcpy(h.data(), d_sz, (size_t)n * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(d_sz);
+  int64_t mx = 0, total = 0;
+  for (int i = 0; i < n; i++) { counts[i] = (int64_t)h[2 * i] | ((int64_t)h[2 * i + 1] << 31); mx = counts[i] > mx ? counts[i] : mx; total += counts[i]; }
+  const size_t pad = ((size_t)mx + 255) / 256 * 256;
+  char* out = (char*)malloc((size_t)(total > 0 ? total : 1));
+  if (!out) { gm::set_error("gm_dist_allgatherv_host: out of host memory"); return GM_ERR_NOMEM; }
+  if (pad > 0) {
+    char* d = nullptr;
+    GM_TRY_HIP(hipMalloc((void**)&d, pad * (size_t)n));
+    if (my_bytes) GM_TRY_HIP(hipMemcpy(d + (size_t)r * pad, mine, (size_t)my_bytes, hipMemcpyHostToDevice));
+    GM_TRY_NCCL(gm::g_rccl.AllGather(d + (size_t)r * pad, d, pad, ncclChar, gm::g_comm, (hipStream_t)0));
+    GM_TRY_HIP(hipStreamSynchronize((hipStream_t)0));
+    size_t off = 0;
+    for (int i = 0; i < n; i++) {
+      if (counts[i]) GM_TRY_HIP(hipMemcpy(out + off, d + (size_t)i * pad, (size_t)counts[i], hipMemcpyDeviceToHost));
+      off += (size_t)counts[i];
+    }
+    (void)hipFree(d);
+  }
+  *all = out;
   return GM_OK;
 }
 

@@ -101,6 +101,7 @@ class DenseSegment {
  public:
   typedef typename std::conditional<std::is_same<T, bool>::value, unsigned char, T>::type store_t;
   int capacity;
+  int logical;           // entries [0, logical) exist (a shard's slice may end in padding slots: their bits stay clear)
   int num_ints;
   store_t* value;        // device; nullptr for bits-only vectors (the active set)
   uint32_t* bit_vector;  // device
@@ -111,7 +112,7 @@ class DenseSegment {
   bool host_valid, dev_valid;
 
   DenseSegment(int n, bool with_values)
-      : capacity(n), num_ints((n + 31) / 32), value(nullptr), bit_vector(nullptr), owns_device(true), mirrored(true),
+      : capacity(n), logical(n), num_ints((n + 31) / 32), value(nullptr), bit_vector(nullptr), owns_device(true), mirrored(true),
         host_valid(true), dev_valid(false) {
     // one spare word so 64-wide kernels may write a full pair of words at the tail
     GM_HIP_OK(hipMalloc((void**)&bit_vector, (size_t)(num_ints + 2) * 4));
@@ -124,7 +125,7 @@ class DenseSegment {
   }
   // borrow existing device arrays (C-ABI fixed-menu entry points): no host mirror
   DenseSegment(int n, store_t* d_value, uint32_t* d_bits)
-      : capacity(n), num_ints((n + 31) / 32), value(d_value), bit_vector(d_bits), owns_device(false), mirrored(false),
+      : capacity(n), logical(n), num_ints((n + 31) / 32), value(d_value), bit_vector(d_bits), owns_device(false), mirrored(false),
         host_valid(false), dev_valid(true) {}
   ~DenseSegment() {
     if (owns_device) {
@@ -151,10 +152,12 @@ class DenseSegment {
   void host_modified() { need_host(); dev_valid = false; }
   void device_modified() { host_valid = false; dev_valid = true; }
 
-  void setAllBits(bool on) {  // exactly `capacity` bits (DenseSegment.h:617-633)
+  void setAllBits(bool on) {  // exactly `logical` bits (DenseSegment.h:617-633 sets exactly `capacity`)
     host_modified();
-    std::fill(hbits.begin(), hbits.end(), on ? 0xffffffffu : 0u);
-    if (on && (capacity & 31)) hbits[num_ints - 1] = (1u << (capacity & 31)) - 1u;
+    std::fill(hbits.begin(), hbits.end(), 0u);
+    if (!on) return;
+    for (int w = 0; w < logical / 32; w++) hbits[w] = 0xffffffffu;
+    if (logical & 31) hbits[logical / 32] = (1u << (logical & 31)) - 1u;
   }
 };
 
@@ -211,20 +214,28 @@ class Graph {
   gm_graph_t* AT;
   bool adjacencyowner;
   std::vector<int32_t> dev_of_native;  // device slot of each native id (host copy; identity if empty)
+  // Several ranks (one process per GPU, see graphmat/mpi_single.h): this object holds shard `get_global_myrank()`
+  // of a 1-D row-sharded graph -- device rows [row_lo, row_hi), the first valid_rows of which are vertices
+  // (the rest pads the slice to a multiple of 64).  vertexproperty / active cover exactly these rows, like the
+  // reference's per-rank segments; one rank: [0, nvertices).
+  int row_lo, row_hi, valid_rows;
   SpVec<DenseSegment<V> >* vertexproperty;
   SpVec<DenseSegment<bool> >* active;
 
  public:
   Graph()
       : nvertices(0), nnz(0), vertexpropertyowner(true), tiles_per_dim(get_global_nrank()),
-        num_threads(default_num_threads()), A(nullptr), AT(nullptr), adjacencyowner(true), vertexproperty(nullptr),
-        active(nullptr) {}
+        num_threads(default_num_threads()), A(nullptr), AT(nullptr), adjacencyowner(true), row_lo(0), row_hi(0), valid_rows(0),
+        vertexproperty(nullptr), active(nullptr) {}
   // Wrap an existing adjacency and device state (used by the C-ABI fixed-menu programs).
   Graph(gm_graph_t* handle, V* d_vp, uint32_t* d_active)
       : vertexpropertyowner(true), tiles_per_dim(1), num_threads(1), A(handle), AT(handle), adjacencyowner(false) {
     gm_graph_desc_t d;
     gm_graph_desc(handle, &d);
     nvertices = d.nvertices;
+    row_lo = d.row_lo;
+    row_hi = d.row_hi;
+    valid_rows = d.row_hi - d.row_lo;
     gm_csr_t c;
     nnz = 0;
     if (gm_graph_csr(handle, GM_DIR_OUT, &c) == GM_OK) nnz = c.nnz;
@@ -291,6 +302,13 @@ class Graph {
     int nat = vertexToNative(vertex, tiles_per_dim, nvertices);
     return dev_of_native.empty() ? nat : dev_of_native[nat - 1] + 1;
   }
+  // 1-based index into this rank's vertexproperty / active vectors, 0 when another rank owns the vertex
+  int localSlot(int vertex) const {
+    if (vertex < 1 || vertex > nvertices) return 0;
+    const int s = vertexToSlot(vertex) - 1 - row_lo;
+    return (s >= 0 && s < row_hi - row_lo) ? s + 1 : 0;
+  }
+  bool sharded() const { return tiles_per_dim > 1; }
 
  private:
   static int default_num_threads() {
@@ -306,13 +324,46 @@ void Graph<V, E>::ReadEdgelist(GraphMat::edgelist_t<E> A_edges) {
   struct timeval start, end;
   gettimeofday(&start, 0);
   tiles_per_dim = GraphMat::get_global_nrank();
-  const size_t ne = (size_t)A_edges.nnz;
+  const int myrank = GraphMat::get_global_myrank();
+  size_t ne = (size_t)A_edges.nnz;
   std::vector<int32_t> src(ne), dst(ne);
   std::vector<E> val(ne);
   for (size_t i = 0; i < ne; i++) {
     src[i] = A_edges.edges[i].src;
     dst[i] = A_edges.edges[i].dst;
     val[i] = A_edges.edges[i].val;
+  }
+  if (tiles_per_dim > 1) {
+    // Several ranks: every rank holds the edges it read (the reference's loader gives rank r the files
+    // <prefix>r, <prefix>r+nranks, ...; GMDP then shuffles edges to their tiles, SpMat.h:422-443).  Here every
+    // rank needs the whole list -- the degree ranking is global and a shard keeps the rows it owns -- so the
+    // per-rank lists are all-gathered (concatenated in rank order: duplicates keep a defined order).
+    static_assert(std::is_trivially_copyable<E>::value, "edge values travel between ranks as bytes");
+    std::vector<int64_t> counts((size_t)tiles_per_dim);
+    auto gather = [&](const void* mine, size_t bytes, std::vector<char>& out) {
+      void* all = nullptr;
+      if (gm_dist_allgatherv_host(mine, (int64_t)bytes, &all, counts.data()) != GM_OK) { printf("GraphMat(HIP): %s\n", gm_last_error()); exit(1); }
+      size_t total = 0;
+      for (int64_t c : counts) total += (size_t)c;
+      out.assign((char*)all, (char*)all + total);
+      gm_host_free(all);
+    };
+    std::vector<char> as, ad, av, am;
+    gather(src.data(), ne * 4, as);
+    gather(dst.data(), ne * 4, ad);
+    gather((const void*)val.data(), ne * sizeof(E), av);
+    const int mn[2] = {A_edges.m, A_edges.n};
+    gather(mn, sizeof(mn), am);
+    ne = as.size() / 4;
+    src.assign((const int32_t*)as.data(), (const int32_t*)as.data() + ne);
+    dst.assign((const int32_t*)ad.data(), (const int32_t*)ad.data() + ne);
+    val.resize(ne);
+    if (ne) memcpy((void*)val.data(), av.data(), ne * sizeof(E));
+    for (size_t i = 0; i + 1 < am.size() / 4; i += 2) {  // the reference's MPI_Allreduce(MAX) over m and n (edgelist.h:279-284)
+      A_edges.m = std::max(A_edges.m, ((const int*)am.data())[i]);
+      A_edges.n = std::max(A_edges.n, ((const int*)am.data())[i + 1]);
+    }
+    A_edges.m = A_edges.n = std::max(A_edges.m, A_edges.n);
   }
   gm_graph_desc_t d;
   memset(&d, 0, sizeof(d));
@@ -324,8 +375,9 @@ void Graph<V, E>::ReadEdgelist(GraphMat::edgelist_t<E> A_edges) {
   d.val_bytes = (int)sizeof(E);
   const char* lay = getenv("GRAPHMAT_LAYOUT");
   d.layout = (lay && !strcmp(lay, "native")) ? GM_LAYOUT_NATIVE : GM_LAYOUT_DEGREE;
-  d.nshards = 1;
-  d.shard = 0;
+  d.nshards = tiles_per_dim;
+  d.shard = myrank;
+  if (tiles_per_dim > 1) d.layout = GM_LAYOUT_DEGREE;  // (shards are slices of the degree-ranked order)
   if (A && adjacencyowner) gm_graph_destroy(A);
   A = AT = nullptr;
   if (gm_graph_create(&A, &d, (int64_t)ne, src.data(), dst.data(), val.data(), nullptr) != GM_OK) {
@@ -338,20 +390,34 @@ void Graph<V, E>::ReadEdgelist(GraphMat::edgelist_t<E> A_edges) {
   gm_graph_maps_to_host(A, dev_of_native.data(), nullptr);
   nvertices = A_edges.m;
   nnz = (long long)ne;
+  gm_graph_desc(A, &d);
+  row_lo = d.row_lo;
+  row_hi = d.row_hi;
+  valid_rows = row_hi - row_lo;
+  if (tiles_per_dim > 1) {
+    // rank k of the degree ranking lives in shard k % nranks at position k / nranks: the vertices of a slice
+    // are a prefix of it, the rest is padding
+    valid_rows = (nvertices - myrank + tiles_per_dim - 1) / tiles_per_dim;
+    if (valid_rows < 0) valid_rows = 0;
+    if (gm_graph_use_rccl(A) != GM_OK) { printf("GraphMat(HIP): %s\n", gm_last_error()); exit(1); }
+  }
+  const int rows = row_hi - row_lo;
   if (vertexproperty && vertexpropertyowner) delete vertexproperty;
   if (active) delete active;
-  vertexproperty = new SpVec<DenseSegment<V> >(nvertices, true);
+  vertexproperty = new SpVec<DenseSegment<V> >(rows, true);
+  vertexproperty->segment->logical = valid_rows;
   V* __v = new V;
   vertexproperty->setAll(*__v);
   delete __v;
-  active = new SpVec<DenseSegment<bool> >(nvertices, false);
+  active = new SpVec<DenseSegment<bool> >(rows, false);
+  active->segment->logical = valid_rows;
   vertexpropertyowner = true;
   detail::warm_code_object();  // one-time code-object load belongs to construction, not to the first run
   {
     // scratch the runs will ask for (messages / reduced values of up to 8 bytes, presence words,
     // the push step's bid and list arrays): allocated here so the first run does not pay hipMalloc
     void* p = nullptr;
-    const size_t n = (size_t)nvertices, words = ((n + 31) / 32 + 2) * 4;
+    const size_t n = (size_t)d.ndevice, words = ((n + 31) / 32 + 2) * 4;
     const size_t want[GM_WS_SLOTS] = {4096, n * 8 + 16, words, n * 8 + 16, words, 0, n * 8 + 64, n * 4 + 64};
     for (int slot = 0; slot < GM_WS_SLOTS; slot++)
       if (want[slot]) (void)gm_graph_workspace(A, slot, want[slot], &p);
@@ -443,10 +509,11 @@ template <class V, class E>
 void Graph<V, E>::setAllActive() { active->segment->setAllBits(true); }
 template <class V, class E>
 void Graph<V, E>::setAllInactive() { active->segment->setAllBits(false); }
+// (per-vertex setters act on the owning rank only, like the reference's SpVec::set on a non-owner)
 template <class V, class E>
-void Graph<V, E>::setActive(int v) { active->set(vertexToSlot(v), true); }
+void Graph<V, E>::setActive(int v) { if (int ls = localSlot(v)) active->set(ls, true); }
 template <class V, class E>
-void Graph<V, E>::setInactive(int v) { active->unset(vertexToSlot(v)); }
+void Graph<V, E>::setInactive(int v) { if (int ls = localSlot(v)) active->unset(ls); }
 
 template <class V, class E>
 void Graph<V, E>::reset() {
@@ -458,6 +525,7 @@ void Graph<V, E>::reset() {
 template <class V, class E>
 void Graph<V, E>::shareVertexProperty(Graph<V, E>& g) {
   // the shared vector is indexed in g's device order: bring this graph's adjacency into it
+  if (sharded()) { printf("GraphMat(HIP): shareVertexProperty is not supported with more than one rank\n"); exit(1); }
   if (A != nullptr && g.A != nullptr && A != g.A) {
     if (gm_graph_relayout_like(A, g.A, nullptr) != GM_OK) {
       printf("GraphMat(HIP): shareVertexProperty: %s\n", gm_last_error());
@@ -474,16 +542,16 @@ template <class V, class E>
 void Graph<V, E>::setAllVertexproperty(const V& val) { vertexproperty->setAll(val); }
 template <class V, class E>
 void Graph<V, E>::setVertexproperty(int v, const V& val) {
-  vertexproperty->set(vertexToSlot(v), val);
+  if (int ls = localSlot(v)) vertexproperty->set(ls, val);
 }
 template <class V, class E>
 V Graph<V, E>::getVertexproperty(const int v) const {
   V vp;
-  vertexproperty->get(vertexToSlot(v), &vp);
+  if (int ls = localSlot(v)) vertexproperty->get(ls, &vp);  // (a non-owner gets a default-constructed value, as in the reference)
   return vp;
 }
 template <class V, class E>
-bool Graph<V, E>::vertexNodeOwner(const int v) const { return v >= 1 && v <= nvertices; }
+bool Graph<V, E>::vertexNodeOwner(const int v) const { return localSlot(v) != 0; }
 template <class V, class E>
 int Graph<V, E>::getNumberOfVertices() const { return nvertices; }
 
@@ -494,7 +562,8 @@ void Graph<V, E>::getVertexEdgelist(GraphMat::edgelist_t<V>& myedges) {
   for (int v = 1; v <= nvertices; v++) {
     myedges.edges[v - 1].src = v;
     myedges.edges[v - 1].dst = 1;
-    myedges.edges[v - 1].val = vertexproperty->segment->hvalue[vertexToSlot(v) - 1];
+    if (int ls = localSlot(v)) myedges.edges[v - 1].val = vertexproperty->segment->hvalue[ls - 1];
+    else myedges.edges[v - 1].val = V();
   }
 }
 
@@ -510,9 +579,9 @@ void Graph<V, E>::getEdgelist(GraphMat::edgelist_t<E>& myedges) {
   std::vector<int32_t> nod((size_t)c.ncols);
   gm_graph_maps_to_host(A, nullptr, nod.data());
   size_t k = 0;
-  for (int r = 0; r < c.nrows; r++)
+  for (int r = 0; r < c.nrows; r++)  // (the rows of this rank's shard)
     for (int64_t e = rp[r]; e < rp[r + 1]; e++, k++) {
-      myedges.edges[k].src = nativeToVertex(nod[r] + 1, tiles_per_dim, nvertices);
+      myedges.edges[k].src = nativeToVertex(nod[c.row_base + r] + 1, tiles_per_dim, nvertices);
       myedges.edges[k].dst = nativeToVertex(nod[ci[e]] + 1, tiles_per_dim, nvertices);
       myedges.edges[k].val = vv[e];
     }
@@ -525,8 +594,29 @@ void Graph<V, E>::saveVertexproperty(std::string fname, bool includeHeader) cons
   vertexproperty->segment->need_host();
   std::ofstream f((fname + std::to_string(get_global_myrank())).c_str());
   if (includeHeader) f << nvertices << " " << 1 << " " << nvertices << std::endl;
-  for (int v = 1; v <= nvertices; v++)
-    f << v << " " << vertexproperty->segment->hvalue[vertexToSlot(v) - 1] << std::endl;
+  for (int v = 1; v <= nvertices; v++)  // (each rank writes the vertices it owns into its own file, like the reference)
+    if (int ls = localSlot(v)) f << v << " " << vertexproperty->segment->hvalue[ls - 1] << std::endl;
+}
+
+// several ranks: every rank reduces the vertices it owns (in native order), rank 0's result is then combined with
+// the other ranks' in rank order and everybody gets it -- multinode/reduce.h:38-70 of the reference, including its
+// quirk that every rank's partial result starts from the caller's initial value
+template <class T, class R>
+static void combine_over_ranks(T* val, R reduce) {
+  static_assert(std::is_trivially_copyable<T>::value, "map-reduce results travel between ranks as bytes");
+  const int nr = get_global_nrank();
+  std::vector<int64_t> counts((size_t)nr);
+  void* all = nullptr;
+  if (gm_dist_allgatherv_host((const void*)val, (int64_t)sizeof(T), &all, counts.data()) != GM_OK) { printf("GraphMat(HIP): %s\n", gm_last_error()); exit(1); }
+  T res;
+  memcpy((void*)&res, all, sizeof(T));
+  for (int r = 1; r < nr; r++) {
+    T other, t = res;
+    memcpy((void*)&other, (const char*)all + (size_t)r * sizeof(T), sizeof(T));
+    reduce(t, other, &res);
+  }
+  gm_host_free(all);
+  *val = res;
 }
 
 // Host-side element-wise helpers.  The callbacks are host function pointers, so they run
@@ -544,25 +634,30 @@ void Graph<V, E>::applyReduceAllVertices(T* val, void (*ApplyFn)(V*, T*, void*),
                                          void (*ReduceFn)(const T&, const T&, T*, void*), void* param) {
   vertexproperty->segment->need_host();
   auto& h = vertexproperty->segment->hvalue;
-  const int n = (int)h.size();
+  const int n = nvertices, rows = row_hi - row_lo;
   const int nthreads = num_threads;  // chunking of reduce.h:57-66
   const int per = (n + nthreads - 1) / nthreads;
   for (int p = 0; p < nthreads; p++) {
     int s = std::min(per * p, n), e = std::min(per * (p + 1), n);
     bool first = false;
     T local;
-    for (int i = s; i < e; i++) {  // native order, like the reference's segment walk
+    for (int i = s; i < e; i++) {  // native order, like the reference's segment walk; the vertices this rank owns
+      const int slot = (dev_of_native.empty() ? i : dev_of_native[i]) - row_lo;
+      if (slot < 0 || slot >= rows) continue;
       T t2;
-      ApplyFn(&h[dev_of_native.empty() ? i : dev_of_native[i]], &t2, param);
+      ApplyFn(&h[slot], &t2, param);
       if (first) { T t = local; ReduceFn(t, t2, &local, param); }
       else { local = t2; first = true; }
     }
     if (first) { T t = *val; ReduceFn(t, local, val, param); }
   }
+  if (sharded()) combine_over_ranks(val, [&](const T& a, const T& b, T* c) { ReduceFn(a, b, c, param); });
 }
+
 
 template <class V, class E>
 void Graph<V, E>::applyToAllEdges(void (*ApplyFn)(E*, const V&, const V&, void*), void* param) {
+  if (sharded()) { printf("GraphMat(HIP): applyToAllEdges is not supported with more than one rank (it needs both endpoints' properties)\n"); exit(1); }
   vertexproperty->segment->need_host();
   const auto& h = vertexproperty->segment->hvalue;
   for (int dir : {GM_DIR_OUT, GM_DIR_IN}) {
@@ -693,11 +788,13 @@ void Graph<V, E>::applyReduceAllVertices(T* val, Map map, Reduce reduce) {
     if (first) { T a = total; reduce(a, t, &total); } else { total = t; first = true; }
   }
   if (first) { T a = *val; reduce(a, total, val); }  // like reduce.h:93-96: combined with the caller's value
+  if (sharded()) combine_over_ranks(val, reduce);
 }
 
 template <class V, class E>
 template <class F, class>
 void Graph<V, E>::applyToAllEdges(F f) {
+  if (sharded()) { printf("GraphMat(HIP): applyToAllEdges is not supported with more than one rank (it needs both endpoints' properties)\n"); exit(1); }
   auto* seg = vertexproperty->segment;
   seg->need_device();
   int ntile = 1;

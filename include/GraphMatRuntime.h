@@ -36,8 +36,11 @@ template <class T, class U, class V, class E>
 struct run_graph_program_temp_structure<T, U, V> graph_program_init(const GraphProgram<T, U, V, E>& gp,
                                                                     const Graph<V, E>& g) {
   struct run_graph_program_temp_structure<T, U, V> rgpts;
-  rgpts.px = new GraphMat::SpVec<GraphMat::DenseSegment<T> >(g.nvertices);
-  rgpts.py = new GraphMat::SpVec<GraphMat::DenseSegment<U> >(g.nvertices);
+  // x holds every shard's slice (the whole device id space), y this rank's rows; one rank: both nvertices
+  gm_graph_desc_t d;
+  gm_graph_desc(g.A, &d);
+  rgpts.px = new GraphMat::SpVec<GraphMat::DenseSegment<T> >(d.ndevice);
+  rgpts.py = new GraphMat::SpVec<GraphMat::DenseSegment<U> >(d.row_hi - d.row_lo);
   return rgpts;
 }
 

@@ -38,7 +38,7 @@ struct edgelist_t {
   }
   edgelist_t(edge_t<T>* e, int _m, int _n, int _nnz) : edges(e), m(_m), n(_n), nnz(_nnz) {}
   void clear() {
-    if (nnz > 0) free(edges);
+    if (edges != nullptr) free(edges);
     edges = nullptr;
     nnz = 0;
     m = 0;
@@ -55,6 +55,10 @@ inline int edge_value_kind() {
   if (std::is_same<T, double>::value) return GM_VAL_F64;
   return GM_VAL_RAW((int)sizeof(T));  // opaque: binary files only
 }
+template <typename T>
+inline typename std::enable_if<std::is_constructible<T, int>::value>::type assign_one(T& v) { v = T(1); }
+template <typename T>
+inline typename std::enable_if<!std::is_constructible<T, int>::value>::type assign_one(T&) {}
 }  // namespace detail
 
 // Edge-list files: binary or text, with or without the "m n nnz" header, with or without
@@ -73,7 +77,7 @@ void load_edgelist(const char* dir, edgelist_t<T>* edgelist, bool binaryformat =
     std::string fname = fname_ss.str();
     FILE* probe = fopen(fname.c_str(), "rb");
     if (!probe) {
-      if (i == 0 && nrank == 1 && (probe = fopen(dir, "rb")) != nullptr) {
+      if (i == 0 && myrank == 0 && (probe = fopen(dir, "rb")) != nullptr) {  // (rank 0 alone reads an unsplit file)
         fname = dir;
       } else {
         if (i == myrank) printf("Could not open file: %s\n", fname.c_str());
@@ -98,6 +102,7 @@ void load_edgelist(const char* dir, edgelist_t<T>* edgelist, bool binaryformat =
       e.src = s[k];
       e.dst = d[k];
       memcpy(&e.val, (const char*)v + (size_t)k * sizeof(T), sizeof(T));
+      if (!edgeweights) detail::assign_one(e.val);  // unweighted files: every edge gets (T)1 (edgelist.h:186-188 of the reference)
     }
     gm_host_free(s);
     gm_host_free(d);

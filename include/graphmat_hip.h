@@ -301,6 +301,17 @@ int gm_dist_unique_id(void* out, size_t bytes);
 int gm_dist_init(int rank, int nranks, const void* unique_id, size_t bytes);
 int gm_dist_finalize(void);
 int gm_dist_info(int* rank, int* nranks); /* *nranks = 0 before gm_dist_init */
+/* What an application's MPI_Init can call (include/graphmat/mpi_single.h does): rank / size / local GPU from the
+ * launcher's environment (GRAPHMAT_RANK|RANK|OMPI_COMM_WORLD_RANK|PMI_RANK|SLURM_PROCID, ..._NRANKS|WORLD_SIZE|...,
+ * LOCAL_RANK|...), the unique id through a rendezvous file (GRAPHMAT_RENDEZVOUS, else /tmp/graphmat_rdv_<MASTER_PORT>).
+ * A single process (no such variables) is left alone.  GRAPHMAT_DIST_TRANSPORT=shm replaces RCCL by a host
+ * shared-memory transport with the same entry points: for trying multi-rank runs on a 1-GPU box (RCCL wants one
+ * rank per GPU), slow, tests only. */
+int gm_dist_init_from_env(int* rank, int* nranks);
+int gm_dist_barrier(void);
+/* all-gather of host buffers of different sizes: *all = malloc'ed concatenation in rank order (gm_host_free),
+ * counts[r] = bytes contributed by rank r */
+int gm_dist_allgatherv_host(const void* mine, int64_t my_bytes, void** all, int64_t* counts);
 int gm_graph_use_rccl(gm_graph_t* g);
 int gm_graph_exchange_is_native(const gm_graph_t* g);
 /* out[0] exchange calls, out[1] overlapped parts started, out[2] bytes this rank contributed to all-gathers,
