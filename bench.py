@@ -285,7 +285,9 @@ def main():
         cb = ex.callback()
         g._cb = cb
         _lib.check(L.gm_graph_set_exchange(g.h, cb, None))
-        if backend == "nccl" and os.environ.get("GM_BENCH_EXCHANGE", "rccl") == "rccl":
+        # (GRAPHMAT_DIST_TRANSPORT=shm: the library's shared-memory test transport, so that the native exchange code
+        # can be tried with several ranks on a 1-GPU box next to GM_BENCH_BACKEND=gloo)
+        if (backend == "nccl" or os.environ.get("GRAPHMAT_DIST_TRANSPORT") == "shm") and os.environ.get("GM_BENCH_EXCHANGE", "rccl") == "rccl":
             from graphmat_amd import dist as gdist
             ok = 1
             try:
@@ -302,7 +304,7 @@ def main():
             except Exception as e:  # pragma: no cover
                 log(rank, "native RCCL exchange unavailable: %r" % (e,))
                 ok = 0
-            okt = torch.tensor([ok], dtype=torch.int32, device=dev)
+            okt = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             native = int(okt.item()) == 1
             if native:
@@ -473,6 +475,7 @@ def main():
                    "V": nv, "E": E, "parallelism": "1d-rows x%d" % world, "exchange": (("native RCCL (gm_dist.hip), " if native else "torch.distributed callback, ") if world > 1 else "") +
                                                                             ("two-stage overlapped all-gather" if overlapped else
                                                                              ("all-gather between send and multiply" if world > 1 else "none")), "id_layout_nparts": nparts,
+                   "exchange_fell_back_to_broadcasts": bool(ex is not None and ex.no_fast_path and not native),
                    "device_order": "native" if args.native_layout else "degree-ranked, dealt over shards",
                    "col_tiles": int(g.col_tiles),
                    "rows_per_shard": S, "exchanged_rows_per_shard": int(g.xchg_rows),

@@ -103,7 +103,8 @@ class MessageExchange:
                 self._pending.append((w, scatter))
                 return
             except Exception as e:
-                print("graphmat_amd.dist: async all_gather_into_tensor failed (%r); using broadcasts" % (e,), flush=True)
+                print("graphmat_amd.dist: WARNING: async all_gather_into_tensor failed (%r); falling back to per-slice broadcasts "
+                      "(slower; MessageExchange.no_fast_path is set and bench.py reports it)" % (e,), flush=True)
                 self.no_fast_path = True
         for r in range(n):
             lo = r * S + first
@@ -154,7 +155,8 @@ class MessageExchange:
                     self.x_bits[: n * W].view(n, W)[:, :WL].copy_(sb.view(n, WL))
                 return
             except Exception as e:  # fall back to per-slice broadcasts (same result)
-                print("graphmat_amd.dist: all_gather_into_tensor path failed (%r); using broadcasts" % (e,), flush=True)
+                print("graphmat_amd.dist: WARNING: all_gather_into_tensor path failed (%r); falling back to per-slice broadcasts "
+                      "(slower; MessageExchange.no_fast_path is set and bench.py reports it)" % (e,), flush=True)
                 self.no_fast_path = True
         hs = []
         for r, (lo, hi) in enumerate(self.ranges):

@@ -48,3 +48,21 @@ def test_native_rccl_exchange_single_rank():
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env, cwd=ROOT)
     text = out.stdout.decode()
     assert out.returncode == 0 and "MULTI_OK" in text and "native-rccl" in text, text[-3000:]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_exchange_several_ranks_over_shared_memory(world):
+    """The native exchange's rank arithmetic (slice offsets, staged live prefixes, part regions, sparse blocks) with
+    more than one participant: RCCL cannot put two ranks on one GPU, so the library's shared-memory test transport
+    (GRAPHMAT_DIST_TRANSPORT=shm: the same all-gather / all-reduce entry points over host memory) carries the bytes
+    while gm_dist.hip's exchange code runs unchanged.  Every result must equal the oracle's."""
+    from graphmat_amd import build
+    build.build()
+    from oracle import binding
+    binding.build()
+    env = dict(os.environ, GM_BACKEND="gloo", GM_SCALE="13", GM_EXCHANGE="native", GRAPHMAT_DIST_TRANSPORT="shm")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "multi_check.py")]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env, cwd=ROOT)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "MULTI_OK" in text and "native-rccl" in text, text[-3000:]
