@@ -549,6 +549,13 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
   v.tile_min_row = tile_split;
   v.hot_base = 0;
   v.hot_len = D.ndevice;
+  v.hot_slices = 1;
+  v.hot_stride = 0;
+  if (D.layout == GM_LAYOUT_DEGREE && D.nshards > 1) {  // rank k lives in slice k % G at position k / G
+    v.hot_slices = D.nshards;
+    v.hot_stride = D.ndevice / D.nshards;
+    v.hot_len = v.hot_stride;
+  }
   return GM_OK;
 }
 

@@ -829,9 +829,18 @@ k_spmv_wave16(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int n
   constexpr int kHot = sizeof(T) == 4 ? kHotEntries : 1;
   __shared__ T s_hot[kHot];
   // (a column tile's columns are a slice [hot_base, hot_base + hot_len) of the device order, busiest first)
-  const int nhot = kHot > 1 ? (A.hot_len < kHot ? A.hot_len : kHot) : 0;
+  // Sharded graphs: the degree ranking is dealt over the NS slices of x, so the hot set is the first kHot / NS
+  // entries of every slice (s_hot[q * per + i] = x[q * stride + i]).
+  const int NS = A.hot_slices > 1 ? A.hot_slices : 1;
+  const int per = kHot > 1 ? ((A.hot_len < kHot / NS ? A.hot_len : kHot / NS)) : 0;  // hot entries per slice
+  const int nhot = per * NS;
   const T* __restrict__ xhot = x + A.hot_base;
-  for (int i = threadIdx.x; i < nhot; i += kWave16Block) s_hot[i] = xhot[i];
+  if (NS == 1) {
+    for (int i = threadIdx.x; i < nhot; i += kWave16Block) s_hot[i] = xhot[i];
+  } else {
+    for (int i = threadIdx.x; i < nhot; i += kWave16Block) s_hot[i] = x[(size_t)(i / per) * A.hot_stride + (i % per)];
+  }
+  const float inv_stride = NS > 1 ? 1.0f / (float)A.hot_stride : 0.f;
   __syncthreads();
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -869,8 +878,17 @@ k_spmv_wave16(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int n
     for (int r = 0; r < G; r++) {
       if (c[r] >= 0 && !dense && !bit_get(xbits, c[r])) c[r] = -1;
       if (c[r] >= 0) {
-        const unsigned rel = (unsigned)(c[r] - A.hot_base);
-        m[r] = rel < (unsigned)nhot ? s_hot[rel] : x[c[r]];
+        if (NS == 1) {
+          const unsigned rel = (unsigned)(c[r] - A.hot_base);
+          m[r] = rel < (unsigned)nhot ? s_hot[rel] : x[c[r]];
+        } else {
+          // slice q of the column and its position in it (float estimate of the quotient, fixed up exactly)
+          int q = (int)((float)c[r] * inv_stride);
+          q = q >= NS ? NS - 1 : q;
+          int pos = c[r] - q * A.hot_stride;
+          if (pos < 0) { q--; pos += A.hot_stride; } else if (pos >= A.hot_stride) { q++; pos -= A.hot_stride; }
+          m[r] = pos < per ? s_hot[q * per + pos] : x[c[r]];
+        }
       }
     }
   };

@@ -179,6 +179,10 @@ typedef struct {
   int32_t hot_base;           /* the columns of this adjacency lie in device ids [hot_base, hot_base + hot_len) and   */
   int32_t hot_len;            /*   the busiest come first: the kernels keep x[hot_base ...] in LDS.  Whole graph:
                                  0 / ncols; a column tile: its slice of the device order                              */
+  int32_t hot_slices;         /* sharded graphs (nshards = G > 1): the degree ranking is dealt over the G slices of x, */
+  int32_t hot_stride;         /*   so the busiest entries are the first ones of EVERY slice: the hot set is the first
+                                 kHot / hot_slices entries of each slice [q * hot_stride, ...), q < hot_slices (1 / 0:
+                                 one slice)                                                                           */
 } gm_csr_t;
 
 #define GM_GIANT_CHUNK 4096 /* edges per piece of the parallel giant-row pass */
