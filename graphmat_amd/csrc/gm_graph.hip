@@ -307,7 +307,7 @@ static int partition_mid(const int32_t* mid_row, int nmid, const int64_t* rowptr
 }
 
 static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* idx_sorted, unsigned long long kept,
-                      const void* d_val, hipStream_t s, CsrOwned* out, int tile_split = 0);
+                      const void* d_val, hipStream_t s, CsrOwned* out, int tile_split = -1);
 static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* idx_sorted, unsigned long long kept,
                        const void* d_val, hipStream_t s, const CsrOwned* whole);
 
@@ -345,16 +345,17 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   idx_in.alloc(0);
   tmp.alloc(0);
   const bool tiled = by_dst && g->ntiles > 1;
-  if ((rc = finish_csr(g, keys_out.as<uint64_t>(), idx_out.as<uint32_t>(), kept, d_val, s, out, tiled ? g_tile_min_row : 0))) return rc;
+  if ((rc = finish_csr(g, keys_out.as<uint64_t>(), idx_out.as<uint32_t>(), kept, d_val, s, out, tiled ? g_tile_min_row : -1))) return rc;
   if (tiled) rc = build_tiles(g, keys_out.as<uint64_t>(), idx_out.as<uint32_t>(), kept, d_val, s, out);
   return rc;
 }
 
 // CSR arrays and work decomposition from `kept` sorted keys (row << 32 | native col) and, for the
 // edge values, the input position of every sorted edge.
-// tile_split > 0 (whole-graph CSR of a tiled graph): also list the wave rows of at most tile_split edges.
+// tile_split >= 0 (whole-graph CSR of a tiled graph): also list the wave rows of at most tile_split edges.
 static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* idx_sorted, unsigned long long kept,
                       const void* d_val, hipStream_t s, CsrOwned* out, int tile_split) {
+  const int short_row = g_short_row;
   const gm_graph_desc_t& D = g->desc;
   const int nrows = D.row_hi - D.row_lo;
   int rc;
@@ -411,7 +412,7 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
   if ((rc = cnt.alloc(32))) return rc;
   unsigned int nseg = 0, nblk = 0, nmid = 0, ngiant = 0;
   if (nrows > 0) {
-    hipLaunchKernelGGL(k_row_flags, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr.as<int64_t>(), nrows, g_short_row,
+    hipLaunchKernelGGL(k_row_flags, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr.as<int64_t>(), nrows, short_row,
                        giant_row, f0.as<unsigned char>(), f1.as<unsigned char>(), f2.as<unsigned char>());
     GM_TRY_HIP(hipGetLastError());
     rocprim::counting_iterator<int32_t> ids(0);
@@ -436,7 +437,7 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
     // row-blocks = the segments that hold short rows with at least one edge
     if ((rc = blkl.alloc((size_t)(nseg + 1) * 4))) return rc;
     hipLaunchKernelGGL(k_seg_flags, dim3(grid_for(nseg)), dim3(kT), 0, s, rowptr.as<int64_t>(), seg.as<int32_t>(),
-                       (int)nseg, g_short_row, f0.as<unsigned char>());
+                       (int)nseg, short_row, f0.as<unsigned char>());
     GM_TRY_HIP(rocprim::select(tmp.p, tb, ids, f0.as<unsigned char>(), blkl.as<int32_t>(), cnt.as<unsigned int>() + 3,
                                (size_t)nseg, s));
     GM_TRY_HIP(hipMemcpyAsync(h, cnt.as<unsigned int>() + 3, 4, hipMemcpyDeviceToHost, s));
@@ -462,7 +463,7 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
       if ((rc = mid2.alloc((size_t)(nrows + 1) * 4))) return rc;
       unsigned int n_all = 0;
       if ((rc = partition_mid(mid.as<int32_t>(), (int)nmid, rowptr.as<int64_t>(), long_limit, (int64_t)1 << 62, mid2.as<int32_t>(), &nmid_long, &n_all, s))) return rc;
-      if (tile_split > 0) {  // the wave rows that stay untiled, same layout
+      if (tile_split >= 0) {  // the wave rows that stay untiled, same layout
         if ((rc = umid.alloc((size_t)(nmid + 1) * 4))) return rc;
         if ((rc = partition_mid(mid.as<int32_t>(), (int)nmid, rowptr.as<int64_t>(), long_limit, (int64_t)tile_split, umid.as<int32_t>(), &numid_long, &numid, s))) return rc;
       }
@@ -541,7 +542,7 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
   v.gterm_off = out->gterm_off;
   v.ngchunk = (int32_t)h_gcr.size();
   v.giant_edges = h_gto.back();
-  v.short_row = g_short_row;
+  v.short_row = short_row;
   v.nmid_long = nmid_long;
   v.umid_row = out->umid_row;
   v.numid = (int32_t)numid;

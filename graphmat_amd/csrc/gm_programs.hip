@@ -452,7 +452,8 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "giant_row") && value >= 64) { gm::g_giant_row = value; return GM_OK; }
   if (key && !strcmp(key, "rank_cap") && value >= 0) { gm::g_rank_cap = value; return GM_OK; }
   if (key && !strcmp(key, "rank_by") && value >= 0 && value <= 2) { gm::g_rank_by = value; return GM_OK; }
-  if (key && !strcmp(key, "tile_min_row") && value >= GM_SHORT_ROW) { gm::g_tile_min_row = value; return GM_OK; }
+  // (0 = every row is tiled; otherwise at least the short-row limit: the untiled row-block kernel takes every row up to that limit)
+  if (key && !strcmp(key, "tile_min_row") && (value == 0 || value >= gm::g_short_row)) { gm::g_tile_min_row = value; return GM_OK; }
   if (key && !strcmp(key, "col_tiles") && value >= 0 && value <= GM_MAX_TILES) { gm::g_col_tiles = value; return GM_OK; }
   if (key && !strcmp(key, "push_edge_permille") && value >= 0 && value <= 1000) { GraphMat::detail::push_edge_permille() = value; return GM_OK; }
   if (key && !strcmp(key, "sparse_step_edges") && value >= 0) { GraphMat::detail::sparse_step_edges() = value; return GM_OK; }

@@ -842,11 +842,12 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         // pass gathers from one slice of x and continues the row's fold from the value y holds -- and
         // only the short rows take the untiled row-blocks.  Same fold order, same bits.
         int ntile = 1;
-        if (dense_x && !multi && row_bits == nullptr && rk != REDUCE_LAST && !(debug_flags() & dev::DBG_NO_TILES))
+        if (dense_x && !multi && row_bits == nullptr && rk != REDUCE_LAST && dev::stageable<T>::value && !(debug_flags() & dev::DBG_NO_TILES))
           gm_graph_tiles(g, GM_DIR_OUT, &ntile);
         if (ntile > 1) {
           gm_csr_t As = Aout;  // the rows that are not tiled: row-blocks and the shorter wave rows
           As.mid_row = Aout.umid_row; As.nmid = Aout.numid; As.nmid_long = Aout.numid_long; As.ngiant = 0; As.ngchunk = 0;
+          if (Aout.tile_min_row == 0) { As.nblk = 0; As.nmid = 0; }  // every row is tiled
           if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, As, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk);
           else launch_spmv<P, T, U, V, E, false>(g, pa, As, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk);
           for (int t = 0; t < ntile; t++) {

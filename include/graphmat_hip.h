@@ -175,7 +175,7 @@ typedef struct {
   const int32_t* umid_row;    /* tiled graphs, whole-graph CSR only: the wave rows that are NOT tiled (more than      */
   int32_t numid;              /*   GM_SHORT_ROW and at most tile_min_row edges), laid out like mid_row: the first    */
   int32_t numid_long;         /*   numid_long entries are the long ones                                              */
-  int32_t tile_min_row;       /* rows of more than this many edges are multiplied tile by tile (0: not tiled)        */
+  int32_t tile_min_row;       /* rows of more than this many edges are multiplied tile by tile (-1: not tiled)       */
   int32_t hot_base;           /* the columns of this adjacency lie in device ids [hot_base, hot_base + hot_len) and   */
   int32_t hot_len;            /*   the busiest come first: the kernels keep x[hot_base ...] in LDS.  Whole graph:
                                  0 / ncols; a column tile: its slice of the device order                              */

@@ -102,7 +102,7 @@ def test_tile_structure(env, tile_min, tiles, threads, minrow):
 
 
 @pytest.mark.parametrize("scale,threads,tiles,minrow", [(10, 1, 2, 64), (12, 4, 3, 64), (14, 1, 8, 100), (16, 2, 4, 64),
-                                                         (16, 1, 16, 1024), (18, 1, 4, 1024)])
+                                                         (16, 1, 16, 1024), (18, 1, 4, 1024), (14, 2, 4, 0), (17, 1, 8, 0)])
 def test_pagerank_tiled_bit_exact(env, tile_min, scale, threads, tiles, minrow):
     api, ob = env
     tile_min(minrow)
@@ -120,6 +120,14 @@ def test_pagerank_tiled_bit_exact(env, tile_min, scale, threads, tiles, minrow):
     pr, _, it = g.pagerank(-1)
     opr, oit, _ = og.pagerank(-1)
     assert it == oit and (f32bits(pr) == f32bits(opr)).all()
+
+
+def test_tile_threshold_must_be_zero_or_at_least_the_short_row_limit(env):
+    api, _ = env
+    L = api._lib.lib()
+    assert L.gm_set_option(b"tile_min_row", 7) != 0   # rows of 8..64 edges would be multiplied twice
+    assert L.gm_set_option(b"tile_min_row", 0) == 0 and L.gm_set_option(b"tile_min_row", 64) == 0
+    assert L.gm_set_option(b"tile_min_row", 1024) == 0
 
 
 def test_other_programs_on_a_tiled_graph(env, tile_min):
