@@ -472,7 +472,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "PageRank (alpha=0.3, fp32, fixed iteration count) on RMAT scale-%d, a/b/c=.57/.19/.19, "
                                "edge factor %d, seed %d, duplicates and self loops kept" % (args.scale, args.edge_factor, args.seed),
-                   "V": nv, "E": E, "parallelism": "1d-rows x%d" % world, "exchange": (("native RCCL (gm_dist.hip), " if native else "torch.distributed callback, ") if world > 1 else "") +
+                   "V": nv, "E": E, "parallelism": "1d-rows x%d" % world, "exchange": ((("native exchange (gm_dist.hip) over %s, " % ("shared memory [test transport]" if os.environ.get("GRAPHMAT_DIST_TRANSPORT") == "shm" else "RCCL"))
+                                                                              if native else "torch.distributed callback, ") if world > 1 else "") +
                                                                             ("two-stage overlapped all-gather" if overlapped else
                                                                              ("all-gather between send and multiply" if world > 1 else "none")), "id_layout_nparts": nparts,
                    "exchange_fell_back_to_broadcasts": bool(ex is not None and ex.no_fast_path and not native),
