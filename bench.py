@@ -428,6 +428,14 @@ def main():
     roof = None
     name = max(kern, key=lambda k: kern[k][0])
     ms, launches, alg_bytes = kern[name]
+    tiled = int(g.col_tiles) > 1
+    if tiled:
+        # column tiles: a row's pieces are spread over T launches of both kernel classes, so the unit is the whole
+        # multiply of one iteration (every row-block and wave launch of its T tiles; giant rows aside)
+        name = "multiply"
+        ms = stats["rowblock_ms"] + stats["wave_ms"]
+        launches = stats["rowblock_launches"] + stats["wave_launches"]
+        alg_bytes = kern["k_spmv_rowblock"][2] + kern["k_spmv_wave"][2]
     if launches > 0 and ms > 0:
         # the two-stage multi-GPU schedule launches every multiply kernel twice per iteration (tail rows,
         # head rows): the algorithmic bytes are per iteration, so is the time they are divided by
@@ -443,18 +451,20 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 per = tj.get("scale%d" % args.scale, {})
-                if tj.get("kernels_fingerprint") == kernels_fingerprint() and int(g.col_tiles) <= 1:
-                    traffic = per.get(name + "_bytes_per_launch")
-                    if name == "k_spmv_wave" and traffic is not None:
-                        traffic += per.get("k_spmv_wave16_bytes_per_launch", 0)
+                if tj.get("kernels_fingerprint") == kernels_fingerprint() and tj.get("col_tiles", {}).get("scale%d" % args.scale) == int(g.col_tiles):
+                    names = {"k_spmv_wave": ["k_spmv_wave", "k_spmv_wave16"], "multiply": ["k_spmv_rowblock", "k_spmv_wave", "k_spmv_wave16"]}.get(name, [name])
+                    parts = [per.get(k + "_bytes_per_iteration") for k in names]
+                    traffic = int(sum(parts)) if all(v is not None for v in parts) else None
                     traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernels (profiles/pmc_traffic.json)"
                 else:
                     traffic_note = "profiles/pmc_traffic.json was measured on other kernel sources: not quoted"
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "kernel": ("k_spmv_wave16+k_spmv_wave" if name == "k_spmv_wave" else name) + "<PageRank>", "achieved": round(ach, 1),
+        kname = {"k_spmv_wave": "k_spmv_wave16+k_spmv_wave", "multiply": "k_spmv_rowblock+k_spmv_wave16+k_spmv_wave over %d column tiles" % int(g.col_tiles)}.get(name, name)
+        roof = {"bound": "hbm", "kernel": kname + "<PageRank>", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg_bytes,
+                "unit_note": ("one launch unit = all %d launches of these kernels in one iteration" % per_step) if per_step > 1 else "one launch per iteration",
                 "launches_per_iteration": per_step,
                 "rowblock_avg_ms": round(stats["rowblock_ms"] / max(args.steps, 1), 4),
                 "wave_avg_ms": round(stats["wave_ms"] / max(args.steps, 1), 4),

@@ -130,9 +130,11 @@ typedef struct {
                             GM_LAYOUT_DEGREE the vertices without any edge sit at the tail of
                             each slice.  Multiple of 64; = slice size for GM_LAYOUT_NATIVE.   */
   int32_t col_tiles;     /* column tiles of the GM_DIR_OUT adjacency (see gm_graph_tile): 0 = library default
-                            (gm_set_option("col_tiles"), else environment GRAPHMAT_COL_TILES, else none),
-                            1 = none, 2..GM_MAX_TILES = that many.  GM_LAYOUT_DEGREE with one shard only
-                            (ignored otherwise).  Output: the number of tiles built (1 = none).             */
+                            (gm_set_option("col_tiles"), else environment GRAPHMAT_COL_TILES, else automatic:
+                            slices of ~32 MB of a 4-byte message vector once its live part reaches 96 MB, i.e.
+                            none up to RMAT-25, 4 at RMAT-26, 8 at RMAT-27), 1 = none, 2..GM_MAX_TILES = that many.
+                            GM_LAYOUT_DEGREE with one shard only (ignored otherwise).  Output: the number of tiles
+                            built (1 = none).                                                                 */
 } gm_graph_desc_t;
 
 /* One direction of the adjacency as laid out in HBM (see DESIGN.md "data layout"). */
@@ -214,13 +216,13 @@ int gm_graph_csr(const gm_graph_t* g, int direction, gm_csr_t* out);
  * row's tile-0 edges, then its tile-1 edges, ... carrying the running value in y, is exactly the
  * reference's ascending-native-column fold: results do not change, but every pass gathers from
  * an x slice T times smaller (L2-resident hot part, LDS-resident hottest entries).
- * Only rows of more than tile_min_row edges (gm_set_option("tile_min_row"), default
- * GM_TILE_MIN_ROW) are tiled -- their per-tile pieces stay long enough for the wave kernels; the
- * shorter rows keep the untiled kernels (gm_csr_t.umid_row lists the untiled wave rows).
+ * Only rows of more than tile_min_row edges (gm_set_option("tile_min_row"), default GM_TILE_MIN_ROW = the
+ * short-row limit: every wave row) are tiled; the shorter rows keep the untiled kernels -- tiling them too only
+ * multiplies their bookkeeping (gm_csr_t.umid_row lists the wave rows that stay untiled when the threshold is higher).
  * *d_prev_bits = presence bits of the rows that have an edge in an earlier tile (the rows whose
  * running value y already holds when tile `tile` is multiplied). */
 #define GM_MAX_TILES 64
-#define GM_TILE_MIN_ROW 1024
+#define GM_TILE_MIN_ROW 64
 int gm_graph_tiles(const gm_graph_t* g, int direction, int* ntiles); /* *ntiles = 1: not tiled */
 int gm_graph_tile(const gm_graph_t* g, int direction, int tile, gm_csr_t* out, const uint32_t** d_prev_bits);
 /* rowbits of GM_DIR_OUT | rowbits of GM_DIR_IN (graphs built with both directions; ALL_EDGES programs) */

@@ -35,7 +35,7 @@ def tile_min(env):
     def set_(v):
         api._lib.check(api._lib.lib().gm_set_option(b"tile_min_row", v))
     yield set_
-    set_(1024)
+    set_(64)
 
 
 @pytest.mark.parametrize("tiles,threads,minrow", [(2, 1, 64), (5, 3, 64), (8, 1, 200), (64, 2, 64)])
