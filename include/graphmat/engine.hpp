@@ -860,6 +860,9 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
             if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, At, xq, xb, d_vp, y, pb, tacc, s, &st.spmv_launches, &timer, &aux, rk);
             else launch_spmv<P, T, U, V, E, false>(g, pa, At, xq, xb, d_vp, y, pb, tacc, s, &st.spmv_launches, &timer, &aux, rk);
           }
+          // (a probed strategy is cross-checked against the ordered fold of the WHOLE rows; a mismatch redoes this
+          // iteration untiled with the ordered fold, which then also governs the tiled iterations that follow)
+          check_probed(Aout, Aout.rowbits, nullptr, acc, ybits);
         } else {
           if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves, xsum);
           else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves, xsum);

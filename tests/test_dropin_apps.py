@@ -268,15 +268,17 @@ def test_probed_reduce_strategies_are_cross_checked():
     float max, a+b with a quirk at one value) must end up with the ordered fold -- by the probe's adversarial
     operands or by the device-side cross-check -- and every result must equal a host fold with the program's function."""
     exe = _need(os.path.join(OWN_APPS, "reduce_probe_cases"))
-    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=dict(os.environ, GRAPHMAT_VERBOSE="1"))
-    text = out.stdout.decode()
-    assert out.returncode == 0 and "PROBECASES PASS" in text, text[-3000:]
-    sect = {name: body for name, body in re.findall(r"== (\w+)\n(.*?)(?=\n== |\nPROBECASES)", text, flags=re.S)}
-    assert "reduce strategy 3" in sect["PlainAdd"] and "0 mismatching rows" in sect["PlainAdd"]
-    assert "reduce strategy 0" in sect["SatAdd"] and "reduce strategy 0" in sect["FloatMax"]
-    assert "reduce strategy 3" in sect["QuirkAdd"] and "using the ordered fold" in sect["QuirkAdd"]
-    for name in sect:
-        assert "results-ok" in sect[name], name
+    for tiles in ("1", "3"):  # untiled, and with column tiles (the cross-check then compares whole rows after the last tile)
+        out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
+                             env=dict(os.environ, GRAPHMAT_VERBOSE="1", GRAPHMAT_COL_TILES=tiles))
+        text = out.stdout.decode()
+        assert out.returncode == 0 and "PROBECASES PASS" in text, text[-3000:]
+        sect = {name: body for name, body in re.findall(r"== (\w+)\n(.*?)(?=\n== |\nPROBECASES)", text, flags=re.S)}
+        assert "reduce strategy 3" in sect["PlainAdd"] and "0 mismatching rows" in sect["PlainAdd"]
+        assert "reduce strategy 0" in sect["SatAdd"] and "reduce strategy 0" in sect["FloatMax"]
+        assert "reduce strategy 3" in sect["QuirkAdd"] and "using the ordered fold" in sect["QuirkAdd"]
+        for name in sect:
+            assert "results-ok" in sect[name], (tiles, name)
 
 
 @pytest.mark.gpu
