@@ -247,13 +247,32 @@ def main():
         _lib.check(L.gm_set_option(b"tile_min_row", args.tile_min_row))
     # ---- synthetic input, generated in HBM ------------------------------------------------
     t0 = time.time()
-    nv, src, dst, _ = api.rmat_on_device(args.scale, args.edge_factor, args.seed, weights=False, device=local_rank)
-    E = src.numel()
+    # N > 1 with the library's own communicator: distributed build -- every rank generates 1/N of the edge list and
+    # the library hands each edge to the shard that owns its row (gm_graph_desc_t.edges_local), so no rank ever
+    # holds or sorts the whole graph.  Without the communicator (gloo, GM_BENCH_EXCHANGE=python): whole list per rank.
+    want_native = world > 1 and (backend == "nccl" or os.environ.get("GRAPHMAT_DIST_TRANSPORT") == "shm") and \
+        os.environ.get("GM_BENCH_EXCHANGE", "rccl") == "rccl"
+    have_comm = False
+    if want_native:
+        from graphmat_amd import dist as gdist
+        ok = 1
+        try:
+            gdist.init_native_rccl(device=dev)
+        except Exception as e:  # pragma: no cover
+            log(rank, "native RCCL communicator unavailable: %r" % (e,))
+            ok = 0
+        okt = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        have_comm = int(okt.item()) == 1
+    local_build = have_comm and not args.native_layout and os.environ.get("GM_BENCH_BUILD", "local") == "local"
+    nv, src, dst, _ = api.rmat_on_device(args.scale, args.edge_factor, args.seed, weights=False, device=local_rank,
+                                         part=((rank, world) if local_build else None))
+    E = args.edge_factor * nv
     nparts = args.ref_threads * 16
     # device order chosen by the library: degree-ranked, dealt over the `world` shards
     g = api.Graph(nv, src, dst, None, ref_threads=args.ref_threads, device=local_rank, keep_values=False,
                   layout=(_lib.GM_LAYOUT_NATIVE if args.native_layout else _lib.GM_LAYOUT_DEGREE), nshards=world, shard=rank,
-                  col_tiles=(args.col_tiles if args.col_tiles >= 0 else 0))
+                  col_tiles=(args.col_tiles if args.col_tiles >= 0 else 0), edges_local=local_build)
     S = g.row_hi - g.row_lo
     ranges = [(r * S, (r + 1) * S) for r in range(world)] if world > 1 else [(0, g.ndevice)]
     del src, dst
@@ -261,8 +280,9 @@ def main():
     torch.cuda.synchronize()
     build_s = time.time() - t0
     c_out = g.csr(api.GM_DIR_OUT)
-    log(rank, "RMAT-%d V=%d E=%d built in %.1fs; rank0 rows [%d,%d) nnz=%d blocks=%d wave_rows=%d giant_rows=%d" % (
-        args.scale, nv, E, build_s, ranges[rank][0], ranges[rank][1], c_out.nnz, c_out.nblk, c_out.nmid, c_out.ngiant))
+    log(rank, "RMAT-%d V=%d E=%d built in %.1fs%s; rank0 rows [%d,%d) nnz=%d blocks=%d wave_rows=%d giant_rows=%d" % (
+        args.scale, nv, E, build_s, " (distributed: each rank generated E/%d edges)" % world if local_build else "",
+        ranges[rank][0], ranges[rank][1], c_out.nnz, c_out.nblk, c_out.nmid, c_out.ngiant))
 
     ex = None
     # N > 1.  The message buffers are torch tensors adopted by the library, so either exchange
@@ -287,11 +307,9 @@ def main():
         _lib.check(L.gm_graph_set_exchange(g.h, cb, None))
         # (GRAPHMAT_DIST_TRANSPORT=shm: the library's shared-memory test transport, so that the native exchange code
         # can be tried with several ranks on a 1-GPU box next to GM_BENCH_BACKEND=gloo)
-        if (backend == "nccl" or os.environ.get("GRAPHMAT_DIST_TRANSPORT") == "shm") and os.environ.get("GM_BENCH_EXCHANGE", "rccl") == "rccl":
-            from graphmat_amd import dist as gdist
+        if have_comm:
             ok = 1
             try:
-                gdist.init_native_rccl(device=dev)
                 # the two implementations must produce the same bits: a few iterations each from the same state
                 st_a = g.new_pr_state()
                 g.run_degree(st_a)
@@ -489,6 +507,8 @@ def main():
                    "exchange_fell_back_to_broadcasts": bool(ex is not None and ex.no_fast_path and not native),
                    "device_order": "native" if args.native_layout else "degree-ranked, dealt over shards",
                    "col_tiles": int(g.col_tiles),
+                   "graph_build": ("distributed: each rank generates E/N edges, edges shuffled to the shard owning their row" if local_build
+                                   else ("every rank sorts the whole edge list" if world > 1 else "single GPU")),
                    "rows_per_shard": S, "exchanged_rows_per_shard": int(g.xchg_rows),
                    "max_in_degree_rank0": max_deg,
                    "giant_row_groups_replayed": int(cnt64[0]), "giant_row_groups_serial": int(cnt64[1])},

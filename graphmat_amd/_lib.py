@@ -24,7 +24,7 @@ class GraphDesc(C.Structure):
     _fields_ = [("nvertices", C.c_int32), ("nparts", C.c_int32), ("row_lo", C.c_int32), ("row_hi", C.c_int32),
                 ("directions", C.c_int32), ("val_bytes", C.c_int32), ("ids_on_device", C.c_int32),
                 ("ids_are_native", C.c_int32), ("layout", C.c_int32), ("nshards", C.c_int32), ("shard", C.c_int32),
-                ("ndevice", C.c_int32), ("xchg_rows", C.c_int32), ("col_tiles", C.c_int32)]
+                ("ndevice", C.c_int32), ("xchg_rows", C.c_int32), ("col_tiles", C.c_int32), ("edges_local", C.c_int32)]
 
 
 class Csr(C.Structure):

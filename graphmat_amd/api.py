@@ -36,8 +36,10 @@ def _stream():
 class Graph:
     def __init__(self, nv, src, dst, val=None, ref_threads=1, directions=GM_DIR_OUT | GM_DIR_IN, device=0,
                  row_range=None, keep_values=True, nranks_layout=1, layout=GM_LAYOUT_DEGREE, nshards=1, shard=0,
-                 col_tiles=0):
+                 col_tiles=0, edges_local=False):
         """src/dst: 1-based ids, numpy (host) or torch.cuda int32 tensors (device).
+        edges_local: src/dst/val are this rank's PART of the edge list (distributed build over the
+        library's communicator, dist.init_native_rccl; graphmat_hip.h gm_graph_desc_t.edges_local).
 
         layout GM_LAYOUT_DEGREE (default): the library picks the device order (degree-ranked,
         dealt over `nshards`); GM_LAYOUT_NATIVE: device order = native order, optional
@@ -73,7 +75,7 @@ class Graph:
             nnz = src.size
         self.nnz_input = int(nnz)
         d = _lib.GraphDesc(self.nv, self.nparts, int(lo), int(hi), directions, 4 if vp else 0,
-                           1 if on_dev else 0, 0, layout, nshards, shard, 0, 0, int(col_tiles))
+                           1 if on_dev else 0, 0, layout, nshards, shard, 0, 0, int(col_tiles), 1 if edges_local else 0)
         h = C.c_void_p()
         check(self.L.gm_graph_create(C.byref(h), C.byref(d), nnz, sp, dp, vp, _stream()))
         self.h = h
@@ -269,15 +271,21 @@ def copy_from_device(host_array, dev_ptr):
         raise RuntimeError("hipMemcpy failed: %d" % rc)
 
 
-def rmat_on_device(scale, edge_factor=16, seed=1, weights=False, device=0):
-    """RMAT edges generated in HBM (bit-identical to generators.rmat_edges)."""
+def rmat_on_device(scale, edge_factor=16, seed=1, weights=False, device=0, part=None):
+    """RMAT edges generated in HBM (bit-identical to generators.rmat_edges).
+    part=(i, n): only the i-th of n consecutive chunks of the edge list (a rank's part of a distributed build)."""
     L = _lib.lib()
     dev = torch.device("cuda", device)
     nv = 1 << scale
-    ne = edge_factor * nv
+    total = edge_factor * nv
+    first, ne = 0, total
+    if part is not None:
+        i, n = part
+        first = total * i // n
+        ne = total * (i + 1) // n - first
     src = torch.empty(ne, dtype=torch.int32, device=dev)
     dst = torch.empty(ne, dtype=torch.int32, device=dev)
     val = torch.empty(ne, dtype=torch.int32, device=dev) if weights else None
-    check(L.gm_rmat_generate(scale, seed, 0, ne, src.data_ptr(), dst.data_ptr(),
+    check(L.gm_rmat_generate(scale, seed, first, ne, src.data_ptr(), dst.data_ptr(),
                              val.data_ptr() if weights else None, 1 if weights else 0, _stream()))
     return nv, src, dst, val

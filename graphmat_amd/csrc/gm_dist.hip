@@ -119,7 +119,32 @@ static ncclResult_t shm_all_gather(const void* send, void* recv, size_t count, n
   }
   return ncclSuccess;
 }
+// sum of 32-bit integer arrays (the degree counts of a distributed graph build), a chunk of the segment at a time
+static ncclResult_t shm_all_reduce_sum32(const void* send, void* recv, size_t count, hipStream_t s) {
+  const int n = g_shm.nranks, r = g_shm.rank;
+  if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
+  const size_t chunk = ((g_shm.data_bytes / (size_t)(n + 1)) & ~(size_t)63) / 4;  // words per rank slot (+1 result slot)
+  uint32_t* slots = (uint32_t*)g_shm.data;
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t len = count - off < chunk ? count - off : chunk;
+    if (hipMemcpy(slots + (size_t)r * chunk, (const uint32_t*)send + off, len * 4, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    shm_barrier();
+    if (r == 0) {
+      uint32_t* out = slots + (size_t)n * chunk;
+      for (size_t i = 0; i < len; i++) {
+        uint32_t a = slots[i];
+        for (int q = 1; q < n; q++) a += slots[(size_t)q * chunk + i];
+        out[i] = a;
+      }
+    }
+    shm_barrier();
+    if (hipMemcpy((uint32_t*)recv + off, slots + (size_t)n * chunk, len * 4, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    shm_barrier();
+  }
+  return ncclSuccess;
+}
 static ncclResult_t shm_all_reduce(const void* send, void* recv, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t, hipStream_t s) {
+  if ((t == ncclUint32 || t == ncclInt32) && op == ncclSum && count != 1) return shm_all_reduce_sum32(send, recv, count, s);
   if (t != ncclInt32 || count != 1 || (op != ncclMin && op != ncclMax && op != ncclSum)) return ncclInvalidArgument;
   if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
   int v = 0;
@@ -194,6 +219,27 @@ struct RcclExchange {
   long long calls = 0, parts = 0, sparse_gathers = 0;
   unsigned long long bytes_sent = 0;  // bytes this rank contributed to all-gathers
 };
+
+// ---- collectives of a distributed graph build (gm_graph.hip, gm_graph_desc_t.edges_local) ----------------
+int dist_world(int* rank, int* nranks) {
+  if (rank) *rank = g_comm ? g_rank : 0;
+  if (nranks) *nranks = g_comm ? g_nranks : 0;
+  return g_comm ? 1 : 0;
+}
+int dist_all_reduce_sum_u32(uint32_t* d, size_t n, hipStream_t s) {
+  if (!g_comm) { set_error("distributed build: call gm_dist_init first"); return GM_ERR_INVALID; }
+  if (n == 0 || g_nranks == 1) return GM_OK;
+  GM_TRY_NCCL(g_rccl.AllReduce(d, d, n, ncclUint32, ncclSum, g_comm, s));
+  return GM_OK;
+}
+// recv = the ranks' `bytes` bytes at d_send, in rank order (separate buffers)
+int dist_all_gather_bytes(const void* d_send, void* d_recv, size_t bytes, hipStream_t s) {
+  if (!g_comm) { set_error("distributed build: call gm_dist_init first"); return GM_ERR_INVALID; }
+  if (bytes == 0) return GM_OK;
+  if (g_nranks == 1) { GM_TRY_HIP(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, s)); return GM_OK; }
+  GM_TRY_NCCL(g_rccl.AllGather(d_send, d_recv, bytes, ncclChar, g_comm, s));
+  return GM_OK;
+}
 
 static int grow(void** p, size_t* have, size_t need) {
   if (*have >= need) return GM_OK;

@@ -350,6 +350,156 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   return rc;
 }
 
+// ---- distributed build (gm_graph_desc_t.edges_local): this rank holds a part of the edge list ----------
+// key = (row inside its owner's slice) << 32 | NATIVE col, owner = the shard whose slice holds the row
+__global__ void __launch_bounds__(kT)
+k_owner_keys(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t nnz, int by_dst, int nparts, int nv,
+             int S, int ids_are_native, const int32_t* __restrict__ dev_of_native, uint64_t* __restrict__ keys,
+             uint16_t* __restrict__ owner, uint32_t* __restrict__ pos) {
+  const int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (e >= nnz) return;
+  const int s = src[e], d = dst[e];
+  const int sn = ids_are_native ? s : to_native0(s, nparts, nv);
+  const int dn = ids_are_native ? d : to_native0(d, nparts, nv);
+  const int r = dev_of_native[by_dst ? dn : sn];
+  const int q = r / S;
+  keys[e] = ((uint64_t)(uint32_t)(r - q * S) << 32) | (uint32_t)(by_dst ? sn : dn);
+  owner[e] = (uint16_t)q;
+  pos[e] = (uint32_t)e;
+}
+// bounds[q] = first position of the sorted owner list whose owner is >= q  (q in [0, n_owners])
+__global__ void k_owner_bounds(const uint16_t* __restrict__ owner_sorted, int64_t n, int n_owners, int64_t* __restrict__ bounds) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q > n_owners) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int)owner_sorted[mid] < q) lo = mid + 1; else hi = mid;
+  }
+  bounds[q] = lo;
+}
+// the edges in bucket order (owner, then input position): keys and values ready to travel
+__global__ void __launch_bounds__(kT)
+k_bucket_gather(const uint64_t* __restrict__ keys, const void* __restrict__ val, int val_bytes, const uint32_t* __restrict__ pos,
+                int64_t n, uint64_t* __restrict__ keys_b, void* __restrict__ val_b) {
+  const int64_t j = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t p = pos[j];
+  keys_b[j] = keys[p];
+  if (val_b) {
+    if (val_bytes == 4) ((uint32_t*)val_b)[j] = ((const uint32_t*)val)[p];
+    else if (val_bytes == 8) ((uint64_t*)val_b)[j] = ((const uint64_t*)val)[p];
+    else {
+      const unsigned char* a = (const unsigned char*)val + (size_t)p * val_bytes;
+      unsigned char* b = (unsigned char*)val_b + (size_t)j * val_bytes;
+      for (int i = 0; i < val_bytes; i++) b[i] = a[i];
+    }
+  }
+}
+__global__ void __launch_bounds__(kT)
+k_iota(uint32_t* __restrict__ a, int64_t n) {
+  const int64_t j = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (j < n) a[j] = (uint32_t)j;
+}
+
+// One direction from this rank's part of the edges: bucket them by the shard that owns their row, hand every
+// shard its bucket (one padded all-gather per owner; a rank keeps what is addressed to it, in rank order, so
+// duplicates of an edge stay in "rank, then input position" order), sort what arrived, build the CSR.
+static int build_direction_local(gm_graph* g, int by_dst, int64_t nnz, const int32_t* d_src, const int32_t* d_dst,
+                                 const void* d_val, hipStream_t s, CsrOwned* out) {
+  const gm_graph_desc_t& D = g->desc;
+  // (whether values travel is a property of the graph, not of this rank's part: a rank without edges may pass no array)
+  const int N = D.nshards, me = D.shard, S = D.row_hi - D.row_lo, vb = D.val_bytes > 0 ? D.val_bytes : 0;
+  const int64_t missing_vals = (vb && nnz > 0 && !d_val) ? 1 : 0;
+  int rc;
+  DevBuf keys, owner_in, owner_out, pos_in, pos_out, tmp, bounds_d, send_k, send_v;
+  std::vector<int64_t> bounds((size_t)N + 1, 0);
+  if (nnz > 0) {
+    if ((rc = keys.alloc((size_t)nnz * 8)) || (rc = owner_in.alloc((size_t)nnz * 2)) || (rc = owner_out.alloc((size_t)nnz * 2)) ||
+        (rc = pos_in.alloc((size_t)nnz * 4)) || (rc = pos_out.alloc((size_t)nnz * 4)) || (rc = bounds_d.alloc((size_t)(N + 1) * 8)))
+      return rc;
+    hipLaunchKernelGGL(k_owner_keys, dim3(grid_for(nnz)), dim3(kT), 0, s, d_src, d_dst, nnz, by_dst, D.nparts, D.nvertices, S,
+                       D.ids_are_native, (const int32_t*)g->dev_of_native, keys.as<uint64_t>(), owner_in.as<uint16_t>(),
+                       pos_in.as<uint32_t>());
+    size_t tb = 0;
+    const unsigned ob = (unsigned)std::max(1, bits_for((uint32_t)(N - 1)));
+    GM_TRY_HIP(rocprim::radix_sort_pairs(nullptr, tb, owner_in.as<uint16_t>(), owner_out.as<uint16_t>(), pos_in.as<uint32_t>(),
+                                         pos_out.as<uint32_t>(), (size_t)nnz, 0u, ob, s));
+    if ((rc = tmp.alloc(tb))) return rc;
+    GM_TRY_HIP(rocprim::radix_sort_pairs(tmp.p, tb, owner_in.as<uint16_t>(), owner_out.as<uint16_t>(), pos_in.as<uint32_t>(),
+                                         pos_out.as<uint32_t>(), (size_t)nnz, 0u, ob, s));
+    hipLaunchKernelGGL(k_owner_bounds, dim3((N + 1 + 63) / 64), dim3(64), 0, s, (const uint16_t*)owner_out.as<uint16_t>(), nnz, N,
+                       bounds_d.as<int64_t>());
+    GM_TRY_HIP(hipMemcpyAsync(bounds.data(), bounds_d.p, (size_t)(N + 1) * 8, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+  }
+  // cnt[p * N + q] = edges on rank p whose row shard q owns
+  std::vector<int64_t> mine((size_t)N + 1), cnt((size_t)N * N), bytes((size_t)N);
+  for (int q = 0; q < N; q++) mine[(size_t)q] = bounds[(size_t)q + 1] - bounds[(size_t)q];
+  mine[(size_t)N] = missing_vals;
+  {
+    void* all = nullptr;
+    if ((rc = gm_dist_allgatherv_host(mine.data(), (int64_t)(N + 1) * 8, &all, bytes.data())) != GM_OK) return rc;
+    int64_t bad = 0;
+    for (int p = 0; p < N; p++) {
+      memcpy(&cnt[(size_t)p * N], (const int64_t*)all + (size_t)p * (N + 1), (size_t)N * 8);
+      bad += ((const int64_t*)all)[(size_t)p * (N + 1) + N];
+    }
+    gm_host_free(all);
+    if (bad) { set_error("gm_graph_create: val_bytes = %d but %lld rank(s) passed edges without values", vb, (long long)bad); return GM_ERR_INVALID; }
+  }
+  int64_t maxm = 0, kept = 0;
+  for (int q = 0; q < N; q++)
+    for (int p = 0; p < N; p++) maxm = std::max(maxm, cnt[(size_t)p * N + q]);
+  for (int p = 0; p < N; p++) kept += cnt[(size_t)p * N + me];
+  if (kept >= (1ll << 32)) { set_error("gm_graph_create: shard %d would hold more than 2^32-1 edges", me); return GM_ERR_UNSUPPORTED; }
+  // send buffers in bucket order, padded so that a full-size block can be read from every bucket start
+  if ((rc = send_k.alloc((size_t)(nnz + maxm) * 8)) || (vb && (rc = send_v.alloc((size_t)(nnz + maxm) * vb)))) return rc;
+  if (nnz > 0)
+    hipLaunchKernelGGL(k_bucket_gather, dim3(grid_for(nnz)), dim3(kT), 0, s, (const uint64_t*)keys.as<uint64_t>(), d_val, vb,
+                       (const uint32_t*)pos_out.as<uint32_t>(), nnz, send_k.as<uint64_t>(), vb ? send_v.p : nullptr);
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  keys.alloc(0); owner_in.alloc(0); owner_out.alloc(0); pos_in.alloc(0); pos_out.alloc(0); tmp.alloc(0);
+  DevBuf rk_in, rk_out, ri_in, ri_out, rvals, gk, gv;
+  if ((rc = rk_in.alloc((size_t)kept * 8)) || (rc = gk.alloc((size_t)N * maxm * 8)) ||
+      (vb && ((rc = rvals.alloc((size_t)kept * vb)) || (rc = gv.alloc((size_t)N * maxm * vb)))))
+    return rc;
+  for (int q = 0; q < N; q++) {
+    int64_t m = 0;
+    for (int p = 0; p < N; p++) m = std::max(m, cnt[(size_t)p * N + q]);
+    if (m == 0) continue;
+    if ((rc = dist_all_gather_bytes(send_k.as<uint64_t>() + bounds[(size_t)q], gk.p, (size_t)m * 8, s))) return rc;
+    if (vb && (rc = dist_all_gather_bytes((const char*)send_v.p + (size_t)bounds[(size_t)q] * vb, gv.p, (size_t)m * vb, s))) return rc;
+    if (q == me) {
+      int64_t off = 0;
+      for (int p = 0; p < N; p++) {
+        const int64_t c = cnt[(size_t)p * N + me];
+        if (c > 0) {
+          GM_TRY_HIP(hipMemcpyAsync(rk_in.as<uint64_t>() + off, gk.as<uint64_t>() + (size_t)p * m, (size_t)c * 8, hipMemcpyDeviceToDevice, s));
+          if (vb) GM_TRY_HIP(hipMemcpyAsync((char*)rvals.p + (size_t)off * vb, (const char*)gv.p + (size_t)p * m * vb, (size_t)c * vb, hipMemcpyDeviceToDevice, s));
+        }
+        off += c;
+      }
+    }
+    GM_TRY_HIP(hipStreamSynchronize(s));  // the gather buffers are reused by the next owner
+  }
+  gk.alloc(0); gv.alloc(0); send_k.alloc(0); send_v.alloc(0);
+  if ((rc = rk_out.alloc((size_t)kept * 8)) || (rc = ri_in.alloc((size_t)kept * 4)) || (rc = ri_out.alloc((size_t)kept * 4))) return rc;
+  if (kept > 0) {
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(kept)), dim3(kT), 0, s, ri_in.as<uint32_t>(), kept);
+    size_t tb = 0;
+    const unsigned end_bit = 32 + (unsigned)bits_for((uint32_t)S);
+    GM_TRY_HIP(rocprim::radix_sort_pairs(nullptr, tb, rk_in.as<uint64_t>(), rk_out.as<uint64_t>(), ri_in.as<uint32_t>(),
+                                         ri_out.as<uint32_t>(), (size_t)kept, 0u, end_bit, s));
+    if ((rc = tmp.alloc(tb))) return rc;
+    GM_TRY_HIP(rocprim::radix_sort_pairs(tmp.p, tb, rk_in.as<uint64_t>(), rk_out.as<uint64_t>(), ri_in.as<uint32_t>(),
+                                         ri_out.as<uint32_t>(), (size_t)kept, 0u, end_bit, s));
+  }
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  rk_in.alloc(0); ri_in.alloc(0); tmp.alloc(0);
+  return finish_csr(g, rk_out.as<uint64_t>(), ri_out.as<uint32_t>(), (unsigned long long)kept, vb ? rvals.p : nullptr, s, out, -1);
+}
+
 // CSR arrays and work decomposition from `kept` sorted keys (row << 32 | native col) and, for the
 // edge values, the input position of every sorted edge.
 // tile_split >= 0 (whole-graph CSR of a tiled graph): also list the wave rows of at most tile_split edges.
@@ -674,6 +824,7 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
   if (nnz > 0)
     hipLaunchKernelGGL(k_degree, dim3(grid_for(nnz)), dim3(kT), 0, s, d_src, d_dst, nnz, D.nparts, nv, D.ids_are_native,
                        deg.as<uint32_t>(), g_rank_by);
+  if (D.edges_local && (rc = dist_all_reduce_sum_u32(deg.as<uint32_t>(), (size_t)nv, s))) return rc;  // counts of all parts
   hipLaunchKernelGGL(k_rank_keys, dim3(grid_for(nv)), dim3(kT), 0, s, deg.as<uint32_t>(), nv, keys_in.as<uint32_t>(),
                      ids_in.as<int32_t>(), (uint32_t)(g_rank_by == 0 ? g_rank_cap : 0));
   size_t tb = 0;
@@ -847,6 +998,16 @@ int gm_graph_create(gm_graph_t** gout, const gm_graph_desc_t* desc, int64_t nnz,
     return GM_ERR_INVALID;
   }
   if (nnz >= (1ll << 32)) { gm::set_error("gm_graph_create: more than 2^32-1 edges per call is unsupported"); return GM_ERR_UNSUPPORTED; }
+  if (desc->edges_local) {
+    int wr = 0, wn = 0;
+    if (desc->layout != GM_LAYOUT_DEGREE) { gm::set_error("gm_graph_create: edges_local needs GM_LAYOUT_DEGREE"); return GM_ERR_INVALID; }
+    if (desc->nshards > 65535) { gm::set_error("gm_graph_create: edges_local supports at most 65535 shards"); return GM_ERR_UNSUPPORTED; }
+    if (!gm::dist_world(&wr, &wn) || wn != desc->nshards || wr != desc->shard) {
+      gm::set_error("gm_graph_create: edges_local is a collective over the gm_dist communicator (have rank %d of %d, graph is shard %d of %d)",
+                    wr, wn, desc->shard, desc->nshards);
+      return GM_ERR_INVALID;
+    }
+  }
   hipStream_t s = (hipStream_t)stream;
   gm_graph* g = new gm_graph();
   memset((void*)g, 0, sizeof(*g));
@@ -900,8 +1061,13 @@ int gm_graph_create(gm_graph_t** gout, const gm_graph_desc_t* desc, int64_t nnz,
   if (desc->layout == GM_LAYOUT_DEGREE) rc = gm::build_degree_layout(g, nnz, d_src, d_dst, s);
   else g->desc.col_tiles = 1;
   if (rc != GM_OK) { gm_graph_destroy(g); return rc; }
-  if (desc->directions & GM_DIR_OUT) rc = gm::build_direction(g, 1, nnz, d_src, d_dst, d_val, s, &g->out);
-  if (rc == GM_OK && (desc->directions & GM_DIR_IN)) rc = gm::build_direction(g, 0, nnz, d_src, d_dst, d_val, s, &g->in);
+  if (desc->edges_local) {
+    if (desc->directions & GM_DIR_OUT) rc = gm::build_direction_local(g, 1, nnz, d_src, d_dst, d_val, s, &g->out);
+    if (rc == GM_OK && (desc->directions & GM_DIR_IN)) rc = gm::build_direction_local(g, 0, nnz, d_src, d_dst, d_val, s, &g->in);
+  } else {
+    if (desc->directions & GM_DIR_OUT) rc = gm::build_direction(g, 1, nnz, d_src, d_dst, d_val, s, &g->out);
+    if (rc == GM_OK && (desc->directions & GM_DIR_IN)) rc = gm::build_direction(g, 0, nnz, d_src, d_dst, d_val, s, &g->in);
+  }
   if (rc != GM_OK) { gm_graph_destroy(g); return rc; }
   if (g->out.present && g->in.present) {
     const int nw = (g->desc.row_hi - g->desc.row_lo + 31) / 32 + 2;

@@ -92,4 +92,10 @@ struct gm_graph {
   void* native_xchg;
   hipStream_t run_stream;       // the stream of the run in progress (gm_graph_set_run_stream): collectives are enqueued on it
 };
-namespace gm { void free_native_exchange(gm_graph* g); }
+namespace gm {
+void free_native_exchange(gm_graph* g);
+// collectives over the gm_dist communicator for a distributed graph build (gm_dist.hip)
+int dist_world(int* rank, int* nranks);  // 1 when a communicator exists
+int dist_all_reduce_sum_u32(uint32_t* d, size_t n, hipStream_t s);
+int dist_all_gather_bytes(const void* d_send, void* d_recv, size_t bytes, hipStream_t s);
+}

@@ -333,36 +333,26 @@ void Graph<V, E>::ReadEdgelist(GraphMat::edgelist_t<E> A_edges) {
     dst[i] = A_edges.edges[i].dst;
     val[i] = A_edges.edges[i].val;
   }
+  long long ne_global = (long long)ne;
   if (tiles_per_dim > 1) {
     // Several ranks: every rank holds the edges it read (the reference's loader gives rank r the files
-    // <prefix>r, <prefix>r+nranks, ...; GMDP then shuffles edges to their tiles, SpMat.h:422-443).  Here every
-    // rank needs the whole list -- the degree ranking is global and a shard keeps the rows it owns -- so the
-    // per-rank lists are all-gathered (concatenated in rank order: duplicates keep a defined order).
+    // <prefix>r, <prefix>r+nranks, ...; GMDP then shuffles edges to their tiles, SpMat.h:422-443).  Here the
+    // library does the shuffle (gm_graph_desc_t.edges_local): degree counts are all-reduced, each edge travels to
+    // the shard owning its row, duplicates keep the order "rank, then position".  Only m, n and the edge count are
+    // combined here -- the reference's MPI_Allreduce(MAX) over m and n (edgelist.h:279-284).
     static_assert(std::is_trivially_copyable<E>::value, "edge values travel between ranks as bytes");
     std::vector<int64_t> counts((size_t)tiles_per_dim);
-    auto gather = [&](const void* mine, size_t bytes, std::vector<char>& out) {
-      void* all = nullptr;
-      if (gm_dist_allgatherv_host(mine, (int64_t)bytes, &all, counts.data()) != GM_OK) { printf("GraphMat(HIP): %s\n", gm_last_error()); exit(1); }
-      size_t total = 0;
-      for (int64_t c : counts) total += (size_t)c;
-      out.assign((char*)all, (char*)all + total);
-      gm_host_free(all);
-    };
-    std::vector<char> as, ad, av, am;
-    gather(src.data(), ne * 4, as);
-    gather(dst.data(), ne * 4, ad);
-    gather((const void*)val.data(), ne * sizeof(E), av);
-    const int mn[2] = {A_edges.m, A_edges.n};
-    gather(mn, sizeof(mn), am);
-    ne = as.size() / 4;
-    src.assign((const int32_t*)as.data(), (const int32_t*)as.data() + ne);
-    dst.assign((const int32_t*)ad.data(), (const int32_t*)ad.data() + ne);
-    val.resize(ne);
-    if (ne) memcpy((void*)val.data(), av.data(), ne * sizeof(E));
-    for (size_t i = 0; i + 1 < am.size() / 4; i += 2) {  // the reference's MPI_Allreduce(MAX) over m and n (edgelist.h:279-284)
-      A_edges.m = std::max(A_edges.m, ((const int*)am.data())[i]);
-      A_edges.n = std::max(A_edges.n, ((const int*)am.data())[i + 1]);
+    const long long mine[3] = {A_edges.m, A_edges.n, (long long)ne};
+    void* all = nullptr;
+    if (gm_dist_allgatherv_host(mine, (int64_t)sizeof(mine), &all, counts.data()) != GM_OK) { printf("GraphMat(HIP): %s\n", gm_last_error()); exit(1); }
+    ne_global = 0;
+    for (int r = 0; r < tiles_per_dim; r++) {
+      const long long* o = (const long long*)all + 3 * r;
+      A_edges.m = std::max(A_edges.m, (int)o[0]);
+      A_edges.n = std::max(A_edges.n, (int)o[1]);
+      ne_global += o[2];
     }
+    gm_host_free(all);
     A_edges.m = A_edges.n = std::max(A_edges.m, A_edges.n);
   }
   gm_graph_desc_t d;
@@ -377,7 +367,10 @@ void Graph<V, E>::ReadEdgelist(GraphMat::edgelist_t<E> A_edges) {
   d.layout = (lay && !strcmp(lay, "native")) ? GM_LAYOUT_NATIVE : GM_LAYOUT_DEGREE;
   d.nshards = tiles_per_dim;
   d.shard = myrank;
-  if (tiles_per_dim > 1) d.layout = GM_LAYOUT_DEGREE;  // (shards are slices of the degree-ranked order)
+  if (tiles_per_dim > 1) {
+    d.layout = GM_LAYOUT_DEGREE;  // (shards are slices of the degree-ranked order)
+    d.edges_local = 1;
+  }
   if (A && adjacencyowner) gm_graph_destroy(A);
   A = AT = nullptr;
   if (gm_graph_create(&A, &d, (int64_t)ne, src.data(), dst.data(), val.data(), nullptr) != GM_OK) {
@@ -389,7 +382,7 @@ void Graph<V, E>::ReadEdgelist(GraphMat::edgelist_t<E> A_edges) {
   dev_of_native.assign((size_t)A_edges.m, 0);
   gm_graph_maps_to_host(A, dev_of_native.data(), nullptr);
   nvertices = A_edges.m;
-  nnz = (long long)ne;
+  nnz = ne_global;
   gm_graph_desc(A, &d);
   row_lo = d.row_lo;
   row_hi = d.row_hi;

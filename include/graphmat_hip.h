@@ -135,6 +135,14 @@ typedef struct {
                             none up to RMAT-25, 4 at RMAT-26, 8 at RMAT-27), 1 = none, 2..GM_MAX_TILES = that many.
                             GM_LAYOUT_DEGREE with one shard only (ignored otherwise).  Output: the number of tiles
                             built (1 = none).                                                                 */
+  int32_t edges_local;   /* 0: every rank passes the whole edge list (edges of other shards' rows are dropped).
+                            1: distributed build -- this rank passes only ITS part of the edge list (any disjoint
+                            split; duplicates of an edge keep the order "rank, then position" in which the parts
+                            would be concatenated).  Collective over the gm_dist communicator, which must have
+                            nshards ranks with this process as rank `shard`; GM_LAYOUT_DEGREE only.  The degree
+                            counts are summed over the ranks (all-reduce), every rank derives the same ranking,
+                            and each edge travels to the shard that owns its row per direction, so a rank sorts
+                            and keeps ~1/nshards of the edges and never holds the whole list.                    */
 } gm_graph_desc_t;
 
 /* One direction of the adjacency as laid out in HBM (see DESIGN.md "data layout"). */
@@ -198,8 +206,9 @@ typedef struct {
 
 /* src/dst: 1-based vertex ids as in the .mtx (or native ids, see desc).  Edges whose
  * row falls outside the shard are dropped per direction, so every rank passes the full
- * edge list (GM_LAYOUT_DEGREE needs it to rank the vertices).  The input arrays are not
- * modified. */
+ * edge list (GM_LAYOUT_DEGREE needs it to rank the vertices) -- unless desc->edges_local is
+ * set, in which case the call is a collective and each rank passes its own part.  The input
+ * arrays are not modified. */
 int gm_graph_create(gm_graph_t** g, const gm_graph_desc_t* desc, int64_t nnz, const int32_t* src,
                     const int32_t* dst, const void* val, gm_stream_t stream);
 int gm_graph_destroy(gm_graph_t* g);

@@ -66,3 +66,32 @@ def test_native_exchange_several_ranks_over_shared_memory(world):
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env, cwd=ROOT)
     text = out.stdout.decode()
     assert out.returncode == 0 and "MULTI_OK" in text and "native-rccl" in text, text[-3000:]
+
+
+def test_bench_two_ranks_distributed_build_and_native_exchange():
+    """bench.py as the driver launches it at N > 1 (torch.distributed.run, one rank per process), on this 1-GPU box with
+    gloo for torch.distributed and the library's shared-memory transport for its own communicator: every rank generates
+    half of the edge list, the library shuffles the edges to their shards (gm_graph_desc_t.edges_local), the native
+    exchange is cross-checked against the callback inside bench.py, and the JSON line says what ran.  The value must
+    match a run that builds every shard from the whole edge list (GM_BENCH_BUILD=whole) in everything but timing."""
+    import json
+    from graphmat_amd import build
+    build.build()
+    lines = {}
+    for mode in ("local", "whole"):
+        env = dict(os.environ, GM_BENCH_BACKEND="gloo", GRAPHMAT_DIST_TRANSPORT="shm", GM_BENCH_BUILD=mode)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "16", "--steps", "3",
+               "--warmup", "1", "--cpu-scale", "0"]
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env, cwd=ROOT)
+        text = out.stdout.decode()
+        assert out.returncode == 0, (text + out.stderr.decode())[-3000:]
+        js = [json.loads(l) for l in text.splitlines() if l.startswith("{")]
+        assert len(js) == 1, text[-2000:]
+        lines[mode] = js[0]
+    a, b = lines["local"], lines["whole"]
+    assert a["n_gpus"] == 2 and a["config"]["graph_build"].startswith("distributed") and "native exchange" in a["config"]["exchange"]
+    assert b["config"]["graph_build"].startswith("every rank sorts")
+    for k in ("E", "V", "rows_per_shard", "exchanged_rows_per_shard", "max_in_degree_rank0"):
+        assert a["config"][k] == b["config"][k], k
+    assert a["value"] > 0 and a["steps"] == 3

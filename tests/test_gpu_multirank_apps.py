@@ -27,9 +27,15 @@ def _launch(exe, args, nranks, tmp_path, transport):
             env["GRAPHMAT_DIST_TRANSPORT"] = transport
         procs.append(subprocess.Popen([exe] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env))
     outs = []
-    for p in procs:
-        out, _ = p.communicate(timeout=600)
-        outs.append(out.decode())
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=240)
+            outs.append(out.decode())
+    except subprocess.TimeoutExpired:
+        for p in procs:  # a rank stuck in a collective would otherwise outlive the test
+            if p.poll() is None:
+                p.kill()
+        raise
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
     return outs

@@ -97,6 +97,39 @@ def main():
     if not this:
         print("rank %d: SSSP differs from the oracle (%d vs %d iterations, %d mismatches)" % (rank, its, oits, int((dist_ != odist).sum())), flush=True)
     ok &= this
+    if native:
+        # distributed build: every rank passes an uneven, consecutive part of the edge list (a block of edges
+        # appears twice with different values, the copies on different ranks); the shard it builds must equal,
+        # array for array, the one built from the whole list
+        dup = slice(len(s) // world - 40, len(s) // world + 40) if world > 1 else slice(100, 180)
+        s2, d2 = np.concatenate([s, s[dup]]), np.concatenate([d, d[dup]])
+        v2 = np.concatenate([v, (v[dup] + 3).astype(v.dtype)])
+        cuts = [0] + [len(s2) * (r + 1) // world + (17 if r + 1 < world else 0) for r in range(world)]
+        mine = slice(cuts[rank], cuts[rank + 1])
+        g_all = api.Graph(nv, s2, d2, v2, ref_threads=2, device=device, layout=api.GM_LAYOUT_DEGREE, nshards=world, shard=rank)
+        for variant in ("host", "device", "all-on-rank-0"):
+            on_device = variant == "device"
+            if variant == "all-on-rank-0":  # (what the C++ loader does with a single input file: the other ranks pass nothing)
+                mine = slice(0, len(s2)) if rank == 0 else slice(0, 0)
+            part = [torch.from_numpy(a[mine].copy()).to(torch.device("cuda", device)) if on_device else a[mine] for a in (s2, d2, v2)]
+            g_loc = api.Graph(nv, part[0], part[1], part[2], ref_threads=2, device=device, layout=api.GM_LAYOUT_DEGREE, nshards=world,
+                              shard=rank, edges_local=True)
+            same = (g_loc.row_lo, g_loc.row_hi, g_loc.ndevice, g_loc.xchg_rows) == (g_all.row_lo, g_all.row_hi, g_all.ndevice, g_all.xchg_rows)
+            same &= all(bool(np.array_equal(a, b)) for a, b in zip(g_loc.maps_to_host(), g_all.maps_to_host()))
+            for direction in (api.GM_DIR_OUT, api.GM_DIR_IN):
+                for a, b in zip(g_loc.csr_to_host(direction), g_all.csr_to_host(direction)):
+                    same &= bool(np.array_equal(a, b))
+            attach(g_loc)
+            pr_loc, _, _ = g_loc.pagerank(4)
+            if on_device:
+                attach(g_all)
+                pr_all, _, _ = g_all.pagerank(4)
+                same &= bool((pr_loc.view(np.uint32) == pr_all.view(np.uint32)).all())
+            if not same:
+                print("rank %d: distributed build (%s) differs from the whole-list build" % (rank, variant), flush=True)
+            ok &= same
+            g_loc.close()
+        g_all.close()
     # SGD / RMSE with K=128 fp32 latent vectors (BASELINE config 5 shape) on a sharded bipartite
     # ratings graph: the dedicated kernels exchange 512-byte x rows; bit-exact against the oracle
     rng = np.random.default_rng(7)
