@@ -115,6 +115,12 @@ struct PhaseTimer {
 struct AuxStream {
   hipStream_t s = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
+  // defer: the giant-row passes launched next are not waited for by their launch_spmv call; whoever needs their
+  // rows calls wait_join (the two-stage schedule starts them before the tail stage and joins before the head apply)
+  bool defer = false;
+  void wait_join(hipStream_t main) {
+    if (s) (void)hipStreamWaitEvent(main, join, 0);
+  }
   void attach(void* stream, void* fork_ev, void* join_ev) {
     s = (hipStream_t)stream;
     fork = (hipEvent_t)fork_ev;
@@ -231,7 +237,8 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
                     AuxStream* aux, const uint32_t* want = nullptr, bool grouped = false, const uint32_t* xsum = nullptr) {
   constexpr int WPB = dev::kBlock / 64;  // rows (waves) per workgroup of k_spmv_wave
   if (A.nnz == 0) return;
-  const bool overlap = aux != nullptr && aux->s != nullptr && A.ngiant > 0 && (A.nblk > 0 || A.nmid > 0);
+  const bool defer = aux != nullptr && aux->s != nullptr && aux->defer;
+  const bool overlap = aux != nullptr && aux->s != nullptr && A.ngiant > 0 && (defer || A.nblk > 0 || A.nmid > 0);
   if (A.ngiant > 0) {
     hipStream_t gs = s;
     if (overlap) {
@@ -321,7 +328,7 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
     (*launches)++;
     if (timer) timer->mark(TAG_WAVE);
   }
-  if (overlap) GM_HIP_OK(hipStreamWaitEvent(s, aux->join, 0));
+  if (overlap && !defer) GM_HIP_OK(hipStreamWaitEvent(s, aux->join, 0));
 }
 
 // rk: REDUCE_* chosen for this run.  Programs with a declared kind only instantiate that one.
@@ -565,10 +572,21 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       At.nmid_long = Aout.nmid_long > ms ? Aout.nmid_long - ms : 0;
       Ah.nblk = bs; Ah.nmid = ms;
       Ah.nmid_long = Aout.nmid_long < ms ? Aout.nmid_long : ms;
+      // The giant rows belong to the head, but their serial chains are the longest thing in a shard's iteration (the
+      // hub row does not shrink with the number of shards): they start on the auxiliary stream before the TAIL stage
+      // and are joined only before the head rows are applied, so they overlap both stages' multiplies.
+      gm_csr_t Ag = Aout;
+      Ag.nblk = 0; Ag.nmid = 0; Ag.nmid_long = 0;
+      const bool early_giants = Aout.ngiant > 0 && aux.s != nullptr && !(debug_flags() & dev::DBG_LATE_GIANTS);
+      if (early_giants) { Ah.ngiant = 0; Ah.ngchunk = 0; }
       auto fail = [&](const char* what) { printf("GraphMat(HIP): %s\n", what); exit(1); };
-      auto stage = [&](const dev::ProgArg<P>& pa, const gm_csr_t& A, int r0, int r1, bool more) {
+      auto multiply = [&](const dev::ProgArg<P>& pa, const gm_csr_t& A) {
         if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, A, xcur, nullptr, d_vp, y, ybits, dev::ACC_STATIC_BITS, s, &st.spmv_launches, &timer, &aux, rk);
         else launch_spmv<P, T, U, V, E, false>(g, pa, A, xcur, nullptr, d_vp, y, ybits, dev::ACC_STATIC_BITS, s, &st.spmv_launches, &timer, &aux, rk);
+      };
+      auto stage = [&](const dev::ProgArg<P>& pa, const gm_csr_t& A, int r0, int r1, bool more, bool join_giants) {
+        multiply(pa, A);
+        if (join_giants) aux.wait_join(s);
         const int cnt = r1 - r0;
         const int ag = grid_for(cnt) < dev::kApplyMaxBlocks ? grid_for(cnt) : dev::kApplyMaxBlocks;
         hipLaunchKernelGGL((dev::k_apply<P, U, V, false>), dim3(ag), dim3(dev::kBlock), 0, s, pa, (const U*)(y + r0), Aout.rowbits + r0 / 32,
@@ -596,8 +614,13 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         dev::ProgArg<P> pa = dev::make_prog_arg(gp);
         const bool more = it + 1 < iterations;
         timer.mark(TAG_START);
-        stage(pa, At, rs, n_live, more);
-        stage(pa, Ah, 0, rs, more);
+        if (early_giants) {
+          aux.defer = true;
+          multiply(pa, Ag);
+          aux.defer = false;
+        }
+        stage(pa, At, rs, n_live, more, false);
+        stage(pa, Ah, 0, rs, more, early_giants);
         if (more && gm_graph_exchange(g, GM_XCHG_WAIT, xnext, (int64_t)sizeof(T), nullptr, nullptr) != 0) fail("message exchange wait failed");
         if (n_live < n) GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
         gp->do_every_iteration(it);

@@ -15,8 +15,12 @@ def main():
     ap.add_argument("--nshards", type=int, default=8)
     ap.add_argument("--shards", type=int, nargs="+", default=[0, 1, 7])
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--staged", action="store_true", help="also time the two-stage schedule of a sharded run (tail rows, then head "
+                    "rows, each multiplied / applied / sent separately) with an exchange that moves nothing, and the plain loop, by the wall clock")
     args = ap.parse_args()
-    from graphmat_amd import api
+    import time
+    from graphmat_amd import _lib, api
+    L = _lib.lib()
     nv, src, dst, _ = api.rmat_on_device(args.scale, 16, 1)
     for shard in args.shards:
         g = api.Graph(nv, src, dst, None, keep_values=False, nshards=args.nshards, shard=shard)
@@ -32,6 +36,36 @@ def main():
         print("shard %d of %d (RMAT-%d): %d edges, %d giant rows; per iteration: total %.3f ms = send %.3f + rowblock %.3f + wave %.3f + apply %.3f; "
               "giant passes %.3f ms (overlapped on the auxiliary stream)" % (shard, args.nshards, args.scale, c.nnz, c.ngiant, s["total_ms"] / k,
               s["send_ms"] / k, s["rowblock_ms"] / k, s["wave_ms"] / k, s["apply_ms"] / k, s["giant_ms"] / k), flush=True)
+        if args.staged:
+            # a do-nothing exchange makes the run "sharded": the engine picks the two-stage schedule (needs the second
+            # message buffer) or, with debug flag 128, the plain loop with one exchange per iteration
+            dev = torch.device("cuda", 0)
+            bufs = [torch.zeros(g.ndevice * 4 + 64, dtype=torch.uint8, device=dev), torch.zeros((g.ndevice + 31) // 32 + 2, dtype=torch.int32, device=dev),
+                    torch.zeros(g.ndevice * 4 + 64, dtype=torch.uint8, device=dev)]
+            for slot, b in zip((1, 2, 9), bufs):
+                _lib.check(L.gm_graph_adopt_workspace(g.h, slot, b.data_ptr(), b.numel() * b.element_size()))
+            calls = [0]
+
+            def nothing(ctx, kind, ptr, elt, bits, flag):
+                calls[0] += 1
+                return 0
+            cb = _lib.EXCHANGE_FN(nothing)
+            _lib.check(L.gm_graph_set_exchange(g.h, cb, None))
+            g.enable_timing(False)
+            res = {}
+            for name, flags in (("two-stage", 0), ("plain", 128), ("late", 4096)):
+                L.gm_set_option(b"debug_flags", flags)
+                g.run_pagerank(st, 3)
+                torch.cuda.synchronize()
+                calls[0] = 0
+                t0 = time.perf_counter()
+                g.run_pagerank(st, args.iters)
+                torch.cuda.synchronize()
+                res[name] = ((time.perf_counter() - t0) * 1e3 / args.iters, calls[0])
+            L.gm_set_option(b"debug_flags", 0)
+            print("   wall clock per iteration with a do-nothing exchange: two-stage schedule %.3f ms (%d exchange calls; %.3f ms when the giant rows "
+                  "start with the head stage), plain loop %.3f ms (%d)" % (res["two-stage"][0], res["two-stage"][1], res["late"][0], res["plain"][0], res["plain"][1]), flush=True)
+            del bufs
         g.close()
         del st
         torch.cuda.empty_cache()
