@@ -115,6 +115,10 @@ struct PhaseTimer {
 struct AuxStream {
   hipStream_t s = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
+  // long_rows: the long wave rows of the passes launched next also go to this stream, behind the giant passes (set by
+  // the column-tile loop: per tile the kernels are small and each ends with a tail of a few busy waves -- overlapping the
+  // one-wave-per-row kernel with the throughput-bound ones is worth 3 % at RMAT-26; untiled it costs 3-15 %)
+  bool long_rows = false;
   // defer: the giant-row passes launched next are not waited for by their launch_spmv call; whoever needs their
   // rows calls wait_join (the two-stage schedule starts them before the tail stage and joins before the head apply)
   bool defer = false;
@@ -239,11 +243,24 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
   if (A.nnz == 0) return;
   const bool defer = aux != nullptr && aux->s != nullptr && aux->defer;
   const bool overlap = aux != nullptr && aux->s != nullptr && A.ngiant > 0 && (defer || A.nblk > 0 || A.nmid > 0);
+  // The long wave rows (one wave each, serial in the row's length: the launch ends with a tail in which a few waves
+  // finish their rows on an otherwise idle chip) go to the auxiliary stream as well, behind the giant passes, while the
+  // throughput-bound row-block and 16-rows-per-wave kernels run on the main stream.
+  bool long_on_aux = false;
+  if constexpr (wave16_ok<U, USE_VP, RK>())
+    long_on_aux = aux != nullptr && aux->s != nullptr && aux->long_rows && !defer && !(grouped && want != nullptr) && A.nmid > 0 && A.nmid_long > 0 &&
+                  (A.nblk > 0 || A.nmid > A.nmid_long) && !(debug_flags() & dev::DBG_NO_WAVE16);
+  bool forked = false;
+  auto fork_aux = [&]() {
+    if (forked) return;
+    GM_HIP_OK(hipEventRecord(aux->fork, s));
+    GM_HIP_OK(hipStreamWaitEvent(aux->s, aux->fork, 0));
+    forked = true;
+  };
   if (A.ngiant > 0) {
     hipStream_t gs = s;
     if (overlap) {
-      GM_HIP_OK(hipEventRecord(aux->fork, s));
-      GM_HIP_OK(hipStreamWaitEvent(aux->s, aux->fork, 0));
+      fork_aux();
       gs = aux->s;
       if (timer) timer->aux_mark(gs);
     }
@@ -310,9 +327,20 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
       if constexpr (wave16_ok<U, USE_VP, RK>()) {
         // ordered folds: the long rows at the head of the list get a wave each, the rest are folded 16 to a wave
         const int nlong = A.nmid_long < A.nmid ? A.nmid_long : A.nmid;
-        if (nlong > 0)
-          hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, RK>), dim3((nlong + WPB - 1) / WPB), dim3(dev::kBlock), 0, s,
+        if (nlong > 0) {
+          hipStream_t ls = s;
+          if (long_on_aux) {
+            fork_aux();
+            ls = aux->s;
+            if (timer) timer->aux_mark(ls);
+          }
+          hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, RK>), dim3((nlong + WPB - 1) / WPB), dim3(dev::kBlock), 0, ls,
                              pa, A, A.mid_row, nlong, x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
+          if (long_on_aux) {
+            if (timer) timer->aux_mark(ls);
+            GM_HIP_OK(hipEventRecord(aux->join, ls));  // (re-recorded behind the giant passes' record: the wait below sees this one)
+          }
+        }
         const int rest = A.nmid - nlong;
         if (rest > 0) {
           const int groups = (rest + dev::kWaveRows - 1) / dev::kWaveRows;
@@ -326,9 +354,10 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
                          dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
                          debug_flags(), want);
     (*launches)++;
-    if (timer) timer->mark(TAG_WAVE);
+    if (timer && !long_on_aux) timer->mark(TAG_WAVE);
   }
-  if (overlap && !defer) GM_HIP_OK(hipStreamWaitEvent(s, aux->join, 0));
+  if ((overlap && !defer) || long_on_aux) GM_HIP_OK(hipStreamWaitEvent(s, aux->join, 0));
+  if (long_on_aux && timer) timer->mark(TAG_WAVE);  // the wave rows are done when both streams are
 }
 
 // rk: REDUCE_* chosen for this run.  Programs with a declared kind only instantiate that one.
@@ -514,7 +543,9 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   PhaseTimer timer(gm_graph_timing_enabled(g) != 0, s);
   AuxStream aux;
   tick("first frontier counted", (int)frontier_v);
-  if (!(debug_flags() & dev::DBG_NO_OVERLAP)) aux.attach(res_stream, res_fork, res_join);
+  if (!(debug_flags() & dev::DBG_NO_OVERLAP)) {
+    aux.attach(res_stream, res_fork, res_join);
+  }
 
   // row-filter bits (program_row_filter): one pass over the vertex properties now, kept current by k_apply
   uint32_t* d_want = nullptr;
@@ -873,6 +904,9 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
           if (Aout.tile_min_row == 0) { As.nblk = 0; As.nmid = 0; }  // every row is tiled
           if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, As, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk);
           else launch_spmv<P, T, U, V, E, false>(g, pa, As, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk);
+          // (running this untiled pass on a stream of its own next to the tile passes -- its rows are no tile's rows --
+          // was measured too: 7.06 -> 7.03 ms at RMAT-26, not worth a third stream)
+          aux.long_rows = !(debug_flags() & dev::DBG_LONG_ON_MAIN);
           for (int t = 0; t < ntile; t++) {
             gm_csr_t At;
             const uint32_t* prev = nullptr;
@@ -883,6 +917,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
             if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, At, xq, xb, d_vp, y, pb, tacc, s, &st.spmv_launches, &timer, &aux, rk);
             else launch_spmv<P, T, U, V, E, false>(g, pa, At, xq, xb, d_vp, y, pb, tacc, s, &st.spmv_launches, &timer, &aux, rk);
           }
+          aux.long_rows = false;
           // (a probed strategy is cross-checked against the ordered fold of the WHOLE rows; a mismatch redoes this
           // iteration untiled with the ordered fold, which then also governs the tiled iterations that follow)
           check_probed(Aout, Aout.rowbits, nullptr, acc, ybits);
