@@ -28,6 +28,7 @@ int g_giant_row = 0;  // 0 = choose per graph (see pick_giant_threshold)
 int g_rank_cap = 0;   // experiment: > 0 ranks only vertices of total degree >= cap; the others keep native order behind them
 int g_rank_by = 0;    // experiment: 0 rank vertices by total degree, 1 by out-degree, 2 by in-degree
 int g_tile_min_row = GM_TILE_MIN_ROW;  // rows of more than this many edges are tiled
+int g_long_mid = 0;  // > 0: experiment -- wave rows of more than this many edges get a wave each (0 = GM_LONG_MID rule)
 int g_col_tiles = 0;  // default number of column tiles for graphs whose descriptor says 0 (0 = environment GRAPHMAT_COL_TILES, else none)
 
 constexpr int kT = 256;
@@ -605,7 +606,7 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
     GM_TRY_HIP(hipMemsetAsync(cnt.p, 0, 4, s));
     // (with a million wave rows there are plenty of 16-row groups to keep the chip busy, and rows of up to
     // 4096 edges can be grouped too: RMAT-26 8.02 -> 7.87 ms; on RMAT-22 that limit costs 17 %)
-    const int64_t long_limit = nmid >= (1u << 20) ? 4 * (int64_t)GM_LONG_MID : (int64_t)GM_LONG_MID;
+    const int64_t long_limit = g_long_mid > 0 ? (int64_t)g_long_mid : nmid >= (1u << 20) ? 4 * (int64_t)GM_LONG_MID : (int64_t)GM_LONG_MID;
     if (g->ntiles > 1) {
       // tiled device order = (tile, degree rank): the long rows are no prefix of the row-ordered list,
       // so the list is partitioned instead: [long rows][the rest], each part in row order

@@ -383,7 +383,9 @@ int gm_run_sgd(gm_graph_t* g, void* d_latent, int K, int real_bytes, double lamb
 int gm_run_rmse(gm_graph_t* g, void* d_latent, int K, int real_bytes, gm_stream_t stream);
 
 /* runtime options.  "force_ordered" (0/1): run PageRank with the plain serial long-row fold
- * instead of the exact parallel replay (A/B check; results are bit-identical). */
+ * instead of the exact parallel replay (A/B check; results are bit-identical).  Graph-build experiments (read when a
+ * graph is created): "short_row", "giant_row", "rank_by", "rank_cap", "col_tiles", "tile_min_row", "long_mid" (wave rows
+ * of more than this many edges get a wave each instead of sharing one 16 to a wave; 0 = GM_LONG_MID rule). */
 int gm_set_option(const char* key, int value);
 
 /* ---- timing of the last gm_run_* call on this graph -------------------------------------
@@ -392,7 +394,9 @@ typedef struct {
   int32_t iterations;
   float send_ms, spmv_ms, apply_ms, total_ms; /* spmv_ms = rowblock_ms + wave_ms + giant_ms */
   int32_t spmv_launches;
-  float rowblock_ms, wave_ms, giant_ms;       /* the three multiply+reduce kernels, separately */
+  float rowblock_ms, wave_ms, giant_ms;       /* the three multiply+reduce kernel classes, separately; giant_ms is the time of
+                                                 the auxiliary stream: the giant-row passes and, in column-tile passes, the
+                                                 long wave rows that overlap the other kernels there */
   int32_t rowblock_launches, wave_launches, giant_launches;
   int32_t sparse_exchanges;                   /* iterations whose messages travelled as lists (GM_XCHG_GATHER) */
 } gm_run_stats_t;
