@@ -265,14 +265,40 @@ def main():
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         have_comm = int(okt.item()) == 1
     local_build = have_comm and not args.native_layout and os.environ.get("GM_BENCH_BUILD", "local") == "local"
-    nv, src, dst, _ = api.rmat_on_device(args.scale, args.edge_factor, args.seed, weights=False, device=local_rank,
-                                         part=((rank, world) if local_build else None))
-    E = args.edge_factor * nv
+    E = args.edge_factor * (1 << args.scale)
     nparts = args.ref_threads * 16
-    # device order chosen by the library: degree-ranked, dealt over the `world` shards
-    g = api.Graph(nv, src, dst, None, ref_threads=args.ref_threads, device=local_rank, keep_values=False,
-                  layout=(_lib.GM_LAYOUT_NATIVE if args.native_layout else _lib.GM_LAYOUT_DEGREE), nshards=world, shard=rank,
-                  col_tiles=(args.col_tiles if args.col_tiles >= 0 else 0), edges_local=local_build)
+
+    def build_graph(local):
+        nv_, src_, dst_, _ = api.rmat_on_device(args.scale, args.edge_factor, args.seed, weights=False, device=local_rank,
+                                                part=((rank, world) if local else None))
+        # device order chosen by the library: degree-ranked, dealt over the `world` shards
+        g_ = api.Graph(nv_, src_, dst_, None, ref_threads=args.ref_threads, device=local_rank, keep_values=False,
+                       layout=(_lib.GM_LAYOUT_NATIVE if args.native_layout else _lib.GM_LAYOUT_DEGREE), nshards=world, shard=rank,
+                       col_tiles=(args.col_tiles if args.col_tiles >= 0 else 0), edges_local=local)
+        return nv_, src_, dst_, g_
+    g = None
+    if local_build:
+        # (a failed collective build must not take the run down: every rank then falls back to the whole edge list)
+        ok, kept = 1, 0
+        try:
+            nv, src, dst, g = build_graph(True)
+            kept = int(g.csr(api.GM_DIR_OUT).nnz)
+        except Exception as e:  # pragma: no cover
+            log(rank, "distributed graph build failed: %r" % (e,))
+            ok = 0
+        okt = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        tot = torch.tensor([kept], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        if int(okt.item()) == 1 and int(tot.item()) != E:  # every edge must have arrived at exactly one shard
+            log(rank, "distributed graph build kept %d of %d edges: not used" % (int(tot.item()), E))
+            okt[0] = 0
+        if int(okt.item()) != 1:
+            local_build = False
+            g = None
+            torch.cuda.empty_cache()
+    if g is None:
+        nv, src, dst, g = build_graph(False)
     S = g.row_hi - g.row_lo
     ranges = [(r * S, (r + 1) * S) for r in range(world)] if world > 1 else [(0, g.ndevice)]
     del src, dst
