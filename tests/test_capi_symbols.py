@@ -91,6 +91,13 @@ def test_error_convention_invalid_arguments(lib):
     d = _lib.GraphDesc(1000, 16, 0, 1000, 3, 0, 0, 0, 1, 4, 4, 0, 0)
     assert lib.gm_graph_create(C.byref(h), C.byref(d), 0, None, None, None, None) == 1
     assert b"invalid shard" in lib.gm_last_error()
+    # distributed build (edges_local) without the library's communicator, and with the native layout
+    d = _lib.GraphDesc(1000, 16, 0, 1000, 3, 0, 0, 0, 1, 2, 0, 0, 0, 0, 1)
+    assert lib.gm_graph_create(C.byref(h), C.byref(d), 0, None, None, None, None) == 1
+    assert b"collective over the gm_dist communicator" in lib.gm_last_error()
+    d = _lib.GraphDesc(1024, 16, 0, 1024, 3, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1)
+    assert lib.gm_graph_create(C.byref(h), C.byref(d), 0, None, None, None, None) == 1
+    assert b"GM_LAYOUT_DEGREE" in lib.gm_last_error()
     # null handles
     assert lib.gm_graph_desc(None, C.byref(d)) == 1
     assert lib.gm_run_pagerank(None, None, 0.3, 1, None, None) == 1
