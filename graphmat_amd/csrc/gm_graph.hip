@@ -273,6 +273,7 @@ struct DevBuf {
     if (e != hipSuccess) { set_error("hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); p = nullptr; return GM_ERR_NOMEM; }
     return GM_OK;
   }
+  void free() { if (p) { (void)hipFree(p); p = nullptr; } }
   template <class T> T* as() { return (T*)p; }
   void* release() { void* q = p; p = nullptr; return q; }
 };
@@ -342,9 +343,9 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   unsigned long long kept = 0;
   GM_TRY_HIP(hipMemcpyAsync(&kept, kept_d.p, 8, hipMemcpyDeviceToHost, s));
   GM_TRY_HIP(hipStreamSynchronize(s));
-  keys_in.alloc(0);
-  idx_in.alloc(0);
-  tmp.alloc(0);
+  keys_in.free();
+  idx_in.free();
+  tmp.free();
   const bool tiled = by_dst && g->ntiles > 1;
   if ((rc = finish_csr(g, keys_out.as<uint64_t>(), idx_out.as<uint32_t>(), kept, d_val, s, out, tiled ? g_tile_min_row : -1))) return rc;
   if (tiled) rc = build_tiles(g, keys_out.as<uint64_t>(), idx_out.as<uint32_t>(), kept, d_val, s, out);
@@ -460,7 +461,7 @@ static int build_direction_local(gm_graph* g, int by_dst, int64_t nnz, const int
     hipLaunchKernelGGL(k_bucket_gather, dim3(grid_for(nnz)), dim3(kT), 0, s, (const uint64_t*)keys.as<uint64_t>(), d_val, vb,
                        (const uint32_t*)pos_out.as<uint32_t>(), nnz, send_k.as<uint64_t>(), vb ? send_v.p : nullptr);
   GM_TRY_HIP(hipStreamSynchronize(s));
-  keys.alloc(0); owner_in.alloc(0); owner_out.alloc(0); pos_in.alloc(0); pos_out.alloc(0); tmp.alloc(0);
+  keys.free(); owner_in.free(); owner_out.free(); pos_in.free(); pos_out.free(); tmp.free();
   DevBuf rk_in, rk_out, ri_in, ri_out, rvals, gk, gv;
   if ((rc = rk_in.alloc((size_t)kept * 8)) || (rc = gk.alloc((size_t)N * maxm * 8)) ||
       (vb && ((rc = rvals.alloc((size_t)kept * vb)) || (rc = gv.alloc((size_t)N * maxm * vb)))))
@@ -484,7 +485,7 @@ static int build_direction_local(gm_graph* g, int by_dst, int64_t nnz, const int
     }
     GM_TRY_HIP(hipStreamSynchronize(s));  // the gather buffers are reused by the next owner
   }
-  gk.alloc(0); gv.alloc(0); send_k.alloc(0); send_v.alloc(0);
+  gk.free(); gv.free(); send_k.free(); send_v.free();
   if ((rc = rk_out.alloc((size_t)kept * 8)) || (rc = ri_in.alloc((size_t)kept * 4)) || (rc = ri_out.alloc((size_t)kept * 4))) return rc;
   if (kept > 0) {
     hipLaunchKernelGGL(k_iota, dim3(grid_for(kept)), dim3(kT), 0, s, ri_in.as<uint32_t>(), kept);
@@ -497,7 +498,7 @@ static int build_direction_local(gm_graph* g, int by_dst, int64_t nnz, const int
                                          ri_out.as<uint32_t>(), (size_t)kept, 0u, end_bit, s));
   }
   GM_TRY_HIP(hipStreamSynchronize(s));
-  rk_in.alloc(0); ri_in.alloc(0); tmp.alloc(0);
+  rk_in.free(); ri_in.free(); tmp.free();
   return finish_csr(g, rk_out.as<uint64_t>(), ri_out.as<uint32_t>(), (unsigned long long)kept, vb ? rvals.p : nullptr, s, out, -1);
 }
 
@@ -775,9 +776,9 @@ static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t*
     GM_TRY_HIP(hipMemcpyAsync(h_bounds.data(), bounds.p, (size_t)(T + 1) * 8, hipMemcpyDeviceToHost, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
   }
-  tk_in.alloc(0);
-  pos_in.alloc(0);
-  tmp.alloc(0);
+  tk_in.free();
+  pos_in.free();
+  tmp.free();
   int64_t largest = 0;
   for (int t = 0; t < T; t++) largest = std::max(largest, h_bounds[t + 1] - h_bounds[t]);
   DevBuf keys_t, idx_t;

@@ -835,10 +835,12 @@ k_spmv_wave16(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int n
   const int per = kHot > 1 ? ((A.hot_len < kHot / NS ? A.hot_len : kHot / NS)) : 0;  // hot entries per slice
   const int nhot = per * NS;
   const T* __restrict__ xhot = x + A.hot_base;
-  if (NS == 1) {
-    for (int i = threadIdx.x; i < nhot; i += kWave16Block) s_hot[i] = xhot[i];
-  } else {
-    for (int i = threadIdx.x; i < nhot; i += kWave16Block) s_hot[i] = x[(size_t)(i / per) * A.hot_stride + (i % per)];
+  if constexpr (kHot > 1) {
+    if (NS == 1) {
+      for (int i = threadIdx.x; i < nhot; i += kWave16Block) s_hot[i] = xhot[i];
+    } else {
+      for (int i = threadIdx.x; i < nhot; i += kWave16Block) s_hot[i] = x[(size_t)(i / per) * A.hot_stride + (i % per)];
+    }
   }
   const float inv_stride = NS > 1 ? 1.0f / (float)A.hot_stride : 0.f;
   __syncthreads();
