@@ -74,6 +74,7 @@ SIGNATURES = {
     "gm_graph_maps": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "gm_graph_maps_to_host": (C.c_int, [_P, _P, _P]),
     "gm_graph_set_vals": (C.c_int, [_P, C.c_int, _P]),
+    "gm_graph_sync_tile_vals": (C.c_int, [_P, _P]),
     "gm_rmat_generate": (C.c_int, [C.c_int, C.c_uint64, C.c_int64, C.c_int64, _P, _P, _P, C.c_int, _P]),
     "gm_graph_set_exchange": (C.c_int, [_P, EXCHANGE_FN, _P]),
     "gm_graph_set_exchange_caps": (C.c_int, [_P, C.c_int]),

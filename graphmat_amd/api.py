@@ -271,6 +271,16 @@ def copy_from_device(host_array, dev_ptr):
         raise RuntimeError("hipMemcpy failed: %d" % rc)
 
 
+def copy_to_device(dev_ptr, host_array):
+    """hipMemcpy of host_array.nbytes bytes to a raw device pointer (tests rewrite library-owned arrays in place)."""
+    if host_array.nbytes == 0:
+        return
+    copy_from_device(np.zeros(0, np.uint8), None)  # (binds libamdhip64)
+    rc = _hip.hipMemcpy(dev_ptr, host_array.ctypes.data, host_array.nbytes, 1)  # hipMemcpyHostToDevice
+    if rc != 0:
+        raise RuntimeError("hipMemcpy failed: %d" % rc)
+
+
 def rmat_on_device(scale, edge_factor=16, seed=1, weights=False, device=0, part=None):
     """RMAT edges generated in HBM (bit-identical to generators.rmat_edges).
     part=(i, n): only the i-th of n consecutive chunks of the edge list (a rank's part of a distributed build)."""

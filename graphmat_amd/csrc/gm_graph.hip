@@ -924,6 +924,23 @@ k_csr_to_coo(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col
   }
 }
 
+// tile copies of the edge values from the whole-graph CSR: a row's edges there are the concatenation of its pieces in
+// tile order, so `done[r]` (edges of row r already handed to earlier tiles) locates a piece.  One wave per row.
+__global__ void __launch_bounds__(kT)
+k_tile_vals(const int64_t* __restrict__ rowptr_whole, const unsigned char* __restrict__ vals_whole, const int64_t* __restrict__ rowptr_tile,
+            unsigned char* __restrict__ vals_tile, int nrows, int val_bytes, int64_t* __restrict__ done) {
+  const int row = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int64_t a = rowptr_tile[row], len = rowptr_tile[row + 1] - a;
+  if (len == 0) return;
+  const int64_t from = rowptr_whole[row] + done[row];
+  const int64_t bytes = len * val_bytes;
+  const unsigned char* src = vals_whole + from * val_bytes;
+  unsigned char* dst = vals_tile + a * val_bytes;
+  for (int64_t b = threadIdx.x & 63; b < bytes; b += 64) dst[b] = src[b];
+  if ((threadIdx.x & 63) == 0) done[row] += len;
+}
+
 static void free_csr(CsrOwned* c) {
   if (c->rowptr) (void)hipFree(c->rowptr);
   if (c->colidx) (void)hipFree(c->colidx);
@@ -1257,8 +1274,28 @@ int gm_graph_set_vals(gm_graph_t* g, int direction, const void* h_vals) {
   if (!g || !h_vals) { gm::set_error("gm_graph_set_vals: null argument"); return GM_ERR_INVALID; }
   gm::CsrOwned* c = direction == GM_DIR_OUT ? &g->out : direction == GM_DIR_IN ? &g->in : nullptr;
   if (!c || !c->present || !c->vals) { gm::set_error("gm_graph_set_vals: direction %d has no edge values", direction); return GM_ERR_INVALID; }
-  if (g->ntiles > 1) { gm::set_error("gm_graph_set_vals: not supported on a graph with column tiles (the tiles hold copies of the edge values)"); return GM_ERR_UNSUPPORTED; }
   if (c->view.nnz) GM_TRY_HIP(hipMemcpy(c->vals, h_vals, (size_t)c->view.nnz * c->view.val_bytes, hipMemcpyHostToDevice));
+  return direction == GM_DIR_OUT ? gm_graph_sync_tile_vals(g, nullptr) : GM_OK;
+}
+
+int gm_graph_sync_tile_vals(gm_graph_t* g, gm_stream_t stream) {
+  if (!g) { gm::set_error("gm_graph_sync_tile_vals: null graph"); return GM_ERR_INVALID; }
+  if (g->ntiles <= 1 || !g->out_tiles || !g->out.present || !g->out.vals) return GM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int nrows = g->out.view.nrows, vb = g->out.view.val_bytes;
+  gm::DevBuf done;
+  int rc;
+  if ((rc = done.alloc((size_t)(nrows + 1) * 8))) return rc;
+  GM_TRY_HIP(hipMemsetAsync(done.p, 0, (size_t)(nrows + 1) * 8, s));
+  // (rows of at most tile_min_row edges have no tile pieces; the tiled rows' pieces cover them completely)
+  for (int t = 0; t < g->ntiles; t++) {
+    gm::CsrOwned& T = g->out_tiles[t];
+    if (!T.vals || T.view.nnz == 0) continue;
+    hipLaunchKernelGGL(gm::k_tile_vals, dim3((nrows + gm::kT / 64 - 1) / (gm::kT / 64)), dim3(gm::kT), 0, s, (const int64_t*)g->out.rowptr,
+                       (const unsigned char*)g->out.vals, (const int64_t*)T.rowptr, (unsigned char*)T.vals, nrows, vb, done.as<int64_t>());
+  }
+  GM_TRY_HIP(hipGetLastError());
+  GM_TRY_HIP(hipStreamSynchronize(s));
   return GM_OK;
 }
 

@@ -666,7 +666,7 @@ void Graph<V, E>::applyToAllEdges(void (*ApplyFn)(E*, const V&, const V&, void*)
         if (dir == GM_DIR_OUT) ApplyFn(&vv[e], h[ci[e]], h[r], param);
         else ApplyFn(&vv[e], h[r], h[ci[e]], param);
       }
-    gm_graph_set_vals(A, dir, vv.data());
+    if (gm_graph_set_vals(A, dir, vv.data()) != GM_OK) { printf("GraphMat(HIP): %s\n", gm_last_error()); exit(1); }
   }
 }
 
@@ -801,6 +801,7 @@ void Graph<V, E>::applyToAllEdges(F f) {
                        dir == GM_DIR_OUT ? 1 : 0, f);
   }
   GM_HIP_OK(hipDeviceSynchronize());
+  if (gm_graph_sync_tile_vals(A, nullptr) != GM_OK) { printf("GraphMat(HIP): %s\n", gm_last_error()); exit(1); }  // (column tiles hold copies)
 }
 
 template <class V, class E>

@@ -250,8 +250,11 @@ int gm_graph_maps_to_host(const gm_graph_t* g, int32_t* h_dev_of_native, int32_t
 int gm_graph_csr_to_host(const gm_graph_t* g, int direction, int64_t* h_rowptr, int32_t* h_colidx, void* h_vals);
 
 /* overwrite a direction's edge values from a host array laid out like gm_graph_csr_to_host's
- * (Graph::applyToAllEdges) */
+ * (Graph::applyToAllEdges); the column tiles' copies of the values follow */
 int gm_graph_set_vals(gm_graph_t* g, int direction, const void* h_vals);
+/* After edge values were rewritten in place on the device (through gm_csr_t.vals of gm_graph_csr): bring the column
+ * tiles' copies of the GM_DIR_OUT values up to date.  No-op for untiled graphs and graphs without edge values. */
+int gm_graph_sync_tile_vals(gm_graph_t* g, gm_stream_t stream);
 
 /* ---- synthetic RMAT edges generated on the device ---------------------------------
  * Same integer-only definition as graphmat_amd/generators.py:rmat_edges (bit-identical).

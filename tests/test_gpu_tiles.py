@@ -143,3 +143,43 @@ def test_other_programs_on_a_tiled_graph(env, tile_min):
     dist, it = g.sssp(1)
     odist, oit = og.sssp(1)
     assert it == oit and (dist == odist).all()
+
+
+@pytest.mark.parametrize("tiles,minrow", [(3, 64), (8, 200)])
+def test_edge_value_updates_reach_the_tiles(env, tile_min, tiles, minrow):
+    """The column tiles hold copies of the edge values: gm_graph_set_vals (Graph::applyToAllEdges, host form) and
+    gm_graph_sync_tile_vals (after an in-place rewrite on the device, the functor form) must bring them up to date."""
+    api, _ = env
+    import ctypes as C
+    tile_min(minrow)
+    nv, s, d, v = gen.rmat_edges(12, 16, 5, weights="hash")
+    g = api.Graph(nv, s, d, v, ref_threads=2, col_tiles=tiles)
+    assert g.col_tiles > 1
+    L = api._lib.lib()
+    rp, ci, vv = g.csr_to_host(api.GM_DIR_OUT)
+    rowlen = np.diff(rp)
+    rows_of_edge = np.repeat(np.arange(nv), rowlen)
+
+    def tiles_hold(expected):
+        for t in range(g.col_tiles):
+            c, _ = g.tile(api.GM_DIR_OUT, t)
+            if not c.nnz:
+                continue
+            tvv = np.zeros(c.nnz, np.int32)
+            api.copy_from_device(tvv, c.vals)
+            keep = (rowlen[rows_of_edge] > minrow) & (ci >= c.hot_base) & (ci < c.hot_base + c.hot_len)
+            assert c.nnz == int(keep.sum())
+            if not (tvv == expected[keep]).all():
+                return False
+        return True
+    assert tiles_hold(vv)
+    # host form: new values for every edge of the direction
+    new = (vv * 3 + 1).astype(np.int32)
+    api._lib.check(L.gm_graph_set_vals(g.h, api.GM_DIR_OUT, new.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(g.csr_to_host(api.GM_DIR_OUT)[2], new) and tiles_hold(new)
+    # device form: rewrite the library's array in place, then sync
+    newer = (new ^ 0x55).astype(np.int32)
+    api.copy_to_device(g.csr(api.GM_DIR_OUT).vals, newer)
+    assert not tiles_hold(newer)
+    api._lib.check(L.gm_graph_sync_tile_vals(g.h, None))
+    assert tiles_hold(newer)
