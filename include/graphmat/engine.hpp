@@ -322,7 +322,7 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
       const int groups = (A.nmid + 63) / 64;
       hipLaunchKernelGGL((dev::k_spmv_wave_grouped<P, T, U, V, E, USE_VP, RK>), dim3((groups + WPB - 1) / WPB),
                          dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
-                         debug_flags(), want);
+                         debug_flags(), want, xsum);
     } else if (wave16_ok<U, USE_VP, RK>() && !(debug_flags() & dev::DBG_NO_WAVE16)) {
       if constexpr (wave16_ok<U, USE_VP, RK>()) {
         // ordered folds: the long rows at the head of the list get a wave each, the rest are folded 16 to a wave

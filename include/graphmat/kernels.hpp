@@ -617,8 +617,10 @@ template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
 __device__ __forceinline__ void wave_row(const P& p, const gm_csr_t& A, const int row, const int64_t e0, const int64_t e1,
                                          const int lane, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
                                          const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits,
-                                         const int accumulate, const int dbg, U* out_acc = nullptr, bool* out_has = nullptr) {
+                                         const int accumulate, const int dbg, U* out_acc = nullptr, bool* out_has = nullptr,
+                                         const uint32_t* __restrict__ xsum = nullptr) {
   // (out_acc / out_has, ordered kind only: hand the result back instead of storing it -- k_check_rows)
+  // (xsum, REDUCE_LAST only: 1 bit per 64 x entries "any present" (k_bits_summary), tested before the presence bit)
   const bool dense = (xbits == nullptr);
   V vprow;
   if constexpr (USE_VP) vprow = vp[row];
@@ -640,7 +642,7 @@ __device__ __forceinline__ void wave_row(const P& p, const gm_csr_t& A, const in
         c[u] = (u < depth && k >= e0) ? stream_load(&A.colidx[k]) : -1;
       }
 #pragma unroll
-      for (int u = 0; u < DMAX; u++) pres[u] = c[u] >= 0 && (dense || bit_get(xbits, c[u]));
+      for (int u = 0; u < DMAX; u++) pres[u] = c[u] >= 0 && (dense || ((xsum == nullptr || bit_get(xsum, c[u] >> 6)) && bit_get(xbits, c[u])));
 #pragma unroll
       for (int u = 0; u < DMAX; u++) {
         const unsigned long long mask = __ballot(pres[u]);
@@ -944,7 +946,8 @@ template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_wave_grouped(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nlist, const T* __restrict__ x,
                     const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
-                    uint32_t* __restrict__ ybits, int accumulate, int dbg, const uint32_t* __restrict__ want) {
+                    uint32_t* __restrict__ ybits, int accumulate, int dbg, const uint32_t* __restrict__ want,
+                    const uint32_t* __restrict__ xsum = nullptr) {
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int lane = threadIdx.x & 63;
   const int idx = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 64 + lane;
@@ -962,7 +965,7 @@ k_spmv_wave_grouped(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows,
     todo &= todo - 1;
     const int rr = __builtin_amdgcn_readlane(row, r);
     const int64_t a = wave_bcast(e0, r), b = wave_bcast(e1, r);
-    wave_row<P, T, U, V, E, USE_VP, RK>(p, A, rr, a, b, lane, x, xbits, vp, y, ybits, accumulate, dbg);
+    wave_row<P, T, U, V, E, USE_VP, RK>(p, A, rr, a, b, lane, x, xbits, vp, y, ybits, accumulate, dbg, nullptr, nullptr, xsum);
   }
 }
 
