@@ -537,6 +537,7 @@ def main():
                    "col_tiles": int(g.col_tiles),
                    "graph_build": ("distributed: each rank generates E/N edges, edges shuffled to the shard owning their row" if local_build
                                    else ("every rank sorts the whole edge list" if world > 1 else "single GPU")),
+                   "graph_build_s": round(build_s, 2),
                    "rows_per_shard": S, "exchanged_rows_per_shard": int(g.xchg_rows),
                    "max_in_degree_rank0": max_deg,
                    "giant_row_groups_replayed": int(cnt64[0]), "giant_row_groups_serial": int(cnt64[1])},
