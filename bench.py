@@ -202,6 +202,7 @@ def main():
     ap.add_argument("--native-layout", action="store_true", help="device order = native order (single GPU; for A/B)")
     ap.add_argument("--tile-min-row", type=int, default=-1, help="experiment: rows of more than this many edges are tiled (0 = all rows)")
     ap.add_argument("--col-tiles", type=int, default=-1, help="column tiles of the OUT adjacency (-1 = default for the scale, 1 = none)")
+    ap.add_argument("--lib-option", action="append", default=[], metavar="KEY=VALUE", help="gm_set_option(KEY, VALUE) before the graph is built (experiments)")
     ap.add_argument("--debug-flags", type=int, default=0, help="ablation only (results become invalid): 1 skip fold, 2 skip gathers")
     args = ap.parse_args()
 
@@ -243,6 +244,9 @@ def main():
         _lib.check(L.gm_set_option(b"rank_cap", args.rank_cap))
     if args.rank_by:
         _lib.check(L.gm_set_option(b"rank_by", args.rank_by))
+    for kv in args.lib_option:
+        k, v = kv.split("=", 1)
+        _lib.check(L.gm_set_option(k.encode(), int(v)))
     if args.tile_min_row >= 0:
         _lib.check(L.gm_set_option(b"tile_min_row", args.tile_min_row))
     # ---- synthetic input, generated in HBM ------------------------------------------------

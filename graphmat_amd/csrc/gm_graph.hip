@@ -28,6 +28,7 @@ int g_giant_row = 0;  // 0 = choose per graph (see pick_giant_threshold)
 int g_rank_cap = 0;   // experiment: > 0 ranks only vertices of total degree >= cap; the others keep native order behind them
 int g_rank_by = 0;    // experiment: 0 rank vertices by total degree, 1 by out-degree, 2 by in-degree
 int g_tile_min_row = GM_TILE_MIN_ROW;  // rows of more than this many edges are tiled
+int g_tile_balance = 1;  // column tiles serve equally many gathers (1) or hold equally many vertices with edges (0)
 int g_long_mid = 0;  // > 0: experiment -- wave rows of more than this many edges get a wave each (0 = GM_LONG_MID rule)
 int g_col_tiles = 0;  // default number of column tiles for graphs whose descriptor says 0 (0 = environment GRAPHMAT_COL_TILES, else none)
 
@@ -88,14 +89,31 @@ k_live_flags(const uint32_t* __restrict__ deg, int nv, uint32_t* __restrict__ li
   int v = blockIdx.x * kT + threadIdx.x;
   if (v < nv) live[v] = deg[v] ? 1u : 0u;
 }
-// tile of the k-th ranked vertex: (live vertices before it in NATIVE order) / tile size; 255 = no edges
+// how often every vertex is a column of the GM_DIR_OUT adjacency (= a source): the gathers its x entry will serve
 __global__ void __launch_bounds__(kT)
-k_tile_of_ranked(const int32_t* __restrict__ order, int nv, const uint32_t* __restrict__ deg, const uint32_t* __restrict__ live_before,
-                 int tile_size, uint8_t* __restrict__ tile) {
+k_col_weight(const int32_t* __restrict__ src, int64_t nnz, int nparts, int nv, int ids_are_native, uint32_t* __restrict__ w) {
+  int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (e >= nnz) return;
+  const int s = src[e];
+  atomicAdd(&w[ids_are_native ? s : to_native0(s, nparts, nv)], 1u);
+}
+// tile of the k-th ranked vertex: tiles are contiguous NATIVE ranges that serve equally many gathers (weight_before =
+// column occurrences of the vertices before it in native order, `total` of all); 255 = no edges
+__global__ void __launch_bounds__(kT)
+k_tile_of_ranked(const int32_t* __restrict__ order, int nv, const uint32_t* __restrict__ deg, const uint32_t* __restrict__ weight_before,
+                 unsigned long long total, int ntiles, uint8_t* __restrict__ tile) {
   int k = blockIdx.x * kT + threadIdx.x;
   if (k >= nv) return;
   const int v = order[k];
-  tile[k] = deg[v] ? (uint8_t)(live_before[v] / (uint32_t)tile_size) : (uint8_t)255;
+  unsigned long long t = total ? (unsigned long long)weight_before[v] * (unsigned long long)ntiles / total : 0ull;
+  if (t >= (unsigned long long)ntiles) t = (unsigned long long)ntiles - 1ull;
+  tile[k] = deg[v] ? (uint8_t)t : (uint8_t)255;
+}
+// tile of a device id: the last t with base[t] <= d
+__device__ __forceinline__ int tile_of_dev(int d, const int32_t* __restrict__ base, int ntiles) {
+  int t = 0;
+  while (t + 1 < ntiles && base[t + 1] <= d) t++;
+  return t;
 }
 
 // rank k -> device id (k % nshards) * S + k / nshards
@@ -713,17 +731,18 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
 }
 
 // ---- column tiles (graphmat_hip.h: gm_graph_tile) ------------------------------------------------
-// tile of every sorted edge: device id of its column / tile_size; 255 = not tiled (short row)
+// tile of every sorted edge: the tile whose device-id range holds its column; 255 = not tiled (short row)
+struct TileBases { int32_t b[GM_MAX_TILES + 1]; };
 __global__ void __launch_bounds__(kT)
 k_tile_keys(const uint64_t* __restrict__ keys, int64_t n, const int64_t* __restrict__ rowptr, int short_row,
-            const int32_t* __restrict__ dev_of_native, int tile_size, uint8_t* __restrict__ tkey, uint32_t* __restrict__ pos) {
+            const int32_t* __restrict__ dev_of_native, TileBases bases, int ntiles, uint8_t* __restrict__ tkey, uint32_t* __restrict__ pos) {
   const int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x;
   if (k >= n) return;
   const uint64_t key = keys[k];
   const int row = (int)(key >> 32);
   const int cn = (int)(uint32_t)key;
   const bool tiled = rowptr[row + 1] - rowptr[row] > short_row;
-  tkey[k] = tiled ? (uint8_t)(dev_of_native[cn] / tile_size) : (uint8_t)255;
+  tkey[k] = tiled ? (uint8_t)tile_of_dev(dev_of_native[cn], bases.b, ntiles) : (uint8_t)255;
   pos[k] = (uint32_t)k;
 }
 // first position of every tile in the tile-sorted key array (lower bounds of 0..ntiles)
@@ -761,9 +780,11 @@ static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t*
       (rc = pos_out.alloc((size_t)kept * 4)) || (rc = bounds.alloc((size_t)(GM_MAX_TILES + 2) * 8)))
     return rc;
   std::vector<int64_t> h_bounds((size_t)T + 1, 0);
+  TileBases bases;
+  memcpy(bases.b, g->tile_base, sizeof(bases.b));
   if (kept > 0) {
     hipLaunchKernelGGL(k_tile_keys, dim3(grid_for((int64_t)kept)), dim3(kT), 0, s, keys_sorted, (int64_t)kept,
-                       (const int64_t*)whole->rowptr, whole->view.tile_min_row, (const int32_t*)g->dev_of_native, (int)g->tile_size,
+                       (const int64_t*)whole->rowptr, whole->view.tile_min_row, (const int32_t*)g->dev_of_native, bases, T,
                        tk_in.as<uint8_t>(), pos_in.as<uint32_t>());
     GM_TRY_HIP(hipGetLastError());
     size_t tb = 0;  // stable: inside a tile the edges keep their (row, native col) order
@@ -794,8 +815,8 @@ static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t*
                          (const uint32_t*)pos_out.as<uint32_t>() + h_bounds[t], n, keys_t.as<uint64_t>(), idx_t.as<uint32_t>());
     if ((rc = finish_csr(g, keys_t.as<uint64_t>(), idx_t.as<uint32_t>(), (unsigned long long)n, d_val, s, &g->out_tiles[t]))) return rc;
     gm_csr_t& v = g->out_tiles[t].view;
-    v.hot_base = t * g->tile_size;
-    v.hot_len = std::min(g->tile_size, g->nlive - v.hot_base);
+    v.hot_base = g->tile_base[t];
+    v.hot_len = g->tile_base[t + 1] - g->tile_base[t];
     if (t + 1 < T) {
       uint32_t* nxt = nullptr;
       GM_TRY_HIP(hipMalloc((void**)&nxt, (size_t)nw * 4));
@@ -845,46 +866,57 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
   GM_TRY_HIP(hipMemcpyAsync(&nz, nzd.p, 8, hipMemcpyDeviceToHost, s));
   GM_TRY_HIP(hipStreamSynchronize(s));
   g->nlive = (int32_t)nz;
-  // column tiles: contiguous NATIVE ranges holding equally many live vertices; the device order
-  // becomes (tile, degree rank inside the tile), vertices without edges last.  A stable sort of the
-  // ranked list by tile does it.
+  // column tiles: contiguous NATIVE ranges; the device order becomes (tile, degree rank inside the tile),
+  // vertices without edges last.  A stable sort of the ranked list by tile does it.
   int T = D.col_tiles;
   if (T == 0) T = g_col_tiles;
   if (T == 0) { const char* e = getenv("GRAPHMAT_COL_TILES"); if (e) T = atoi(e); }
   if (T == 0) {
-    // automatic: tiles pay once the live part of a 4-byte message vector outgrows what the caches hold
-    // (measured, PageRank on RMAT: 24 / 25 untiled best; 26: 4 tiles +5 %; 27: 8 tiles +21 %): slices of ~32 MB
-    // from 96 MB on
-    const unsigned long long bytes = nz * 4ull;
-    T = bytes >= (96ull << 20) ? (int)((bytes + (16ull << 20)) / (32ull << 20)) : 1;
+    // automatic: tiles pay once the live part of a 4-byte message vector outgrows what the caches hold.  Measured,
+    // PageRank on RMAT with tiles that serve equally many gathers (best tile count, GTEPS against untiled): RMAT-24
+    // (34 MiB live) none; RMAT-25 (65 MiB) 4: 156 vs 154; RMAT-26 (125 MiB) 6: 159 vs 140; RMAT-27 (239 MiB) 10: 151 vs 116
+    // -- about one tile per 28 MiB on top of 1.6, from 60 MiB on
+    const double mib = (double)nz * 4.0 / 1048576.0;
+    T = mib >= 60.0 ? (int)(1.6 + mib / 28.4 + 0.5) : 1;
   }
   if (T < 1 || G > 1 || nz < 2) T = 1;
   if (T > GM_MAX_TILES) T = GM_MAX_TILES;
   if (T > 1) {
-    int tsize = (int)((nz + T - 1) / T);
-    tsize = (tsize + 63) / 64 * 64;
-    T = (int)((nz + tsize - 1) / tsize);
-    if (T > 1) {
-      DevBuf live, lpre, tk_in, tk_out, order2;
-      if ((rc = live.alloc((size_t)nv * 4)) || (rc = lpre.alloc((size_t)nv * 4)) || (rc = tk_in.alloc((size_t)nv)) ||
-          (rc = tk_out.alloc((size_t)nv)) || (rc = order2.alloc((size_t)nv * 4)))
-        return rc;
-      hipLaunchKernelGGL(k_live_flags, dim3(grid_for(nv)), dim3(kT), 0, s, deg.as<uint32_t>(), nv, live.as<uint32_t>());
-      size_t sb = 0;
-      GM_TRY_HIP(rocprim::exclusive_scan(nullptr, sb, live.as<uint32_t>(), lpre.as<uint32_t>(), 0u, (size_t)nv, rocprim::plus<uint32_t>(), s));
-      if ((rc = tmp.alloc(sb))) return rc;
-      GM_TRY_HIP(rocprim::exclusive_scan(tmp.p, sb, live.as<uint32_t>(), lpre.as<uint32_t>(), 0u, (size_t)nv, rocprim::plus<uint32_t>(), s));
-      hipLaunchKernelGGL(k_tile_of_ranked, dim3(grid_for(nv)), dim3(kT), 0, s, order.as<int32_t>(), nv, deg.as<uint32_t>(),
-                         lpre.as<uint32_t>(), tsize, tk_in.as<uint8_t>());
-      sb = 0;
-      GM_TRY_HIP(rocprim::radix_sort_pairs(nullptr, sb, tk_in.as<uint8_t>(), tk_out.as<uint8_t>(), order.as<int32_t>(),
-                                           order2.as<int32_t>(), (size_t)nv, 0u, 8u, s));
-      if ((rc = tmp.alloc(sb))) return rc;
-      GM_TRY_HIP(rocprim::radix_sort_pairs(tmp.p, sb, tk_in.as<uint8_t>(), tk_out.as<uint8_t>(), order.as<int32_t>(),
-                                           order2.as<int32_t>(), (size_t)nv, 0u, 8u, s));
-      GM_TRY_HIP(hipMemcpyAsync(order.p, order2.p, (size_t)nv * 4, hipMemcpyDeviceToDevice, s));
-      g->tile_size = tsize;
-    }
+    // Tiles are contiguous NATIVE ranges cut so that every tile serves about the same number of gathers (a vertex weighs
+    // as often as it is a column of the GM_DIR_OUT adjacency; on RMAT the busy tiles then hold fewer vertices, i.e. a
+    // smaller slice of x where most gathers go).  gm_set_option("tile_balance", 0) cuts them into equally many vertices
+    // with edges instead: RMAT-26 best 4 such tiles 7.07 ms against 6.74 ms with 6 gather-balanced ones.
+    DevBuf w, wpre, tk_in, tk_out, order2, bnd;
+    if ((rc = w.alloc((size_t)(nv + 1) * 4)) || (rc = wpre.alloc((size_t)(nv + 1) * 4)) || (rc = tk_in.alloc((size_t)nv)) ||
+        (rc = tk_out.alloc((size_t)nv)) || (rc = order2.alloc((size_t)nv * 4)) || (rc = bnd.alloc((size_t)(GM_MAX_TILES + 2) * 8)))
+      return rc;
+    GM_TRY_HIP(hipMemsetAsync(w.p, 0, (size_t)(nv + 1) * 4, s));
+    if (g_tile_balance == 1 && nnz > 0)
+      hipLaunchKernelGGL(k_col_weight, dim3(grid_for(nnz)), dim3(kT), 0, s, d_src, nnz, D.nparts, nv, D.ids_are_native, w.as<uint32_t>());
+    else
+      hipLaunchKernelGGL(k_live_flags, dim3(grid_for(nv)), dim3(kT), 0, s, deg.as<uint32_t>(), nv, w.as<uint32_t>());
+    size_t sb = 0;
+    GM_TRY_HIP(rocprim::exclusive_scan(nullptr, sb, w.as<uint32_t>(), wpre.as<uint32_t>(), 0u, (size_t)nv + 1, rocprim::plus<uint32_t>(), s));
+    if ((rc = tmp.alloc(sb))) return rc;
+    GM_TRY_HIP(rocprim::exclusive_scan(tmp.p, sb, w.as<uint32_t>(), wpre.as<uint32_t>(), 0u, (size_t)nv + 1, rocprim::plus<uint32_t>(), s));
+    uint32_t total = 0;
+    GM_TRY_HIP(hipMemcpyAsync(&total, wpre.as<uint32_t>() + nv, 4, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(k_tile_of_ranked, dim3(grid_for(nv)), dim3(kT), 0, s, order.as<int32_t>(), nv, deg.as<uint32_t>(),
+                       wpre.as<uint32_t>(), (unsigned long long)total, T, tk_in.as<uint8_t>());
+    sb = 0;
+    GM_TRY_HIP(rocprim::radix_sort_pairs(nullptr, sb, tk_in.as<uint8_t>(), tk_out.as<uint8_t>(), order.as<int32_t>(),
+                                         order2.as<int32_t>(), (size_t)nv, 0u, 8u, s));
+    if ((rc = tmp.alloc(sb))) return rc;
+    GM_TRY_HIP(rocprim::radix_sort_pairs(tmp.p, sb, tk_in.as<uint8_t>(), tk_out.as<uint8_t>(), order.as<int32_t>(),
+                                         order2.as<int32_t>(), (size_t)nv, 0u, 8u, s));
+    GM_TRY_HIP(hipMemcpyAsync(order.p, order2.p, (size_t)nv * 4, hipMemcpyDeviceToDevice, s));
+    // where every tile starts in the new order (vertices without edges carry key 255 and sort to the end)
+    hipLaunchKernelGGL(k_tile_bounds, dim3(1), dim3(128), 0, s, (const uint8_t*)tk_out.p, (int64_t)nv, T, bnd.as<int64_t>());
+    int64_t hb[GM_MAX_TILES + 2];
+    GM_TRY_HIP(hipMemcpyAsync(hb, bnd.p, (size_t)(T + 1) * 8, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    for (int t = 0; t <= T; t++) g->tile_base[t] = (int32_t)hb[t];
   }
   g->ntiles = T;
   D.col_tiles = T;
@@ -1204,7 +1236,7 @@ int gm_graph_relayout_like(gm_graph_t* g, const gm_graph_t* like, gm_stream_t st
   // ... and its column tiles (the tile of a column is a function of its device id)
   gm::free_tiles(g);
   g->ntiles = like->ntiles > 1 ? like->ntiles : 1;
-  g->tile_size = like->tile_size;
+  memcpy(g->tile_base, like->tile_base, sizeof(g->tile_base));
   g->nlive = like->nlive;
   g->desc.col_tiles = g->ntiles;
   // the other graph's order ranks ITS edges: this graph's vertices with edges may sit anywhere in it

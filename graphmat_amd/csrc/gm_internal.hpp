@@ -83,7 +83,7 @@ struct gm_graph {
   struct SplitMemo { int valid, permille; int32_t asked, rs, bs, ms; } split_memo[2][2];
   // column tiles of the GM_DIR_OUT adjacency (gm_graph_tile); ntiles <= 1: none
   int ntiles;
-  int32_t tile_size;            // device ids [t * tile_size, (t+1) * tile_size) belong to tile t (the last one ends at nlive)
+  int32_t tile_base[GM_MAX_TILES + 1];  // device ids [tile_base[t], tile_base[t+1]) belong to tile t (tile_base[ntiles] = nlive)
   int32_t nlive;                // vertices with at least one edge (they come first in the device order)
   gm::CsrOwned* out_tiles;      // [ntiles]
   uint32_t** out_tile_prev;     // [ntiles] presence bits of the rows with an edge in an earlier tile

@@ -131,8 +131,8 @@ typedef struct {
                             each slice.  Multiple of 64; = slice size for GM_LAYOUT_NATIVE.   */
   int32_t col_tiles;     /* column tiles of the GM_DIR_OUT adjacency (see gm_graph_tile): 0 = library default
                             (gm_set_option("col_tiles"), else environment GRAPHMAT_COL_TILES, else automatic:
-                            slices of ~32 MB of a 4-byte message vector once its live part reaches 96 MB, i.e.
-                            none up to RMAT-25, 4 at RMAT-26, 8 at RMAT-27), 1 = none, 2..GM_MAX_TILES = that many.
+                            about one tile per 28 MiB of a 4-byte message vector's live part once that reaches 60 MiB, i.e.
+                            none up to RMAT-24, 4 at RMAT-25, 6 at RMAT-26, 10 at RMAT-27), 1 = none, 2..GM_MAX_TILES = that many.
                             GM_LAYOUT_DEGREE with one shard only (ignored otherwise).  Output: the number of tiles
                             built (1 = none).                                                                 */
   int32_t edges_local;   /* 0: every rank passes the whole edge list (edges of other shards' rows are dropped).
@@ -217,8 +217,8 @@ int gm_graph_csr(const gm_graph_t* g, int direction, gm_csr_t* out);
 /* ---- column tiles of a direction's adjacency ------------------------------------------------
  * The gathers of x are what bounds the multiply on large graphs (one 4-byte gather per edge; at
  * RMAT-26 x is 268 MB and 28 % of the gathers miss the 4 MB L2s).  With col_tiles = T > 1 the
- * library cuts the NATIVE id space into T contiguous ranges holding equally many vertices with
- * edges, lays the device order out as (tile, degree rank inside the tile) -- a tile's slice of x
+ * library cuts the NATIVE id space into T contiguous ranges that serve equally many gathers (a
+ * vertex counts as often as it is a column), lays the device order out as (tile, degree rank inside the tile) -- a tile's slice of x
  * is contiguous with its busiest entries first -- and keeps, for the rows of more than
  * GM_SHORT_ROW edges, one CSR per tile (only the edges whose column lies in the tile; same row
  * ids, columns still in ascending native order).  Because the tiles are native ranges, folding a
@@ -388,7 +388,8 @@ int gm_run_rmse(gm_graph_t* g, void* d_latent, int K, int real_bytes, gm_stream_
 /* runtime options.  "force_ordered" (0/1): run PageRank with the plain serial long-row fold
  * instead of the exact parallel replay (A/B check; results are bit-identical).  Graph-build experiments (read when a
  * graph is created): "short_row", "giant_row", "rank_by", "rank_cap", "col_tiles", "tile_min_row", "long_mid" (wave rows
- * of more than this many edges get a wave each instead of sharing one 16 to a wave; 0 = GM_LONG_MID rule). */
+ * of more than this many edges get a wave each instead of sharing one 16 to a wave; 0 = GM_LONG_MID rule), "tile_balance"
+ * (1: column tiles serve equally many gathers, the default; 0: they hold equally many vertices with edges). */
 int gm_set_option(const char* key, int value);
 
 /* ---- timing of the last gm_run_* call on this graph -------------------------------------

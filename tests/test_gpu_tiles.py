@@ -59,17 +59,21 @@ def test_tile_structure(env, tile_min, tiles, threads, minrow):
     import torch
     seen = 0
     prev_rows = np.zeros(nv, bool)
+    prev_native_max = None
+    gathers = []
     for t in range(T):
         c, prev = g.tile(api.GM_DIR_OUT, t)
         lo, hi = c.hot_base, c.hot_base + c.hot_len
         assert lo == (0 if t == 0 else last_hi) and hi <= nlive
         last_hi = hi
-        # the slice is a contiguous native range, busiest first
+        # the slice is a contiguous native range, busiest first (a tile may be empty: tiles are cut by gathers served,
+        # and one hub can outweigh a tile's share on a small graph)
         natives = nod[lo:hi]
-        if t > 0:
-            assert natives.min() > prev_native_max
-        prev_native_max = natives.max()
-        assert (np.diff(deg[natives]) <= 0).all()
+        if natives.size:
+            if prev_native_max is not None:
+                assert natives.min() > prev_native_max
+            prev_native_max = natives.max()
+            assert (np.diff(deg[natives]) <= 0).all()
         # expected content: long rows' edges with column in [lo, hi), untiled order
         trp = np.zeros(c.nrows + 1, np.int64)
         tci = np.zeros(max(c.nnz, 1), np.int32)
@@ -89,8 +93,12 @@ def test_tile_structure(env, tile_min, tiles, threads, minrow):
         assert (got == prev_rows).all()
         prev_rows |= np.diff(trp) > 0
         seen += c.nnz
+        gathers.append(int(((ci >= lo) & (ci < hi)).sum()))  # edges of ALL rows whose column lies in the tile
     assert last_hi == nlive
     assert seen == int(rowlen[rowlen > minrow].sum())
+    # tiles serve about equally many gathers: none exceeds its share by more than the heaviest column
+    colw = np.bincount(ci, minlength=nv)
+    assert max(gathers) <= len(ci) / T + colw.max()
     # the wave rows that stay untiled: more than 64 and at most minrow edges, long ones first
     c = g.csr(api.GM_DIR_OUT)
     assert c.tile_min_row == minrow
