@@ -97,15 +97,29 @@ k_col_weight(const int32_t* __restrict__ src, int64_t nnz, int nparts, int nv, i
   const int s = src[e];
   atomicAdd(&w[ids_are_native ? s : to_native0(s, nparts, nv)], 1u);
 }
+// final weight of a vertex from its column count: count^p (p = pw100 / 100) plus c for every vertex with edges
+__global__ void __launch_bounds__(kT)
+k_tile_weight(const uint32_t* __restrict__ deg, const uint32_t* __restrict__ cnt, int nv, uint32_t c, int pw100, int by_vertices,
+              unsigned long long* __restrict__ w) {
+  int v = blockIdx.x * kT + threadIdx.x;
+  if (v >= nv) return;
+  unsigned long long x = 0;
+  if (deg[v]) {
+    if (by_vertices) x = 1;
+    else if (pw100 == 100) x = (unsigned long long)cnt[v] + c;
+    else x = (unsigned long long)(powf((float)cnt[v], (float)pw100 * 0.01f) + 0.5f) + c;
+  }
+  w[v] = x;
+}
 // tile of the k-th ranked vertex: tiles are contiguous NATIVE ranges that serve equally many gathers (weight_before =
 // column occurrences of the vertices before it in native order, `total` of all); 255 = no edges
 __global__ void __launch_bounds__(kT)
-k_tile_of_ranked(const int32_t* __restrict__ order, int nv, const uint32_t* __restrict__ deg, const uint32_t* __restrict__ weight_before,
+k_tile_of_ranked(const int32_t* __restrict__ order, int nv, const uint32_t* __restrict__ deg, const unsigned long long* __restrict__ weight_before,
                  unsigned long long total, int ntiles, uint8_t* __restrict__ tile) {
   int k = blockIdx.x * kT + threadIdx.x;
   if (k >= nv) return;
   const int v = order[k];
-  unsigned long long t = total ? (unsigned long long)weight_before[v] * (unsigned long long)ntiles / total : 0ull;
+  unsigned long long t = total ? (unsigned long long)((double)weight_before[v] * (double)ntiles / (double)total) : 0ull;
   if (t >= (unsigned long long)ntiles) t = (unsigned long long)ntiles - 1ull;
   tile[k] = deg[v] ? (uint8_t)t : (uint8_t)255;
 }
@@ -886,24 +900,32 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     // as often as it is a column of the GM_DIR_OUT adjacency; on RMAT the busy tiles then hold fewer vertices, i.e. a
     // smaller slice of x where most gathers go).  gm_set_option("tile_balance", 0) cuts them into equally many vertices
     // with edges instead: RMAT-26 best 4 such tiles 7.07 ms against 6.74 ms with 6 gather-balanced ones.
-    DevBuf w, wpre, tk_in, tk_out, order2, bnd;
-    if ((rc = w.alloc((size_t)(nv + 1) * 4)) || (rc = wpre.alloc((size_t)(nv + 1) * 4)) || (rc = tk_in.alloc((size_t)nv)) ||
-        (rc = tk_out.alloc((size_t)nv)) || (rc = order2.alloc((size_t)nv * 4)) || (rc = bnd.alloc((size_t)(GM_MAX_TILES + 2) * 8)))
+    DevBuf cnt, w, wpre, tk_in, tk_out, order2, bnd;
+    if ((rc = cnt.alloc((size_t)nv * 4)) || (rc = w.alloc((size_t)(nv + 1) * 8)) || (rc = wpre.alloc((size_t)(nv + 1) * 8)) ||
+        (rc = tk_in.alloc((size_t)nv)) || (rc = tk_out.alloc((size_t)nv)) || (rc = order2.alloc((size_t)nv * 4)) ||
+        (rc = bnd.alloc((size_t)(GM_MAX_TILES + 2) * 8)))
       return rc;
-    GM_TRY_HIP(hipMemsetAsync(w.p, 0, (size_t)(nv + 1) * 4, s));
-    if (g_tile_balance == 1 && nnz > 0)
-      hipLaunchKernelGGL(k_col_weight, dim3(grid_for(nnz)), dim3(kT), 0, s, d_src, nnz, D.nparts, nv, D.ids_are_native, w.as<uint32_t>());
-    else
-      hipLaunchKernelGGL(k_live_flags, dim3(grid_for(nv)), dim3(kT), 0, s, deg.as<uint32_t>(), nv, w.as<uint32_t>());
+    GM_TRY_HIP(hipMemsetAsync(cnt.p, 0, (size_t)nv * 4, s));
+    GM_TRY_HIP(hipMemsetAsync(w.p, 0, (size_t)(nv + 1) * 8, s));
+    // g_tile_balance: 0 = vertices; 1 = gathers; 2..65536 = gathers + (value - 1) per vertex; 100000 + X = gathers^(X/100)  (experiments)
+    const int by_vertices = (g_tile_balance == 0 || nnz == 0) ? 1 : 0;
+    const int pw100 = g_tile_balance >= 100000 ? g_tile_balance - 100000 : 100;
+    const uint32_t addc = (g_tile_balance >= 2 && g_tile_balance <= 65536) ? (uint32_t)(g_tile_balance - 1) : 0u;
+    if (!by_vertices)
+      hipLaunchKernelGGL(k_col_weight, dim3(grid_for(nnz)), dim3(kT), 0, s, d_src, nnz, D.nparts, nv, D.ids_are_native, cnt.as<uint32_t>());
+    hipLaunchKernelGGL(k_tile_weight, dim3(grid_for(nv)), dim3(kT), 0, s, deg.as<uint32_t>(), cnt.as<uint32_t>(), nv, addc, pw100, by_vertices,
+                       w.as<unsigned long long>());
     size_t sb = 0;
-    GM_TRY_HIP(rocprim::exclusive_scan(nullptr, sb, w.as<uint32_t>(), wpre.as<uint32_t>(), 0u, (size_t)nv + 1, rocprim::plus<uint32_t>(), s));
+    GM_TRY_HIP(rocprim::exclusive_scan(nullptr, sb, w.as<unsigned long long>(), wpre.as<unsigned long long>(), 0ull, (size_t)nv + 1,
+                                       rocprim::plus<unsigned long long>(), s));
     if ((rc = tmp.alloc(sb))) return rc;
-    GM_TRY_HIP(rocprim::exclusive_scan(tmp.p, sb, w.as<uint32_t>(), wpre.as<uint32_t>(), 0u, (size_t)nv + 1, rocprim::plus<uint32_t>(), s));
-    uint32_t total = 0;
-    GM_TRY_HIP(hipMemcpyAsync(&total, wpre.as<uint32_t>() + nv, 4, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(rocprim::exclusive_scan(tmp.p, sb, w.as<unsigned long long>(), wpre.as<unsigned long long>(), 0ull, (size_t)nv + 1,
+                                       rocprim::plus<unsigned long long>(), s));
+    unsigned long long total = 0;
+    GM_TRY_HIP(hipMemcpyAsync(&total, wpre.as<unsigned long long>() + nv, 8, hipMemcpyDeviceToHost, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
     hipLaunchKernelGGL(k_tile_of_ranked, dim3(grid_for(nv)), dim3(kT), 0, s, order.as<int32_t>(), nv, deg.as<uint32_t>(),
-                       wpre.as<uint32_t>(), (unsigned long long)total, T, tk_in.as<uint8_t>());
+                       wpre.as<unsigned long long>(), total, T, tk_in.as<uint8_t>());
     sb = 0;
     GM_TRY_HIP(rocprim::radix_sort_pairs(nullptr, sb, tk_in.as<uint8_t>(), tk_out.as<uint8_t>(), order.as<int32_t>(),
                                          order2.as<int32_t>(), (size_t)nv, 0u, 8u, s));

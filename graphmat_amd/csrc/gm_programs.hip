@@ -454,7 +454,7 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "rank_by") && value >= 0 && value <= 2) { gm::g_rank_by = value; return GM_OK; }
   // (0 = every row is tiled; otherwise at least the short-row limit: the untiled row-block kernel takes every row up to that limit)
   if (key && !strcmp(key, "long_mid") && value >= 0) { gm::g_long_mid = value; return GM_OK; }
-  if (key && !strcmp(key, "tile_balance") && (value == 0 || value == 1)) { gm::g_tile_balance = value; return GM_OK; }
+  if (key && !strcmp(key, "tile_balance") && value >= 0 && value <= 100400) { gm::g_tile_balance = value; return GM_OK; }
   if (key && !strcmp(key, "tile_min_row") && (value == 0 || value >= gm::g_short_row)) { gm::g_tile_min_row = value; return GM_OK; }
   if (key && !strcmp(key, "col_tiles") && value >= 0 && value <= GM_MAX_TILES) { gm::g_col_tiles = value; return GM_OK; }
   if (key && !strcmp(key, "push_edge_permille") && value >= 0 && value <= 1000) { GraphMat::detail::push_edge_permille() = value; return GM_OK; }
