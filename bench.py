@@ -142,6 +142,84 @@ def extra_bfs(scale, edge_factor, seed, ref_threads, local_rank, rank):
             "runs": runs}
 
 
+def sgd_sampled_rows_check(g, nv, src, dst, val, lat0, lat1, users, items, K, lam, step, nsample, dev):
+    """One ALL_EDGES SGD iteration recomputed for `nsample` user rows and `nsample` item rows from the same initial
+    state, independently of the kernels (torch elementwise ops only, nothing shared with the library or the oracle),
+    with the reference's formulas AND evaluation order (/root/reference src/SGD.cpp:77-120: sequential K-term dot,
+    error = rating - estimate, res = message * error; include/GMDP/singlenode/spmspv3.h:38-90: a row's results
+    folded one by one in ascending NATIVE column order, the first one assigned; apply: lv += step * (-lambda * lv +
+    sum)).  Every op is a separate IEEE fp32 multiply or add, so the comparison is expected to be bit-exact; the
+    bound north_star states is 1e-6 relative.  Returns rows checked, rows bit-identical, the largest relative error."""
+    nparts = g.nparts
+    h = nv // nparts
+    vmax = h * nparts
+
+    def native(v0):  # include/Graph.h:111-130 on 0-based ids
+        return torch.where(v0 >= vmax, v0, v0 // nparts + (v0 % nparts) * h)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    dov = g.dev_of_vertex
+    lam32 = torch.tensor(np.float32(lam), device=dev)
+    step32 = torch.tensor(np.float32(step), device=dev)
+    checked = exact = 0
+    worst = 0.0
+    for side in ("items", "users"):
+        if side == "items":   # an item row receives from its raters (OUT pass: rows = destinations)
+            R = users + 1 + torch.randperm(items, generator=gen, device=dev)[:nsample].long()
+            rows_all, cols_all = dst, src
+        else:                 # a user row receives from the items it rated (IN pass: rows = sources)
+            R = 1 + torch.randperm(users, generator=gen, device=dev)[:nsample].long()
+            rows_all, cols_all = src, dst
+        R, _ = torch.sort(R)
+        mark = torch.zeros(nv + 1, dtype=torch.bool, device=dev)
+        mark[R] = True
+        idx = torch.nonzero(mark[rows_all.long()]).squeeze(1)  # ascending = input order
+        rows = rows_all[idx].long()
+        cols = cols_all[idx].long()
+        rating = val[idx].to(torch.float32)
+        del mark, idx
+        rank_of = torch.full((nv + 1,), -1, dtype=torch.int64, device=dev)
+        rank_of[R] = torch.arange(R.numel(), device=dev)
+        key = rank_of[rows] * (1 << 32) + native(cols - 1)
+        del rank_of
+        key, order = torch.sort(key, stable=True)       # (row, native column), duplicates in input order
+        rr = key >> 32
+        cols, rating = cols[order], rating[order]
+        count = torch.bincount(rr, minlength=R.numel())
+        start = torch.cumsum(count, 0) - count
+        m = lat0[dov[cols - 1], :K]
+        vp_e = lat0[dov[R - 1], :K][rr]
+        est = torch.zeros(cols.numel(), dtype=torch.float32, device=dev)
+        for k in range(K):
+            est = est + m[:, k] * vp_e[:, k]
+        err = rating - est
+        terms = m * err[:, None]
+        del m, vp_e, est
+        acc = torch.zeros((R.numel(), K), dtype=torch.float32, device=dev)
+        for j in range(int(count.max())):
+            live = torch.nonzero(count > j).squeeze(1)
+            t = terms[start[live] + j]
+            if j == 0:
+                acc[live] = t
+            else:
+                acc[live] = acc[live] + t
+        vp = lat0[dov[R - 1], :K]
+        t1 = (-lam32) * vp
+        t2 = t1 + acc
+        t3 = step32 * t2
+        want = torch.where((count > 0)[:, None], vp + t3, vp)
+        got = lat1[dov[R - 1], :K]
+        same = (want.view(torch.int32) == got.view(torch.int32)).all(dim=1)
+        rel = ((want - got).abs() / want.abs().clamp(min=1e-30)).max()
+        # the update itself, not hidden behind the old value: (got - vp) against (want - vp), relative to the update
+        upd = ((got - vp) - t3).abs().max() / t3.abs().max().clamp(min=1e-30)
+        checked += int(R.numel())
+        exact += int(same.sum())
+        worst = max(worst, float(rel), float(upd))
+        del terms, acc
+    return checked, exact, worst
+
+
 def extra_sgd(users, items, per_user, iters, local_rank, rank):
     """BASELINE config 5 shape on one GPU: SGD/CF, K=128 fp32 latent vectors, one ALL_EDGES iteration."""
     from graphmat_amd import _lib, api
@@ -156,11 +234,17 @@ def extra_sgd(users, items, per_user, iters, local_rank, rank):
     val = torch.randint(1, 6, (src.numel(),), generator=gen, device=dev).to(torch.int32)
     E = src.numel()
     g = api.Graph(nv, src, dst, val, device=local_rank, keep_values=True)
-    del src, dst, val
     lat = torch.rand((g.rows, K + 1), generator=gen, device=dev, dtype=torch.float32)
+    lat0 = lat.clone()
     it = C.c_int(0)
-    _lib.check(L.gm_run_sgd(g.h, lat.data_ptr(), K, 4, 0.001, 1e-5, 1, C.byref(it), None))  # warm
+    _lib.check(L.gm_run_sgd(g.h, lat.data_ptr(), K, 4, 0.001, 1e-5, 1, C.byref(it), None))  # warm, and the checked one
     torch.cuda.synchronize()
+    nsample = min(1024, users, items)
+    checked, exact, worst = sgd_sampled_rows_check(g, nv, src, dst, val, lat0, lat, users, items, K, 0.001, 1e-5, nsample, dev)
+    log(rank, "extra sgd: %d sampled rows recomputed with torch in the reference's order: %d bit-identical, max rel err %.3g"
+        % (checked, exact, worst))
+    del src, dst, val, lat0
+    torch.cuda.empty_cache()
     t0 = time.perf_counter()
     _lib.check(L.gm_run_sgd(g.h, lat.data_ptr(), K, 4, 0.001, 1e-5, iters, C.byref(it), None))
     torch.cuda.synchronize()
@@ -176,7 +260,11 @@ def extra_sgd(users, items, per_user, iters, local_rank, rank):
                         % (users, items, E), "ms_per_iteration": round(dt * 1e3, 3), "iterations_timed": iters,
             "edge_visits_per_s_e9": round(2 * E / dt / 1e9, 3), "alg_bytes": balg, "hbm_gbps": round(balg / dt / 1e9, 1),
             "hbm_frac": round(balg / dt / 1e9 / HBM_PEAK_GBPS, 4), "gather_inclusive_gbps": round(2 * E * K * 4 / dt / 1e9, 1),
-            "tflops": round(flops / dt / 1e12, 2), "result_finite": finite}
+            "tflops": round(flops / dt / 1e12, 2), "result_finite": finite,
+            "rows_checked": checked, "rows_bit_identical": exact, "max_rel_err": worst, "rel_tol": 1e-6,
+            "rows_check": "first iteration, %d sampled item rows + %d sampled user rows recomputed from the same initial state by "
+                          "an independent torch fp32 evaluation in the reference's order (bench.py sgd_sampled_rows_check)" % (nsample, nsample),
+            "rows_ok": bool(checked >= 2 * nsample and worst <= 1e-6)}
 
 
 def main():

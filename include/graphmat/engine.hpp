@@ -40,6 +40,28 @@ inline int& debug_flags() {
   return f;
 }
 
+// form of the 16-rows-per-wave kernel: 0 = one workgroup per 64 rows with an 8192-entry LDS hot set;
+// 1..4 = persistent workgroups with a large hot set (512 threads / 30720 entries, 1024 / 22528, 512 / 16384, 256 / 8192)
+inline int& wave16_form() {
+  static int v = 0;
+  return v;
+}
+// persistent kernels: workgroups per CU (0 = as many as the LDS allows)
+inline int& persist_per_cu() {
+  static int v = 0;
+  return v;
+}
+inline int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 // top-down steps are taken while the active set owns less than this many thousandths of the edges
 inline int& push_edge_permille() {
   static int v = 50;
@@ -345,6 +367,26 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
         if (rest > 0) {
           const int groups = (rest + dev::kWaveRows - 1) / dev::kWaveRows;
           constexpr int W16 = dev::kWave16Block / 64;
+          bool done = false;
+          if constexpr (sizeof(T) == 4) {
+            const int form = wave16_form();
+            auto persistent = [&](auto block_c, auto hot_c, int fit) {
+              constexpr int BLOCK = decltype(block_c)::value, HOT = decltype(hot_c)::value;
+              int per_cu = persist_per_cu() > 0 && persist_per_cu() < fit ? persist_per_cu() : fit;
+              int grid = cu_count() * per_cu;
+              const int need = (groups + BLOCK / 64 - 1) / (BLOCK / 64);
+              if (grid > need) grid = need;
+              hipLaunchKernelGGL((dev::k_spmv_wave16p<P, T, U, V, E, BLOCK, HOT>), dim3(grid), dim3(BLOCK), 0, s, pa, A,
+                                 A.mid_row + nlong, rest, x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
+              done = true;
+            };
+            if (form == 1) persistent(std::integral_constant<int, 512>(), std::integral_constant<int, 30720>(), 1);
+            else if (form == 2) persistent(std::integral_constant<int, 1024>(), std::integral_constant<int, 22528>(), 1);
+            else if (form == 3) persistent(std::integral_constant<int, 512>(), std::integral_constant<int, 16384>(), 1);
+            else if (form == 4) persistent(std::integral_constant<int, 256>(), std::integral_constant<int, 8192>(), 3);
+            else if (form == 5) persistent(std::integral_constant<int, 512>(), std::integral_constant<int, 10240>(), 2);
+          }
+          if (!done)
           hipLaunchKernelGGL((dev::k_spmv_wave16<P, T, U, V, E>), dim3((groups + W16 - 1) / W16), dim3(dev::kWave16Block), 0, s, pa, A,
                              A.mid_row + nlong, rest, x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
         }

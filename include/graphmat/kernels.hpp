@@ -814,42 +814,61 @@ k_spmv_wave(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nli
 constexpr int kWaveRows = 16;
 constexpr int kHotEntries = 8192;
 constexpr int kWave16Block = 256;  // (512 threads sharing one hot set: no difference; 1024: slower)
-template <class P, class T, class U, class V, class E>
-__global__ void __launch_bounds__(kWave16Block)
-k_spmv_wave16(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nlist, const T* __restrict__ x,
-              const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
-              uint32_t* __restrict__ ybits, int accumulate, int dbg, const uint32_t* __restrict__ want) {
-  static_assert(sizeof(U) == 4 || sizeof(U) == 8, "LDS tile of 4- or 8-byte products");
-  constexpr int G = kWaveRows;
-  constexpr int kStride = 64 + 16 / (int)sizeof(U);  // padded row of the tile (keeps 16-byte alignment, staggers banks)
-  __shared__ __attribute__((aligned(16))) U s_t[kWave16Block / 64][G][kStride];
-  __shared__ unsigned long long s_mask[kWave16Block / 64][G];
-  // the hottest x entries (device order is degree-ranked: they are the first ones) live in LDS: at
-  // RMAT-26 the first 8192 vertices are the source of 14 % of the edges (34 % at RMAT-22), and a gather
-  // served from LDS is one request less for the L2 (RMAT-26 wave rows 6.10 -> 5.87 ms; 4096 / 8192 /
-  // 12288 / 16384 entries: 5.94 / 5.87 / 5.90 / 7.52 ms -- the last leaves one workgroup per CU)
-  constexpr int kHot = sizeof(T) == 4 ? kHotEntries : 1;
-  __shared__ T s_hot[kHot];
-  // (a column tile's columns are a slice [hot_base, hot_base + hot_len) of the device order, busiest first)
-  // Sharded graphs: the degree ranking is dealt over the NS slices of x, so the hot set is the first kHot / NS
-  // entries of every slice (s_hot[q * per + i] = x[q * stride + i]).
-  const int NS = A.hot_slices > 1 ? A.hot_slices : 1;
-  const int per = kHot > 1 ? ((A.hot_len < kHot / NS ? A.hot_len : kHot / NS)) : 0;  // hot entries per slice
-  const int nhot = per * NS;
-  const T* __restrict__ xhot = x + A.hot_base;
-  if constexpr (kHot > 1) {
+
+// The hottest x entries of the adjacency's column slice, kept in LDS by the wave kernels (device order is
+// degree-ranked: they are the first ones of the slice; a column tile's columns are the slice
+// [hot_base, hot_base + hot_len) of the device order, busiest first).  Sharded graphs: the degree ranking is
+// dealt over the NS slices of x, so the hot set is the first HOT / NS entries of every slice
+// (s_hot[q * per + i] = x[q * stride + i]).
+template <class T>
+struct HotSet {
+  const T* s_hot;
+  int base, nhot, NS, per, stride;
+  float inv_stride;
+  __device__ __forceinline__ T get(const T* __restrict__ x, int c) const {
     if (NS == 1) {
-      for (int i = threadIdx.x; i < nhot; i += kWave16Block) s_hot[i] = xhot[i];
+      const unsigned rel = (unsigned)(c - base);
+      return rel < (unsigned)nhot ? s_hot[rel] : x[c];
+    }
+    // slice q of the column and its position in it (float estimate of the quotient, fixed up exactly)
+    int q = (int)((float)c * inv_stride);
+    q = q >= NS ? NS - 1 : q;
+    int pos = c - q * stride;
+    if (pos < 0) { q--; pos += stride; } else if (pos >= stride) { q++; pos -= stride; }
+    return pos < per ? s_hot[q * per + pos] : x[c];
+  }
+};
+// fills s_hot (all threads of the workgroup; the caller synchronises) and describes it
+template <class T, int HOT, int BLOCK>
+__device__ __forceinline__ HotSet<T> hot_load(const gm_csr_t& A, const T* __restrict__ x, T* s_hot) {
+  HotSet<T> h;
+  h.s_hot = s_hot;
+  h.base = A.hot_base;
+  h.NS = A.hot_slices > 1 ? A.hot_slices : 1;
+  h.stride = A.hot_stride;
+  h.per = HOT > 1 ? ((A.hot_len < HOT / h.NS ? A.hot_len : HOT / h.NS)) : 0;  // hot entries per slice
+  h.nhot = h.per * h.NS;
+  h.inv_stride = h.NS > 1 ? 1.0f / (float)A.hot_stride : 0.f;
+  if constexpr (HOT > 1) {
+    if (h.NS == 1) {
+      const T* __restrict__ xhot = x + A.hot_base;
+      for (int i = threadIdx.x; i < h.nhot; i += BLOCK) s_hot[i] = xhot[i];
     } else {
-      for (int i = threadIdx.x; i < nhot; i += kWave16Block) s_hot[i] = x[(size_t)(i / per) * A.hot_stride + (i % per)];
+      for (int i = threadIdx.x; i < h.nhot; i += BLOCK) s_hot[i] = x[(size_t)(i / h.per) * A.hot_stride + (i % h.per)];
     }
   }
-  const float inv_stride = NS > 1 ? 1.0f / (float)A.hot_stride : 0.f;
-  __syncthreads();
-  const P& p = *reinterpret_cast<const P*>(pa.b);
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int first = (blockIdx.x * (kWave16Block / 64) + wv) * G;
-  if (first >= nlist) return;
+  return h;
+}
+
+// one wave folds the kWaveRows list entries [first, first + kWaveRows) (s_t / s_mask: the wave's LDS tile)
+template <class P, class T, class U, class V, class E, int KSTRIDE>
+__device__ __forceinline__ void wave16_group(const P& p, const gm_csr_t& A, const int32_t* __restrict__ rows, const int nlist,
+                                             const int first, const int lane, const T* __restrict__ x,
+                                             const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
+                                             uint32_t* __restrict__ ybits, const int accumulate, const int dbg,
+                                             const uint32_t* __restrict__ want, const HotSet<T>& hot, U (*s_t)[KSTRIDE],
+                                             unsigned long long* s_mask) {
+  constexpr int G = kWaveRows;
   const bool dense = (xbits == nullptr);
   // lane r < G owns list entry first + r
   int my_row = -1;
@@ -881,19 +900,7 @@ k_spmv_wave16(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int n
 #pragma unroll
     for (int r = 0; r < G; r++) {
       if (c[r] >= 0 && !dense && !bit_get(xbits, c[r])) c[r] = -1;
-      if (c[r] >= 0) {
-        if (NS == 1) {
-          const unsigned rel = (unsigned)(c[r] - A.hot_base);
-          m[r] = rel < (unsigned)nhot ? s_hot[rel] : x[c[r]];
-        } else {
-          // slice q of the column and its position in it (float estimate of the quotient, fixed up exactly)
-          int q = (int)((float)c[r] * inv_stride);
-          q = q >= NS ? NS - 1 : q;
-          int pos = c[r] - q * A.hot_stride;
-          if (pos < 0) { q--; pos += A.hot_stride; } else if (pos >= A.hot_stride) { q++; pos -= A.hot_stride; }
-          m[r] = pos < per ? s_hot[q * per + pos] : x[c[r]];
-        }
-      }
+      if (c[r] >= 0) m[r] = hot.get(x, c[r]);
     }
   };
   if (nsteps > 0) fetch(0);
@@ -906,16 +913,16 @@ k_spmv_wave16(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int n
       if (pres) {
         const int64_t k = wave_bcast(my_e0, r) + (int64_t)step * 64 + lane;
         p.P::process_message(m[r], edge_at<E>(A.vals, k), no_vp, term);
-        s_t[wv][r][lane] = term;
+        s_t[r][lane] = term;
       }
       const unsigned long long mask = __ballot(pres);
-      if (lane == 0) s_mask[wv][r] = mask;
+      if (lane == 0) s_mask[r] = mask;
     }
     __builtin_amdgcn_wave_barrier();
     if (step + 1 < nsteps) fetch(step + 1);  // in flight during the folds below
     if (lane < G && !(dbg & DBG_SKIP_FOLD)) {
-      unsigned long long mask = s_mask[wv][lane];
-      const U* t = s_t[wv][lane];
+      unsigned long long mask = s_mask[lane];
+      const U* t = s_t[lane];
       if (mask == ~0ull) {
         int k = 0;
         if (!has) { acc = t[0]; has = true; k = 1; }
@@ -935,6 +942,59 @@ k_spmv_wave16(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int n
     y[my_row] = acc;
     if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[my_row >> 5], 1u << (my_row & 31));
   }
+}
+
+template <class P, class T, class U, class V, class E>
+__global__ void __launch_bounds__(kWave16Block)
+k_spmv_wave16(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nlist, const T* __restrict__ x,
+              const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
+              uint32_t* __restrict__ ybits, int accumulate, int dbg, const uint32_t* __restrict__ want) {
+  static_assert(sizeof(U) == 4 || sizeof(U) == 8, "LDS tile of 4- or 8-byte products");
+  constexpr int G = kWaveRows;
+  constexpr int kStride = 64 + 16 / (int)sizeof(U);  // padded row of the tile (keeps 16-byte alignment, staggers banks)
+  __shared__ __attribute__((aligned(16))) U s_t[kWave16Block / 64][G][kStride];
+  __shared__ unsigned long long s_mask[kWave16Block / 64][G];
+  // the hottest x entries live in LDS: at RMAT-26 the first 8192 vertices are the source of 14 % of the edges
+  // (34 % at RMAT-22), and a gather served from LDS is one request less for the L2 (RMAT-26 wave rows 6.10 ->
+  // 5.87 ms; 4096 / 8192 / 12288 / 16384 entries: 5.94 / 5.87 / 5.90 / 7.52 ms -- the last leaves one
+  // workgroup per CU; the persistent form below is how a larger set pays)
+  constexpr int kHot = sizeof(T) == 4 ? kHotEntries : 1;
+  __shared__ T s_hot[kHot];
+  const HotSet<T> hot = hot_load<T, kHot, kWave16Block>(A, x, s_hot);
+  __syncthreads();
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int first = (blockIdx.x * (kWave16Block / 64) + wv) * G;
+  if (first >= nlist) return;
+  wave16_group<P, T, U, V, E, kStride>(p, A, rows, nlist, first, lane, x, xbits, vp, y, ybits, accumulate, dbg, want, hot, s_t[wv], s_mask[wv]);
+}
+
+// Persistent form with a LARGE hot set: the grid is a few workgroups per CU (not one per 64 rows), each
+// loads HOT entries of the slice's busiest x values into LDS once and then its waves walk the row list,
+// group after group (group g goes to wave g mod #waves: the list is degree-ranked, so consecutive groups
+// cost about the same and the interleaving balances the waves).  With the set loaded once per workgroup
+// instead of once per 64 rows it can take most of the CU's 160 KB.
+template <class P, class T, class U, class V, class E, int BLOCK, int HOT>
+__global__ void __launch_bounds__(BLOCK)
+k_spmv_wave16p(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nlist, const T* __restrict__ x,
+               const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
+               uint32_t* __restrict__ ybits, int accumulate, int dbg, const uint32_t* __restrict__ want) {
+  static_assert(sizeof(U) == 4 || sizeof(U) == 8, "LDS tile of 4- or 8-byte products");
+  static_assert(sizeof(T) == 4, "4-byte messages");
+  constexpr int G = kWaveRows;
+  constexpr int kStride = 64 + 16 / (int)sizeof(U);
+  __shared__ __attribute__((aligned(16))) U s_t[BLOCK / 64][G][kStride];
+  __shared__ unsigned long long s_mask[BLOCK / 64][G];
+  __shared__ T s_hot[HOT];
+  const HotSet<T> hot = hot_load<T, HOT, BLOCK>(A, x, s_hot);
+  __syncthreads();
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ngroups = (nlist + G - 1) / G;
+  const int nwaves = gridDim.x * (BLOCK / 64);
+  // wave w of the grid = workgroup (w mod gridDim.x), so neighbouring groups go to different CUs
+  for (int g = wv * gridDim.x + blockIdx.x; g < ngroups; g += nwaves)
+    wave16_group<P, T, U, V, E, kStride>(p, A, rows, nlist, g * G, lane, x, xbits, vp, y, ybits, accumulate, dbg, want, hot, s_t[wv], s_mask[wv]);
 }
 
 // The same for programs with a row filter once most rows have dropped out: a wave takes 64

@@ -382,6 +382,35 @@ def test_config2_rmat22_against_oracle(env):
     depth, parent, it = g.bfs(1)
     od, op, oit, _ = og.bfs(1)
     assert it == oit and (depth == od).all() and (parent == op).all()
+    # the same configuration on the COLUMN-TILED multiply (what bench.py times at RMAT-26, where the tile count
+    # is chosen automatically): forced 4 and 6 tiles against the same oracle result, bit for bit
+    opr, oit, _ = og.pagerank(10, degree=odeg)
+    g.close()
+    for tiles in (4, 6):
+        nv, src, dst, _ = api.rmat_on_device(22, 16, 1)
+        gt = api.Graph(nv, src, dst, None, ref_threads=1, keep_values=False, col_tiles=tiles)
+        del src, dst
+        assert gt.col_tiles == tiles
+        pr, deg, it = gt.pagerank(10)
+        assert (deg == odeg).all() and it == 10
+        assert (f32bits(pr) == f32bits(opr)).all(), "RMAT-22 PageRank with %d column tiles differs from the oracle" % tiles
+        gt.close()
+
+
+@pytest.mark.timeout(900)
+def test_fullscale_pagerank_rmat26_tiled_equals_untiled():
+    """The headline configuration (PageRank on RMAT-26) runs on automatically chosen column tiles; the CPU oracle
+    cannot hold 1.07 G edges.  This ties the timed path to the oracle-tested one: 10 iterations on the automatic
+    tiling and on the untiled graph (col_tiles=1) must leave bit-identical vertex state
+    (tools/fullscale_checks.py --tiled-vs-untiled; the untiled kernels are the ones compared with the oracle at
+    RMAT-10..22, the forced-tile ones at RMAT-10..22 above and in test_gpu_tiles.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fullscale_checks.py"), "--scale", "26",
+                          "--tiled-vs-untiled", "10"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=850)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "TILED == UNTILED" in text, text[-3000:]
 
 
 def test_sgd_with_giant_rows(env):

@@ -191,3 +191,25 @@ def test_edge_value_updates_reach_the_tiles(env, tile_min, tiles, minrow):
     assert not tiles_hold(newer)
     api._lib.check(L.gm_graph_sync_tile_vals(g.h, None))
     assert tiles_hold(newer)
+
+
+@pytest.mark.parametrize("form", [1, 2, 3, 4, 5])
+def test_persistent_wave16_forms_bit_exact(env, tile_min, form):
+    """The persistent forms of the 16-rows-per-wave kernel (large LDS hot set loaded once per workgroup,
+    gm_set_option("wave16_form")) fold exactly like the one-workgroup-per-64-rows form: tiled and untiled
+    PageRank against the oracle, bit for bit."""
+    api, ob = env
+    tile_min(64)
+    L = api._lib.lib()
+    nv, s, d, v = gen.rmat_edges(16, 16, seed=5)
+    og = ob.OracleGraph(nv, s, d, v, 1)
+    opr, oit, _ = og.pagerank(6)
+    try:
+        api._lib.check(L.gm_set_option(b"wave16_form", form))
+        for tiles in (1, 4):
+            g = api.Graph(nv, s, d, v, ref_threads=1, col_tiles=tiles)
+            pr, deg, it = g.pagerank(6)
+            assert it == oit == 6 and (f32bits(pr) == f32bits(opr)).all(), "form %d, %d tiles" % (form, tiles)
+            g.close()
+    finally:
+        L.gm_set_option(b"wave16_form", 0)

@@ -63,14 +63,46 @@ def check_bfs(g, nv, src, dst, nat, source, dev):
             "parents_not_max_native": wrong_parent, "source_ok": bool(src_ok), "unreached_untouched": bool(unreached_ok)}
 
 
+def tiled_vs_untiled(api, args):
+    """PageRank state after N iterations: automatic column tiles (the bench path) vs col_tiles=1 (the path the oracle
+    tests cover), same edges, compared bit for bit in VERTEX order (the two graphs have different device orders)."""
+    states = []
+    for tiles in (0, 1):
+        nv, src, dst, _ = api.rmat_on_device(args.scale, 16, 1)
+        g = api.Graph(nv, src, dst, None, ref_threads=args.ref_threads, keep_values=False, col_tiles=tiles)
+        del src, dst
+        st = g.new_pr_state()
+        g.run_degree(st)
+        it = g.run_pagerank(st, args.tiled_vs_untiled)
+        states.append((g.col_tiles, it, g.to_vertex_order(st[:, 0].contiguous()).clone(), g.to_vertex_order(st[:, 1].contiguous()).clone()))
+        print("RMAT-%d col_tiles=%d (asked %d): %d iterations" % (args.scale, g.col_tiles, tiles, it))
+        g.close()
+        del g, st
+        torch.cuda.empty_cache()
+    (ta, ia, pa, da), (tb, ib, pb, db) = states
+    if args.scale >= 25 and ta <= 1:
+        print("the automatic policy chose no tiles at this scale: nothing compared => FAIL")
+        return 1
+    diff = int((pa != pb).sum()) + int((da != db).sum())
+    same = ia == ib == args.tiled_vs_untiled and diff == 0
+    print("PageRank %d iterations, %d tiles vs untiled: %d differing words => %s"
+          % (args.tiled_vs_untiled, ta, diff, "TILED == UNTILED (bit-identical)" if same else "FAIL"))
+    return 0 if same else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=int, default=26)
     ap.add_argument("--ref-threads", type=int, default=1)
     ap.add_argument("--pr-iters", type=int, default=5)
+    ap.add_argument("--tiled-vs-untiled", type=int, default=0, metavar="ITERS",
+                    help="only this check: ITERS PageRank iterations on the automatically tiled graph and on the "
+                         "untiled one (col_tiles=1) must leave bit-identical state")
     args = ap.parse_args()
     from graphmat_amd import api
     dev = torch.device("cuda", 0)
+    if args.tiled_vs_untiled:
+        sys.exit(tiled_vs_untiled(api, args))
     nv, src, dst, _ = api.rmat_on_device(args.scale, 16, 1)
     E = src.numel()
     g = api.Graph(nv, src, dst, None, ref_threads=args.ref_threads, keep_values=False)
