@@ -24,6 +24,7 @@ def _deps():
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = FLAGS + (["-DGRAPHMAT_ABLATION"] if os.environ.get("GRAPHMAT_ABLATION") == "1" else [])  # in-kernel ablation switches
     objs = []
     procs = []
     deps_mtime = max(os.path.getmtime(p) for p in _deps())
@@ -32,7 +33,7 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if (not force) and os.path.exists(obj) and os.path.getmtime(obj) >= deps_mtime:
             continue
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -12,6 +12,7 @@
 // the 570 MB library.
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
@@ -39,145 +40,31 @@ struct RcclApi {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
 };
 static RcclApi g_rccl;
 static ncclComm_t g_comm = nullptr;
 static int g_rank = 0, g_nranks = 1;
 
-// ---- host shared-memory transport (GRAPHMAT_DIST_TRANSPORT=shm) ---------------------------------------
-// RCCL wants one rank per GPU, so a multi-rank run cannot be tried on a 1-GPU box with it.  This transport
-// has the same four entry points but moves the bytes through a POSIX shared-memory segment (device -> host
-// -> barrier -> device, blocking): slow and for tests only, like gloo is for the Python callback path.
-struct ShmHeader {
-  std::atomic<int> count;
-  std::atomic<int> generation;
-  char pad[56];
-};
-struct ShmState {
-  ShmHeader* hdr = nullptr;
-  char* data = nullptr;
-  size_t data_bytes = 0;
-  int rank = 0, nranks = 1;
-  std::string name;
-};
-static ShmState g_shm;
-static void shm_barrier() {
-  ShmHeader* h = g_shm.hdr;
-  const int gen = h->generation.load(std::memory_order_acquire);
-  if (h->count.fetch_add(1, std::memory_order_acq_rel) == g_shm.nranks - 1) {
-    h->count.store(0, std::memory_order_relaxed);
-    h->generation.store(gen + 1, std::memory_order_release);
-  } else {
-    while (h->generation.load(std::memory_order_acquire) == gen) usleep(20);
-  }
-}
-static size_t nccl_type_bytes(ncclDataType_t t) { return (t == ncclChar || t == ncclUint8) ? 1 : (t == ncclInt64 || t == ncclUint64 || t == ncclFloat64) ? 8 : 4; }
-static ncclResult_t shm_get_unique_id(ncclUniqueId* id) {
-  memset(id, 0, sizeof(*id));
-  snprintf(id->internal, sizeof(id->internal), "/graphmat_shm_%d_%ld", (int)getpid(), (long)time(nullptr));
-  return ncclSuccess;
-}
-static ncclResult_t shm_comm_init(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank) {
-  const char* mb = getenv("GRAPHMAT_SHM_MB");
-  const size_t bytes = sizeof(ShmHeader) + (size_t)(mb ? atoi(mb) : 64) * 1024 * 1024;
-  int fd = shm_open(id.internal, O_CREAT | O_RDWR, 0600);
-  if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) return ncclSystemError;
-  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (p == MAP_FAILED) return ncclSystemError;
-  g_shm.hdr = (ShmHeader*)p;  // a fresh segment is zero-filled: counters start at 0
-  g_shm.data = (char*)p + sizeof(ShmHeader);
-  g_shm.data_bytes = bytes - sizeof(ShmHeader);
-  g_shm.rank = rank;
-  g_shm.nranks = nranks;
-  g_shm.name = id.internal;
-  *comm = (ncclComm_t)&g_shm;
-  shm_barrier();
-  return ncclSuccess;
-}
-static ncclResult_t shm_comm_destroy(ncclComm_t) {
-  if (g_shm.hdr) {
-    shm_barrier();
-    munmap((void*)g_shm.hdr, g_shm.data_bytes + sizeof(ShmHeader));
-    if (g_shm.rank == 0) shm_unlink(g_shm.name.c_str());
-    g_shm.hdr = nullptr;
-  }
-  return ncclSuccess;
-}
-static ncclResult_t shm_all_gather(const void* send, void* recv, size_t count, ncclDataType_t t, ncclComm_t, hipStream_t s) {
-  const size_t bytes = count * nccl_type_bytes(t);
-  const int n = g_shm.nranks, r = g_shm.rank;
-  if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
-  const size_t chunk = (g_shm.data_bytes / (size_t)n) & ~(size_t)63;
-  for (size_t off = 0; off < bytes; off += chunk) {
-    const size_t len = bytes - off < chunk ? bytes - off : chunk;
-    if (hipMemcpy(g_shm.data + (size_t)r * chunk, (const char*)send + off, len, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
-    shm_barrier();
-    for (int q = 0; q < n; q++)
-      if (hipMemcpy((char*)recv + (size_t)q * bytes + off, g_shm.data + (size_t)q * chunk, len, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
-    shm_barrier();
-  }
-  return ncclSuccess;
-}
-// sum of 32-bit integer arrays (the degree counts of a distributed graph build), a chunk of the segment at a time
-static ncclResult_t shm_all_reduce_sum32(const void* send, void* recv, size_t count, hipStream_t s) {
-  const int n = g_shm.nranks, r = g_shm.rank;
-  if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
-  const size_t chunk = ((g_shm.data_bytes / (size_t)(n + 1)) & ~(size_t)63) / 4;  // words per rank slot (+1 result slot)
-  uint32_t* slots = (uint32_t*)g_shm.data;
-  for (size_t off = 0; off < count; off += chunk) {
-    const size_t len = count - off < chunk ? count - off : chunk;
-    if (hipMemcpy(slots + (size_t)r * chunk, (const uint32_t*)send + off, len * 4, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
-    shm_barrier();
-    if (r == 0) {
-      uint32_t* out = slots + (size_t)n * chunk;
-      for (size_t i = 0; i < len; i++) {
-        uint32_t a = slots[i];
-        for (int q = 1; q < n; q++) a += slots[(size_t)q * chunk + i];
-        out[i] = a;
-      }
-    }
-    shm_barrier();
-    if (hipMemcpy((uint32_t*)recv + off, slots + (size_t)n * chunk, len * 4, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
-    shm_barrier();
-  }
-  return ncclSuccess;
-}
-static ncclResult_t shm_all_reduce(const void* send, void* recv, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t, hipStream_t s) {
-  if ((t == ncclUint32 || t == ncclInt32) && op == ncclSum && count != 1) return shm_all_reduce_sum32(send, recv, count, s);
-  if (t != ncclInt32 || count != 1 || (op != ncclMin && op != ncclMax && op != ncclSum)) return ncclInvalidArgument;
-  if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
-  int v = 0;
-  if (hipMemcpy(&v, send, 4, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
-  ((int*)g_shm.data)[g_shm.rank] = v;
-  shm_barrier();
-  int acc = ((int*)g_shm.data)[0];
-  for (int q = 1; q < g_shm.nranks; q++) {
-    const int o = ((int*)g_shm.data)[q];
-    acc = op == ncclMin ? (o < acc ? o : acc) : op == ncclMax ? (o > acc ? o : acc) : acc + o;
-  }
-  shm_barrier();
-  if (hipMemcpy(recv, &acc, 4, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
-  return ncclSuccess;
-}
-static const char* shm_error_string(ncclResult_t r) { return r == ncclSuccess ? "ok" : "shared-memory transport error"; }
-
+// librccl is bound with dlopen when gm_dist_init is first called.  GRAPHMAT_RCCL_LIBRARY names another library with
+// the same entry points (the test suite's host shared-memory stand-in, tests/support/, so that several ranks can
+// run on a 1-GPU box; nothing of it is compiled into this library).
 static int bind_rccl() {
   if (g_rccl.handle) return GM_OK;
-  const char* tr = getenv("GRAPHMAT_DIST_TRANSPORT");
-  if (tr && !strcmp(tr, "shm")) {  // test transport: same entry points over host shared memory
-    g_rccl.GetUniqueId = shm_get_unique_id;
-    g_rccl.CommInitRank = shm_comm_init;
-    g_rccl.CommDestroy = shm_comm_destroy;
-    g_rccl.AllGather = shm_all_gather;
-    g_rccl.AllReduce = shm_all_reduce;
-    g_rccl.GetErrorString = shm_error_string;
-    g_rccl.handle = (void*)&g_shm;
-    return GM_OK;
+  const char* name = getenv("GRAPHMAT_RCCL_LIBRARY");
+  void* h = nullptr;
+  if (name && *name) {
+    h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { set_error("gm_dist: cannot load GRAPHMAT_RCCL_LIBRARY=%s: %s", name, dlerror()); return GM_ERR_UNSUPPORTED; }
+  } else {
+    h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { set_error("gm_dist: cannot load librccl.so.1: %s", dlerror()); return GM_ERR_UNSUPPORTED; }
   }
-  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) { set_error("gm_dist: cannot load librccl.so.1: %s", dlerror()); return GM_ERR_UNSUPPORTED; }
 #define GM_BIND(field, sym)                                                                  \
   *(void**)(&g_rccl.field) = dlsym(h, sym);                                                  \
   if (!g_rccl.field) { set_error("gm_dist: librccl has no symbol %s", sym); dlclose(h); return GM_ERR_UNSUPPORTED; }
@@ -187,6 +74,11 @@ static int bind_rccl() {
   GM_BIND(AllGather, "ncclAllGather")
   GM_BIND(AllReduce, "ncclAllReduce")
   GM_BIND(GetErrorString, "ncclGetErrorString")
+  GM_BIND(Send, "ncclSend")
+  GM_BIND(Recv, "ncclRecv")
+  GM_BIND(GroupStart, "ncclGroupStart")
+  GM_BIND(GroupEnd, "ncclGroupEnd")
+  GM_BIND(Broadcast, "ncclBroadcast")
 #undef GM_BIND
   g_rccl.handle = h;
   return GM_OK;
@@ -491,54 +383,132 @@ int gm_graph_exchange_counters(const gm_graph_t* g, int64_t out[4]) {
   return GM_OK;
 }
 
-// rank / size / local device from the launcher's environment, the unique id through a rendezvous file
+// rank / size / local device from the launcher's environment, the unique id through a rendezvous file.
+//
+// A process joins a communicator only on an UNAMBIGUOUS multi-rank launch: GRAPHMAT_NRANKS (+ GRAPHMAT_RANK), or a
+// launcher's own pair of variables both present (torchrun RANK + WORLD_SIZE, Open MPI OMPI_COMM_WORLD_*, PMI_*, and
+// for Slurm the per-STEP variables SLURM_STEP_NUM_TASKS + SLURM_PROCID that only `srun` sets -- SLURM_NTASKS describes
+// the allocation, so a single process started inside an sbatch script is one rank, not eight).  A lone WORLD_SIZE in
+// a shell is ignored.  GRAPHMAT_NRANKS=1 forces a single-process run whatever else is set.
 int gm_dist_init_from_env(int* rank_out, int* nranks_out) {
-  auto env_int = [](const char* const* names, int dflt) {
-    for (int i = 0; names[i]; i++) { const char* v = getenv(names[i]); if (v && *v) return atoi(v); }
-    return dflt;
-  };
-  static const char* const rk[] = {"GRAPHMAT_RANK", "RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "SLURM_PROCID", nullptr};
-  static const char* const sz[] = {"GRAPHMAT_NRANKS", "WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS", nullptr};
-  static const char* const lr[] = {"GRAPHMAT_LOCAL_RANK", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID", nullptr};
-  const int nranks = env_int(sz, 1), rank = env_int(rk, 0);
-  if (rank_out) *rank_out = rank;
-  if (nranks_out) *nranks_out = nranks;
+  auto env = [](const char* n) -> const char* { const char* v = getenv(n); return (v && *v) ? v : nullptr; };
+  struct Family { const char *size, *rank, *local; };
+  static const Family fam[] = {{"GRAPHMAT_NRANKS", "GRAPHMAT_RANK", "GRAPHMAT_LOCAL_RANK"},
+                               {"WORLD_SIZE", "RANK", "LOCAL_RANK"},
+                               {"OMPI_COMM_WORLD_SIZE", "OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_LOCAL_RANK"},
+                               {"PMI_SIZE", "PMI_RANK", "MPI_LOCALRANKID"},
+                               {"SLURM_STEP_NUM_TASKS", "SLURM_PROCID", "SLURM_LOCALID"}};
+  int nranks = 1, rank = 0, local = -1;
+  for (const Family& f : fam) {
+    const char *sz = env(f.size), *rk = env(f.rank);
+    if (!sz) continue;
+    if (f.size == fam[0].size && atoi(sz) <= 1) break;  // GRAPHMAT_NRANKS=1: explicit single process
+    if (!rk) continue;                                   // a size without its rank is not a launch
+    nranks = atoi(sz);
+    rank = atoi(rk);
+    if (const char* l = env(f.local)) local = atoi(l);
+    else if (const char* l2 = env("GRAPHMAT_LOCAL_RANK")) local = atoi(l2);
+    break;
+  }
+  if (rank_out) *rank_out = nranks > 1 ? rank : 0;
+  if (nranks_out) *nranks_out = nranks > 1 ? nranks : 1;
   if (nranks <= 1) return GM_OK;  // single process: nothing to set up
   if (gm::g_comm) return GM_OK;
   if (rank < 0 || rank >= nranks) { gm::set_error("gm_dist_init_from_env: rank %d of %d", rank, nranks); return GM_ERR_INVALID; }
   int ndev = 0;
   GM_TRY_HIP(hipGetDeviceCount(&ndev));
   if (ndev < 1) { gm::set_error("gm_dist_init_from_env: no GPU"); return GM_ERR_HIP; }
-  GM_TRY_HIP(hipSetDevice(env_int(lr, rank) % ndev));
-  // rendezvous file: GRAPHMAT_RENDEZVOUS, else /tmp/graphmat_rdv_<MASTER_PORT or parent pid>
+  GM_TRY_HIP(hipSetDevice((local >= 0 ? local : rank) % ndev));
+  // Rendezvous file: GRAPHMAT_RENDEZVOUS (must be on a file system every rank sees; the default below is node-local,
+  // which is this library's scope: the GPUs of one node), else /tmp/graphmat_rdv_<uid>_<job>, where <job> names THIS
+  // launch as well as the launcher lets us: Slurm job + step, the PMIx / Open MPI job id, torchrun's run id + port, else
+  // the parent pid (ranks of one mpirun / torchrun agent share their parent).  Rank 0 removes whatever an earlier,
+  // crashed launch may have left under that name BEFORE publishing, creates the file exclusively (no symlink is
+  // followed: O_EXCL | O_NOFOLLOW, mode 0600) and writes a header with its start time; the other ranks accept only a
+  // file that is complete, carries the magic, and was written no earlier than 120 s before they started -- a stale file
+  // of an older launch is ignored and waited out.  A wrong id can still only lead to ncclCommInitRank not completing,
+  // and that is bounded too (GRAPHMAT_INIT_TIMEOUT seconds, default 180): an error instead of a hang.
   std::string path;
-  if (const char* e = getenv("GRAPHMAT_RENDEZVOUS")) path = e;
+  if (const char* e = env("GRAPHMAT_RENDEZVOUS")) path = e;
   else {
-    const char* port = getenv("MASTER_PORT");
-    path = std::string("/tmp/graphmat_rdv_") + (port && *port ? std::string(port) : std::to_string((long)getppid()));
+    std::string job;
+    if (env("SLURM_JOB_ID")) job = std::string("slurm") + env("SLURM_JOB_ID") + "_" + (env("SLURM_STEP_ID") ? env("SLURM_STEP_ID") : "0");
+    else if (env("PMIX_NAMESPACE")) job = std::string("pmix") + env("PMIX_NAMESPACE");
+    else if (env("OMPI_MCA_ess_base_jobid")) job = std::string("ompi") + env("OMPI_MCA_ess_base_jobid");
+    else if (env("MASTER_PORT")) job = std::string("port") + env("MASTER_PORT") + "_" + (env("TORCHELASTIC_RUN_ID") ? env("TORCHELASTIC_RUN_ID") : "none");
+    else job = std::string("ppid") + std::to_string((long)getppid());
+    for (char& c : job) if (!((c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_' || c == '-')) c = '_';
+    path = std::string("/tmp/graphmat_rdv_") + std::to_string((long)getuid()) + "_" + job;
   }
+  struct Header { char magic[8]; int64_t written_at; int32_t nranks; int32_t pad; };
+  const time_t started = time(nullptr);
   char id[GM_DIST_ID_BYTES];
   if (rank == 0) {
     int rc = gm_dist_unique_id(id, sizeof(id));
     if (rc) return rc;
-    const std::string tmp = path + ".tmp";
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) { if (f) fclose(f); gm::set_error("gm_dist_init_from_env: cannot write %s", tmp.c_str()); return GM_ERR_IO; }
-    fclose(f);
-    if (rename(tmp.c_str(), path.c_str()) != 0) { gm::set_error("gm_dist_init_from_env: cannot publish %s", path.c_str()); return GM_ERR_IO; }
+    (void)unlink(path.c_str());  // an earlier launch's leftover
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    (void)unlink(tmp.c_str());
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+    Header h;
+    memcpy(h.magic, "GMRDV01", 8);
+    h.written_at = (int64_t)started;
+    h.nranks = nranks;
+    h.pad = 0;
+    bool ok = fd >= 0 && write(fd, &h, sizeof(h)) == (ssize_t)sizeof(h) && write(fd, id, sizeof(id)) == (ssize_t)sizeof(id);
+    if (fd >= 0) ok = (close(fd) == 0) && ok;
+    if (!ok) { (void)unlink(tmp.c_str()); gm::set_error("gm_dist_init_from_env: cannot write %s", tmp.c_str()); return GM_ERR_IO; }
+    if (rename(tmp.c_str(), path.c_str()) != 0) { (void)unlink(tmp.c_str()); gm::set_error("gm_dist_init_from_env: cannot publish %s", path.c_str()); return GM_ERR_IO; }
   } else {
     bool got = false;
     for (int tries = 0; tries < 60000 && !got; tries++) {  // up to ~60 s
-      FILE* f = fopen(path.c_str(), "rb");
-      if (f) { got = fread(id, 1, sizeof(id), f) == sizeof(id); fclose(f); }
+      const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW);
+      if (fd >= 0) {
+        Header h;
+        got = read(fd, &h, sizeof(h)) == (ssize_t)sizeof(h) && memcmp(h.magic, "GMRDV01", 8) == 0 && h.nranks == nranks &&
+              h.written_at >= (int64_t)started - 120 && read(fd, id, sizeof(id)) == (ssize_t)sizeof(id);
+        (void)close(fd);
+      }
       if (!got) usleep(1000);
     }
-    if (!got) { gm::set_error("gm_dist_init_from_env: rank 0 never published %s", path.c_str()); return GM_ERR_IO; }
+    if (!got) { gm::set_error("gm_dist_init_from_env: rank 0 never published a fresh %s (GRAPHMAT_RENDEZVOUS names the file)", path.c_str()); return GM_ERR_IO; }
   }
-  int rc = gm_dist_init(rank, nranks, id, sizeof(id));
+  // ncclCommInitRank blocks until every rank has arrived: bound it
+  int timeout_s = 180;
+  if (const char* t = env("GRAPHMAT_INIT_TIMEOUT")) timeout_s = atoi(t) > 0 ? atoi(t) : timeout_s;
+  struct InitJob { std::atomic<int> done{0}; int rc = GM_OK; int rank, nranks, dev; char id[GM_DIST_ID_BYTES]; std::string err; };
+  InitJob* job = new InitJob();  // (leaked on a timeout: the worker may still be inside RCCL)
+  job->rank = rank;
+  job->nranks = nranks;
+  GM_TRY_HIP(hipGetDevice(&job->dev));
+  memcpy(job->id, id, sizeof(id));
+  pthread_t th;
+  auto worker = [](void* p) -> void* {
+    InitJob* j = (InitJob*)p;
+    (void)hipSetDevice(j->dev);
+    j->rc = gm_dist_init(j->rank, j->nranks, j->id, sizeof(j->id));
+    if (j->rc != GM_OK) j->err = gm_last_error();
+    j->done.store(1, std::memory_order_release);
+    return nullptr;
+  };
+  if (pthread_create(&th, nullptr, worker, job) != 0) { delete job; gm::set_error("gm_dist_init_from_env: cannot start a thread"); return GM_ERR_INVALID; }
+  for (int64_t waited_ms = 0; !job->done.load(std::memory_order_acquire); waited_ms += 5) {
+    if (waited_ms > (int64_t)timeout_s * 1000) {
+      pthread_detach(th);
+      gm::set_error("gm_dist_init_from_env: rank %d of %d: the communicator was not set up within %d s -- are all %d ranks running, and is %s "
+                    "this launch's rendezvous file?  (GRAPHMAT_NRANKS=1 runs a single process; GRAPHMAT_INIT_TIMEOUT changes the limit)",
+                    rank, nranks, timeout_s, nranks, path.c_str());
+      return GM_ERR_UNSUPPORTED;
+    }
+    usleep(5000);
+  }
+  pthread_join(th, nullptr);
+  int rc = job->rc;
+  if (rc != GM_OK) gm::set_error("%s", job->err.c_str());
+  delete job;
   if (rc) return rc;
   rc = gm_dist_barrier();  // everybody has read the file
-  if (rank == 0) (void)remove(path.c_str());
+  if (rank == 0) (void)unlink(path.c_str());
   return rc;
 }
 

@@ -961,6 +961,15 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
   return GM_OK;
 }
 
+// does any endpoint (0-based native ids) of these edges have a device id >= limit?
+__global__ void __launch_bounds__(kT)
+k_any_dev_beyond(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t nnz, const int32_t* __restrict__ dev_of_native,
+                 int limit, unsigned int* __restrict__ flag) {
+  const int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (k >= nnz) return;
+  if (dev_of_native[src[k]] >= limit || dev_of_native[dst[k]] >= limit) *flag = 1u;
+}
+
 // edges of a CSR direction back as native (src, dst) pairs, in CSR order
 __global__ void __launch_bounds__(kT)
 k_csr_to_coo(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, int nrows, int row_base,
@@ -1220,9 +1229,21 @@ int gm_graph_relayout_like(gm_graph_t* g, const gm_graph_t* like, gm_stream_t st
   if (!g || !like) { gm::set_error("gm_graph_relayout_like: null graph"); return GM_ERR_INVALID; }
   if (g == like) return GM_OK;
   const gm_graph_desc_t &a = g->desc, &b = like->desc;
-  if (a.nvertices != b.nvertices || a.nparts != b.nparts || a.row_lo != 0 || a.row_hi != a.ndevice || b.row_lo != 0 ||
-      b.row_hi != b.ndevice || a.ndevice != b.ndevice) {
-    gm::set_error("gm_graph_relayout_like: graphs must have the same vertices and be unsharded");
+  // Sharded graphs (one process per shard, both graphs cut the same way): a COLLECTIVE over the gm_dist communicator.
+  // In the other graph's order a row may belong to another shard, so every rank hands the edges it holds back to the
+  // distributed build (build_direction_local: the owner of each edge's row under the adopted order receives it).
+  const bool sharded = a.nshards > 1 || b.nshards > 1;
+  if (sharded) {
+    int wr = 0, wn = 0;
+    if (a.nvertices != b.nvertices || a.nparts != b.nparts || a.nshards != b.nshards || a.shard != b.shard || a.ndevice != b.ndevice ||
+        a.row_lo != b.row_lo || a.row_hi != b.row_hi || a.layout != GM_LAYOUT_DEGREE || b.layout != GM_LAYOUT_DEGREE ||
+        !gm::dist_world(&wr, &wn) || wn != a.nshards || wr != a.shard) {
+      gm::set_error("gm_graph_relayout_like: sharded graphs must be the same shard of the same cut, with the gm_dist communicator up");
+      return GM_ERR_INVALID;
+    }
+  } else if (a.nvertices != b.nvertices || a.nparts != b.nparts || a.row_lo != 0 || a.row_hi != a.ndevice || b.row_lo != 0 ||
+             b.row_hi != b.ndevice || a.ndevice != b.ndevice) {
+    gm::set_error("gm_graph_relayout_like: graphs must have the same vertices and the same cut");
     return GM_ERR_INVALID;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -1255,9 +1276,26 @@ int gm_graph_relayout_like(gm_graph_t* g, const gm_graph_t* like, gm_stream_t st
     GM_TRY_HIP(hipMemcpyAsync(g->native_of_dev, like->native_of_dev, (size_t)b.ndevice * 4, hipMemcpyDeviceToDevice, s));
   }
   g->desc.layout = b.layout;
-  // ... and its column tiles (the tile of a column is a function of its device id)
+  // ... and its column tiles (the tile of a column is a function of its device id) -- but only if every vertex that has
+  // an edge in g lies inside like's tiles: a vertex without edges in `like` sits behind the last tile in like's order
+  // (device id >= tile_base[T]) whatever its native id, so with such columns the tiles would no longer be contiguous
+  // native ranges -- the tile-after-tile fold would leave the ascending-native-column order and the tile copies of the
+  // edge values would not line up with the whole CSR.  Such a graph simply keeps the untiled multiply.
   gm::free_tiles(g);
-  g->ntiles = like->ntiles > 1 ? like->ntiles : 1;
+  int like_tiles = like->ntiles > 1 ? like->ntiles : 1;
+  if (sharded) like_tiles = 1;
+  if (like_tiles > 1 && nnz > 0) {
+    gm::DevBuf flag;
+    if ((rc = flag.alloc(4))) return rc;
+    GM_TRY_HIP(hipMemsetAsync(flag.p, 0, 4, s));
+    hipLaunchKernelGGL(gm::k_any_dev_beyond, dim3(gm::grid_for(nnz)), dim3(gm::kT), 0, s, src.as<int32_t>(), dst.as<int32_t>(), nnz,
+                       (const int32_t*)like->dev_of_native, like->tile_base[like_tiles], flag.as<unsigned int>());
+    unsigned int outside = 0;
+    GM_TRY_HIP(hipMemcpyAsync(&outside, flag.p, 4, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    if (outside) like_tiles = 1;
+  }
+  g->ntiles = like_tiles;
   memcpy(g->tile_base, like->tile_base, sizeof(g->tile_base));
   g->nlive = like->nlive;
   g->desc.col_tiles = g->ntiles;
@@ -1267,8 +1305,13 @@ int gm_graph_relayout_like(gm_graph_t* g, const gm_graph_t* like, gm_stream_t st
   g->desc.ids_are_native = 1;
   g->desc.val_bytes = val_bytes;
   rc = GM_OK;
-  if (g->desc.directions & GM_DIR_OUT) rc = gm::build_direction(g, 1, nnz, src.as<int32_t>(), dst.as<int32_t>(), vals, s, &g->out);
-  if (rc == GM_OK && (g->desc.directions & GM_DIR_IN)) rc = gm::build_direction(g, 0, nnz, src.as<int32_t>(), dst.as<int32_t>(), vals, s, &g->in);
+  if (sharded) {  // this rank's edges (the rows it owned under the old order) go to their new owners
+    if (g->desc.directions & GM_DIR_OUT) rc = gm::build_direction_local(g, 1, nnz, src.as<int32_t>(), dst.as<int32_t>(), vals, s, &g->out);
+    if (rc == GM_OK && (g->desc.directions & GM_DIR_IN)) rc = gm::build_direction_local(g, 0, nnz, src.as<int32_t>(), dst.as<int32_t>(), vals, s, &g->in);
+  } else {
+    if (g->desc.directions & GM_DIR_OUT) rc = gm::build_direction(g, 1, nnz, src.as<int32_t>(), dst.as<int32_t>(), vals, s, &g->out);
+    if (rc == GM_OK && (g->desc.directions & GM_DIR_IN)) rc = gm::build_direction(g, 0, nnz, src.as<int32_t>(), dst.as<int32_t>(), vals, s, &g->in);
+  }
   g->desc.ids_are_native = saved_native;
   g->desc.val_bytes = saved_vb;
   if (vals) (void)hipFree(vals);

@@ -461,6 +461,7 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "sparse_step_edges") && value >= 0) { GraphMat::detail::sparse_step_edges() = value; return GM_OK; }
   if (key && !strcmp(key, "wave16_form") && value >= 0 && value <= 5) { GraphMat::detail::wave16_form() = value; return GM_OK; }
   if (key && !strcmp(key, "persist_per_cu") && value >= 0 && value <= 8) { GraphMat::detail::persist_per_cu() = value; return GM_OK; }
+  if (key && !strcmp(key, "iteration_trace") && (value == 0 || value == 1)) { GraphMat::detail::iteration_trace() = value; return GM_OK; }
   if (key && !strcmp(key, "debug_flags")) { GraphMat::detail::debug_flags() = value; return GM_OK; }
   gm::set_error("gm_set_option: unknown option");
   return GM_ERR_INVALID;

@@ -309,6 +309,9 @@ class Graph {
     return (s >= 0 && s < row_hi - row_lo) ? s + 1 : 0;
   }
   bool sharded() const { return tiles_per_dim > 1; }
+  // several ranks: a device array over ALL device ids holding every shard's vertex properties (all-gathered with the
+  // graph's message exchange; owned by the graph's workspace, valid until the next call)
+  const V* gathered_vertexproperty();
 
  private:
   static int default_num_threads() {
@@ -518,7 +521,8 @@ void Graph<V, E>::reset() {
 template <class V, class E>
 void Graph<V, E>::shareVertexProperty(Graph<V, E>& g) {
   // the shared vector is indexed in g's device order: bring this graph's adjacency into it
-  if (sharded()) { printf("GraphMat(HIP): shareVertexProperty is not supported with more than one rank\n"); exit(1); }
+  // (with several ranks this is a collective: every rank's part of the edges travels to the shard that owns its row in
+  // g's order -- gm_graph_relayout_like; the reference's two graphs share one 2-D tile distribution instead)
   if (A != nullptr && g.A != nullptr && A != g.A) {
     if (gm_graph_relayout_like(A, g.A, nullptr) != GM_OK) {
       printf("GraphMat(HIP): shareVertexProperty: %s\n", gm_last_error());
@@ -649,10 +653,38 @@ void Graph<V, E>::applyReduceAllVertices(T* val, void (*ApplyFn)(V*, T*, void*),
 
 
 template <class V, class E>
+const V* Graph<V, E>::gathered_vertexproperty() {
+  gm_graph_desc_t d;
+  gm_graph_desc(A, &d);
+  void* buf = nullptr;
+  if (gm_graph_workspace(A, 13, (size_t)d.ndevice * sizeof(V) + 64, &buf) != GM_OK) { printf("GraphMat(HIP): %s\n", gm_last_error()); exit(1); }
+  const int rows = d.row_hi - d.row_lo;
+  vertexproperty->segment->need_device();
+  GM_HIP_OK(hipMemcpy((char*)buf + (size_t)d.row_lo * sizeof(V), vertexproperty->segment->value, (size_t)rows * sizeof(V), hipMemcpyDeviceToDevice));
+  gm_graph_set_run_stream(A, nullptr);
+  if (gm_graph_exchange(A, GM_XCHG_MESSAGES, buf, (int64_t)sizeof(V), nullptr, nullptr) != GM_OK) { printf("GraphMat(HIP): vertex property exchange failed: %s\n", gm_last_error()); exit(1); }
+  GM_HIP_OK(hipDeviceSynchronize());
+  return (const V*)buf;
+}
+
+template <class V, class E>
 void Graph<V, E>::applyToAllEdges(void (*ApplyFn)(E*, const V&, const V&, void*), void* param) {
-  if (sharded()) { printf("GraphMat(HIP): applyToAllEdges is not supported with more than one rank (it needs both endpoints' properties)\n"); exit(1); }
-  vertexproperty->segment->need_host();
-  const auto& h = vertexproperty->segment->hvalue;
+  // (several ranks: the other endpoint may live on another shard -- the reference moves the properties along the tile
+  // rows and columns, GMDP/multinode/applyedges.h:45-161; here every shard's properties are all-gathered once, with the
+  // exchange that carries the message vector, and read through a host copy indexed by device id)
+  std::vector<V> hall;
+  if (sharded()) {
+    gm_graph_desc_t d;
+    gm_graph_desc(A, &d);
+    vertexproperty->segment->need_device();
+    const V* dv = gathered_vertexproperty();
+    hall.resize((size_t)d.ndevice);
+    GM_HIP_OK(hipMemcpy((void*)hall.data(), dv, (size_t)d.ndevice * sizeof(V), hipMemcpyDeviceToHost));
+  } else {
+    vertexproperty->segment->need_host();
+  }
+  const V* h = sharded() ? hall.data() : vertexproperty->segment->hvalue.data();
+  const int rbase = sharded() ? row_lo : 0;
   for (int dir : {GM_DIR_OUT, GM_DIR_IN}) {
     gm_csr_t c;
     if (gm_graph_csr(A, dir, &c) != GM_OK) continue;
@@ -663,8 +695,8 @@ void Graph<V, E>::applyToAllEdges(void (*ApplyFn)(E*, const V&, const V&, void*)
     for (int r = 0; r < c.nrows; r++)
       for (int64_t e = rp[r]; e < rp[r + 1]; e++) {
         // OUT: row = destination, col = source;  IN: row = source, col = destination
-        if (dir == GM_DIR_OUT) ApplyFn(&vv[e], h[ci[e]], h[r], param);
-        else ApplyFn(&vv[e], h[r], h[ci[e]], param);
+        if (dir == GM_DIR_OUT) ApplyFn(&vv[e], h[ci[e]], h[rbase + r], param);
+        else ApplyFn(&vv[e], h[rbase + r], h[ci[e]], param);
       }
     if (gm_graph_set_vals(A, dir, vv.data()) != GM_OK) { printf("GraphMat(HIP): %s\n", gm_last_error()); exit(1); }
   }
@@ -715,10 +747,11 @@ __global__ void __launch_bounds__(kBlock) k_vertices_reduce(const V* __restrict_
 }
 // one wave per row of one direction's CSR; rows_are_dst: row = destination, column = source
 template <class V, class E, class F>
+// (vp is indexed by device id: for a shard, the all-gathered copy of every shard's properties; rows are local)
 __global__ void __launch_bounds__(kBlock) k_edges_apply(gm_csr_t A, E* __restrict__ vals, const V* __restrict__ vp, int rows_are_dst, F f) {
   const int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (row >= A.nrows) return;
-  const V vr = vp[row];
+  const V vr = vp[A.row_base + row];
   for (int64_t e = A.rowptr[row] + (threadIdx.x & 63); e < A.rowptr[row + 1]; e += 64) {
     const V vc = vp[A.colidx[e]];
     E v = vals[e];
@@ -787,17 +820,15 @@ void Graph<V, E>::applyReduceAllVertices(T* val, Map map, Reduce reduce) {
 template <class V, class E>
 template <class F, class>
 void Graph<V, E>::applyToAllEdges(F f) {
-  if (sharded()) { printf("GraphMat(HIP): applyToAllEdges is not supported with more than one rank (it needs both endpoints' properties)\n"); exit(1); }
   auto* seg = vertexproperty->segment;
   seg->need_device();
-  int ntile = 1;
-  gm_graph_tiles(A, GM_DIR_OUT, &ntile);
-  if (ntile > 1) { printf("GraphMat(HIP): applyToAllEdges on a graph with column tiles is not supported (the tiles hold copies of the edge values)\n"); exit(1); }
+  const V* vp_all = sharded() ? gathered_vertexproperty() : (const V*)seg->value;  // an edge needs both endpoints' properties
   for (int dir : {GM_DIR_OUT, GM_DIR_IN}) {
     gm_csr_t c;
     if (gm_graph_csr(A, dir, &c) != GM_OK || c.vals == nullptr || c.nrows == 0) continue;
+    if (!sharded()) c.row_base = 0;
     hipLaunchKernelGGL((dev::k_edges_apply<V, E, F>), dim3((c.nrows + dev::kBlock / 64 - 1) / (dev::kBlock / 64)), dim3(dev::kBlock), 0, 0, c,
-                       (E*)const_cast<void*>(c.vals) /* library-owned edge values, rewritten in place */, (const V*)seg->value,
+                       (E*)const_cast<void*>(c.vals) /* library-owned edge values, rewritten in place */, vp_all,
                        dir == GM_DIR_OUT ? 1 : 0, f);
   }
   GM_HIP_OK(hipDeviceSynchronize());

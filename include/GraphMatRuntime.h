@@ -98,6 +98,9 @@ void run_graph_program(
          (init_end.tv_sec - init_start.tv_sec) * 1e3 + (init_end.tv_usec - init_start.tv_usec) * 1e-3);
 #endif
 
+#ifdef __TIMING
+  detail::iteration_trace() = 1;  // the reference's per-iteration lines (:150-248)
+#endif
   int it = detail::run_on_device<Prog, T, U, V, E>(
       gp, g.A, gp->getOrder(), gp->getActivity(), gp->getProcessMessageRequiresVertexprop(),
       (V*)g.vertexproperty->segment->value, g.active->segment->bit_vector, x, xbits, y, ybits, iterations, 0);
@@ -105,12 +108,6 @@ void run_graph_program(
   g.vertexproperty->segment->device_modified();
   g.active->segment->device_modified();
   if (px) { px->segment->device_modified(); py->segment->device_modified(); }
-#ifdef __TIMING
-  gm_run_stats_t st;
-  if (gm_graph_last_stats(g.A, &st) == GM_OK && st.total_ms > 0)
-    printf("Send message time = %.3f ms \nSPMV time = %.3f ms \nApply time = %.3f ms \n", st.send_ms, st.spmv_ms,
-           st.apply_ms);
-#endif
   printf("Completed %d iterations \n", it);
 }
 

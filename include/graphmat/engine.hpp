@@ -62,6 +62,15 @@ inline int cu_count() {
   return n;
 }
 
+// per-iteration trace in the reference's own words (include/GraphMatRuntime.h:150-248 under __TIMING): phase times and
+// "Iteration %d :: %f msec :: updated %d vertices :: changed %d vertices".  The host synchronises after every phase, so
+// this is a diagnostic mode (set by run_graph_program in -D__TIMING builds, gm_set_option("iteration_trace", 1), or
+// GRAPHMAT_ITERATION_TRACE=1).
+inline int& iteration_trace() {
+  static int v = (getenv("GRAPHMAT_ITERATION_TRACE") && getenv("GRAPHMAT_ITERATION_TRACE")[0] == '1') ? 1 : 0;
+  return v;
+}
+
 // top-down steps are taken while the active set owns less than this many thousandths of the edges
 inline int& push_edge_permille() {
   static int v = 50;
@@ -158,13 +167,19 @@ struct AuxStream {
 };
 
 // ---- which exact strategy may evaluate a program's reduce_function ------------------------------
-// A program can say so (program_traits<P>::reduce).  Otherwise the runtime asks the function
+// A program can say so (program_traits<P>::reduce).  Otherwise -- and only when the user opts in with
+// GRAPHMAT_TRUST_PROBE=1 -- the runtime asks the function
 // itself: reduce_function is an ordinary host-callable method, so it is run on the host on
 // random operands and compared, bit for bit, with float a+b, with a=b, and (integral types) with
 // wrapping +, min and max.  Only an exact match on every sample selects the corresponding
 // strategy; anything else keeps the always-correct ordered fold.  GRAPHMAT_NO_PROBE=1 disables it.
+// The probe is OPT-IN (GRAPHMAT_TRUST_PROBE=1): a finite set of operands plus a sampled device cross-check is
+// evidence, not a proof, and this library's contract is the reference's bits (SPMV.h:54-59: `c = a; reduce(c, b)`
+// in stored order).  Without the opt-in a program that declares no trait gets the ordered fold -- always exact.
 template <class P, class U>
 int probe_reduce_kind(const P* gp) {
+  const char* on = getenv("GRAPHMAT_TRUST_PROBE");
+  if (!(on && on[0] == '1')) return REDUCE_ORDERED;
   const char* off = getenv("GRAPHMAT_NO_PROBE");
   if (off && off[0] == '1') return REDUCE_ORDERED;
   // arithmetic reduction types only: the function is called on the host with synthetic operands, which is
@@ -298,7 +313,7 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
         gm_graph_workspace(g, 6, (size_t)A.giant_edges * sizeof(U) + 64, &p6);
         terms = (U*)p6;
         if (xbits != nullptr) {
-          gm_graph_workspace(g, 7, (size_t)A.giant_edges / 8 + 64, &p7);
+          gm_graph_workspace(g, 14, (size_t)A.giant_edges / 8 + 64, &p7);  // (slot 7 holds the active-set list of sharded ACTIVE_ONLY runs)
           tpres = (unsigned long long*)p7;
         }
         hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa,
@@ -607,7 +622,8 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   // the rows, a third of the edges) and starts their exchange; stage 2 does the same for the HEAD
   // rows (the busy ones) while stage 1's messages travel.  Each row is still folded by one kernel
   // in stored order, so results are those of the plain loop below.
-  if (multi && act == ALL_VERTICES && order == OUT_EDGES && iterations > 0 && !(debug_flags() & dev::DBG_NO_PIPELINE)) {
+  const bool trace = iteration_trace() != 0;
+  if (multi && act == ALL_VERTICES && order == OUT_EDGES && iterations > 0 && !(debug_flags() & dev::DBG_NO_PIPELINE) && !trace) {
     void* x2v = nullptr;
     size_t x2_bytes = 0;
     int x2_ext = 0;
@@ -721,8 +737,27 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
 
   int it = 0;
   tick("setup done", 0);
+  // trace mode: host clock per phase, counts per iteration (the reference's __TIMING lines)
+  struct timeval tr_iter, tr_last;
+  auto lap = [&](const char* label) {
+    if (!trace) return;
+    (void)hipStreamSynchronize(s);
+    if (aux.s) (void)hipStreamSynchronize(aux.s);
+    struct timeval now;
+    gettimeofday(&now, 0);
+    if (label) printf("%s = %.3f ms \n", label, (now.tv_sec - tr_last.tv_sec) * 1e3 + (now.tv_usec - tr_last.tv_usec) * 1e-3);
+    tr_last = now;
+  };
+  auto count_bits = [&](const uint32_t* bits, int nbits) -> long long {
+    int64_t c = 0;
+    if (bits == nullptr || nbits <= 0) return 0;
+    if (gm_popcount_bits(bits, (int64_t)nbits, &c, (gm_stream_t)s) != GM_OK) return -1;
+    return (long long)c;
+  };
   while (true) {
     tick("iteration", it);
+    if (trace) { (void)hipStreamSynchronize(s); gettimeofday(&tr_iter, 0); tr_last = tr_iter; }
+    long long tr_updated = -1;
     if (verbose && can_push) printf("GraphMat(HIP):   active set: %llu vertices, %llu out-edges (max %llu)\n", frontier_v, frontier_e, frontier_maxdeg);
     dev::ProgArg<P> pa = dev::make_prog_arg(gp);  // re-captured every iteration (do_every_iteration may change it)
     // Clear(&x) / Clear(&y) (:139-140): x presence words are fully rewritten by send.  With
@@ -759,6 +794,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       hipLaunchKernelGGL((dev::k_send_list<P, T, V>), dim3(grid_for(nf)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
                          (const int32_t*)d_list, nf, x, desc.row_lo);
       timer.mark(TAG_SEND);
+      lap("Send message time");
       GM_HIP_OK(hipMemsetAsync(d_tcount, 0, 4, s));
       const unsigned pieces = (unsigned)(frontier_e / dev::kPieceEdges + frontier_v);  // upper bound of the pieces
       piece_offsets(nf);
@@ -779,6 +815,12 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         }
       }
       timer.mark(TAG_WAVE);
+      lap("SPMV time");
+      if (trace) {  // vertices that received a message = destinations first touched by this step
+        unsigned int tc = 0;
+        GM_HIP_OK(hipMemcpy(&tc, d_tcount, 4, hipMemcpyDeviceToHost));
+        tr_updated = (long long)tc;
+      }
       // the active set has been consumed: rewrite the active vector and the list for the next step
       GM_HIP_OK(hipMemsetAsync(d_active, 0, (size_t)nwords * 4, s));
       GM_HIP_OK(hipMemsetAsync(d_striped, 0, striped_bytes, s));
@@ -800,6 +842,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       st.spmv_launches += 2;
       listed = true;
       timer.mark(TAG_APPLY);
+      lap("Apply time");
     } else {
       // Clear(&x) / Clear(&y) (:139-140): x presence words are fully rewritten by send.  With
       // every x entry present (ALL_VERTICES) y's presence is the static set of non-empty rows.
@@ -845,6 +888,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         }
       }
       timer.mark(TAG_SEND);
+      lap("Send message time");
       // multiply + reduce (:160-176)
       const uint32_t* xb = dense_x ? nullptr : (lazy_send ? (const uint32_t*)d_active : (const uint32_t*)xbits);  // (may change below)
       const uint32_t* apply_bits = ybits;
@@ -983,6 +1027,8 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         else launch_spmv<P, T, U, V, E, false>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
         if (order == IN_EDGES) check_probed(Ain, static_bits ? Ain.rowbits : (const uint32_t*)ybits, d_want, acc, ybits);
       }
+      lap("SPMV time");
+      if (trace) tr_updated = count_bits(apply_bits, n_live);  // y.getNNZ(): rows that received a message
       // setAllInactive (:184) + apply (:195-225): the active vector is rewritten by k_apply
       // (when top-down steps are possible the kernel also sizes and lists the next active set)
       // the changed vertices are also listed when the next active set is bound to be small: it cannot
@@ -1008,6 +1054,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       if (n_live < n)  // setAllInactive for the rows k_apply does not visit
         GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
       timer.mark(TAG_APPLY);
+      lap("Apply time");
     }
     int converged = 0;
     if (iterations <= 0) {  // the flag only matters when running until convergence (:257-259)
@@ -1029,6 +1076,15 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       else if (multi) gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &converged);  // :226 Allreduce(LAND)
     }
     gp->do_every_iteration(it);  // :236
+    if (trace) {
+      lap("Do every iteration time");
+      const long long changed = count_bits(d_active, n);  // g.active->getNNZ() before ALL_VERTICES re-activates (:248-252)
+      (void)hipStreamSynchronize(s);
+      struct timeval now;
+      gettimeofday(&now, 0);
+      printf("Iteration %d :: %f msec :: updated %lld vertices :: changed %lld vertices \n", it,
+             (now.tv_sec - tr_iter.tv_sec) * 1e3 + (now.tv_usec - tr_iter.tv_usec) * 1e-3, tr_updated, changed);
+    }
     if (act == ALL_VERTICES && iterations > 0 && it + 1 == iterations) {
       // last iteration of a fixed-count run: leave the graph all-active (:250-252)
       hipLaunchKernelGGL(dev::k_fill_u32, dim3(grid_for(nwords)), dim3(dev::kBlock), 0, s, d_active, (int64_t)nwords,

@@ -357,7 +357,16 @@ __device__ __forceinline__ E edge_at(const void* __restrict__ vals, int64_t k) {
 // earlier pass (their presence is read from ybits); ACC_STATIC_BITS = do not write presence
 // bits (every x entry is present, so y's presence equals the graph's static row bits)
 enum { ACC_READ_PREV = 1, ACC_STATIC_BITS = 2 };
-enum { DBG_SKIP_FOLD = 1, DBG_SKIP_GATHER = 2, DBG_FIRST_CHUNK_ONLY = 4, DBG_NO_REPLAY = 8, DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64, DBG_NO_PIPELINE = 128, DBG_NO_LAZY_SEND = 256, DBG_NO_WAVE16 = 512, DBG_NO_TILES = 1024, DBG_NO_SPARSE_XCHG = 2048, DBG_LATE_GIANTS = 4096, DBG_LONG_ON_MAIN = 8192 };
+// The first four are tested INSIDE the multiply kernels (skip the fold, skip the gathers ...): they exist for ablation
+// builds only (-DGRAPHMAT_ABLATION, graphmat_amd/build.py with GRAPHMAT_ABLATION=1).  In a production build they are 0,
+// so every `dbg & DBG_*` in a kernel is a compile-time false and the tests are not in the code.  The others pick
+// between exact strategies on the host side of a launch and are always available.
+#ifdef GRAPHMAT_ABLATION
+#define GM_ABL(bit) (bit)
+#else
+#define GM_ABL(bit) 0
+#endif
+enum { DBG_SKIP_FOLD = GM_ABL(1), DBG_SKIP_GATHER = GM_ABL(2), DBG_FIRST_CHUNK_ONLY = GM_ABL(4), DBG_NO_REPLAY = GM_ABL(8), DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64, DBG_NO_PIPELINE = 128, DBG_NO_LAZY_SEND = 256, DBG_NO_WAVE16 = 512, DBG_NO_TILES = 1024, DBG_NO_SPARSE_XCHG = 2048, DBG_LATE_GIANTS = 4096, DBG_LONG_ON_MAIN = 8192 };
 
 // presence bits of a wave's 64 consecutive rows: one atomicOr per 32-row word (not per row:
 // same-word atomics from 32 lanes serialise in the L2); nothing when the bits are static

@@ -320,11 +320,14 @@ int gm_dist_init(int rank, int nranks, const void* unique_id, size_t bytes);
 int gm_dist_finalize(void);
 int gm_dist_info(int* rank, int* nranks); /* *nranks = 0 before gm_dist_init */
 /* What an application's MPI_Init can call (include/graphmat/mpi_single.h does): rank / size / local GPU from the
- * launcher's environment (GRAPHMAT_RANK|RANK|OMPI_COMM_WORLD_RANK|PMI_RANK|SLURM_PROCID, ..._NRANKS|WORLD_SIZE|...,
- * LOCAL_RANK|...), the unique id through a rendezvous file (GRAPHMAT_RENDEZVOUS, else /tmp/graphmat_rdv_<MASTER_PORT>).
- * A single process (no such variables) is left alone.  GRAPHMAT_DIST_TRANSPORT=shm replaces RCCL by a host
- * shared-memory transport with the same entry points: for trying multi-rank runs on a 1-GPU box (RCCL wants one
- * rank per GPU), slow, tests only. */
+ * launcher's environment -- only from an unambiguous multi-rank launch: GRAPHMAT_NRANKS + GRAPHMAT_RANK, or a launcher's
+ * own pair (torchrun WORLD_SIZE + RANK, Open MPI OMPI_COMM_WORLD_SIZE + _RANK, PMI_SIZE + PMI_RANK, srun
+ * SLURM_STEP_NUM_TASKS + SLURM_PROCID; a size without its rank, or SLURM_NTASKS of an allocation, is not a launch);
+ * GRAPHMAT_NRANKS=1 forces a single process.  The unique id travels through a rendezvous file (GRAPHMAT_RENDEZVOUS, else
+ * /tmp/graphmat_rdv_<uid>_<job id of the launch>; node-local by default), created exclusively by rank 0 and accepted
+ * only when fresh; setting the communicator up is bounded by GRAPHMAT_INIT_TIMEOUT seconds (default 180): an error,
+ * not a hang.  A single process is left alone.  librccl is bound with dlopen at that moment; GRAPHMAT_RCCL_LIBRARY names
+ * another library with the same entry points (the test suite's shared-memory stand-in, tests/support/). */
 int gm_dist_init_from_env(int* rank, int* nranks);
 int gm_dist_barrier(void);
 /* all-gather of host buffers of different sizes: *all = malloc'ed concatenation in rank order (gm_host_free),
@@ -411,7 +414,7 @@ int gm_graph_last_stats(const gm_graph_t* g, gm_run_stats_t* out);
  * Device scratch owned by the graph, grown on demand and reused across runs (the
  * reference allocates x/y per run_graph_program call, GraphMatRuntime.h:110-120).
  * slot in [0, GM_WS_SLOTS). */
-#define GM_WS_SLOTS 14
+#define GM_WS_SLOTS 16
 int gm_graph_workspace(gm_graph_t* g, int slot, size_t bytes, void** d_ptr);
 /* Let the caller provide a scratch slot (e.g. a torch tensor it also hands to its collective
  * library): slot 1 = message values x (nvertices * elt bytes), slot 2 = x presence bits

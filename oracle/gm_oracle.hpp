@@ -274,6 +274,12 @@ struct Graph {
 //   static bool changed(V& old, const V& now)  -- the V::operator!= of the app
 // Returns the number of iterations completed; per-iteration "changed" counts
 // (the reference's `active->getNNZ()` print, :247) go to changed_hist if given.
+// wall-clock seconds spent in send / multiply+reduce / apply since the last reset: the reference's __TIMING phases
+// (:150-232), kept so that bench.py's cpu_baseline can report where the CPU's time goes
+inline double* phase_seconds() {
+  static double t[4] = {0, 0, 0, 0};
+  return t;
+}
 template <class P, class V, class E>
 int run_graph_program(P& prog, Graph<V, E>& g, int iterations, std::vector<int>* changed_hist = nullptr,
                       std::vector<int>* updated_hist = nullptr) {
@@ -285,6 +291,7 @@ int run_graph_program(P& prog, Graph<V, E>& g, int iterations, std::vector<int>*
   if (prog.activity == ALL_VERTICES) g.set_all_active();  // :121-123
   int it = 0;
   while (true) {
+    const double t_0 = omp_get_wtime();
     x.clear();  // :139
     y.clear();  // :140
     // send: xbits = active & vpbits; x[i] = send_message(vp[i]); the bool result
@@ -300,6 +307,7 @@ int run_graph_program(P& prog, Graph<V, E>& g, int iterations, std::vector<int>*
         word &= word - 1;
       }
     }
+    const double t_1 = omp_get_wtime();
     // multiply + reduce (:160-176); OUT_EDGES -> AT, IN_EDGES -> A, ALL_EDGES ->
     // AT then A accumulating into the same y
     if (prog.order == OUT_EDGES) {
@@ -310,6 +318,7 @@ int run_graph_program(P& prog, Graph<V, E>& g, int iterations, std::vector<int>*
       spmspv(g.AT(), x, g.vp, y, prog);
       spmspv(g.A(), x, g.vp, y, prog);
     }
+    const double t_2 = omp_get_wtime();
     g.set_all_inactive();  // :184
     // apply on set bits of y; changed => active, not converged (:195-225)
     int converged = 1;
@@ -328,6 +337,10 @@ int run_graph_program(P& prog, Graph<V, E>& g, int iterations, std::vector<int>*
         word &= word - 1;
       }
     }
+    const double t_3 = omp_get_wtime();
+    phase_seconds()[0] += t_1 - t_0;
+    phase_seconds()[1] += t_2 - t_1;
+    phase_seconds()[2] += t_3 - t_2;
     prog.do_every_iteration(it);  // :236
     if (updated_hist) updated_hist->push_back(y.nnz());
     if (changed_hist) {

@@ -251,6 +251,12 @@ int gmo_degree(void* gv, int* degree_out) {
 
 // PageRank pass of src/PageRank.cpp:139-150.  pr is in/out; iterations<=0 means
 // until convergence.  Returns iterations completed.
+// seconds in send / multiply+reduce / apply since the last call with reset != 0 (gm_oracle.hpp: phase_seconds)
+void gmo_phase_seconds(double out[3], int reset) {
+  double* t = phase_seconds();
+  for (int i = 0; i < 3; i++) { out[i] = t[i]; if (reset) t[i] = 0; }
+}
+
 int gmo_pagerank(void* gv, float alpha, int iterations, float* pr, const int* degree, int* changed_hist,
                  int hist_cap) {
   OGraph* og = (OGraph*)gv;

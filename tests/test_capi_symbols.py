@@ -130,3 +130,39 @@ def test_error_convention_of_the_service_entry_points(lib, tmp_path):
     assert b"header says 3 edges" in lib.gm_last_error()
     assert lib.gm_edgelist_write(None, 1, 1, 1, 1, 3, 3, 0, None, None, None) == 1
     assert lib.gm_set_option(b"push_edge_permille", 2000) == 1 and lib.gm_set_option(b"push_edge_permille", 50) == 0
+
+
+def test_product_has_no_test_transport_and_the_stand_in_exports_what_gm_dist_binds():
+    """The shared-memory stand-in for librccl lives with the tests (tests/support/), is bound through the same dlopen
+    hook as librccl (GRAPHMAT_RCCL_LIBRARY) and exports every entry point gm_dist.hip binds; nothing of it is
+    compiled into the product."""
+    import ctypes as C
+    src = open(os.path.join(ROOT, "graphmat_amd", "csrc", "gm_dist.hip")).read()
+    assert "shm_open" not in src and "GRAPHMAT_DIST_TRANSPORT" not in src
+    bound = re.findall(r'GM_BIND\(\w+, "(nccl\w+)"\)', src)
+    assert len(bound) >= 10
+    from tests.support import build as shm_build
+    so = C.CDLL(shm_build.build())
+    for name in bound:
+        assert hasattr(so, name), name
+
+
+def test_launch_detection_from_the_environment(lib):
+    """gm_dist_init_from_env joins a communicator only on an unambiguous multi-rank launch: a lone WORLD_SIZE, a size
+    without its rank, or SLURM_NTASKS of an allocation (sbatch without srun) must leave a single process alone --
+    these calls return at once instead of waiting for ranks that do not exist (no GPU is touched)."""
+    import ctypes as C
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from graphmat_amd import _lib; L = _lib.lib(); "
+            "r = C.c_int(-1); n = C.c_int(-1); rc = L.gm_dist_init_from_env(C.byref(r), C.byref(n)); print('RESULT', rc, r.value, n.value)" % ROOT)
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SLURM_NTASKS", "SLURM_PROCID",
+                                                            "GRAPHMAT_NRANKS", "GRAPHMAT_RANK", "PMI_SIZE", "PMI_RANK")}
+    for extra in ({}, {"WORLD_SIZE": "8"}, {"SLURM_NTASKS": "8", "SLURM_PROCID": "0"}, {"PMI_SIZE": "4"},
+                  {"GRAPHMAT_NRANKS": "1", "WORLD_SIZE": "8", "RANK": "3"}):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(base, **extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+        assert b"RESULT 0 0 1" in out.stdout, (extra, out.stdout[-500:])
+    # an invalid rank of a real launch is an error, not a hang
+    out = subprocess.run([sys.executable, "-c", code], env=dict(base, GRAPHMAT_NRANKS="2", GRAPHMAT_RANK="5"), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=120)
+    assert b"RESULT 1 " in out.stdout, out.stdout[-500:]

@@ -290,3 +290,42 @@ def test_reference_unit_test_closed_forms_on_the_device():
     assert "CLOSEDFORMS PASS" in text, text[-2000:]
     lines = re.findall(r"^CLOSED (\w+) (\w+)$", text, flags=re.M)
     assert len(lines) == 10 and all(v == "ok" for _, v in lines), lines
+
+
+@pytest.mark.gpu
+def test_edge_updates_and_shared_properties_on_tiled_graphs():
+    """apps/tiled_edge_update.cpp: applyToAllEdges (device functor and host function pointer) on a graph whose multiply
+    runs on column tiles -- large graphs are tiled automatically, so the functor form must not refuse them and the tile
+    copies of the edge values must follow -- and shareVertexProperty between a tiled graph and graphs whose vertices
+    with edges are / are not a subset of its own (gm_graph_relayout_like keeps the tiles only when they stay contiguous
+    native ranges)."""
+    text = _run(_need(os.path.join(OWN_APPS, "tiled_edge_update")))
+    assert "TILEDEDGES PASS" in text, text[-2000:]
+    assert re.search(r"graph 1: [2-9] column tiles", text)
+    assert re.search(r"B1 \(not a subset\) 1, B2 \(subset\) [2-9]", text)
+
+
+@pytest.mark.gpu
+def test_reference_pagerank_timing_build_prints_the_per_iteration_lines(golden_dir, ref):
+    """The reference's tracing flavour (-D__TIMING) of the UNCHANGED src/PageRank.cpp: per iteration the phase lines and
+    "Iteration %d :: %f msec :: updated %d vertices :: changed %d vertices" (include/GraphMatRuntime.h:150-248 of the
+    reference).  The counts of the PageRank run are G1's changed_per_iteration; "updated" = vertices with an in-edge;
+    the Degree pass before it changes nothing under PR's operator!= (SURVEY section 8 note 3)."""
+    g1 = ref["G1_pagerank_test_bin_mtx"]
+    text = _run(_need(os.path.join(REF_APPS, "PageRank__TIMING")), os.path.join(golden_dir, g1["file"]))
+    lines = re.findall(r"^Iteration (\d+) :: ([0-9.]+) msec :: updated (-?\d+) vertices :: changed (-?\d+) vertices", text, flags=re.M)
+    n_deg, n_pr = g1["degree_iterations"], g1["pagerank_iterations"]
+    assert len(lines) == n_deg + n_pr, text[-2000:]
+    assert [int(l[0]) for l in lines] == list(range(n_deg)) + list(range(n_pr))
+    assert [int(l[3]) for l in lines[n_deg:]] == g1["changed_per_iteration"]
+    assert [int(l[3]) for l in lines[:n_deg]] == [0] * n_deg
+    from graphmat_amd.mtx import read_mtx_bin
+    nv, s, d, v = read_mtx_bin(os.path.join(golden_dir, g1["file"]))
+    with_in_edge = len(set(d.tolist()))
+    with_out_edge = len(set(s.tolist()))
+    assert [int(l[2]) for l in lines[n_deg:]] == [with_in_edge] * n_pr
+    assert [int(l[2]) for l in lines[:n_deg]] == [with_out_edge] * n_deg   # Degree runs over IN_EDGES: rows = sources
+    for name in ("Send message time", "SPMV time", "Apply time", "Do every iteration time"):
+        assert text.count(name + " = ") == n_deg + n_pr, name
+    rows = re.findall(r"^(\d+) : (\d+) ([0-9.]+)$", text, flags=re.M)
+    assert [r[2] for r in rows] == g1["pagerank_6dp"]

@@ -13,6 +13,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _shm_lib():
+    """tests/support/libgm_shm_transport.so (built on demand): the test suite's stand-in for librccl"""
+    sys.path.insert(0, ROOT)
+    from tests.support import build as shm_build
+    return shm_build.build()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -53,14 +60,14 @@ def test_native_rccl_exchange_single_rank():
 @pytest.mark.parametrize("world", [2, 3])
 def test_native_exchange_several_ranks_over_shared_memory(world):
     """The native exchange's rank arithmetic (slice offsets, staged live prefixes, part regions, sparse blocks) with
-    more than one participant: RCCL cannot put two ranks on one GPU, so the library's shared-memory test transport
-    (GRAPHMAT_DIST_TRANSPORT=shm: the same all-gather / all-reduce entry points over host memory) carries the bytes
+    more than one participant: RCCL cannot put two ranks on one GPU, so the test suite's shared-memory stand-in for librccl
+    (GRAPHMAT_RCCL_LIBRARY=tests/support/libgm_shm_transport.so: the same entry points over host memory) carries the bytes
     while gm_dist.hip's exchange code runs unchanged.  Every result must equal the oracle's."""
     from graphmat_amd import build
     build.build()
     from oracle import binding
     binding.build()
-    env = dict(os.environ, GM_BACKEND="gloo", GM_SCALE="13", GM_EXCHANGE="native", GRAPHMAT_DIST_TRANSPORT="shm")
+    env = dict(os.environ, GM_BACKEND="gloo", GM_SCALE="13", GM_EXCHANGE="native", GRAPHMAT_RCCL_LIBRARY=_shm_lib())
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "multi_check.py")]
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env, cwd=ROOT)
@@ -70,7 +77,7 @@ def test_native_exchange_several_ranks_over_shared_memory(world):
 
 def test_bench_two_ranks_distributed_build_and_native_exchange():
     """bench.py as the driver launches it at N > 1 (torch.distributed.run, one rank per process), on this 1-GPU box with
-    gloo for torch.distributed and the library's shared-memory transport for its own communicator: every rank generates
+    gloo for torch.distributed and the shared-memory stand-in for librccl for the library's own communicator: every rank generates
     half of the edge list, the library shuffles the edges to their shards (gm_graph_desc_t.edges_local), the native
     exchange is cross-checked against the callback inside bench.py, and the JSON line says what ran.  The value must
     match a run that builds every shard from the whole edge list (GM_BENCH_BUILD=whole) in everything but timing."""
@@ -79,7 +86,7 @@ def test_bench_two_ranks_distributed_build_and_native_exchange():
     build.build()
     lines = {}
     for mode in ("local", "whole"):
-        env = dict(os.environ, GM_BENCH_BACKEND="gloo", GRAPHMAT_DIST_TRANSPORT="shm", GM_BENCH_BUILD=mode)
+        env = dict(os.environ, GM_BENCH_BACKEND="gloo", GRAPHMAT_RCCL_LIBRARY=_shm_lib(), GM_BENCH_BUILD=mode)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "16", "--steps", "3",
                "--warmup", "1", "--cpu-scale", "0"]

@@ -3,7 +3,7 @@
 include/graphmat/mpi_single.h turns the applications' MPI_Init / MPI_Comm_rank / MPI_Barrier into the library's own
 communicator (gm_dist_init_from_env), Graph<V,E> then holds one shard per rank and the messages travel through
 gm_dist.hip.  RCCL wants one rank per GPU, so on the 1-GPU test box the ranks use the shared-memory test transport
-(GRAPHMAT_DIST_TRANSPORT=shm, same entry points); a single rank runs over RCCL itself.  Expected values come from the
+(GRAPHMAT_RCCL_LIBRARY=tests/support/libgm_shm_transport.so, same entry points); a single rank runs over RCCL itself.  Expected values come from the
 oracle with the matching layout parameter (the reference's id permutation depends on the number of ranks:
 nparts = threads * 16 * nranks, include/Graph.h:117)."""
 import os
@@ -23,8 +23,9 @@ def _launch(exe, args, nranks, tmp_path, transport):
     rdv = str(tmp_path / "rendezvous")
     for r in range(nranks):
         env = dict(os.environ, GRAPHMAT_RANK=str(r), GRAPHMAT_NRANKS=str(nranks), GRAPHMAT_LOCAL_RANK="0", GRAPHMAT_RENDEZVOUS=rdv)
-        if transport:
-            env["GRAPHMAT_DIST_TRANSPORT"] = transport
+        if transport:  # "shm": the test suite's stand-in for librccl (tests/support/shm_transport.hip)
+            from tests.support import build as shm_build
+            env["GRAPHMAT_RCCL_LIBRARY"] = shm_build.build()
         procs.append(subprocess.Popen([exe] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env))
     outs = []
     try:
@@ -92,3 +93,45 @@ def test_unchanged_bfs_one_process_per_shard(golden_dir, tmp_path, nranks, trans
     assert len(seen) >= 10
     for vid, (depth, parent) in seen.items():
         assert depth == int(od[vid - 1]) and parent == int(np.int64(op[vid - 1])), (vid, depth, parent)
+
+
+@pytest.mark.parametrize("nranks,transport", [(2, "shm")])
+def test_unchanged_delta_stepping_one_process_per_shard(golden_dir, tmp_path, nranks, transport):
+    """src/DeltaStepping.cpp with two ranks: two sharded graphs (light / heavy edges) share one vertex-property vector
+    (Graph::shareVertexProperty is then a collective relayout: every rank's edges travel to the shard owning their row in
+    the other graph's order).  Distances and the reachable count equal the SSSP oracle's."""
+    from graphmat_amd.mtx import read_mtx_bin
+    from oracle import binding as ob
+    fixture = os.path.join(golden_dir, "2_10_upper_triangle.bin.mtx")
+    nv, s, d, v = read_mtx_bin(fixture)
+    dist, _ = ob.OracleGraph(nv, s, d, v, nranks).sssp(1)
+    for delta in (10, 40):
+        outs = _launch(_need("DeltaStepping"), [fixture, delta, 1], nranks, tmp_path, transport)
+        assert "Reachable vertices = %d" % int((dist != 0xFFFFFFFF).sum()) in outs[0], outs[0][-2000:]
+        seen = {}
+        for text in outs:
+            for vtx, dv in re.findall(r"^(\d+) : distance = (\d+|INF)$", text, flags=re.M):
+                assert int(vtx) not in seen
+                seen[int(vtx)] = dv
+        assert len(seen) >= 20
+        for vtx, dv in seen.items():
+            exp = dist[vtx - 1]
+            assert (dv == "INF" and exp == 0xFFFFFFFF) or int(dv) == exp, (vtx, dv, exp)
+
+
+@pytest.mark.parametrize("nranks,transport", [(1, None), (2, "shm"), (3, "shm")])
+def test_apply_to_all_edges_with_several_ranks(tmp_path, nranks, transport):
+    """apps/sharded_edge_ops.cpp: applyToAllEdges (function pointer and device functor) when the other endpoint's
+    property lives on another shard; every edge is checked by the rank owning its source row, then a weighted multiply
+    reads the rewritten values."""
+    exe = os.path.join(ROOT, "build", "apps", "sharded_edge_ops")
+    if not os.path.exists(exe):
+        pytest.skip("sharded_edge_ops was not prebuilt")
+    outs = _launch(exe, [], nranks, tmp_path, transport)
+    total = 0
+    for r, text in enumerate(outs):
+        m = re.search(r"SHARDEDEDGES rank (\d+) ok (\d+) edges of (\d+)", text)
+        assert m, text[-2000:]
+        total += int(m.group(2))
+        want_total = int(m.group(3))
+    assert total == want_total

@@ -26,11 +26,11 @@ def _newest_header():
     return newest
 
 
-def _compile(src, out, rpath):
+def _compile(src, out, rpath, extra=()):
     if os.path.exists(out) and os.path.getmtime(out) >= max(
             os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "graphmat_amd", "libgraphmat_hip.so")), _newest_header()):
         return
-    cmd = [HIPCC] + FLAGS + [src, "-o", out, "-Wl,-rpath," + rpath]
+    cmd = [HIPCC] + FLAGS + list(extra) + [src, "-o", out, "-Wl,-rpath," + rpath]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         sys.stderr.write(r.stdout.decode())
@@ -61,9 +61,11 @@ def build(verbose=False, jobs=None):
         os.makedirs(outdir, exist_ok=True)
         for app in ("PageRank", "BFS", "SGD", "SSSP", "IncrementalPageRank", "TopologicalSort", "DeltaStepping"):
             work.append((os.path.join(REF, "src", app + ".cpp"), os.path.join(outdir, app)))
+        # the reference's own tracing build (-D__TIMING, its Makefile's `timing` flavour): per-iteration lines
+        work.append((os.path.join(REF, "src", "PageRank.cpp"), os.path.join(outdir, "PageRank__TIMING"), ("-D__TIMING",)))
     jobs = jobs or max(1, min(6, (os.cpu_count() or 2) - 1))
     with ThreadPoolExecutor(max_workers=jobs) as pool:
-        list(pool.map(lambda w: _compile(w[0], w[1], "$ORIGIN/../../graphmat_amd"), work))
+        list(pool.map(lambda w: _compile(w[0], w[1], "$ORIGIN/../../graphmat_amd", w[2] if len(w) > 2 else ()), work))
     built = [w[1] for w in work]
     if verbose:
         print("\n".join(built))
