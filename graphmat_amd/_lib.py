@@ -96,6 +96,8 @@ SIGNATURES = {
     "gm_run_sssp": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_int), _P]),
     "gm_run_sgd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), _P]),
     "gm_run_rmse": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "gm_run_sgd_bipartite": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                       C.POINTER(C.c_int), _P]),
     "gm_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "gm_graph_enable_timing": (C.c_int, [_P, C.c_int]),
     "gm_graph_last_stats": (C.c_int, [_P, C.POINTER(RunStats)]),

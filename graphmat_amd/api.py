@@ -243,6 +243,21 @@ class Graph:
                                 _stream()))
         return self.to_vertex_order(st)[:, :K].cpu().numpy(), it.value
 
+    def sgd_bipartite(self, lv, nusers, nitems, lam, step, iterations, blocks=4):
+        """gm_run_sgd_bipartite: this graph holds the ratings of THIS rank's users only (contiguous native ranges of
+        users, ascending with the rank of the library's communicator; users are vertices 1..nusers, items the next
+        nitems ids); only the items' running sums travel.  lv: [nv, K] float32, all vertices.  Returns (latent after
+        the run in vertex order -- current for the items and for this rank's users --, iterations done, bytes this
+        rank received per iteration)."""
+        st, K = self._latent_to_device(lv)
+        item_rows = self.dev_of_vertex[nusers:nusers + nitems].to(torch.int32).contiguous()
+        it = C.c_int(0)
+        check(self.L.gm_run_sgd_bipartite(self.h, st.data_ptr(), K, st.element_size(), item_rows.data_ptr(), nitems, blocks, lam, step,
+                                          iterations, C.byref(it), _stream()))
+        moved = C.c_int64(0)
+        self.L.gm_graph_note_get(self.h, 1, C.byref(moved))
+        return self.to_vertex_order(st)[:, :K].cpu().numpy(), it.value, moved.value
+
     def rmse_sum(self, lv):
         """sum over vertices of sqerr after one RMSE pass (caller: sqrt(sum/nnz))."""
         st, K = self._latent_to_device(lv)

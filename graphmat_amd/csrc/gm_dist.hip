@@ -124,6 +124,21 @@ int dist_all_reduce_sum_u32(uint32_t* d, size_t n, hipStream_t s) {
   GM_TRY_NCCL(g_rccl.AllReduce(d, d, n, ncclUint32, ncclSum, g_comm, s));
   return GM_OK;
 }
+int dist_ring_step(const void* d_send, size_t send_bytes, void* d_recv, size_t recv_bytes, hipStream_t s) {
+  if (!g_comm) { set_error("gm_dist: call gm_dist_init first"); return GM_ERR_INVALID; }
+  if (g_nranks == 1) return GM_OK;
+  GM_TRY_NCCL(g_rccl.GroupStart());
+  if (send_bytes > 0 && g_rank + 1 < g_nranks) GM_TRY_NCCL(g_rccl.Send(d_send, send_bytes, ncclChar, g_rank + 1, g_comm, s));
+  if (recv_bytes > 0 && g_rank > 0) GM_TRY_NCCL(g_rccl.Recv(d_recv, recv_bytes, ncclChar, g_rank - 1, g_comm, s));
+  GM_TRY_NCCL(g_rccl.GroupEnd());
+  return GM_OK;
+}
+int dist_broadcast(void* d_buf, size_t bytes, int root, hipStream_t s) {
+  if (!g_comm) { set_error("gm_dist: call gm_dist_init first"); return GM_ERR_INVALID; }
+  if (g_nranks == 1 || bytes == 0) return GM_OK;
+  GM_TRY_NCCL(g_rccl.Broadcast(d_buf, d_buf, bytes, ncclChar, root, g_comm, s));
+  return GM_OK;
+}
 // recv = the ranks' `bytes` bytes at d_send, in rank order (separate buffers)
 int dist_all_gather_bytes(const void* d_send, void* d_recv, size_t bytes, hipStream_t s) {
   if (!g_comm) { set_error("distributed build: call gm_dist_init first"); return GM_ERR_INVALID; }

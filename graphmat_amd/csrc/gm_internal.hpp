@@ -98,4 +98,8 @@ void free_native_exchange(gm_graph* g);
 int dist_world(int* rank, int* nranks);  // 1 when a communicator exists
 int dist_all_reduce_sum_u32(uint32_t* d, size_t n, hipStream_t s);
 int dist_all_gather_bytes(const void* d_send, void* d_recv, size_t bytes, hipStream_t s);
+// one step of a ring pipeline: send `send_bytes` to rank+1 and receive `recv_bytes` from rank-1 (either may be 0: the
+// ends of the pipeline, or a rank idle in this step).  Every rank of the communicator calls it for every step.
+int dist_ring_step(const void* d_send, size_t send_bytes, void* d_recv, size_t recv_bytes, hipStream_t s);
+int dist_broadcast(void* d_buf, size_t bytes, int root, hipStream_t s);
 }

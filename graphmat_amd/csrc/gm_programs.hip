@@ -212,7 +212,8 @@ constexpr int kSgdTile = 16;       // measured on 2e8 ratings: tile 8 / 16 / 32 
 template <int K, int MODE>
 __global__ void __launch_bounds__(kSgdMulBlock)
 k_sgd_multiply(gm_csr_t A, const float* __restrict__ x, const float* __restrict__ vp, float* __restrict__ y,
-               const uint32_t* __restrict__ prev_bits, int accumulate) {
+               const uint32_t* __restrict__ prev_bits, int accumulate,
+               const int32_t* __restrict__ rows = nullptr /* only these rows (a block of the bipartite exchange), or all */, int nlist = 0) {
   static_assert(K % 64 == 0 && 256 % K == 0, "K must be 64, 128 or 256");
   constexpr int PER = K / 64;        // components per lane in phase B
   constexpr int LPR = K / 4;         // lanes that cover one x row with a float4 each
@@ -223,7 +224,11 @@ k_sgd_multiply(gm_csr_t A, const float* __restrict__ x, const float* __restrict_
   __shared__ float s_v[WPB][K];
   __shared__ __attribute__((aligned(16))) float s_x[WPB][kSgdTile][XS];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * WPB + wv;
+  int row = blockIdx.x * WPB + wv;
+  if (rows != nullptr) {
+    if (row >= nlist) return;
+    row = rows[row];
+  }
   if (row >= A.nrows) return;
   const int64_t e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
   if (e1 == e0) return;
@@ -366,6 +371,134 @@ int run_sgd_wide(gm_graph_t* g, float* d_latent, float lambda, float step, int i
   if (iters_done) *iters_done = iterations;
   return GM_OK;
 }
+// ---- SGD on a bipartite ratings graph split by USERS: only the item side travels ----------------------------------
+// Row sharding makes a shard's item rows read practically every user vector, so gm_run_sgd's exchange moves all of x
+// (config 5: 11 M x 512 B = 5.6 GB per GPU and iteration).  The reference partitions 2-D and moves the smaller operand
+// (include/GMDP/multinode/spmspv3.h:74-170).  Here rank k holds the edges of a contiguous NATIVE range of users (ranges
+// ascending with the rank) as an ordinary single-GPU graph over all vertices, and every rank keeps a copy of the items:
+//   * a user's fold (IN pass: rows = sources) sees all of its items locally;
+//   * an item's fold over its users in ascending native order is the concatenation of the ranks' segments in rank
+//     order, so its running K-vector travels rank 0 -> 1 -> ... -> N-1, each rank continuing the ordered fold where
+//     the previous one stopped (k_sgd_multiply with the received values as y and their presence flags) -- in `blocks`
+//     blocks of items, block b being on rank k at step k + b (a systolic ring: every rank busy after N - 1 steps);
+//   * rank N-1 ends up with every item's complete sum and broadcasts them; every rank applies them to its copy of the
+//     items (the same arithmetic everywhere, so the copies stay identical) and its own users' sums to its users.
+// Per rank and iteration: nitems * K * 4 bytes received along the ring + the same again from the broadcast
+// (config 5: 2 x 512 MB instead of 5.6 GB).  The bits are those of one GPU.
+__global__ void __launch_bounds__(kSgdBlock)
+k_rows_pack(const float* __restrict__ y, const uint32_t* __restrict__ bits_a, const uint32_t* __restrict__ bits_b, const int32_t* __restrict__ rows,
+            int n, int K, float* __restrict__ out, int32_t* __restrict__ flags) {  // out[i][:] = y[rows[i]][:], flags[i] = presence
+  const int64_t i = (int64_t)blockIdx.x * kSgdBlock + threadIdx.x;
+  if (i >= (int64_t)n * K) return;
+  const int r = (int)(i / K), c = (int)(i % K);
+  const int row = rows[r];
+  out[i] = y[(int64_t)row * K + c];
+  if (c == 0) {
+    uint32_t b = (bits_a[row >> 5] >> (row & 31)) & 1u;
+    if (bits_b) b |= (bits_b[row >> 5] >> (row & 31)) & 1u;
+    flags[r] = (int32_t)b;
+  }
+}
+__global__ void __launch_bounds__(kSgdBlock)
+k_rows_unpack(const float* __restrict__ in, const int32_t* __restrict__ flags, const int32_t* __restrict__ rows, int n, int K,
+              float* __restrict__ y, uint32_t* __restrict__ bits) {  // y[rows[i]][:] = in[i][:], presence bit set from flags
+  const int64_t i = (int64_t)blockIdx.x * kSgdBlock + threadIdx.x;
+  if (i >= (int64_t)n * K) return;
+  const int r = (int)(i / K), c = (int)(i % K);
+  const int row = rows[r];
+  y[(int64_t)row * K + c] = in[i];
+  if (c == 0 && flags[r]) atomicOr(&bits[row >> 5], 1u << (row & 31));
+}
+
+template <int K>
+int run_sgd_bipartite(gm_graph_t* g, float* d_latent, const int32_t* d_item_rows, int nitems, int blocks, float lambda, float step,
+                      int iterations, int* iters_done, hipStream_t s) {
+  const gm_graph_desc_t& d = g->desc;
+  const int n = d.row_hi - d.row_lo;
+  int rank = 0, nranks = 1;
+  if (!dist_world(&rank, &nranks)) { rank = 0; nranks = 1; }
+  if (blocks < 1) blocks = 1;
+  if (blocks > nitems) blocks = nitems > 0 ? nitems : 1;
+  void *px = nullptr, *py = nullptr, *pk = nullptr, *pb = nullptr;
+  int rc;
+  const size_t nw = (size_t)(n + 31) / 32 + 2;
+  if ((rc = gm_graph_workspace(g, 1, (size_t)d.ndevice * K * 4 + 64, &px))) return rc;
+  if ((rc = gm_graph_workspace(g, 3, (size_t)n * K * 4 + 64, &py))) return rc;
+  if ((rc = gm_graph_workspace(g, 6, (size_t)nitems * (K + 1) * 4 + 256, &pk))) return rc;  // packed item sums + their flags
+  if ((rc = gm_graph_workspace(g, 4, nw * 4 * 2, &pb))) return rc;                            // presence bits: received / applied
+  float* pack = (float*)pk;
+  int32_t* flags = (int32_t*)(pack + (size_t)nitems * K);
+  uint32_t* got = (uint32_t*)pb;          // item rows that carry a value from the earlier ranks
+  uint32_t* app = got + nw;               // rows apply() visits: this rank's users with ratings + items with any rating
+  const int wgrid = (n + kSgdMulBlock / 64 - 1) / (kSgdMulBlock / 64);
+  const int egrid = (int)(((int64_t)n * K + kSgdBlock - 1) / kSgdBlock);
+  auto grid_items = [&](int cnt) { return (int)(((int64_t)cnt * K + kSgdBlock - 1) / kSgdBlock); };
+  auto block_lo = [&](int b) { return (int)((int64_t)nitems * b / blocks); };
+  gm_run_stats_t st;
+  memset(&st, 0, sizeof(st));
+  hipEvent_t ev0, ev1;
+  GM_TRY_HIP(hipEventCreate(&ev0));
+  GM_TRY_HIP(hipEventCreate(&ev1));
+  GM_TRY_HIP(hipEventRecord(ev0, s));
+  unsigned long long moved = 0;
+  for (int it = 0; it < iterations; it++) {
+    hipLaunchKernelGGL((k_sgd_send<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)d_latent, (float*)px, n);
+    // users: rows of the by-source adjacency, all of their items are here
+    hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3(wgrid), dim3(kSgdMulBlock), 0, s, g->in.view, (const float*)px,
+                       (const float*)d_latent, (float*)py, (const uint32_t*)nullptr, 0);
+    // items: the ring.  Step t: this rank works on block t - rank.
+    GM_TRY_HIP(hipMemsetAsync(got, 0, nw * 4, s));
+    for (int t = 0; t < nranks + blocks - 1; t++) {
+      const int b = t - rank;
+      const bool mine = b >= 0 && b < blocks;
+      const int lo = mine ? block_lo(b) : 0, cnt = mine ? block_lo(b + 1) - lo : 0;
+      // block b arrives from the previous rank (which finished it in step t - 1) ...
+      const size_t bytes_f = (size_t)cnt * K * 4, bytes_i = (size_t)cnt * 4;
+      // ... while the block this rank finished in step t - 1 (block t - 1 - rank) moves on to the next rank
+      const int bs = t - 1 - rank;
+      const bool sending = bs >= 0 && bs < blocks && rank + 1 < nranks;
+      const int slo = sending ? block_lo(bs) : 0, scnt = sending ? block_lo(bs + 1) - slo : 0;
+      if (nranks > 1) {
+        if ((rc = dist_ring_step(pack + (size_t)slo * K, (size_t)scnt * K * 4, pack + (size_t)lo * K, rank > 0 ? bytes_f : 0, s))) return rc;
+        if ((rc = dist_ring_step(flags + slo, (size_t)scnt * 4, flags + lo, rank > 0 ? bytes_i : 0, s))) return rc;
+        moved += (rank > 0 ? bytes_f + bytes_i : 0);
+      }
+      if (!mine || cnt == 0) continue;
+      if (rank > 0)
+        hipLaunchKernelGGL(k_rows_unpack, dim3(grid_items(cnt)), dim3(kSgdBlock), 0, s, (const float*)(pack + (size_t)lo * K),
+                           (const int32_t*)(flags + lo), d_item_rows + lo, cnt, K, (float*)py, got);
+      hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3((cnt + kSgdMulBlock / 64 - 1) / (kSgdMulBlock / 64)), dim3(kSgdMulBlock), 0, s,
+                         g->out.view, (const float*)px, (const float*)d_latent, (float*)py, (const uint32_t*)got, rank > 0 ? 1 : 0,
+                         d_item_rows + lo, cnt);
+      // the block as it leaves this rank (sent in the next step; on the last rank: the final sums)
+      hipLaunchKernelGGL(k_rows_pack, dim3(grid_items(cnt)), dim3(kSgdBlock), 0, s, (const float*)py, (const uint32_t*)got,
+                         (const uint32_t*)g->out.rowbits, d_item_rows + lo, cnt, K, pack + (size_t)lo * K, flags + lo);
+    }
+    if (nranks > 1) {
+      // (the last block left rank N-2 in the final step above; rank N-1 now holds every item's complete sum)
+      if ((rc = dist_broadcast(pack, (size_t)nitems * (K + 1) * 4, nranks - 1, s))) return rc;
+      if (rank + 1 < nranks) moved += (unsigned long long)nitems * (K + 1) * 4;
+    }
+    // apply: this rank's users (rows with an out-edge here) and every item that received a rating anywhere
+    GM_TRY_HIP(hipMemcpyAsync(app, g->in.rowbits, nw * 4, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_rows_unpack, dim3(grid_items(nitems)), dim3(kSgdBlock), 0, s, (const float*)pack, (const int32_t*)flags,
+                       d_item_rows, nitems, K, (float*)py, app);
+    hipLaunchKernelGGL((k_sgd_apply<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)py, (const uint32_t*)app, d_latent, n,
+                       lambda, step);
+  }
+  GM_TRY_HIP(hipEventRecord(ev1, s));
+  GM_TRY_HIP(hipEventSynchronize(ev1));
+  GM_TRY_HIP(hipEventElapsedTime(&st.total_ms, ev0, ev1));
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  st.iterations = iterations;
+  g->stats = st;
+  g->note_val[1] = (int64_t)(iterations > 0 ? moved / (unsigned long long)iterations : 0ull);  // bytes received per iteration
+  g->note_set[1] = 1;
+  if (iters_done) *iters_done = iterations;
+  return GM_OK;
+}
+
 template <int K>
 int run_rmse_wide(gm_graph_t* g, float* d_latent, hipStream_t s) {
   const gm_graph_desc_t& d = g->desc;
@@ -461,6 +594,7 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "sparse_step_edges") && value >= 0) { GraphMat::detail::sparse_step_edges() = value; return GM_OK; }
   if (key && !strcmp(key, "wave16_form") && value >= 0 && value <= 5) { GraphMat::detail::wave16_form() = value; return GM_OK; }
   if (key && !strcmp(key, "persist_per_cu") && value >= 0 && value <= 8) { GraphMat::detail::persist_per_cu() = value; return GM_OK; }
+  if (key && !strcmp(key, "giant_maps") && (value == 0 || value == 1)) { GraphMat::detail::giant_maps() = value; return GM_OK; }
   if (key && !strcmp(key, "iteration_trace") && (value == 0 || value == 1)) { GraphMat::detail::iteration_trace() = value; return GM_OK; }
   if (key && !strcmp(key, "debug_flags")) { GraphMat::detail::debug_flags() = value; return GM_OK; }
   gm::set_error("gm_set_option: unknown option");
@@ -520,6 +654,20 @@ int gm_run_sgd(gm_graph_t* g, void* d_latent, int K, int real_bytes, double lamb
   }
   gm::set_error("gm_run_sgd: (K=%d, real_bytes=%d) is not in the fixed menu", K, real_bytes);
   return GM_ERR_UNSUPPORTED;
+}
+
+int gm_run_sgd_bipartite(gm_graph_t* g, void* d_latent, int K, int real_bytes, const int32_t* d_item_rows, int nitems, int blocks,
+                         double lambda, double step, int iterations, int* iters_done, gm_stream_t stream) {
+  if (!g || !d_latent || !d_item_rows || nitems < 0 || iterations < 1) { gm::set_error("gm_run_sgd_bipartite: invalid argument"); return GM_ERR_INVALID; }
+  if (K != 128 || real_bytes != 4) { gm::set_error("gm_run_sgd_bipartite: only K=128 fp32 (the dedicated kernels)"); return GM_ERR_UNSUPPORTED; }
+  const gm_graph_desc_t& d = g->desc;
+  if (d.row_lo != 0 || d.row_hi != d.ndevice || g->xfn != nullptr || !g->out.present || !g->in.present || d.val_bytes != 4 || !g->out.vals ||
+      !g->in.vals) {
+    gm::set_error("gm_run_sgd_bipartite: needs an unsharded graph of this rank's users' ratings, both directions, 4-byte values");
+    return GM_ERR_INVALID;
+  }
+  return gm::run_sgd_bipartite<128>(g, (float*)d_latent, d_item_rows, nitems, blocks, (float)lambda, (float)step, iterations, iters_done,
+                                    (hipStream_t)stream);
 }
 
 int gm_run_rmse(gm_graph_t* g, void* d_latent, int K, int real_bytes, gm_stream_t stream) {

@@ -46,6 +46,11 @@ inline int& wave16_form() {
   static int v = 0;
   return v;
 }
+// giant rows of float sums: precomputed chunk maps (the multi-workgroup exact replay; 0 = one workgroup walks the row)
+inline int& giant_maps() {
+  static int v = 1;
+  return v;
+}
 // persistent kernels: workgroups per CU (0 = as many as the LDS allows)
 inline int& persist_per_cu() {
   static int v = 0;
@@ -307,6 +312,7 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
                   ((RK == REDUCE_COMMUTATIVE || RK == REDUCE_LAST) && sizeof(U) <= 8)) {
       U* terms = nullptr;
       unsigned long long* tpres = nullptr;
+      dev::gchunk_map* maps = nullptr;
       if constexpr (RK == REDUCE_F32_ADD) {
         // pass 1: products of all giant-row edges, spread over the whole chip
         void *p6 = nullptr, *p7 = nullptr;
@@ -316,13 +322,36 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
           gm_graph_workspace(g, 14, (size_t)A.giant_edges / 8 + 64, &p7);  // (slot 7 holds the active-set list of sharded ACTIVE_ONLY runs)
           tpres = (unsigned long long*)p7;
         }
+        // chunk maps (kernels.hpp: k_giant_predict / k_giant_maps): the exact replay of a giant row spread over the
+        // whole chip, its serial part limited to the binade crossings.  float sums over a dense x only.
+        double* psum = nullptr;
+        double* before = nullptr;
+        if constexpr (std::is_same<U, float>::value) {
+          if (xbits == nullptr && want == nullptr && giant_maps() != 0) {
+            void* p15 = nullptr;
+            if (gm_graph_workspace(g, 15, (size_t)A.ngchunk * 32 + 256, &p15) == GM_OK) {
+              psum = (double*)p15;
+              before = psum + A.ngchunk;
+              maps = (dev::gchunk_map*)(before + A.ngchunk);
+            }
+          }
+        }
         hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa,
-                           A, x, xbits, vp, terms, tpres, debug_flags());
+                           A, x, xbits, vp, terms, tpres, debug_flags(), psum);
         (*launches)++;
+        if constexpr (std::is_same<U, float>::value) {
+          if (maps != nullptr) {
+            hipLaunchKernelGGL((dev::k_giant_predict<U>), dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, A, (const double*)psum,
+                               before, (const U*)y, (const uint32_t*)ybits, accumulate);
+            hipLaunchKernelGGL(dev::k_giant_maps, dim3(A.ngchunk), dim3(dev::kGiant), 0, gs, A, (const float*)terms, (const double*)psum,
+                               (const double*)before, maps);
+            (*launches) += 2;
+          }
+        }
       }
       hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa,
                          A, x, xbits, vp, y, ybits, accumulate, debug_flags(), (const U*)terms,
-                         (const unsigned long long*)tpres, want);
+                         (const unsigned long long*)tpres, want, (const dev::gchunk_map*)maps);
     } else {
       hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, REDUCE_ORDERED>),
                          dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, A.giant_row, A.ngiant, x,

@@ -26,6 +26,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "../graphmat_hip.h"
 
 namespace GraphMat {
@@ -1098,7 +1100,8 @@ __device__ __forceinline__ bool ulp_term(uint32_t abits, int eS, ulp_map& out) {
 template <class P, class T, class U, class V, class E, bool USE_VP>
 __global__ void __launch_bounds__(kBlock)
 k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
-              const V* __restrict__ vp, U* __restrict__ terms, unsigned long long* __restrict__ tpres, int dbg) {
+              const V* __restrict__ vp, U* __restrict__ terms, unsigned long long* __restrict__ tpres, int dbg,
+              double* __restrict__ piece_sum /* [ngchunk] sum of the piece's products (float reductions, dense x), or null */) {
   constexpr int PER = GM_GIANT_CHUNK / kBlock;
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int gi = A.gchunk_row[blockIdx.x];
@@ -1124,6 +1127,7 @@ k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t
 #pragma unroll
   for (int j = 0; j < PER; j++)
     if (c[j] >= 0) { if (dbg & DBG_SKIP_GATHER) memset(&m[j], 0, sizeof(T)); else m[j] = x[c[j]]; }
+  double mysum = 0.0;
 #pragma unroll
   for (int j = 0; j < PER; j++) {
     int k = threadIdx.x + j * kBlock;
@@ -1131,10 +1135,24 @@ k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t
       U t;
       p.P::process_message(m[j], edge_at<E>(A.vals, eb + k), vprow, t);
       terms[out0 + k] = t;
+      if constexpr (std::is_same<U, float>::value) mysum += (double)t;
     }
     if (tpres != nullptr) {
       unsigned long long w = __ballot(c[j] >= 0);
       if ((threadIdx.x & 63) == 0 && (k & ~63) < n) tpres[(out0 + (k & ~63)) >> 6] = w;
+    }
+  }
+  if constexpr (std::is_same<U, float>::value) {
+    if (piece_sum != nullptr) {  // (an estimate for k_giant_predict: any summation order will do)
+      __shared__ double s_sum[kBlock / 64];
+      for (int off = 32; off > 0; off >>= 1) mysum += __shfl_down(mysum, off, 64);
+      if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = mysum;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < kBlock / 64; w++) tot += s_sum[w];
+        piece_sum[blockIdx.x] = tot;
+      }
     }
   }
 }
@@ -1146,11 +1164,121 @@ constexpr int kGiant = 512;                     // threads per workgroup of k_sp
 constexpr int kLongPer = 16;                    // consecutive edges per lane and chunk
 constexpr int kLongChunk = kLongPer * kGiant;   // 8192 edges per chunk
 
+// ---- the exact replay spread over MANY workgroups (REDUCE_F32_ADD, every x entry present) -----------
+// One workgroup per row walking 8192-product chunks is a serial chain as long as the row (the 854 K-edge hub row
+// of RMAT-26: 104 chunks, ~1.1 ms -- as long as a whole iteration of a shard of 8).  The ulp-maps of the replay
+// compose associatively while the running sum S stays inside one binade, and a chunk's composed map depends on S
+// only through S's binade: so (1) k_giant_terms also leaves the plain sum of every 4096-product piece, (2)
+// k_giant_predict turns them into an ESTIMATE of S before every chunk (fp64 prefix, started from the exact value y
+// holds when earlier column tiles already contributed), (3) k_giant_maps -- one workgroup per chunk, the whole chip --
+// composes, for every chunk whose estimated S stays inside one binade e with a safety margin, the exact map of its
+// 8192 products against e, and (4) k_spmv_giant merely APPLIES that map when the exact S it has reached really is in
+// binade e and really stays there (S + delta < 2^24 ulps; S only grows: terms are non-negative or the chunk is not
+// mapped) -- otherwise, and around every binade crossing, it replays the chunk itself as before.  The estimate
+// decides only WHICH chunks get a precomputed map, never a value: the bits are those of the serial loop.
+struct gchunk_map {
+  int32_t e;          // biased exponent of the binade the map holds for; 0 = no map for this chunk
+  uint32_t de, dod;   // ulps added when the incoming S is even / odd
+  uint32_t pad;
+};
+__device__ __forceinline__ int lower_piece(const int32_t* __restrict__ gchunk_row, int n, int gi) {  // first piece of giant row gi
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (gchunk_row[mid] < gi) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// one wave per giant row: estimate of the running sum before each of its pieces (64 pieces per step: an inclusive
+// wave scan of their sums -- the summation order does not matter for an estimate)
+template <class U>
+__global__ void __launch_bounds__(kBlock)
+k_giant_predict(gm_csr_t A, const double* __restrict__ piece_sum, double* __restrict__ before, const U* __restrict__ y,
+                const uint32_t* __restrict__ ybits, int accumulate) {
+  const int gi = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (gi >= A.ngiant) return;
+  const int lane = threadIdx.x & 63;
+  const int row = A.giant_row[gi];
+  const int64_t deg = A.rowptr[row + 1] - A.rowptr[row];
+  const int npieces = (int)((deg + GM_GIANT_CHUNK - 1) / GM_GIANT_CHUNK);
+  const int p0 = lower_piece(A.gchunk_row, A.ngchunk, gi);
+  double S = 0.0;
+  if ((accumulate & ACC_READ_PREV) && bit_get(ybits, row)) S = (double)y[row];
+  for (int base = 0; base < npieces; base += 64) {
+    const int i = base + lane;
+    const double mine = i < npieces ? piece_sum[p0 + i] : 0.0;
+    double incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (i < npieces) before[p0 + i] = S + (incl - mine);
+    S += __shfl(incl, 63, 64);
+  }
+}
+// one workgroup per 8192-product chunk (= the even-numbered 4096-pieces of a row): the chunk's composed ulp-map
+__global__ void __launch_bounds__(kGiant)
+k_giant_maps(gm_csr_t A, const float* __restrict__ terms, const double* __restrict__ piece_sum, const double* __restrict__ before,
+             gchunk_map* __restrict__ maps) {
+  const int p = blockIdx.x;
+  const int gi = A.gchunk_row[p];
+  const int row = A.giant_row[gi];
+  const int64_t e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
+  const int64_t rel = A.gchunk_edge[p] - e0;
+  if ((rel / GM_GIANT_CHUNK) & 1) return;  // second half of a chunk
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int n = (int)((e1 - e0 - rel) < kLongChunk ? (e1 - e0 - rel) : kLongChunk);
+  // the binade the estimate says S is in, from before the chunk until after it, with a margin on both sides
+  const double Sa = before[p];
+  double Sb = Sa + piece_sum[p];
+  if (p + 1 < A.ngchunk && A.gchunk_row[p + 1] == gi) Sb += piece_sum[p + 1];
+  const float fa = (float)(Sa * (1.0 - 1e-4)), fb = (float)(Sb * (1.0 + 1e-4));
+  const int ea = (int)((__float_as_uint(fa) >> 23) & 0xff), eb = (int)((__float_as_uint(fb) >> 23) & 0xff);
+  __shared__ ulp_map s_wave[kGiant / 64];
+  __shared__ int s_bad;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  const bool candidate = Sa > 0.0 && ea == eb && ea > 0 && ea < 255 && !(fa < 0.f);
+  if (!candidate) {
+    if (tid == 0) maps[p] = gchunk_map{0, 0u, 0u, 0u};
+    return;
+  }
+  const int64_t t0 = A.gterm_off[gi] + rel;
+  ulp_map mine = {0u, 0u};
+  bool ok = true;
+  const int k0 = tid * kLongPer;
+#pragma unroll
+  for (int j = 0; j < kLongPer; j++) {
+    if (k0 + j < n) {
+      ulp_map t;
+      if (!ulp_term(__float_as_uint(terms[t0 + k0 + j]), ea, t)) ok = false; else mine = ulp_compose(mine, t);
+    }
+  }
+  if (!ok) atomicOr(&s_bad, 1);
+  ulp_map v = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    ulp_map o;
+    o.de = __shfl_up(v.de, off, 64);
+    o.dod = __shfl_up(v.dod, off, 64);
+    if (lane >= off) v = ulp_compose(o, v);
+  }
+  if (lane == 63) s_wave[tid >> 6] = v;
+  __syncthreads();
+  if (tid == 0) {
+    ulp_map tot = {0u, 0u};
+    for (int w = 0; w < kGiant / 64; w++) tot = ulp_compose(tot, s_wave[w]);
+    maps[p] = s_bad ? gchunk_map{0, 0u, 0u, 0u} : gchunk_map{ea, tot.de, tot.dod, 0u};
+  }
+}
+
 template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
 __global__ void __launch_bounds__(kGiant)
 k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
                const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg,
-               const U* __restrict__ terms, const unsigned long long* __restrict__ tpres, const uint32_t* __restrict__ want) {
+               const U* __restrict__ terms, const unsigned long long* __restrict__ tpres, const uint32_t* __restrict__ want,
+               const gchunk_map* __restrict__ maps = nullptr /* precomputed chunk maps (k_giant_maps), or null */) {
   constexpr bool SMALL_U = sizeof(U) <= 8;
   constexpr int CH = kLongChunk, PER = kLongPer;
   // ordered kinds stage the per-edge products (U) of a chunk in LDS for the serial fold
@@ -1254,15 +1382,55 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
       }
     };
     float term[PER], pre[PER];
-    load_chunk(0, pre);
+    // precomputed chunk maps of this row (k_giant_maps), staged in LDS
+    constexpr int kMapsLds = 256;
+    __shared__ gchunk_map s_maps[kMapsLds];
+    __shared__ int s_skip;
+    const int nchunks = (int)((deg + CH - 1) / CH);
+    const bool mapped = maps != nullptr && nchunks <= kMapsLds && !(dbg & DBG_NO_REPLAY);
+    if (mapped) {
+      const int piece0 = lower_piece(A.gchunk_row, A.ngchunk, (int)blockIdx.x);
+      for (int c = tid; c < nchunks; c += kGiant) s_maps[c] = maps[piece0 + 2 * c];
+    } else {
+      load_chunk(0, pre);
+    }
     for (int64_t base = e0; base < e1; base += CH) {
+      __syncthreads();  // previous chunk fully consumed (and, first time round, s_maps / s_Sbits / s_has written)
+      if (mapped) {
+        // Chunks whose map applies -- the exact S is in the binade the map was composed for and stays in it -- are
+        // not even loaded: one lane walks them, however many follow each other, and the workgroup resumes at the
+        // first chunk it has to replay itself (a binade crossing, or a chunk without a map).
+        if (tid == 0) {
+          int c = (int)((base - e0) / CH), skipped = 0;
+          uint32_t sbm = s_Sbits;
+          if (s_has[0] != 0) {
+            while (c < nchunks) {
+              const gchunk_map rec = s_maps[c];
+              const uint32_t Sint = (sbm & 0x7fffffu) | 0x800000u;
+              const uint32_t Safter = Sint + ((Sint & 1u) ? rec.dod : rec.de);
+              if (!(rec.e > 0 && !(sbm >> 31) && (int)((sbm >> 23) & 0xff) == rec.e && Safter < 0x1000000u)) break;
+              sbm = (sbm & 0xff800000u) | (Safter & 0x7fffffu);
+              c++;
+              skipped++;
+            }
+          }
+          if (skipped) {
+            s_Sbits = sbm;
+            atomicAdd(&g_longrow_counters[2], (unsigned long long)skipped * (CH / PER));
+          }
+          s_skip = skipped;
+        }
+        __syncthreads();
+        base += (int64_t)s_skip * CH;
+        if (base >= e1) break;
+        load_chunk(base - e0, pre);
+      }
       const int n = (int)((e1 - base) < CH ? (e1 - base) : CH);
       const int ngroups = (n + PER - 1) / PER;
       const int64_t rel = base - e0;
-      __syncthreads();  // previous chunk fully consumed
 #pragma unroll
       for (int j = 0; j < PER; j++) s_term[j * kGiant + tid] = pre[j];  // linear: slot(k) = k
-      load_chunk(rel + CH, pre);
+      if (!mapped) load_chunk(rel + CH, pre);
       uint32_t presmask = 0;
       if (k0 < n) {
         const int cnt = (n - k0) < PER ? (n - k0) : PER;

@@ -387,6 +387,20 @@ int gm_run_sssp(gm_graph_t* g, uint32_t* d_dist, uint32_t* d_active, int iterati
 int gm_run_sgd(gm_graph_t* g, void* d_latent, int K, int real_bytes, double lambda, double step, int iterations,
                int* iters_done, gm_stream_t stream);
 int gm_run_rmse(gm_graph_t* g, void* d_latent, int K, int real_bytes, gm_stream_t stream);
+/* SGD on a BIPARTITE ratings graph split by users over the ranks of the gm_dist communicator: only the item side
+ * travels (the reference's 2-D scheme also moves the smaller operand, include/GMDP/multinode/spmspv3.h:74-170).
+ * Rank k passes a graph built (unsharded: nshards = 1) from the ratings of ITS users only, where the ranks' user sets
+ * are contiguous ranges of the users' NATIVE ids, ascending with the rank; every rank holds all vertices' latent
+ * vectors (d_latent over g's device order) and keeps the items' current.  d_item_rows[j] = g's device row of item j,
+ * the same item order on every rank (nitems entries, device memory).  An item's ordered fold over its users is the
+ * concatenation of the ranks' segments, so its running sum travels rank 0 -> 1 -> ... in `blocks` blocks of items (a
+ * ring pipeline), the last rank broadcasts the complete sums, and every rank applies them to its copy of the items and
+ * its own users' sums to its users: per rank and iteration 2 * nitems * (K + 1) * 4 bytes are received instead of
+ * nvertices * K * 4, and the bits are those of one GPU.  Vertices must be users (sources only) or items (destinations
+ * only).  K = 128 fp32.  With no communicator (or one rank) this is a single-GPU iteration.  gm_graph_note_get(g, 1)
+ * afterwards: bytes this rank received per iteration. */
+int gm_run_sgd_bipartite(gm_graph_t* g, void* d_latent, int K, int real_bytes, const int32_t* d_item_rows, int nitems, int blocks,
+                         double lambda, double step, int iterations, int* iters_done, gm_stream_t stream);
 
 /* runtime options.  "force_ordered" (0/1): run PageRank with the plain serial long-row fold
  * instead of the exact parallel replay (A/B check; results are bit-identical).  Graph-build experiments (read when a

@@ -268,9 +268,14 @@ def test_probed_reduce_strategies_are_cross_checked():
     float max, a+b with a quirk at one value) must end up with the ordered fold -- by the probe's adversarial
     operands or by the device-side cross-check -- and every result must equal a host fold with the program's function."""
     exe = _need(os.path.join(OWN_APPS, "reduce_probe_cases"))
+    # without the opt-in nothing is probed: every unannotated program gets the ordered fold (exact by default)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=dict(os.environ, GRAPHMAT_VERBOSE="1"))
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "PROBECASES PASS" in text, text[-3000:]
+    assert "reduce strategy 3" not in text and "reduce strategy 2" not in text and text.count("reduce strategy 0") >= 4
     for tiles in ("1", "3"):  # untiled, and with column tiles (the cross-check then compares whole rows after the last tile)
         out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
-                             env=dict(os.environ, GRAPHMAT_VERBOSE="1", GRAPHMAT_COL_TILES=tiles))
+                             env=dict(os.environ, GRAPHMAT_VERBOSE="1", GRAPHMAT_COL_TILES=tiles, GRAPHMAT_TRUST_PROBE="1"))
         text = out.stdout.decode()
         assert out.returncode == 0 and "PROBECASES PASS" in text, text[-3000:]
         sect = {name: body for name, body in re.findall(r"== (\w+)\n(.*?)(?=\n== |\nPROBECASES)", text, flags=re.S)}

@@ -227,9 +227,9 @@ def test_bfs_depths_closed_form(env, n):
 
 
 # ---------------- the exact fp32 replay on long rows ---------------------------------------------
-def _pagerank_custom(api, ob, nv, s, d, pr0, deg, alpha, iters, threads=1):
+def _pagerank_custom(api, ob, nv, s, d, pr0, deg, alpha, iters, threads=1, col_tiles=1):
     import torch
-    g = api.Graph(nv, s, d, np.ones(len(s), np.int32), ref_threads=threads)
+    g = api.Graph(nv, s, d, np.ones(len(s), np.int32), ref_threads=threads, col_tiles=col_tiles)
     st = torch.zeros((nv, 2), dtype=torch.int32, device=g.device)
     st[:, 0] = g.to_device_order(f32bits(pr0).view(np.int32))
     st[:, 1] = g.to_device_order(np.asarray(deg, np.int32))
@@ -269,6 +269,45 @@ def test_long_row_float_sum_is_bit_exact(env, kind):
     a, b, o = _pagerank_custom(api, ob, nv, src, dst, pr0, deg, 0.0, 1)
     assert (f32bits(a) == f32bits(o)).all(), "exact replay differs from the oracle"
     assert (f32bits(b) == f32bits(o)).all(), "serial long-row fold differs from the oracle"
+
+
+@pytest.mark.parametrize("kind,tiles", [("uniform", 1), ("ties", 1), ("growing", 1), ("uniform", 3), ("ties", 4)])
+def test_giant_rows_replayed_by_many_workgroups(env, kind, tiles):
+    """Hub rows of ~200 K terms (25 chunks of 8192): most chunks get a precomputed ulp-map (kernels.hpp: k_giant_predict /
+    k_giant_maps) that k_spmv_giant only applies, the chunks around binade crossings are replayed as before; with column
+    tiles a row's pieces continue from the value y holds.  alpha = 0 makes pagerank := the fp32 row sum.  The bits must be
+    the oracle's (the serial loop's) with the maps on, and the map path must really have been taken."""
+    import ctypes as C
+    api, ob = env
+    L = api._lib.lib()
+    rng = np.random.default_rng(7)
+    nv = 300000
+    hubs = np.array([1, 5, 4242, 300000])
+    src = np.repeat(np.arange(1, nv + 1), len(hubs)).astype(np.int32)
+    dst = np.tile(hubs, nv).astype(np.int32)
+    keep = rng.random(len(src)) < 0.7
+    src, dst = src[keep], dst[keep]
+    if kind == "uniform":   # full mantissas, one order of magnitude: S sits in each binade for ever longer stretches
+        pr0 = (0.5 + 0.5 * rng.random(nv)).astype(np.float32)
+    elif kind == "ties":    # few mantissa bits: round-to-even ties everywhere
+        pr0 = (rng.integers(1, 64, nv) * np.float32(2.0) ** rng.integers(-6, 3, nv)).astype(np.float32)
+    else:                   # terms grow along the row: the estimate of S is far from uniform
+        pr0 = (np.arange(1, nv + 1) / nv * rng.random(nv) * 8).astype(np.float32)
+    deg = np.ones(nv, np.int32)
+    cnt = (C.c_int64 * 4)()
+    L.gm_debug_counters(cnt)  # reset
+    a, b, o = _pagerank_custom(api, ob, nv, src, dst, pr0, deg, 0.0, 1, col_tiles=tiles)
+    L.gm_debug_counters(cnt)
+    assert (f32bits(a) == f32bits(o)).all(), "giant rows with chunk maps differ from the oracle"
+    assert (f32bits(b) == f32bits(o)).all()
+    assert cnt[2] > 0, "no chunk took the precomputed map"
+    # and the single-workgroup replay (maps off) gives the same bits
+    L.gm_set_option(b"giant_maps", 0)
+    try:
+        a2, _, _ = _pagerank_custom(api, ob, nv, src, dst, pr0, deg, 0.0, 1, col_tiles=tiles)
+    finally:
+        L.gm_set_option(b"giant_maps", 1)
+    assert (f32bits(a2) == f32bits(o)).all()
 
 
 def test_edge_cases(env):

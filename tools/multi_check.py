@@ -151,6 +151,31 @@ def main():
     if not ok_sgd:
         print("rank %d: sharded SGD mismatch (exchanges=%d)" % (rank, ex2.calls), flush=True)
     ok &= ok_sgd
+    if native:
+        # the same SGD with the ratings split by USERS (contiguous native ranges, one per rank) and only the items' running
+        # sums travelling (gm_run_sgd_bipartite): the same bits, a fraction of the bytes
+        nat = api.native_index(nu + ni, 16)          # ref_threads=1
+        order = np.argsort(nat[:nu], kind="stable")  # users in ascending native id
+        cuts = [nu * r // world for r in range(world + 1)]
+        mine_users = np.zeros(nu + ni + 1, bool)
+        mine_users[order[cuts[rank]:cuts[rank + 1]] + 1] = True
+        sel = mine_users[rs]
+        g3 = api.Graph(nu + ni, rs[sel], rd[sel], rv[sel], ref_threads=1, device=device)
+        ok_bip = True
+        for blocks in (1, 3, 7):
+            lv3, it4, moved = g3.sgd_bipartite(lv, nu, ni, 0.001, 1e-4, 3, blocks=blocks)
+            rows_mine = np.concatenate([np.nonzero(mine_users[1:nu + 1])[0], np.arange(nu, nu + ni)])
+            this = it4 == 3 and bool(np.array_equal(lv3[rows_mine], olv2[rows_mine]))
+            want_moved = (ni * (K + 1) * 4 if rank > 0 else 0) + (ni * (K + 1) * 4 if rank + 1 < world else 0)
+            this &= moved == want_moved
+            if not this:
+                print("rank %d: bipartite SGD (blocks=%d) differs: %d of %d rows, moved %d (expected %d)" % (
+                    rank, blocks, int((lv3[rows_mine] != olv2[rows_mine]).any(axis=1).sum()), rows_mine.size, moved, want_moved), flush=True)
+            ok_bip &= this
+        if rank == 0:
+            print("bipartite SGD: %d bytes received per rank and iteration instead of %d" % (2 * ni * (K + 1) * 4, (nu + ni) * K * 4), flush=True)
+        ok &= ok_bip
+        g3.close()
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
