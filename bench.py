@@ -30,6 +30,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+GATHER_CEILING = 238e9  # L2-resident random 4-byte gathers per second, whole chip (tools/gather_path_bench.hip, profiles/r03_gather_paths_microbench.txt)
 
 
 def log(rank, *a):
@@ -605,6 +606,17 @@ def main():
         "k_spmv_rowblock": (stats["rowblock_ms"], stats["rowblock_launches"], 4 * e_short + 12 * rows0),
         "k_spmv_wave": (stats["wave_ms"], stats["wave_launches"], 4 * e_mid + 24 * int(c_out.nmid)),
     }
+    # edges by the KERNEL that multiplies them (gm_csr_t.edges_*): with column tiles a wave row's short pieces are
+    # row-block work, so this differs from the split by row class above
+    def class_edges(c):
+        blk, w16, w = int(c.edges_blk), int(c.edges_wave16), int(c.edges_wave)
+        return [blk, w16, w, int(c.nnz) - blk - w16 - w]
+    by_kernel = class_edges(c_out)
+    if int(g.col_tiles) > 1:
+        by_kernel = [by_kernel[0], 0, 0, 0]  # (the whole-graph CSR only multiplies its short rows: tile_min_row = short_row)
+        for t in range(int(g.col_tiles)):
+            ct, _ = g.tile(api.GM_DIR_OUT, t)
+            by_kernel = [a + b for a, b in zip(by_kernel, class_edges(ct))]
     roof = None
     name = max(kern, key=lambda k: kern[k][0])
     ms, launches, alg_bytes = kern[name]
@@ -652,10 +664,22 @@ def main():
                 "wave_avg_ms": round(stats["wave_ms"] / max(args.steps, 1), 4),
                 "aux_streams_avg_ms_overlapped": round(stats["giant_ms"] / max(args.steps, 1), 4),  # giant-row passes + long wave rows
                 "edges_rowblock_wave_giant": [e_short, e_mid, e_giant],
+                "edges_by_kernel": {"k_spmv_rowblock": by_kernel[0], "k_spmv_wave16": by_kernel[1], "k_spmv_wave": by_kernel[2],
+                                    "k_giant_terms+k_spmv_giant": by_kernel[3]},
                 "send_avg_ms": round(stats["send_ms"] / args.steps, 4),
                 "apply_avg_ms": round(stats["apply_ms"] / args.steps, 4),
                 "gather_ceiling_note": "random 4-byte gathers on this chip peak at ~200 G/s L2-resident and ~55-66 G/s over "
                                        "a 268 MB table (tools/gather_bench.hip); one gather per edge is inherent to the path"}
+        # What this formulation can attain: one 4-byte gather of x per edge, and the chip serves at most GATHER_CEILING
+        # such gathers per second even when every one hits the L2 (the per-CU vector-memory path holds ~110 requests in
+        # flight at ~250 cycles each: profiles/r03_tcp_counters_scale26.md; microbenchmark tools/gather_path_bench.hip,
+        # 1 MB table, uniform indices: 238 G/s).  attainable = the unit's algorithmic bytes / (its gathers / ceiling).
+        gathers = sum(by_kernel[:3]) if tiled or name == "multiply" else (by_kernel[0] if name == "k_spmv_rowblock" else by_kernel[1] + by_kernel[2])
+        t_min = gathers / GATHER_CEILING
+        roof["attainable"] = round(alg_bytes / t_min / 1e9, 1)
+        roof["frac_of_attainable"] = round(t_min / (avg_ms * 1e-3), 4)
+        roof["attainable_note"] = ("%.0f G gathers/s ceiling of the chip for L2-resident random 4-byte gathers (profiles/r03_gather_paths_microbench.txt) "
+                                   "x one gather per edge; whole iteration against the same ceiling: %.4f" % (GATHER_CEILING / 1e9, (E / world / GATHER_CEILING) / (ms_per_step * 1e-3)))
     iter_bytes = 4 * E + 48 * nv
     out = {
         "metric": "GTEPS (edges/s) per iter + achieved HBM GB/s, PageRank RMAT-%d" % args.scale,

@@ -236,6 +236,26 @@ k_row_flags(const int64_t* __restrict__ rowptr, int nrows, int short_row, int gi
   isgiant[r] = ((b - a) > giant_row) ? 1 : 0;
 }
 
+// edges per kernel class of the multiply: [0] row-blocks (rows of <= short_row edges), [1] 16-rows-per-wave rows,
+// [2] one-wave-per-row rows (more than long_limit edges), [3] giant rows
+__global__ void __launch_bounds__(kT)
+k_class_edges(const int64_t* __restrict__ rowptr, int nrows, int short_row, int64_t long_limit, int giant_row,
+              unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long s_c[4];
+  if (threadIdx.x < 4) s_c[threadIdx.x] = 0ull;
+  __syncthreads();
+  const int r = blockIdx.x * kT + threadIdx.x;
+  if (r < nrows) {
+    const int64_t len = rowptr[r + 1] - rowptr[r];
+    if (len > 0) {
+      const int cls = len <= short_row ? 0 : len > giant_row ? 3 : len > long_limit ? 2 : 1;
+      atomicAdd(&s_c[cls], (unsigned long long)len);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && s_c[threadIdx.x]) atomicAdd(&out[threadIdx.x], s_c[threadIdx.x]);
+}
+
 // presence bits of the non-empty rows (bit r&31 of word r>>5)
 __global__ void __launch_bounds__(kT)
 k_rowbits(const int64_t* __restrict__ rowptr, int nrows, uint32_t* __restrict__ bits) {
@@ -662,6 +682,20 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
     }
   }
 
+  // edges per kernel class (reporting: the per-kernel edge rates of bench.py)
+  unsigned long long h_class[4] = {0, 0, 0, 0};
+  {
+    const int64_t long_limit = g_long_mid > 0 ? (int64_t)g_long_mid : nmid >= (1u << 20) ? 4 * (int64_t)GM_LONG_MID : (int64_t)GM_LONG_MID;
+    DevBuf cls;
+    if ((rc = cls.alloc(32))) return rc;
+    GM_TRY_HIP(hipMemsetAsync(cls.p, 0, 32, s));
+    if (nrows > 0)
+      hipLaunchKernelGGL(k_class_edges, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr.as<int64_t>(), nrows, short_row, long_limit, giant_row,
+                         cls.as<unsigned long long>());
+    GM_TRY_HIP(hipMemcpyAsync(h_class, cls.p, 32, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+  }
+
   // pieces of the giant rows for the parallel products pass
   DevBuf gcr, gce, gto;
   std::vector<int32_t> h_gcr;
@@ -688,6 +722,9 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
     GM_TRY_HIP(hipMemcpyAsync(gce.p, h_gce.data(), h_gce.size() * 8, hipMemcpyHostToDevice, s));
   }
   GM_TRY_HIP(hipMemcpyAsync(gto.p, h_gto.data(), h_gto.size() * 8, hipMemcpyHostToDevice, s));
+  DevBuf gst;  // per-piece records of the giant-row kernels (no hints yet)
+  if ((rc = gst.alloc(h_gcr.size() * 16 + 16))) return rc;
+  GM_TRY_HIP(hipMemsetAsync(gst.p, 0, h_gcr.size() * 16 + 16, s));
   GM_TRY_HIP(hipStreamSynchronize(s));
 
   out->rowptr = (int64_t*)rowptr.release();
@@ -702,6 +739,7 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
   out->gchunk_edge = (int64_t*)gce.release();
   out->gterm_off = (int64_t*)gto.release();
   out->umid_row = numid > 0 ? (int32_t*)umid.release() : nullptr;
+  out->gchunk_state = gst.release();
   out->present = true;
   gm_csr_t& v = out->view;
   v.nnz = (int64_t)kept;
@@ -732,6 +770,10 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
   v.numid = (int32_t)numid;
   v.numid_long = numid_long;
   v.tile_min_row = tile_split;
+  v.gchunk_state = out->gchunk_state;
+  v.edges_blk = (int64_t)h_class[0];
+  v.edges_wave16 = (int64_t)h_class[1];
+  v.edges_wave = (int64_t)h_class[2];
   v.hot_base = 0;
   v.hot_len = D.ndevice;
   v.hot_slices = 1;
@@ -1017,6 +1059,7 @@ static void free_csr(CsrOwned* c) {
   if (c->gchunk_edge) (void)hipFree(c->gchunk_edge);
   if (c->gterm_off) (void)hipFree(c->gterm_off);
   if (c->umid_row) (void)hipFree(c->umid_row);
+  if (c->gchunk_state) (void)hipFree(c->gchunk_state);
   *c = CsrOwned();
 }
 
@@ -1052,6 +1095,22 @@ int gm_graph_tile(const gm_graph_t* g, int direction, int tile, gm_csr_t* out, c
   }
   *out = g->out_tiles[tile].view;
   if (d_prev_bits) *d_prev_bits = g->out_tile_prev[tile];
+  return GM_OK;
+}
+
+// Collective builds (edges_local): a failure on one rank must fail every rank, or the others wait for ever in the next
+// collective.  Returns GM_OK only when every rank arrived with rc == GM_OK (one all-reduce of a failure count).
+static int agree_on_status(int rc, hipStream_t s) {
+  gm::DevBuf w;
+  if (w.alloc(64) != GM_OK) return rc != GM_OK ? rc : GM_ERR_NOMEM;  // (cannot even ask: report locally)
+  const uint32_t mine = rc != GM_OK ? 1u : 0u;
+  uint32_t total = 0;
+  if (hipMemcpyAsync(w.p, &mine, 4, hipMemcpyHostToDevice, s) != hipSuccess) return rc != GM_OK ? rc : GM_ERR_HIP;
+  int rc2 = gm::dist_all_reduce_sum_u32(w.as<uint32_t>(), 1, s);
+  if (rc2 != GM_OK) return rc != GM_OK ? rc : rc2;
+  if (hipMemcpyAsync(&total, w.p, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return rc != GM_OK ? rc : GM_ERR_HIP;
+  if (rc != GM_OK) return rc;
+  if (total != 0) { gm::set_error("gm_graph_create: the distributed build failed on %u other rank(s)", total); return GM_ERR_INVALID; }
   return GM_OK;
 }
 
@@ -1103,40 +1162,42 @@ int gm_graph_create(gm_graph_t** gout, const gm_graph_desc_t* desc, int64_t nnz,
   const void* d_val = val;
   int rc = GM_OK;
   if (!desc->ids_on_device && nnz > 0) {
-    if ((rc = usrc.alloc((size_t)nnz * 4)) || (rc = udst.alloc((size_t)nnz * 4))) { delete g; return rc; }
+    if ((rc = usrc.alloc((size_t)nnz * 4)) || (rc = udst.alloc((size_t)nnz * 4))) { if (desc->edges_local) (void)agree_on_status(rc, s); delete g; return rc; }
     hipError_t e1 = hipMemcpyAsync(usrc.p, src, (size_t)nnz * 4, hipMemcpyHostToDevice, s);
     hipError_t e2 = hipMemcpyAsync(udst.p, dst, (size_t)nnz * 4, hipMemcpyHostToDevice, s);
-    if (e1 != hipSuccess || e2 != hipSuccess) { gm::set_error("edge upload failed"); delete g; return GM_ERR_HIP; }
+    if (e1 != hipSuccess || e2 != hipSuccess) { gm::set_error("edge upload failed"); if (desc->edges_local) (void)agree_on_status(GM_ERR_HIP, s); delete g; return GM_ERR_HIP; }
     d_src = usrc.as<int32_t>();
     d_dst = udst.as<int32_t>();
     if (val && desc->val_bytes > 0) {
-      if ((rc = uval.alloc((size_t)nnz * desc->val_bytes))) { delete g; return rc; }
+      if ((rc = uval.alloc((size_t)nnz * desc->val_bytes))) { if (desc->edges_local) (void)agree_on_status(rc, s); delete g; return rc; }
       if (hipMemcpyAsync(uval.p, val, (size_t)nnz * desc->val_bytes, hipMemcpyHostToDevice, s) != hipSuccess) {
-        gm::set_error("edge value upload failed"); delete g; return GM_ERR_HIP;
+        gm::set_error("edge value upload failed"); if (desc->edges_local) (void)agree_on_status(GM_ERR_HIP, s); delete g; return GM_ERR_HIP;
       }
       d_val = uval.p;
     }
   }
   if (nnz > 0) {  // every id must name a vertex: 1..nvertices (0..nvertices-1 when ids_are_native)
     gm::DevBuf badc;
-    if ((rc = badc.alloc(16))) { delete g; return rc; }
+    if ((rc = badc.alloc(16))) { if (desc->edges_local) (void)agree_on_status(rc, s); delete g; return rc; }
     const unsigned long long init[2] = {0ull, ~0ull};
     const int lo = desc->ids_are_native ? 0 : 1, hi = desc->ids_are_native ? desc->nvertices - 1 : desc->nvertices;
     unsigned long long bad[2] = {0ull, 0ull};
-    if (hipMemcpyAsync(badc.p, init, 16, hipMemcpyHostToDevice, s) != hipSuccess) { gm::set_error("edge id check: upload failed"); delete g; return GM_ERR_HIP; }
+    if (hipMemcpyAsync(badc.p, init, 16, hipMemcpyHostToDevice, s) != hipSuccess) { gm::set_error("edge id check: upload failed"); if (desc->edges_local) (void)agree_on_status(GM_ERR_HIP, s); delete g; return GM_ERR_HIP; }
     hipLaunchKernelGGL(gm::k_validate_ids, dim3(gm::grid_for(nnz)), dim3(gm::kT), 0, s, d_src, d_dst, nnz, lo, hi, badc.as<unsigned long long>());
     if (hipMemcpyAsync(bad, badc.p, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
       gm::set_error("edge id check failed: %s", hipGetErrorString(hipGetLastError()));
+      if (desc->edges_local) (void)agree_on_status(GM_ERR_HIP, s);
       delete g;
       return GM_ERR_HIP;
     }
     if (bad[0] != 0) {
       gm::set_error("gm_graph_create: %llu edge(s) name a vertex outside [%d, %d] (first: edge %llu); ids are %s", bad[0], lo, hi,
                     bad[1] - 1ull, desc->ids_are_native ? "0-based native ids" : "1-based vertex ids as in the .mtx file");
-      delete g;
-      return GM_ERR_INVALID;
+      rc = GM_ERR_INVALID;
     }
   }
+  if (desc->edges_local) rc = agree_on_status(rc, s);  // (bad ids / failed uploads on ANY rank stop all of them here)
+  if (rc != GM_OK) { delete g; return rc; }
   g->desc.ndevice = desc->nvertices;
   g->desc.xchg_rows = desc->row_hi - desc->row_lo;
   g->ntiles = 1;

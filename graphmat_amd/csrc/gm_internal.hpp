@@ -51,6 +51,7 @@ struct CsrOwned {
   int64_t* gchunk_edge = nullptr;
   int64_t* gterm_off = nullptr;
   int32_t* umid_row = nullptr;
+  void* gchunk_state = nullptr;
   bool present = false;
 };
 

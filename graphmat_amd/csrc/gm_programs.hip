@@ -591,8 +591,10 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "tile_min_row") && (value == 0 || value >= gm::g_short_row)) { gm::g_tile_min_row = value; return GM_OK; }
   if (key && !strcmp(key, "col_tiles") && value >= 0 && value <= GM_MAX_TILES) { gm::g_col_tiles = value; return GM_OK; }
   if (key && !strcmp(key, "push_edge_permille") && value >= 0 && value <= 1000) { GraphMat::detail::push_edge_permille() = value; return GM_OK; }
+  if (key && !strcmp(key, "bits_step_edges") && value >= 0) { GraphMat::detail::bits_step_edges() = value; return GM_OK; }
   if (key && !strcmp(key, "sparse_step_edges") && value >= 0) { GraphMat::detail::sparse_step_edges() = value; return GM_OK; }
-  if (key && !strcmp(key, "wave16_form") && value >= 0 && value <= 5) { GraphMat::detail::wave16_form() = value; return GM_OK; }
+  if (key && !strcmp(key, "wave16_form") && value >= 0 && (value & 15) <= 5 && value < 32) { GraphMat::detail::wave16_form() = value; return GM_OK; }
+  if (key && !strcmp(key, "rowwave_form") && value >= 0 && (value & 15) <= 4 && value < 32) { GraphMat::detail::rowwave_form() = value; return GM_OK; }
   if (key && !strcmp(key, "persist_per_cu") && value >= 0 && value <= 8) { GraphMat::detail::persist_per_cu() = value; return GM_OK; }
   if (key && !strcmp(key, "giant_maps") && (value == 0 || value == 1)) { GraphMat::detail::giant_maps() = value; return GM_OK; }
   if (key && !strcmp(key, "iteration_trace") && (value == 0 || value == 1)) { GraphMat::detail::iteration_trace() = value; return GM_OK; }

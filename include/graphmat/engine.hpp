@@ -41,9 +41,9 @@ inline int& debug_flags() {
 }
 
 // form of the 16-rows-per-wave kernel: 0 = one workgroup per 64 rows with an 8192-entry LDS hot set;
-// 1..4 = persistent workgroups with a large hot set (512 threads / 30720 entries, 1024 / 22528, 512 / 16384, 256 / 8192)
+// 2 = persistent workgroups of 1024 threads with a 22528-entry hot set (large graphs: persistent_forms_pay)
 inline int& wave16_form() {
-  static int v = 0;
+  static int v = 2;  // (RMAT-26, with rowwave_form 4: 6.89 -> 6.65 ms per iteration; each alone -0.03 / -0.13 ms)
   return v;
 }
 // giant rows of float sums: precomputed chunk maps (the multi-workgroup exact replay; 0 = one workgroup walks the row)
@@ -51,11 +51,22 @@ inline int& giant_maps() {
   static int v = 1;
   return v;
 }
+// row-blocks: 0 = one workgroup per block (k_spmv_rowblock); 4 = waves of persistent 1024-thread workgroups sharing a
+// 20480-entry LDS hot set (large graphs: persistent_forms_pay)
+inline int& rowwave_form() {
+  static int v = 4;
+  return v;
+}
 // persistent kernels: workgroups per CU (0 = as many as the LDS allows)
 inline int& persist_per_cu() {
   static int v = 0;
   return v;
 }
+// Persistent workgroups with a large LDS hot set (k_spmv_rowwave, k_spmv_wave16p) trade occupancy -- and LDS the
+// auxiliary stream's kernels would use next to them -- for fewer L2 requests.  Measured on RMAT, PageRank, both forms on
+// against both off: scale 22 +1.7 %, 24 -0.6 %, 25 -3.5 %, 26 +3.5 %, 27 +5.1 % (profiles/r03_persistent_kernels.md):
+// they pay once the message vector is far larger than the caches, i.e. where the column tiles are many.
+inline bool persistent_forms_pay(const gm_csr_t& A) { return (int64_t)A.ncols >= (48ll << 20); }
 inline int cu_count() {
   static int n = 0;
   if (n == 0) {
@@ -82,6 +93,11 @@ inline int& push_edge_permille() {
   return v;
 }
 
+// ... an active set too large to list bids from its bitmap while it owns at most this many out-edges
+inline int& bits_step_edges() {
+  static int v = 2 << 20;  // (measured on RMAT-26: 0.25-1 M edges over 0.25-0.9 M vertices: 0.35 -> 0.1 ms; 6 M edges over 4.9 M: a loss)
+  return v;
+}
 // ... and entirely on lists while it owns at most this many out-edges
 inline int& sparse_step_edges() {
   static int v = 1 << 20;
@@ -312,7 +328,7 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
                   ((RK == REDUCE_COMMUTATIVE || RK == REDUCE_LAST) && sizeof(U) <= 8)) {
       U* terms = nullptr;
       unsigned long long* tpres = nullptr;
-      dev::gchunk_map* maps = nullptr;
+      dev::gchunk_state* maps = nullptr;
       if constexpr (RK == REDUCE_F32_ADD) {
         // pass 1: products of all giant-row edges, spread over the whole chip
         void *p6 = nullptr, *p7 = nullptr;
@@ -322,36 +338,18 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
           gm_graph_workspace(g, 14, (size_t)A.giant_edges / 8 + 64, &p7);  // (slot 7 holds the active-set list of sharded ACTIVE_ONLY runs)
           tpres = (unsigned long long*)p7;
         }
-        // chunk maps (kernels.hpp: k_giant_predict / k_giant_maps): the exact replay of a giant row spread over the
-        // whole chip, its serial part limited to the binade crossings.  float sums over a dense x only.
-        double* psum = nullptr;
-        double* before = nullptr;
+        // piece maps (kernels.hpp: gchunk_state): the exact replay of a giant row spread over the whole chip, its serial
+        // part limited to the binade crossings.  float sums over a dense x only.
         if constexpr (std::is_same<U, float>::value) {
-          if (xbits == nullptr && want == nullptr && giant_maps() != 0) {
-            void* p15 = nullptr;
-            if (gm_graph_workspace(g, 15, (size_t)A.ngchunk * 32 + 256, &p15) == GM_OK) {
-              psum = (double*)p15;
-              before = psum + A.ngchunk;
-              maps = (dev::gchunk_map*)(before + A.ngchunk);
-            }
-          }
+          if (xbits == nullptr && want == nullptr && giant_maps() != 0) maps = (dev::gchunk_state*)A.gchunk_state;
         }
         hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa,
-                           A, x, xbits, vp, terms, tpres, debug_flags(), psum);
+                           A, x, xbits, vp, terms, tpres, debug_flags(), maps);
         (*launches)++;
-        if constexpr (std::is_same<U, float>::value) {
-          if (maps != nullptr) {
-            hipLaunchKernelGGL((dev::k_giant_predict<U>), dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, A, (const double*)psum,
-                               before, (const U*)y, (const uint32_t*)ybits, accumulate);
-            hipLaunchKernelGGL(dev::k_giant_maps, dim3(A.ngchunk), dim3(dev::kGiant), 0, gs, A, (const float*)terms, (const double*)psum,
-                               (const double*)before, maps);
-            (*launches) += 2;
-          }
-        }
       }
       hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa,
                          A, x, xbits, vp, y, ybits, accumulate, debug_flags(), (const U*)terms,
-                         (const unsigned long long*)tpres, want, (const dev::gchunk_map*)maps);
+                         (const unsigned long long*)tpres, want, maps);
     } else {
       hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, REDUCE_ORDERED>),
                          dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, A.giant_row, A.ngiant, x,
@@ -374,7 +372,28 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
       if (timer) timer->mark(TAG_ROWBLOCK);
     }
   } else if (A.nblk > 0) {
-    if (xbits == nullptr)
+    bool done = false;
+    if constexpr (!USE_VP && sizeof(T) == 4 && sizeof(U) == 4 && RK != REDUCE_LAST && std::is_trivially_copyable<T>::value) {
+      // persistent workgroups sharing a large LDS hot set, row-blocks taken by waves (kernels.hpp: k_spmv_rowwave)
+      const int form = rowwave_form() & 15;
+      const bool any_size = (rowwave_form() & 16) != 0;  // (tests: also for small graphs)
+      if (form > 0 && xbits == nullptr && want == nullptr && !program_row_filter<P>::enabled && (persistent_forms_pay(A) || any_size)) {
+        auto persistent = [&](auto block_c, auto hot_c, int fit) {
+          constexpr int BLOCK = decltype(block_c)::value, HOT = decltype(hot_c)::value;
+          const int per_cu = persist_per_cu() > 0 && persist_per_cu() < fit ? persist_per_cu() : fit;
+          int grid = cu_count() * per_cu;
+          const int need = (A.nblk + BLOCK / 64 - 1) / (BLOCK / 64);
+          if (grid > need) grid = need;
+          hipLaunchKernelGGL((dev::k_spmv_rowwave<P, T, U, V, E, BLOCK, HOT>), dim3(grid), dim3(BLOCK), 0, s, pa, A, x, y, ybits, accumulate);
+          done = true;
+        };
+        // (1024 threads / 30720 entries: the row-block time falls by 15 % but the kernels of the auxiliary stream find no
+        // LDS next to it and the iteration gains nothing; 20480 entries leave them room; 512 / 16384 and 256 / 8192: no gain)
+        if (form == 4) persistent(std::integral_constant<int, 1024>(), std::integral_constant<int, 20480>(), 1);
+      }
+    }
+    if (done) {
+    } else if (xbits == nullptr)
       hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP, true, RK>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A,
                          x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
     else
@@ -412,8 +431,10 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
           const int groups = (rest + dev::kWaveRows - 1) / dev::kWaveRows;
           constexpr int W16 = dev::kWave16Block / 64;
           bool done = false;
-          if constexpr (sizeof(T) == 4) {
-            const int form = wave16_form();
+          if constexpr (sizeof(T) == 4 && sizeof(U) == 4) {
+            // (persistent forms pay on large graphs only: the hot set is loaded once per workgroup, but a few
+            // hundred groups cannot feed 256 CUs from 256 workgroups as evenly as thousands of small ones)
+            const int form = persistent_forms_pay(A) || (wave16_form() & 16) ? (wave16_form() & 15) : 0;
             auto persistent = [&](auto block_c, auto hot_c, int fit) {
               constexpr int BLOCK = decltype(block_c)::value, HOT = decltype(hot_c)::value;
               int per_cu = persist_per_cu() > 0 && persist_per_cu() < fit ? persist_per_cu() : fit;
@@ -424,11 +445,9 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
                                  A.mid_row + nlong, rest, x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
               done = true;
             };
-            if (form == 1) persistent(std::integral_constant<int, 512>(), std::integral_constant<int, 30720>(), 1);
-            else if (form == 2) persistent(std::integral_constant<int, 1024>(), std::integral_constant<int, 22528>(), 1);
-            else if (form == 3) persistent(std::integral_constant<int, 512>(), std::integral_constant<int, 16384>(), 1);
-            else if (form == 4) persistent(std::integral_constant<int, 256>(), std::integral_constant<int, 8192>(), 3);
-            else if (form == 5) persistent(std::integral_constant<int, 512>(), std::integral_constant<int, 10240>(), 2);
+            // (measured at RMAT-26, 6 tiles, wave rows alone: 256 threads / 8192 entries per 64 rows 2.13 ms; persistent
+            // 512 / 30720: 2.26; 1024 / 22528: 1.85; 512 / 10240 x 2 per CU: 2.10; 256 / 8192 x 3: worse -- profiles/r03_persistent_kernels.md)
+            if (form == 2) persistent(std::integral_constant<int, 1024>(), std::integral_constant<int, 22528>(), 1);
           }
           if (!done)
           hipLaunchKernelGGL((dev::k_spmv_wave16<P, T, U, V, E>), dim3((groups + W16 - 1) / W16), dim3(dev::kWave16Block), 0, s, pa, A,
@@ -807,7 +826,45 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     // ... and among those, active sets with few out-edges run entirely on lists (nothing scans all vertices)
     const bool sparse = push && frontier_e <= (unsigned long long)sparse_step_edges();
     const bool dense_push = push && !sparse && rk == REDUCE_LAST;
-    if (sparse) {
+    // ... and an active set too large to list whose vertices own only a few out-edges each (the late levels of a
+    // traversal: 10^5..10^6 vertices of degree ~1) bids straight from the active bitmap, one lane per vertex
+    const bool bits_push = can_push && !push && rk == REDUCE_LAST && frontier_v > (unsigned long long)dev::kSparseListCap &&
+                           frontier_e <= (unsigned long long)bits_step_edges() && frontier_maxdeg <= 64ull;
+    if (bits_push) {
+      hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
+                         (const uint32_t*)d_active, x, xbits, n_live, desc.row_lo);
+      timer.mark(TAG_SEND);
+      lap("Send message time");
+      GM_HIP_OK(hipMemsetAsync(d_tcount, 0, 4, s));
+      const int bgrid = grid_for(n_live) < 4096 ? grid_for(n_live) : 4096;
+      hipLaunchKernelGGL(dev::k_push_bid_bits, dim3(bgrid), dim3(dev::kBlock), 0, s, Asrc, (const uint32_t*)d_active, n_live,
+                         native_of_dev, d_best, (const uint32_t*)d_want, d_touched, d_tcount);
+      timer.mark(TAG_WAVE);
+      lap("SPMV time");
+      if (trace) {
+        unsigned int tc = 0;
+        GM_HIP_OK(hipMemcpy(&tc, d_tcount, 4, hipMemcpyDeviceToHost));
+        tr_updated = (long long)tc;
+      }
+      GM_HIP_OK(hipMemsetAsync(d_active, 0, (size_t)nwords * 4, s));
+      GM_HIP_OK(hipMemsetAsync(d_striped, 0, striped_bytes, s));
+      GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
+      const unsigned long long bound = frontier_e < (unsigned long long)n ? frontier_e : (unsigned long long)n;
+      if (bound > 0) {
+        if (use_vp)
+          hipLaunchKernelGGL((dev::k_push_finish<P, T, U, V, E, true, false>), dim3(grid_for((int64_t)bound)), dim3(dev::kBlock), 0, s, pa, Asrc,
+                             (const T*)x, dev_of_native, d_vp, d_best, (const int32_t*)d_touched, (const unsigned int*)d_tcount, d_active,
+                             d_changed, d_striped, d_want, d_list, d_count);
+        else
+          hipLaunchKernelGGL((dev::k_push_finish<P, T, U, V, E, false, false>), dim3(grid_for((int64_t)bound)), dim3(dev::kBlock), 0, s, pa, Asrc,
+                             (const T*)x, dev_of_native, d_vp, d_best, (const int32_t*)d_touched, (const unsigned int*)d_tcount, d_active,
+                             d_changed, d_striped, d_want, d_list, d_count);
+      }
+      st.spmv_launches += 2;
+      listed = true;
+      timer.mark(TAG_APPLY);
+      lap("Apply time");
+    } else if (sparse) {
       // ---- sparse top-down step ----
       if (!list_ready) {
         GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));

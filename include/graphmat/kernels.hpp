@@ -1008,6 +1008,101 @@ k_spmv_wave16p(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int 
     wave16_group<P, T, U, V, E, kStride>(p, A, rows, nlist, g * G, lane, x, xbits, vp, y, ybits, accumulate, dbg, want, hot, s_t[wv], s_mask[wv]);
 }
 
+// Row-blocks by WAVES of persistent workgroups that share a large LDS hot set.  k_spmv_rowblock is bound by the
+// per-CU vector-memory path (TA busy ~100 %: every gather is a request to the L2) and has no room for a hot set -- a
+// workgroup only lives for ~1500 edges.  Here a workgroup stays (a few per CU), loads the busiest HOT x entries of the
+// adjacency's column slice once, and each of its waves takes row-blocks by itself: 64 rows at a time (one lane per
+// row), their edges in steps of 512 -- coalesced column ids, gathers served from LDS where the column is hot, messages
+// staged in the wave's own LDS strip in edge order, then every lane folds the part of its row inside the step, in
+// stored order, carrying its running value in registers.  No workgroup barrier after the hot set is loaded.
+// Dense x, 2-operand programs, 4-byte messages; everything else keeps k_spmv_rowblock.
+template <class P, class T, class U, class V, class E, int BLOCK, int HOT>
+__global__ void __launch_bounds__(BLOCK)
+k_spmv_rowwave(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate) {
+  static_assert(sizeof(T) == 4, "4-byte messages");
+  constexpr int W = BLOCK / 64;
+  constexpr int CH = 512, PER = CH / 64;
+  constexpr int kPadw = CH + CH / 32;
+  __shared__ T s_hot[HOT > 0 ? HOT : 1];
+  __shared__ T s_msg[W][kPadw];
+#define GM_WSLOT(k) ((k) + ((k) >> 5))
+  const HotSet<T> hot = hot_load<T, HOT, BLOCK>(A, x, s_hot);
+  __syncthreads();
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  T* sm = s_msg[wv];
+  const int nwaves = gridDim.x * W;
+  V no_vp;
+  for (int b = wv * gridDim.x + blockIdx.x; b < A.nblk; b += nwaves) {
+    const int sg = A.blk_seg[b];
+    const int r0 = A.seg_row[sg], r1 = A.seg_row[sg + 1];
+    for (int rg = r0; rg < r1; rg += 64) {
+      const int row = rg + lane;
+      int64_t rp0 = 0, rp1 = 0;
+      if (row < r1) { rp0 = A.rowptr[row]; rp1 = A.rowptr[row + 1]; }
+      const int lastl = (r1 - rg - 1) < 63 ? (r1 - rg - 1) : 63;
+      const int64_t g0 = wave_bcast(rp0, 0), g1 = wave_bcast(rp1, lastl);
+      bool has = false;
+      U acc;
+      if (rp1 > rp0 && (accumulate & ACC_READ_PREV) && bit_get(ybits, row)) { acc = y[row]; has = true; }
+      for (int64_t c0 = g0; c0 < g1; c0 += CH) {
+        const int n = (int)((g1 - c0) < CH ? (g1 - c0) : CH);
+        int c[PER];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+          const int k = lane + 64 * j;
+          c[j] = (k < n) ? stream_load(&A.colidx[c0 + k]) : -1;
+        }
+        T m[PER];
+#pragma unroll
+        for (int j = 0; j < PER; j++)
+          if (c[j] >= 0) m[j] = hot.get(x, c[j]);
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+          const int k = lane + 64 * j;
+          if (k < n) sm[GM_WSLOT(k)] = m[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // this lane's row: the part of its segment that lies inside the step, in stored order
+        const int64_t ka = rp0 > c0 ? rp0 : c0, kb = rp1 < c0 + n ? rp1 : c0 + n;
+        if (ka < kb) {
+          int k = (int)(ka - c0);
+          const int ke = (int)(kb - c0);
+          if (!has) {
+            p.P::process_message(sm[GM_WSLOT(k)], edge_at<E>(A.vals, c0 + k), no_vp, acc);
+            has = true;
+            k++;
+          }
+          for (; k + 4 <= ke; k += 4) {
+            T r[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) r[u] = sm[GM_WSLOT(k + u)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              U res;
+              p.P::process_message(r[u], edge_at<E>(A.vals, c0 + k + u), no_vp, res);
+              p.P::reduce_function(acc, res);
+            }
+          }
+          for (; k < ke; k++) {
+            U res;
+            p.P::process_message(sm[GM_WSLOT(k)], edge_at<E>(A.vals, c0 + k), no_vp, res);
+            p.P::reduce_function(acc, res);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      bool wrote = false;
+      if (rp1 > rp0 && has) {
+        y[row] = acc;
+        wrote = true;
+      }
+      publish_row_bits(wrote, row, ybits, accumulate);
+    }
+  }
+#undef GM_WSLOT
+}
+
 // The same for programs with a row filter once most rows have dropped out: a wave takes 64
 // entries of the row list, tests their filter bits with one lane each, and then works through
 // the rows that are still wanted one after the other -- a level of BFS in which few rows are
@@ -1092,6 +1187,23 @@ __device__ __forceinline__ bool ulp_term(uint32_t abits, int eS, ulp_map& out) {
   return true;
 }
 
+// ---- the exact replay spread over MANY workgroups (REDUCE_F32_ADD, every x entry present) -----------
+// One workgroup per row walking 8192-product chunks is a serial chain as long as the row (the 854 K-edge hub row of
+// RMAT-26: 104 chunks, ~1.1 ms -- as long as a whole iteration of a shard of 8).  The ulp-maps of the replay compose
+// associatively while the running sum S stays inside one binade, and a piece's composed map depends on S only
+// through S's binade.  So every 4096-product piece keeps a small record: k_spmv_giant leaves, as a HINT for the next
+// pass over the same rows (the next iteration: a row's partial sums move slowly), the binade S was in throughout the
+// piece's chunk; k_giant_terms -- one workgroup per piece, the whole chip, the products in its registers anyway --
+// composes the piece's exact map against the hinted binade; and k_spmv_giant merely APPLIES the maps of a chunk when
+// the exact S it has reached really is in that binade and really stays there (S + delta < 2^24 ulps; S only grows:
+// terms are non-negative or the piece has no map) -- otherwise, and around every binade crossing, it replays the chunk
+// itself as before.  The hint decides only WHICH pieces get a map, never a value: the bits are the serial loop's.
+struct gchunk_state {
+  int32_t e_hint;     // written by k_spmv_giant: biased exponent S had throughout this piece's chunk last time; 0 = none
+  int32_t e_map;      // written by k_giant_terms: the binade de/dod hold for; 0 = no map this pass
+  uint32_t de, dod;   // ulps the piece adds when the incoming S is even / odd
+};
+
 // ------------------------------------------------------------------------------------
 // giant rows, pass 1 (REDUCE_F32_ADD): the gathers and products of a giant row are spread
 // over many workgroups (one per GM_GIANT_CHUNK edges) because a single CU can only issue
@@ -1101,7 +1213,7 @@ template <class P, class T, class U, class V, class E, bool USE_VP>
 __global__ void __launch_bounds__(kBlock)
 k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
               const V* __restrict__ vp, U* __restrict__ terms, unsigned long long* __restrict__ tpres, int dbg,
-              double* __restrict__ piece_sum /* [ngchunk] sum of the piece's products (float reductions, dense x), or null */) {
+              gchunk_state* __restrict__ state /* per piece: exponent hint in, composed ulp-map out (float sums over a dense x), or null */) {
   constexpr int PER = GM_GIANT_CHUNK / kBlock;
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int gi = A.gchunk_row[blockIdx.x];
@@ -1127,7 +1239,14 @@ k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t
 #pragma unroll
   for (int j = 0; j < PER; j++)
     if (c[j] >= 0) { if (dbg & DBG_SKIP_GATHER) memset(&m[j], 0, sizeof(T)); else m[j] = x[c[j]]; }
-  double mysum = 0.0;
+  // the exact replay spread over the chip (see gchunk_state): with a hint of the binade S will be in, the piece's
+  // products are also composed into one ulp-map here, where they are in registers anyway
+  constexpr bool kMaps = std::is_same<U, float>::value;
+  __shared__ float s_prod[kMaps ? GM_GIANT_CHUNK : 1];
+  int ehint = 0;
+  if constexpr (kMaps) {
+    if (state != nullptr) ehint = state[blockIdx.x].e_hint;
+  }
 #pragma unroll
   for (int j = 0; j < PER; j++) {
     int k = threadIdx.x + j * kBlock;
@@ -1135,24 +1254,52 @@ k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t
       U t;
       p.P::process_message(m[j], edge_at<E>(A.vals, eb + k), vprow, t);
       terms[out0 + k] = t;
-      if constexpr (std::is_same<U, float>::value) mysum += (double)t;
+      if constexpr (kMaps) { if (ehint > 0) s_prod[k] = t; }
     }
     if (tpres != nullptr) {
       unsigned long long w = __ballot(c[j] >= 0);
       if ((threadIdx.x & 63) == 0 && (k & ~63) < n) tpres[(out0 + (k & ~63)) >> 6] = w;
     }
   }
-  if constexpr (std::is_same<U, float>::value) {
-    if (piece_sum != nullptr) {  // (an estimate for k_giant_predict: any summation order will do)
-      __shared__ double s_sum[kBlock / 64];
-      for (int off = 32; off > 0; off >>= 1) mysum += __shfl_down(mysum, off, 64);
-      if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = mysum;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int w = 0; w < kBlock / 64; w++) tot += s_sum[w];
-        piece_sum[blockIdx.x] = tot;
+  if constexpr (kMaps) {
+    if (state == nullptr) return;
+    if (ehint <= 0) {
+      if (threadIdx.x == 0) { state[blockIdx.x].e_map = 0; }
+      return;
+    }
+    __shared__ ulp_map s_wave[kBlock / 64];
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    const int k0 = threadIdx.x * PER, lane = threadIdx.x & 63;
+    ulp_map mine = {0u, 0u};
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      if (k0 + j < n) {
+        ulp_map t;
+        if (!ulp_term(__float_as_uint(s_prod[k0 + j]), ehint, t)) ok = false; else mine = ulp_compose(mine, t);
       }
+    }
+    if (!ok) atomicOr(&s_bad, 1);
+    ulp_map v = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      ulp_map o;
+      o.de = __shfl_up(v.de, off, 64);
+      o.dod = __shfl_up(v.dod, off, 64);
+      if (lane >= off) v = ulp_compose(o, v);
+    }
+    if (lane == 63) s_wave[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      ulp_map tot = {0u, 0u};
+      for (int w = 0; w < kBlock / 64; w++) tot = ulp_compose(tot, s_wave[w]);
+      gchunk_state st = state[blockIdx.x];
+      st.e_map = s_bad ? 0 : ehint;
+      st.de = tot.de;
+      st.dod = tot.dod;
+      state[blockIdx.x] = st;
     }
   }
 }
@@ -1164,23 +1311,6 @@ constexpr int kGiant = 512;                     // threads per workgroup of k_sp
 constexpr int kLongPer = 16;                    // consecutive edges per lane and chunk
 constexpr int kLongChunk = kLongPer * kGiant;   // 8192 edges per chunk
 
-// ---- the exact replay spread over MANY workgroups (REDUCE_F32_ADD, every x entry present) -----------
-// One workgroup per row walking 8192-product chunks is a serial chain as long as the row (the 854 K-edge hub row
-// of RMAT-26: 104 chunks, ~1.1 ms -- as long as a whole iteration of a shard of 8).  The ulp-maps of the replay
-// compose associatively while the running sum S stays inside one binade, and a chunk's composed map depends on S
-// only through S's binade: so (1) k_giant_terms also leaves the plain sum of every 4096-product piece, (2)
-// k_giant_predict turns them into an ESTIMATE of S before every chunk (fp64 prefix, started from the exact value y
-// holds when earlier column tiles already contributed), (3) k_giant_maps -- one workgroup per chunk, the whole chip --
-// composes, for every chunk whose estimated S stays inside one binade e with a safety margin, the exact map of its
-// 8192 products against e, and (4) k_spmv_giant merely APPLIES that map when the exact S it has reached really is in
-// binade e and really stays there (S + delta < 2^24 ulps; S only grows: terms are non-negative or the chunk is not
-// mapped) -- otherwise, and around every binade crossing, it replays the chunk itself as before.  The estimate
-// decides only WHICH chunks get a precomputed map, never a value: the bits are those of the serial loop.
-struct gchunk_map {
-  int32_t e;          // biased exponent of the binade the map holds for; 0 = no map for this chunk
-  uint32_t de, dod;   // ulps added when the incoming S is even / odd
-  uint32_t pad;
-};
 __device__ __forceinline__ int lower_piece(const int32_t* __restrict__ gchunk_row, int n, int gi) {  // first piece of giant row gi
   int lo = 0, hi = n;
   while (lo < hi) {
@@ -1189,96 +1319,13 @@ __device__ __forceinline__ int lower_piece(const int32_t* __restrict__ gchunk_ro
   }
   return lo;
 }
-// one wave per giant row: estimate of the running sum before each of its pieces (64 pieces per step: an inclusive
-// wave scan of their sums -- the summation order does not matter for an estimate)
-template <class U>
-__global__ void __launch_bounds__(kBlock)
-k_giant_predict(gm_csr_t A, const double* __restrict__ piece_sum, double* __restrict__ before, const U* __restrict__ y,
-                const uint32_t* __restrict__ ybits, int accumulate) {
-  const int gi = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (gi >= A.ngiant) return;
-  const int lane = threadIdx.x & 63;
-  const int row = A.giant_row[gi];
-  const int64_t deg = A.rowptr[row + 1] - A.rowptr[row];
-  const int npieces = (int)((deg + GM_GIANT_CHUNK - 1) / GM_GIANT_CHUNK);
-  const int p0 = lower_piece(A.gchunk_row, A.ngchunk, gi);
-  double S = 0.0;
-  if ((accumulate & ACC_READ_PREV) && bit_get(ybits, row)) S = (double)y[row];
-  for (int base = 0; base < npieces; base += 64) {
-    const int i = base + lane;
-    const double mine = i < npieces ? piece_sum[p0 + i] : 0.0;
-    double incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double o = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += o;
-    }
-    if (i < npieces) before[p0 + i] = S + (incl - mine);
-    S += __shfl(incl, 63, 64);
-  }
-}
-// one workgroup per 8192-product chunk (= the even-numbered 4096-pieces of a row): the chunk's composed ulp-map
-__global__ void __launch_bounds__(kGiant)
-k_giant_maps(gm_csr_t A, const float* __restrict__ terms, const double* __restrict__ piece_sum, const double* __restrict__ before,
-             gchunk_map* __restrict__ maps) {
-  const int p = blockIdx.x;
-  const int gi = A.gchunk_row[p];
-  const int row = A.giant_row[gi];
-  const int64_t e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
-  const int64_t rel = A.gchunk_edge[p] - e0;
-  if ((rel / GM_GIANT_CHUNK) & 1) return;  // second half of a chunk
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int n = (int)((e1 - e0 - rel) < kLongChunk ? (e1 - e0 - rel) : kLongChunk);
-  // the binade the estimate says S is in, from before the chunk until after it, with a margin on both sides
-  const double Sa = before[p];
-  double Sb = Sa + piece_sum[p];
-  if (p + 1 < A.ngchunk && A.gchunk_row[p + 1] == gi) Sb += piece_sum[p + 1];
-  const float fa = (float)(Sa * (1.0 - 1e-4)), fb = (float)(Sb * (1.0 + 1e-4));
-  const int ea = (int)((__float_as_uint(fa) >> 23) & 0xff), eb = (int)((__float_as_uint(fb) >> 23) & 0xff);
-  __shared__ ulp_map s_wave[kGiant / 64];
-  __shared__ int s_bad;
-  if (tid == 0) s_bad = 0;
-  __syncthreads();
-  const bool candidate = Sa > 0.0 && ea == eb && ea > 0 && ea < 255 && !(fa < 0.f);
-  if (!candidate) {
-    if (tid == 0) maps[p] = gchunk_map{0, 0u, 0u, 0u};
-    return;
-  }
-  const int64_t t0 = A.gterm_off[gi] + rel;
-  ulp_map mine = {0u, 0u};
-  bool ok = true;
-  const int k0 = tid * kLongPer;
-#pragma unroll
-  for (int j = 0; j < kLongPer; j++) {
-    if (k0 + j < n) {
-      ulp_map t;
-      if (!ulp_term(__float_as_uint(terms[t0 + k0 + j]), ea, t)) ok = false; else mine = ulp_compose(mine, t);
-    }
-  }
-  if (!ok) atomicOr(&s_bad, 1);
-  ulp_map v = mine;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    ulp_map o;
-    o.de = __shfl_up(v.de, off, 64);
-    o.dod = __shfl_up(v.dod, off, 64);
-    if (lane >= off) v = ulp_compose(o, v);
-  }
-  if (lane == 63) s_wave[tid >> 6] = v;
-  __syncthreads();
-  if (tid == 0) {
-    ulp_map tot = {0u, 0u};
-    for (int w = 0; w < kGiant / 64; w++) tot = ulp_compose(tot, s_wave[w]);
-    maps[p] = s_bad ? gchunk_map{0, 0u, 0u, 0u} : gchunk_map{ea, tot.de, tot.dod, 0u};
-  }
-}
 
 template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
 __global__ void __launch_bounds__(kGiant)
 k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
                const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg,
                const U* __restrict__ terms, const unsigned long long* __restrict__ tpres, const uint32_t* __restrict__ want,
-               const gchunk_map* __restrict__ maps = nullptr /* precomputed chunk maps (k_giant_maps), or null */) {
+               gchunk_state* __restrict__ maps = nullptr /* per-piece maps (k_giant_terms) in, binade hints out; or null */) {
   constexpr bool SMALL_U = sizeof(U) <= 8;
   constexpr int CH = kLongChunk, PER = kLongPer;
   // ordered kinds stage the per-edge products (U) of a chunk in LDS for the serial fold
@@ -1382,18 +1429,41 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
       }
     };
     float term[PER], pre[PER];
-    // precomputed chunk maps of this row (k_giant_maps), staged in LDS
+    // this row's piece maps (k_giant_terms), composed per 8192-product chunk and staged in LDS
     constexpr int kMapsLds = 256;
-    __shared__ gchunk_map s_maps[kMapsLds];
+    struct chunk_rec { int32_t e; uint32_t de, dod; };
+    __shared__ chunk_rec s_maps[kMapsLds];
     __shared__ int s_skip;
     const int nchunks = (int)((deg + CH - 1) / CH);
+    const int npieces = (int)((deg + GM_GIANT_CHUNK - 1) / GM_GIANT_CHUNK);
     const bool mapped = maps != nullptr && nchunks <= kMapsLds && !(dbg & DBG_NO_REPLAY);
+    int piece0 = 0;
     if (mapped) {
-      const int piece0 = lower_piece(A.gchunk_row, A.ngchunk, (int)blockIdx.x);
-      for (int c = tid; c < nchunks; c += kGiant) s_maps[c] = maps[piece0 + 2 * c];
+      piece0 = lower_piece(A.gchunk_row, A.ngchunk, (int)blockIdx.x);
+      for (int c = tid; c < nchunks; c += kGiant) {
+        const gchunk_state a = maps[piece0 + 2 * c];
+        chunk_rec r = {a.e_map, a.de, a.dod};
+        if (2 * c + 1 < npieces) {
+          const gchunk_state b = maps[piece0 + 2 * c + 1];
+          if (a.e_map > 0 && b.e_map == a.e_map) {
+            const ulp_map ab = ulp_compose(ulp_map{a.de, a.dod}, ulp_map{b.de, b.dod});
+            r.de = ab.de;
+            r.dod = ab.dod;
+          } else {
+            r.e = 0;
+          }
+        }
+        s_maps[c] = r;
+      }
     } else {
       load_chunk(0, pre);
     }
+    // (lane 0 only) the chunk being replayed and the binade S was in when it started: its hint for the next pass
+    int pend_c = -1, pend_e = 0;
+    auto leave_hint = [&](int c, int e) {  // both pieces of chunk c
+      maps[piece0 + 2 * c].e_hint = e;
+      if (2 * c + 1 < npieces) maps[piece0 + 2 * c + 1].e_hint = e;
+    };
     for (int64_t base = e0; base < e1; base += CH) {
       __syncthreads();  // previous chunk fully consumed (and, first time round, s_maps / s_Sbits / s_has written)
       if (mapped) {
@@ -1403,13 +1473,19 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
         if (tid == 0) {
           int c = (int)((base - e0) / CH), skipped = 0;
           uint32_t sbm = s_Sbits;
-          if (s_has[0] != 0) {
+          const bool h = s_has[0] != 0;
+          if (pend_c >= 0) {  // the chunk just replayed: a hint only if S stayed in one binade
+            const int eo = (h && !(sbm >> 31)) ? (int)((sbm >> 23) & 0xff) : 0;
+            leave_hint(pend_c, (pend_e > 0 && eo == pend_e && eo < 255) ? eo : 0);
+            pend_c = -1;
+          }
+          if (h) {
             while (c < nchunks) {
-              const gchunk_map rec = s_maps[c];
+              const chunk_rec rec = s_maps[c];
               const uint32_t Sint = (sbm & 0x7fffffu) | 0x800000u;
               const uint32_t Safter = Sint + ((Sint & 1u) ? rec.dod : rec.de);
               if (!(rec.e > 0 && !(sbm >> 31) && (int)((sbm >> 23) & 0xff) == rec.e && Safter < 0x1000000u)) break;
-              sbm = (sbm & 0xff800000u) | (Safter & 0x7fffffu);
+              sbm = (sbm & 0xff800000u) | (Safter & 0x7fffffu);  // (same binade: the hint stays what it is)
               c++;
               skipped++;
             }
@@ -1419,6 +1495,10 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
             atomicAdd(&g_longrow_counters[2], (unsigned long long)skipped * (CH / PER));
           }
           s_skip = skipped;
+          if (c < nchunks) {
+            pend_c = c;
+            pend_e = (h && !(sbm >> 31)) ? (int)((sbm >> 23) & 0xff) : 0;
+          }
         }
         __syncthreads();
         base += (int64_t)s_skip * CH;
@@ -1552,6 +1632,11 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
       if (dbg & DBG_FIRST_CHUNK_ONLY) break;
     }
     __syncthreads();
+    if (mapped && tid == 0 && pend_c >= 0) {
+      const uint32_t sbm = s_Sbits;
+      const int eo = (s_has[0] != 0 && !(sbm >> 31)) ? (int)((sbm >> 23) & 0xff) : 0;
+      leave_hint(pend_c, (pend_e > 0 && eo == pend_e && eo < 255) ? eo : 0);
+    }
     if (tid == 0 && s_has[0]) {
       uint32_t sb = s_Sbits;
       U r;
@@ -1752,6 +1837,46 @@ k_push_bid(gm_csr_t S /* rows = sources */, const int32_t* __restrict__ list, in
       if (lane == 0) start = atomicAdd(tcount, (unsigned int)__popcll(fm));
       start = (unsigned int)__shfl((int)start, 0, 64);
       if (first) touched[start + (unsigned int)__popcll(fm & ((1ull << lane) - 1ull))] = c;
+    }
+  }
+}
+
+// The same bids for an active set that is too large to list (more than kSparseListCap vertices) but owns few
+// out-edges, each vertex only a handful (the late levels of a traversal: a million vertices of degree ~1): the
+// active BITMAP is scanned, one lane per vertex, and every active lane walks its own short out-edge list -- no
+// list, no piece offsets.  (A bottom-up level would scan every unvisited row for these few messages.)
+__global__ void __launch_bounds__(kBlock)
+k_push_bid_bits(gm_csr_t S /* rows = sources */, const uint32_t* __restrict__ active, int n,
+                const int32_t* __restrict__ native_of_dev, unsigned long long* __restrict__ best,
+                const uint32_t* __restrict__ want, int32_t* __restrict__ touched, unsigned int* __restrict__ tcount) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n; base += (int64_t)gridDim.x * kBlock) {
+    const int u = (int)base + threadIdx.x;
+    int64_t e = 0, e1 = 0;
+    unsigned long long hi = 0;
+    if (u < n && ((active[u >> 5] >> (u & 31)) & 1u)) {
+      e = S.rowptr[u];
+      e1 = S.rowptr[u + 1];
+      hi = (unsigned long long)((native_of_dev ? native_of_dev[u] : u) + 1) << 32;
+    }
+    while (__ballot(e < e1)) {
+      bool first = false;
+      int c = 0;
+      if (e < e1) {
+        c = S.colidx[e];
+        if (want == nullptr || ((want[c >> 5] >> (c & 31)) & 1u)) {
+          const unsigned long long key = hi | (unsigned long long)(uint32_t)e;
+          if (best[c] < key) first = atomicMax(&best[c], key) == 0ull;
+        }
+        e++;
+      }
+      const unsigned long long fm = __ballot(first);
+      if (fm) {
+        unsigned int start = 0;
+        if (lane == 0) start = atomicAdd(tcount, (unsigned int)__popcll(fm));
+        start = (unsigned int)__shfl((int)start, 0, 64);
+        if (first) touched[start + (unsigned int)__popcll(fm & ((1ull << lane) - 1ull))] = c;
+      }
     }
   }
 }

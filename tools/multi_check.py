@@ -130,6 +130,19 @@ def main():
             ok &= same
             g_loc.close()
         g_all.close()
+        # a bad edge id on ONE rank must fail the collective build on EVERY rank (not leave the others waiting)
+        mine = slice(cuts[rank], cuts[rank + 1])
+        sb = s2[mine].copy()
+        if rank == world - 1 and sb.size:
+            sb[sb.size // 2] = nv + 5
+        try:
+            api.Graph(nv, sb, d2[mine], v2[mine], ref_threads=2, device=device, layout=api.GM_LAYOUT_DEGREE, nshards=world, shard=rank, edges_local=True)
+            refused = False
+        except RuntimeError as e:
+            refused = ("outside" in str(e)) == (rank == world - 1) or "other rank" in str(e)
+        if not refused:
+            print("rank %d: a distributed build with a bad id on the last rank was not refused everywhere" % rank, flush=True)
+        ok &= refused
     # SGD / RMSE with K=128 fp32 latent vectors (BASELINE config 5 shape) on a sharded bipartite
     # ratings graph: the dedicated kernels exchange 512-byte x rows; bit-exact against the oracle
     rng = np.random.default_rng(7)
