@@ -84,7 +84,7 @@ def cpu_baseline(scale, iters, rank):
     """The oracle (CPU restatement of the reference algorithm, OpenMP over the reference's row partitions: 16 per
     layout thread) timed on this box's host cores on a bounded sample (RMAT-<scale>, same generator and seed as the
     GPU run).  The thread count is tuned like a user of the reference would tune OMP_NUM_THREADS (README.md:30-39 of
-    the reference): every power of two from 16 up to ALL physical cores (and all logical ones), each judged on 20
+    the reference): every power of two from 8 up to ALL physical cores (and all logical ones), each judged on 20
     iterations; the best one is then timed in three blocks of `iters` / 3 iterations -- `value` is the MEDIAN block,
     the spread is reported next to it, with the time per phase."""
     from graphmat_amd import api
@@ -94,7 +94,7 @@ def cpu_baseline(scale, iters, rank):
     nv, s, d, _ = api.rmat_on_device(scale, 16, 1)
     s = s.cpu().numpy()
     d = d.cpu().numpy()
-    cand = sorted({c for c in (16, 32, 64, 128, 256, physical, logical) if c <= logical} or {logical})
+    cand = sorted({c for c in (8, 16, 32, 64, 128, 256, physical, logical) if c <= logical} or {logical})
     L = ob.lib()
     L.gmo_phase_seconds.argtypes = [C.POINTER(C.c_double), C.c_int]
     L.gmo_phase_seconds.restype = None
@@ -646,15 +646,19 @@ def main():
                 tj = json.load(open(tpath))
                 per = tj.get("scale%d" % args.scale, {})
                 if tj.get("kernels_fingerprint") == kernels_fingerprint() and tj.get("col_tiles", {}).get("scale%d" % args.scale) == int(g.col_tiles):
-                    names = {"k_spmv_wave": ["k_spmv_wave", "k_spmv_wave16"], "multiply": ["k_spmv_rowblock", "k_spmv_wave", "k_spmv_wave16"]}.get(name, [name])
+                    # (large graphs run the persistent forms k_spmv_rowwave / k_spmv_wave16p instead of, or next to, the plain ones)
+                    names = {"k_spmv_rowblock": ["k_spmv_rowblock", "k_spmv_rowwave"], "k_spmv_wave": ["k_spmv_wave", "k_spmv_wave16", "k_spmv_wave16p"],
+                             "multiply": ["k_spmv_rowblock", "k_spmv_rowwave", "k_spmv_wave", "k_spmv_wave16", "k_spmv_wave16p"]}.get(name, [name])
                     parts = [per.get(k + "_bytes_per_iteration") for k in names]
-                    traffic = int(sum(parts)) if all(v is not None for v in parts) else None
+                    traffic = int(sum(v for v in parts if v is not None)) if any(v is not None for v in parts) else None
                     traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernels (profiles/pmc_traffic.json)"
                 else:
                     traffic_note = "profiles/pmc_traffic.json was measured on other kernel sources: not quoted"
             except Exception:
                 traffic = None
-        kname = {"k_spmv_wave": "k_spmv_wave16+k_spmv_wave", "multiply": "k_spmv_rowblock+k_spmv_wave16+k_spmv_wave" + (" over %d column tiles" % int(g.col_tiles) if tiled else "")}.get(name, name)
+        big = nv >= (48 << 20)  # engine.hpp: persistent_forms_pay
+        kname = {"k_spmv_wave": "k_spmv_wave16+k_spmv_wave", "multiply": ("k_spmv_rowblock/k_spmv_rowwave+k_spmv_wave16p+k_spmv_wave" if big else "k_spmv_rowblock+k_spmv_wave16+k_spmv_wave") +
+                 (" over %d column tiles" % int(g.col_tiles) if tiled else "")}.get(name, name)
         roof = {"bound": "hbm", "kernel": kname + "<PageRank>", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg_bytes,

@@ -412,6 +412,12 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
       if constexpr (wave16_ok<U, USE_VP, RK>()) {
         // ordered folds: the long rows at the head of the list get a wave each, the rest are folded 16 to a wave
         const int nlong = A.nmid_long < A.nmid ? A.nmid_long : A.nmid;
+        const int rest = A.nmid - nlong;
+        const int groups = (rest + dev::kWaveRows - 1) / dev::kWaveRows;
+        // the long rows: a wave each (k_spmv_wave), on the auxiliary stream during column-tile passes.  (Handing them to
+        // the waves of the persistent kernel below -- one launch, long rows first off the same work counter -- was
+        // measured at RMAT-26: 6.6 -> 7.9 ms per iteration.  wave_row's ordered fold is a serial chain per wave and wants
+        // the 32 waves per CU the plain kernel gets, not the 16 of a workgroup that holds 90 KB of LDS.)
         if (nlong > 0) {
           hipStream_t ls = s;
           if (long_on_aux) {
@@ -426,30 +432,24 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
             GM_HIP_OK(hipEventRecord(aux->join, ls));  // (re-recorded behind the giant passes' record: the wait below sees this one)
           }
         }
-        const int rest = A.nmid - nlong;
-        if (rest > 0) {
-          const int groups = (rest + dev::kWaveRows - 1) / dev::kWaveRows;
-          constexpr int W16 = dev::kWave16Block / 64;
-          bool done = false;
-          if constexpr (sizeof(T) == 4 && sizeof(U) == 4) {
-            // (persistent forms pay on large graphs only: the hot set is loaded once per workgroup, but a few
-            // hundred groups cannot feed 256 CUs from 256 workgroups as evenly as thousands of small ones)
-            const int form = persistent_forms_pay(A) || (wave16_form() & 16) ? (wave16_form() & 15) : 0;
-            auto persistent = [&](auto block_c, auto hot_c, int fit) {
-              constexpr int BLOCK = decltype(block_c)::value, HOT = decltype(hot_c)::value;
-              int per_cu = persist_per_cu() > 0 && persist_per_cu() < fit ? persist_per_cu() : fit;
-              int grid = cu_count() * per_cu;
-              const int need = (groups + BLOCK / 64 - 1) / (BLOCK / 64);
-              if (grid > need) grid = need;
-              hipLaunchKernelGGL((dev::k_spmv_wave16p<P, T, U, V, E, BLOCK, HOT>), dim3(grid), dim3(BLOCK), 0, s, pa, A,
-                                 A.mid_row + nlong, rest, x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
-              done = true;
-            };
-            // (measured at RMAT-26, 6 tiles, wave rows alone: 256 threads / 8192 entries per 64 rows 2.13 ms; persistent
-            // 512 / 30720: 2.26; 1024 / 22528: 1.85; 512 / 10240 x 2 per CU: 2.10; 256 / 8192 x 3: worse -- profiles/r03_persistent_kernels.md)
-            if (form == 2) persistent(std::integral_constant<int, 1024>(), std::integral_constant<int, 22528>(), 1);
+        // Large graphs: the 16-row groups go to persistent 1024-thread workgroups that load the slice's 22528 busiest x
+        // entries into LDS once, their waves taking groups in an interleaved order (kernels.hpp: k_spmv_wave16p; measured
+        // in profiles/r03_persistent_kernels.md)
+        bool done = false;
+        if constexpr (sizeof(T) == 4 && sizeof(U) == 4) {
+          const int form = persistent_forms_pay(A) || (wave16_form() & 16) ? (wave16_form() & 15) : 0;
+          if (rest > 0 && form == 2) {
+            constexpr int BLOCK = 1024, HOT = 22528;
+            int grid = cu_count();
+            const int need = (groups + BLOCK / 64 - 1) / (BLOCK / 64);
+            if (grid > need) grid = need;
+            hipLaunchKernelGGL((dev::k_spmv_wave16p<P, T, U, V, E, BLOCK, HOT>), dim3(grid), dim3(BLOCK), 0, s, pa, A, A.mid_row + nlong, rest,
+                               x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
+            done = true;
           }
-          if (!done)
+        }
+        if (!done && rest > 0) {
+          constexpr int W16 = dev::kWave16Block / 64;
           hipLaunchKernelGGL((dev::k_spmv_wave16<P, T, U, V, E>), dim3((groups + W16 - 1) / W16), dim3(dev::kWave16Block), 0, s, pa, A,
                              A.mid_row + nlong, rest, x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
         }

@@ -616,6 +616,51 @@ __device__ __forceinline__ U wave_shfl_down(const U& v, int delta) {
   return r;
 }
 
+// The hottest x entries of the adjacency's column slice, kept in LDS by the wave kernels (device order is
+// degree-ranked: they are the first ones of the slice; a column tile's columns are the slice
+// [hot_base, hot_base + hot_len) of the device order, busiest first).  Sharded graphs: the degree ranking is
+// dealt over the NS slices of x, so the hot set is the first HOT / NS entries of every slice
+// (s_hot[q * per + i] = x[q * stride + i]).
+template <class T>
+struct HotSet {
+  const T* s_hot;
+  int base, nhot, NS, per, stride;
+  float inv_stride;
+  __device__ __forceinline__ T get(const T* __restrict__ x, int c) const {
+    if (NS == 1) {
+      const unsigned rel = (unsigned)(c - base);
+      return rel < (unsigned)nhot ? s_hot[rel] : x[c];
+    }
+    // slice q of the column and its position in it (float estimate of the quotient, fixed up exactly)
+    int q = (int)((float)c * inv_stride);
+    q = q >= NS ? NS - 1 : q;
+    int pos = c - q * stride;
+    if (pos < 0) { q--; pos += stride; } else if (pos >= stride) { q++; pos -= stride; }
+    return pos < per ? s_hot[q * per + pos] : x[c];
+  }
+};
+// fills s_hot (all threads of the workgroup; the caller synchronises) and describes it
+template <class T, int HOT, int BLOCK>
+__device__ __forceinline__ HotSet<T> hot_load(const gm_csr_t& A, const T* __restrict__ x, T* s_hot) {
+  HotSet<T> h;
+  h.s_hot = s_hot;
+  h.base = A.hot_base;
+  h.NS = A.hot_slices > 1 ? A.hot_slices : 1;
+  h.stride = A.hot_stride;
+  h.per = HOT > 1 ? ((A.hot_len < HOT / h.NS ? A.hot_len : HOT / h.NS)) : 0;  // hot entries per slice
+  h.nhot = h.per * h.NS;
+  h.inv_stride = h.NS > 1 ? 1.0f / (float)A.hot_stride : 0.f;
+  if constexpr (HOT > 1) {
+    if (h.NS == 1) {
+      const T* __restrict__ xhot = x + A.hot_base;
+      for (int i = threadIdx.x; i < h.nhot; i += BLOCK) s_hot[i] = xhot[i];
+    } else {
+      for (int i = threadIdx.x; i < h.nhot; i += BLOCK) s_hot[i] = x[(size_t)(i / h.per) * A.hot_stride + (i % h.per)];
+    }
+  }
+  return h;
+}
+
 // ------------------------------------------------------------------------------------
 // multiply+reduce, one wave per row (rows of GM_SHORT_ROW+1 .. GM_GIANT_ROW edges; also
 // giant rows of programs without a faster strategy).  64 edges at a time: coalesced
@@ -826,51 +871,6 @@ constexpr int kWaveRows = 16;
 constexpr int kHotEntries = 8192;
 constexpr int kWave16Block = 256;  // (512 threads sharing one hot set: no difference; 1024: slower)
 
-// The hottest x entries of the adjacency's column slice, kept in LDS by the wave kernels (device order is
-// degree-ranked: they are the first ones of the slice; a column tile's columns are the slice
-// [hot_base, hot_base + hot_len) of the device order, busiest first).  Sharded graphs: the degree ranking is
-// dealt over the NS slices of x, so the hot set is the first HOT / NS entries of every slice
-// (s_hot[q * per + i] = x[q * stride + i]).
-template <class T>
-struct HotSet {
-  const T* s_hot;
-  int base, nhot, NS, per, stride;
-  float inv_stride;
-  __device__ __forceinline__ T get(const T* __restrict__ x, int c) const {
-    if (NS == 1) {
-      const unsigned rel = (unsigned)(c - base);
-      return rel < (unsigned)nhot ? s_hot[rel] : x[c];
-    }
-    // slice q of the column and its position in it (float estimate of the quotient, fixed up exactly)
-    int q = (int)((float)c * inv_stride);
-    q = q >= NS ? NS - 1 : q;
-    int pos = c - q * stride;
-    if (pos < 0) { q--; pos += stride; } else if (pos >= stride) { q++; pos -= stride; }
-    return pos < per ? s_hot[q * per + pos] : x[c];
-  }
-};
-// fills s_hot (all threads of the workgroup; the caller synchronises) and describes it
-template <class T, int HOT, int BLOCK>
-__device__ __forceinline__ HotSet<T> hot_load(const gm_csr_t& A, const T* __restrict__ x, T* s_hot) {
-  HotSet<T> h;
-  h.s_hot = s_hot;
-  h.base = A.hot_base;
-  h.NS = A.hot_slices > 1 ? A.hot_slices : 1;
-  h.stride = A.hot_stride;
-  h.per = HOT > 1 ? ((A.hot_len < HOT / h.NS ? A.hot_len : HOT / h.NS)) : 0;  // hot entries per slice
-  h.nhot = h.per * h.NS;
-  h.inv_stride = h.NS > 1 ? 1.0f / (float)A.hot_stride : 0.f;
-  if constexpr (HOT > 1) {
-    if (h.NS == 1) {
-      const T* __restrict__ xhot = x + A.hot_base;
-      for (int i = threadIdx.x; i < h.nhot; i += BLOCK) s_hot[i] = xhot[i];
-    } else {
-      for (int i = threadIdx.x; i < h.nhot; i += BLOCK) s_hot[i] = x[(size_t)(i / h.per) * A.hot_stride + (i % h.per)];
-    }
-  }
-  return h;
-}
-
 // one wave folds the kWaveRows list entries [first, first + kWaveRows) (s_t / s_mask: the wave's LDS tile)
 template <class P, class T, class U, class V, class E, int KSTRIDE>
 __device__ __forceinline__ void wave16_group(const P& p, const gm_csr_t& A, const int32_t* __restrict__ rows, const int nlist,
@@ -1003,7 +1003,9 @@ k_spmv_wave16p(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int 
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ngroups = (nlist + G - 1) / G;
   const int nwaves = gridDim.x * (BLOCK / 64);
-  // wave w of the grid = workgroup (w mod gridDim.x), so neighbouring groups go to different CUs
+  // wave w of the grid = workgroup (w mod gridDim.x): neighbouring groups -- the list is degree-ranked, so they cost
+  // about the same -- go to different CUs, and the interleaving balances the waves.  (Handing the groups out off a
+  // global work counter instead was measured: 26 000 same-address atomics per launch, 6.6 -> 7.5 ms per iteration.)
   for (int g = wv * gridDim.x + blockIdx.x; g < ngroups; g += nwaves)
     wave16_group<P, T, U, V, E, kStride>(p, A, rows, nlist, g * G, lane, x, xbits, vp, y, ybits, accumulate, dbg, want, hot, s_t[wv], s_mask[wv]);
 }

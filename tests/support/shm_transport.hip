@@ -182,7 +182,7 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
   return ncclSuccess;
 }
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t, hipStream_t s) {
-  if ((t == ncclUint32 || t == ncclInt32) && op == ncclSum && count != 1) return all_reduce_sum32(send, recv, count, s);
+  if ((t == ncclUint32 || t == ncclInt32) && op == ncclSum && (count != 1 || t == ncclUint32)) return all_reduce_sum32(send, recv, count, s);
   if (t != ncclInt32 || count != 1 || (op != ncclMin && op != ncclMax && op != ncclSum)) return ncclInvalidArgument;
   if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
   int v = 0;
