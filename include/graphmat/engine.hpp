@@ -66,7 +66,9 @@ inline int& persist_per_cu() {
 // auxiliary stream's kernels would use next to them -- for fewer L2 requests.  Measured on RMAT, PageRank, both forms on
 // against both off: scale 22 +1.7 %, 24 -0.6 %, 25 -3.5 %, 26 +3.5 %, 27 +5.1 % (profiles/r03_persistent_kernels.md):
 // they pay once the message vector is far larger than the caches, i.e. where the column tiles are many.
-inline bool persistent_forms_pay(const gm_csr_t& A) { return (int64_t)A.ncols >= (48ll << 20); }
+// Not on shards: their hot set is the first entries of EVERY slice of x (a slice lookup per gather) and they are not
+// tiled -- a shard of 8 of RMAT-26 multiplies in 1.11 ms with the plain kernels, 1.30 ms with the persistent ones.
+inline bool persistent_forms_pay(const gm_csr_t& A) { return (int64_t)A.ncols >= (48ll << 20) && A.hot_slices <= 1; }
 inline int cu_count() {
   static int n = 0;
   if (n == 0) {

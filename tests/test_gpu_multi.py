@@ -40,6 +40,23 @@ def test_sharded_runs_match_oracle(world):
     assert out.returncode == 0 and "MULTI_OK" in text, text[-3000:]
 
 
+def test_sharded_runs_with_the_persistent_kernels_match_oracle():
+    """The persistent multiply kernels (k_spmv_rowwave / k_spmv_wave16p) keep, on a sharded graph, the first entries
+    of EVERY shard's slice of x in LDS (the degree ranking is dealt over the slices).  The library picks them for
+    large graphs only (what bench.py --gpus N runs at RMAT-26), so here they are forced on a small one: 3 shards,
+    every program of tools/multi_check.py against the oracle."""
+    from graphmat_amd import build
+    build.build()
+    from oracle import binding
+    binding.build()
+    env = dict(os.environ, GM_BACKEND="gloo", GM_SCALE="14", GM_FORCE_FORMS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "multi_check.py")]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env, cwd=ROOT)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "MULTI_OK" in text, text[-3000:]
+
+
 def test_native_rccl_exchange_single_rank():
     """The library's own RCCL exchange (gm_dist.hip: ncclAllGather / ncclAllReduce on HIP streams, overlapped
     parts on a side stream).  RCCL wants one rank per GPU, so on this 1-GPU box the world has one rank: the

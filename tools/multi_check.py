@@ -49,6 +49,11 @@ def main():
             return NativeCounters(g)
         return attach_exchange(g, **kw)
     from oracle import binding as ob
+    if os.environ.get("GM_FORCE_FORMS") == "1":
+        # the persistent kernels (large LDS hot set dealt over the shards' slices) the library only picks for large graphs
+        from graphmat_amd import _lib as _l
+        _l.check(_l.lib().gm_set_option(b"wave16_form", 16 + 2))
+        _l.check(_l.lib().gm_set_option(b"rowwave_form", 16 + 4))
     scale = int(os.environ.get("GM_SCALE", "14"))
     nv, s, d, v = generators.rmat_edges(scale, 16, seed=21, weights="hash")
     g = api.Graph(nv, s, d, v, ref_threads=2, device=device, layout=api.GM_LAYOUT_DEGREE, nshards=world, shard=rank)
