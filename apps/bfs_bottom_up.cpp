@@ -3,8 +3,9 @@
 // plus the ONE piece of knowledge the runtime cannot discover by itself: a vertex that already
 // has a depth ignores further messages (program_row_filter).  With it the engine skips such
 // rows in the multiply ("bottom-up" levels) without changing any result; without the trait the
-// same program runs, only slower.  The reduction strategy (a = b: last message wins) is found by
-// the runtime's probe of reduce_function.
+// same program runs, only slower.  It also states its reduction strategy (a = b: the last message
+// wins, program_traits<...>::reduce = REDUCE_LAST): a program that declares nothing gets the
+// ordered fold -- always exact, and slower here (no backward scans, no top-down steps).
 //
 //   bfs_bottom_up graph.bin.mtx <source vertex>   -> "vertex <v> depth <d> parent <p>" per reached vertex
 #include <climits>
@@ -41,6 +42,7 @@ class LevelBfs : public GraphMat::GraphProgram<unsigned long long, unsigned long
 };
 
 namespace GraphMat {
+template <> struct program_traits<LevelBfs> { static constexpr reduce_kind reduce = REDUCE_LAST; };
 template <> struct program_row_filter<LevelBfs> {
   static constexpr bool enabled = true;
   static bool wants(const LevelBfs&, const Visit& v) { return v.depth == kUnreached; }

@@ -118,8 +118,8 @@ def test_own_generic_program_label_propagation(golden_dir, tmp_path):
 
 @pytest.mark.gpu
 def test_own_bfs_with_row_filter_trait(golden_dir, ref):
-    """apps/bfs_bottom_up.cpp: a user-written BFS whose only extra is the program_row_filter trait (bottom-up
-    levels); the reduction strategy comes from the runtime's probe.  Golden depths/parents of G2, and the oracle
+    """apps/bfs_bottom_up.cpp: a user-written BFS whose only extras are two traits: program_row_filter (bottom-up
+    levels) and program_traits::reduce = REDUCE_LAST (the declared reduction strategy).  Golden depths/parents of G2, and the oracle
     on an RMAT graph large enough to have row-blocks, wave rows and top-down steps."""
     from graphmat_amd import generators as gen
     from graphmat_amd.mtx import write_mtx_bin
