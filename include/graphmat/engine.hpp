@@ -613,7 +613,8 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       d_list = (int32_t*)pl;
       d_off = (unsigned int*)((char*)pl + ((size_t)n * 4 + 1024) / 256 * 256);  // piece offsets of the listed sources
       d_touched = (int32_t*)pt;
-      if (can_push) GM_HIP_OK(hipMemsetAsync(d_best, 0, (size_t)n * 8, s));
+      // (rows past n_live have no in-edge: nobody ever bids for them -- at RMAT-26 that halves a 537 MB memset)
+      if (can_push) GM_HIP_OK(hipMemsetAsync(d_best, 0, (size_t)n_live * 8, s));
       GM_HIP_OK(hipMemsetAsync(d_stats, 0, 24, s));
       GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
       hipLaunchKernelGGL(dev::k_frontier_stats, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active,
@@ -1044,11 +1045,11 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
                            (const int32_t*)d_list, (int)frontier_v, (const unsigned int*)d_off, native_of_dev, d_best,
                            (const uint32_t*)d_want, (int32_t*)nullptr, (unsigned int*)nullptr);
         if (use_vp)
-          hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, true>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, Asrc,
-                             xq, dev_of_native, (const V*)d_vp, d_best, y, ybits, n);
+          hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, true>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, Asrc,
+                             xq, dev_of_native, (const V*)d_vp, d_best, y, ybits, n_live);  // (only live rows can have been bid for)
         else
-          hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, false>), dim3(grid_for(n)), dim3(dev::kBlock), 0, s, pa, Asrc,
-                             xq, dev_of_native, (const V*)d_vp, d_best, y, ybits, n);
+          hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, false>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, Asrc,
+                             xq, dev_of_native, (const V*)d_vp, d_best, y, ybits, n_live);
         st.spmv_launches += 2;
         timer.mark(TAG_WAVE);
       } else if (order == OUT_EDGES || order == ALL_EDGES) {

@@ -135,3 +135,34 @@ def test_apply_to_all_edges_with_several_ranks(tmp_path, nranks, transport):
         total += int(m.group(2))
         want_total = int(m.group(3))
     assert total == want_total
+
+
+def test_a_rank_that_waits_for_missing_peers_gets_an_error_not_a_hang(tmp_path):
+    """gm_dist_init_from_env bounds the set-up of the communicator (GRAPHMAT_INIT_TIMEOUT): rank 0 of a declared world of
+    two whose peer never starts must stop with a message, and a rank > 0 that finds only a STALE rendezvous file (older
+    than the launch) must not take its id."""
+    import time
+    from tests.support import build as shm_build
+    exe = os.path.join(ROOT, "build", "apps", "api_selftest")
+    if not os.path.exists(exe):
+        pytest.skip("api_selftest was not prebuilt")
+    rdv = str(tmp_path / "rendezvous")
+    env = dict(os.environ, GRAPHMAT_RANK="0", GRAPHMAT_NRANKS="2", GRAPHMAT_LOCAL_RANK="0", GRAPHMAT_RENDEZVOUS=rdv,
+               GRAPHMAT_RCCL_LIBRARY=shm_build.build(), GRAPHMAT_INIT_TIMEOUT="3")
+    t0 = time.time()
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=120)
+    assert out.returncode == 1 and b"was not set up within 3 s" in out.stdout, out.stdout[-1500:]
+    assert time.time() - t0 < 60
+    # rank 1 with a stale file (written "long ago": the header carries rank 0's start time)
+    import struct
+    with open(rdv, "wb") as f:
+        f.write(struct.pack("<8sqii", b"GMRDV01\0", int(time.time()) - 3600, 2, 0) + b"\0" * 128)
+    env["GRAPHMAT_RANK"] = "1"
+    t0 = time.time()
+    try:
+        out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=15)
+        text = out.stdout
+    except subprocess.TimeoutExpired as e:  # still politely waiting for a FRESH file (up to 60 s): what it should do
+        text = e.stdout or b""
+        out = None
+    assert out is None or (out.returncode == 1 and b"never published a fresh" in text), text[-1500:]
