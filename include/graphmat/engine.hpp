@@ -89,6 +89,12 @@ inline int& iteration_trace() {
   return v;
 }
 
+// a=b programs, rows of more than GM_SHORT_ROW edges under a row filter (kernels.hpp: group_rows_last): lanes per row
+inline int& last_rows_lanes() {
+  static int v = 8;
+  return v;
+}
+
 // top-down steps are taken while the active set owns less than this many thousandths of the edges
 inline int& push_edge_permille() {
   static int v = 50;
@@ -407,9 +413,21 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
   if (A.nmid > 0) {
     if (grouped && want != nullptr) {  // a row bitmap governs: 64 list entries per wave, only the wanted rows are worked on
       const int groups = (A.nmid + 63) / 64;
-      hipLaunchKernelGGL((dev::k_spmv_wave_grouped<P, T, U, V, E, USE_VP, RK>), dim3((groups + WPB - 1) / WPB),
-                         dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
-                         debug_flags(), want, xsum);
+      // (running this kernel on the auxiliary stream next to the short rows' kernel was measured: both want every wave
+      // slot of the chip, side by side each takes twice as long -- RMAT-26, first bottom-up level: 1.55 against 1.52 ms)
+      bool done = false;
+      if constexpr (RK == REDUCE_LAST) {
+        if (last_rows_lanes() == 16) {
+          hipLaunchKernelGGL((dev::k_spmv_wave_grouped<P, T, U, V, E, USE_VP, RK, 16>), dim3((groups + WPB - 1) / WPB),
+                             dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
+                             debug_flags(), want, xsum);
+          done = true;
+        }
+      }
+      if (!done)
+        hipLaunchKernelGGL((dev::k_spmv_wave_grouped<P, T, U, V, E, USE_VP, RK>), dim3((groups + WPB - 1) / WPB),
+                           dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
+                           debug_flags(), want, xsum);
     } else if (wave16_ok<U, USE_VP, RK>() && !(debug_flags() & dev::DBG_NO_WAVE16)) {
       if constexpr (wave16_ok<U, USE_VP, RK>()) {
         // ordered folds: the long rows at the head of the list get a wave each, the rest are folded 16 to a wave
