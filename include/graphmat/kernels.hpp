@@ -147,6 +147,59 @@ k_send(ProgArg<P> pa, const V* __restrict__ vp, const uint32_t* __restrict__ act
 }
 
 // ------------------------------------------------------------------------------------
+// apply of iteration i and send of iteration i+1 in one pass over the vertices, for programs whose every vertex
+// sends every iteration (ALL_VERTICES) on one GPU: the plain lean k_apply, then x[i] = send_message(vp[i]) from the
+// property just written -- vp is read once instead of twice and one launch goes away.  The engine uses the messages
+// only if do_every_iteration leaves the program object unchanged (engine.hpp: fused apply + send).
+template <class P, class T, class U, class V>
+__global__ void __launch_bounds__(kBlock)
+k_apply_send(ProgArg<P> pa, const U* __restrict__ y, const uint32_t* __restrict__ ybits, V* __restrict__ vp,
+             uint32_t* __restrict__ active, int n, int* __restrict__ changed_flag, uint32_t* __restrict__ want,
+             T* __restrict__ x, uint32_t* __restrict__ xbits, int row_base) {
+  bool any = false;
+  for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n; base += (int64_t)gridDim.x * kBlock) {
+    const int i = (int)base + threadIdx.x;
+    bool changed = false, applied = false, still = false;
+    if (i < n) {
+      ProgArg<P> local = pa;  // apply() is non-const in the API: give it a private copy
+      P& p = *reinterpret_cast<P*>(local.b);
+      V cur = vp[i];
+      if (bit_get(ybits, i)) {
+        V old_prop = cur;  // (operator!= of user types is not const)
+        p.P::apply(y[i], cur);
+        vp[i] = cur;
+        if (old_prop != cur) changed = true;
+        applied = true;
+        if constexpr (program_row_filter<P>::enabled) still = program_row_filter<P>::wants(p, cur);
+      }
+      const P& ps = *reinterpret_cast<const P*>(pa.b);  // (the send of the NEXT iteration: the program as captured, not apply's copy)
+      T m;
+      ps.P::send_message(cur, m);
+      x[(size_t)row_base + i] = m;
+    }
+    if constexpr (program_row_filter<P>::enabled) {
+      if (want != nullptr) {  // the wave owns the two words of its 64 rows
+        const unsigned long long ma = __ballot(applied), mw = __ballot(still);
+        if ((threadIdx.x & 63) == 0 && i < n && ma != 0ull) {
+          want[i >> 5] = (want[i >> 5] & ~(uint32_t)ma) | (uint32_t)mw;
+          if (i + 32 < n) want[(i >> 5) + 1] = (want[(i >> 5) + 1] & ~(uint32_t)(ma >> 32)) | (uint32_t)(mw >> 32);
+        }
+      }
+    }
+    const unsigned long long m = __ballot(changed);
+    const unsigned long long in_range = __ballot(i < n);
+    if ((threadIdx.x & 63) == 0 && i < n) {
+      active[i >> 5] = (uint32_t)m;
+      if (i + 32 < n) active[(i >> 5) + 1] = (uint32_t)(m >> 32);
+      if (m) any = true;
+      xbits[(row_base + i) >> 5] = (uint32_t)in_range;  // every vertex sent (k_send with no active vector)
+      if (i + 32 < n) xbits[((row_base + i) >> 5) + 1] = (uint32_t)(in_range >> 32);
+    }
+  }
+  if (any) *changed_flag = 1;
+}
+
+// ------------------------------------------------------------------------------------
 // Building a compact list from a grid-stride loop.  Atomics with a result on ONE global counter cost
 // ~10 ns each on this chip, so a wave-level append of tens of thousands of entries takes
 // milliseconds.  A workgroup therefore collects its entries in LDS (LDS atomics) over all its loop
