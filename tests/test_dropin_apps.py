@@ -298,6 +298,16 @@ def test_reference_unit_test_closed_forms_on_the_device():
 
 
 @pytest.mark.gpu
+def test_fused_apply_and_send_respects_do_every_iteration():
+    """apps/mutating_program.cpp: the apply pass also writes the next iteration's messages (k_apply_send); they may be
+    used only while do_every_iteration leaves the program unchanged.  Programs that never / always / sometimes change
+    what send_message computes, against a host evaluation of the reference's loop, with the fusion on and off."""
+    text = _run(_need(os.path.join(OWN_APPS, "mutating_program")))
+    assert "MUTATING PASS" in text, text[-2000:]
+    assert "fuse_apply_send=1: steady ok, every-time ok, sometimes ok" in text and "fuse_apply_send=0: steady ok" in text
+
+
+@pytest.mark.gpu
 def test_edge_updates_and_shared_properties_on_tiled_graphs():
     """apps/tiled_edge_update.cpp: applyToAllEdges (device functor and host function pointer) on a graph whose multiply
     runs on column tiles -- large graphs are tiled automatically, so the functor form must not refuse them and the tile
