@@ -605,7 +605,10 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
 
   void* flag_v = nullptr;
   gm_graph_workspace(g, 0, 4096, &flag_v);
-  int* d_changed = (int*)flag_v;  // words: [0] changed flag, [2] list counter, [4..9] frontier stats (3 x u64)
+  // words: [2] list counter, [3] touched counter, [4..9] frontier stats (3 x u64), [127] changed flag -- directly in front of
+  // the striped statistics, so that one memset clears and one copy fetches "flag + statistics" (every call the host makes
+  // between two short levels of a traversal shows up as idle time on the GPU)
+  int* d_changed = (int*)flag_v + 127;
   unsigned int* d_count = (unsigned int*)flag_v + 2;   // entries of d_list (the active set, when it is small)
   unsigned int* d_tcount = (unsigned int*)flag_v + 3;  // entries of d_touched (destinations bid for in a top-down step)
   unsigned long long* d_stats = (unsigned long long*)flag_v + 2;  // byte offset 16
@@ -616,8 +619,8 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     printf("GraphMat(HIP): %s\n", gm_last_error());
     exit(1);
   }
-  int* h_changed = (int*)res_pinned;
-  h_stats = (unsigned long long*)h_changed;
+  int* h_changed = (int*)res_pinned + 127;  // (the pinned mirror has the layout of flag_v)
+  h_stats = (unsigned long long*)res_pinned;
   unsigned long long* h_striped = (unsigned long long*)res_pinned + 64;
   unsigned long long frontier_v = 0, frontier_e = 0, frontier_maxdeg = 0;
   const int stats_grid = grid_for(n) < 2048 ? grid_for(n) : 2048;
@@ -843,10 +846,11 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     // every x entry present (ALL_VERTICES) y's presence is the static set of non-empty rows.
     const bool static_bits = (act == ALL_VERTICES);
     const T* xq = lazy_send ? (const T*)nullptr : (const T*)x;  // what the multiply side reads messages from (may change below)
-    GM_HIP_OK(hipMemsetAsync(d_changed, 0, sizeof(int), s));
+    const bool want_stats = (can_push || xsparse_ok) && iterations <= 0;
+    // the changed flag and, for steered runs, the striped statistics behind it (k_apply / k_push_finish add to them)
+    GM_HIP_OK(hipMemsetAsync(d_changed, 0, want_stats ? sizeof(int) + striped_bytes : sizeof(int), s));
     timer.mark(TAG_START);
     const bool dense_x = (act == ALL_VERTICES);
-    const bool want_stats = (can_push || xsparse_ok) && iterations <= 0;
     // this iteration's x travels as lists when every shard's active set is small: fewer bytes than the dense
     // slices (entry = id + message against one message per live row) and within the list capacity
     const bool xsp = xsparse_ok && xs_max <= dev::kSparseListCap &&
@@ -878,7 +882,6 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         tr_updated = (long long)tc;
       }
       GM_HIP_OK(hipMemsetAsync(d_active, 0, (size_t)nwords * 4, s));
-      GM_HIP_OK(hipMemsetAsync(d_striped, 0, striped_bytes, s));
       GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
       const unsigned long long bound = frontier_e < (unsigned long long)n ? frontier_e : (unsigned long long)n;
       if (bound > 0) {
@@ -940,7 +943,6 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       }
       // the active set has been consumed: rewrite the active vector and the list for the next step
       GM_HIP_OK(hipMemsetAsync(d_active, 0, (size_t)nwords * 4, s));
-      GM_HIP_OK(hipMemsetAsync(d_striped, 0, striped_bytes, s));
       GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
       const unsigned long long bound = frontier_e < (unsigned long long)n ? frontier_e : (unsigned long long)n;
       if (bound > 0) {
@@ -1154,10 +1156,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
       // have more vertices than the current one has out-edges.  (If it turns out small without having
       // been listed, a k_frontier_list pass builds the list when it is needed.)
       const bool build_list = want_stats && frontier_e <= (4ull << 20);
-      if (want_stats) {
-        GM_HIP_OK(hipMemsetAsync(d_striped, 0, striped_bytes, s));
-        GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
-      }
+      if (want_stats) GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
       listed = build_list;
       // (a workgroup that lists changed vertices ends with one global atomic: fewer, longer-running workgroups then)
       const int apply_cap = build_list ? dev::kApplyMaxBlocks / 4 : dev::kApplyMaxBlocks;
@@ -1176,16 +1175,15 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         hipLaunchKernelGGL((dev::k_apply<P, U, V, false>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y, apply_bits,
                            d_vp, d_active, n_live, d_changed, (const int64_t*)nullptr, (unsigned long long*)nullptr, d_want,
                            (int32_t*)nullptr, (unsigned int*)nullptr);
-      if (n_live < n)  // setAllInactive for the rows k_apply does not visit
+      if (n_live < n && it == 0)  // setAllInactive for the rows k_apply does not visit (they have no edges: once clear, nothing sets them again)
         GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
       timer.mark(TAG_APPLY);
       lap("Apply time");
     }
     int converged = 0;
     if (iterations <= 0) {  // the flag only matters when running until convergence (:257-259)
-      if (want_stats)  // size of the next active set (written by k_apply), fetched with the flag
-        GM_HIP_OK(hipMemcpyAsync(h_striped, d_striped, striped_bytes, hipMemcpyDeviceToHost, s));
-      GM_HIP_OK(hipMemcpyAsync(h_changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, s));
+      // the flag and, behind it, the size of the next active set (written by k_apply): one copy
+      GM_HIP_OK(hipMemcpyAsync(h_changed, d_changed, want_stats ? sizeof(int) + striped_bytes : sizeof(int), hipMemcpyDeviceToHost, s));
       GM_HIP_OK(hipStreamSynchronize(s));
       if (want_stats) {
         frontier_v = frontier_e = frontier_maxdeg = 0;
