@@ -624,6 +624,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   unsigned long long* h_striped = (unsigned long long*)res_pinned + 64;
   unsigned long long frontier_v = 0, frontier_e = 0, frontier_maxdeg = 0;
   const int stats_grid = grid_for(n) < 2048 ? grid_for(n) : 2048;
+  const bool xsparse_candidate = xsparse_ok;  // (the same on every shard: program, run mode and exchange capabilities)
   if (xsparse_ok) {
     void* pg = nullptr;
     if (gm_graph_workspace(g, GM_WS_GATHER, (size_t)desc.nshards * dev::kSparseListCap * sizeof(xentry_t) + 256, &pg) == GM_OK) d_gather = (xentry_t*)pg;
@@ -664,6 +665,13 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
     xs_max = hf[1];
     xs_total = hf[2];
   };
+  if (xsparse_candidate) {
+    // a shard that had to give up the sparse exchange (a workspace it could not get) takes the others with it: from here
+    // on the shards must issue the same collectives (MIN over the shards of "still possible here")
+    int still = xsparse_ok ? 1 : 0;
+    gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &still);
+    if (!still) xsparse_ok = false;
+  }
   if (xsparse_ok) {
     int dummy = 0;
     exchange_state(&dummy);
