@@ -17,10 +17,14 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--staged", action="store_true", help="also time the two-stage schedule of a sharded run (tail rows, then head "
                     "rows, each multiplied / applied / sent separately) with an exchange that moves nothing, and the plain loop, by the wall clock")
+    ap.add_argument("--lib-option", action="append", default=[], metavar="KEY=VALUE", help="gm_set_option(KEY, VALUE) before the graphs are built (experiments)")
     args = ap.parse_args()
     import time
     from graphmat_amd import _lib, api
     L = _lib.lib()
+    for kv in args.lib_option:
+        k, v = kv.split("=")
+        _lib.check(L.gm_set_option(k.encode(), int(v)))
     nv, src, dst, _ = api.rmat_on_device(args.scale, 16, 1)
     for shard in args.shards:
         g = api.Graph(nv, src, dst, None, keep_values=False, nshards=args.nshards, shard=shard)
