@@ -95,7 +95,7 @@ inline int& last_rows_lanes() {
   return v;
 }
 
-// fused apply + send (kernels.hpp: k_apply_send) for ALL_VERTICES programs on one GPU: 1 = on
+// fused apply + send (kernels.hpp: k_apply_send) for ALL_VERTICES programs (single GPU, and the plain loop of sharded runs): 1 = on
 inline int& fuse_apply_send() {
   static int v = 1;
   return v;
@@ -799,6 +799,16 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         if (more && gm_graph_exchange(g, GM_XCHG_WAIT, xnext, (int64_t)sizeof(T), nullptr, nullptr) != 0) fail("message exchange wait failed");
         if (n_live < n) GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
         gp->do_every_iteration(it);
+        if (more) {
+          // the stages sent the next iteration's messages with the program as it was BEFORE do_every_iteration
+          // (GraphMatRuntime.h:236 runs it before the next send): a program that changed sends again, all rows at once
+          const dev::ProgArg<P> pa_next = dev::make_prog_arg(gp);
+          if (memcmp(pa_next.b, pa.b, sizeof(pa.b)) != 0) {
+            hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa_next, (const V*)d_vp,
+                               (const uint32_t*)nullptr, xnext, xbits, n_live, desc.row_lo);
+            if (gm_graph_exchange(g, GM_XCHG_MESSAGES, xnext, (int64_t)sizeof(T), xbits, nullptr) != 0) fail("message exchange callback failed");
+          }
+        }
         T* t = xcur; xcur = xnext; xnext = t;
       }
       hipLaunchKernelGGL(dev::k_fill_u32, dim3(grid_for(nwords)), dim3(dev::kBlock), 0, s, d_active, (int64_t)nwords, 0xffffffffu);
@@ -1173,7 +1183,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         hipLaunchKernelGGL((dev::k_apply<P, U, V, true>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y, apply_bits,
                            d_vp, d_active, n_live, d_changed, Asrc.rowptr, d_striped, d_want, build_list ? d_list : (int32_t*)nullptr,
                            build_list ? d_count : (unsigned int*)nullptr);
-      else if (dense_x && !multi && !lazy_send && !trace && fuse_apply_send() != 0 && !(iterations > 0 && it + 1 >= iterations)) {
+      else if (dense_x && !lazy_send && !trace && fuse_apply_send() != 0 && !(iterations > 0 && it + 1 >= iterations)) {
         // another iteration follows (or may follow): its messages come out of the same pass
         hipLaunchKernelGGL((dev::k_apply_send<P, T, U, V>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y, apply_bits,
                            d_vp, d_active, n_live, d_changed, d_want, x, xbits, desc.row_lo);

@@ -137,6 +137,20 @@ def test_apply_to_all_edges_with_several_ranks(tmp_path, nranks, transport):
     assert total == want_total
 
 
+@pytest.mark.parametrize("nranks,transport", [(2, "shm"), (3, "shm")])
+def test_programs_that_change_in_do_every_iteration_with_several_ranks(tmp_path, nranks, transport):
+    """apps/mutating_program.cpp with one process per shard: the sharded fixed-count runs take the two-stage schedule,
+    which sends the next iteration's messages before do_every_iteration has run -- a program whose send_message depends
+    on what do_every_iteration changes must get them re-sent (and the plain loop's fused apply + send must be dropped)."""
+    exe = os.path.join(ROOT, "build", "apps", "mutating_program")
+    if not os.path.exists(exe):
+        pytest.skip("mutating_program was not prebuilt")
+    outs = _launch(exe, [], nranks, tmp_path, transport)
+    for r, text in enumerate(outs):
+        assert "MUTATING PASS (rank %d of %d)" % (r, nranks) in text, text[-2500:]
+        assert "fuse_apply_send=1: steady ok, every-time ok, sometimes ok" in text
+
+
 def test_a_rank_that_waits_for_missing_peers_gets_an_error_not_a_hang(tmp_path):
     """gm_dist_init_from_env bounds the set-up of the communicator (GRAPHMAT_INIT_TIMEOUT): rank 0 of a declared world of
     two whose peer never starts must stop with a message, and a rank > 0 that finds only a STALE rendezvous file (older
