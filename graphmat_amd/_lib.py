@@ -36,7 +36,7 @@ class Csr(C.Structure):
                 ("ngchunk", C.c_int32), ("giant_edges", C.c_int64), ("short_row", C.c_int32), ("nmid_long", C.c_int32),
                 ("umid_row", C.c_void_p), ("numid", C.c_int32), ("numid_long", C.c_int32), ("tile_min_row", C.c_int32),
                 ("hot_base", C.c_int32), ("hot_len", C.c_int32), ("hot_slices", C.c_int32), ("hot_stride", C.c_int32),
-                ("gchunk_state", C.c_void_p), ("edges_blk", C.c_int64), ("edges_wave16", C.c_int64), ("edges_wave", C.c_int64)]
+                ("gchunk_state", C.c_void_p), ("edges_blk", C.c_int64), ("edges_wave16", C.c_int64), ("edges_wave", C.c_int64), ("rows_keep_stream", C.c_int32), ("pad2_", C.c_int32)]
 
 
 class RunStats(C.Structure):

@@ -30,6 +30,7 @@ int g_rank_by = 0;    // experiment: 0 rank vertices by total degree, 1 by out-d
 int g_tile_min_row = GM_TILE_MIN_ROW;  // rows of more than this many edges are tiled
 int g_tile_balance = 1;  // column tiles serve equally many gathers (1) or hold equally many vertices with edges (0)
 int g_long_mid = 0;  // > 0: experiment -- wave rows of more than this many edges get a wave each (0 = GM_LONG_MID rule)
+int g_own_wave_row = 0;  // column tiles: rows of more than this many edges (whole graph) keep the wave / giant kernels in every tile (0: classes per tile piece)
 int g_col_tiles = 0;  // default number of column tiles for graphs whose descriptor says 0 (0 = environment GRAPHMAT_COL_TILES, else none)
 
 constexpr int kT = 256;
@@ -226,28 +227,32 @@ k_deg_hist(const int64_t* __restrict__ rowptr, int nrows, unsigned int* __restri
 
 // segment starts (runs of rows, see gm_csr_t) and row classes
 __global__ void __launch_bounds__(kT)
-k_row_flags(const int64_t* __restrict__ rowptr, int nrows, int short_row, int giant_row,
+// (own_wave != null, column tiles with row classes fixed per ROW: a flagged row is a one-wave-per-row or giant row in
+// every tile, however short its piece, and no other row is -- gm_csr_t.rows_keep_stream)
+k_row_flags(const int64_t* __restrict__ rowptr, int nrows, int short_row, int giant_row, const unsigned char* __restrict__ own_wave,
             unsigned char* __restrict__ start, unsigned char* __restrict__ ismid, unsigned char* __restrict__ isgiant) {
   int r = blockIdx.x * kT + threadIdx.x;
   if (r >= nrows) return;
   int64_t a = rowptr[r], b = rowptr[r + 1];
-  bool lng = (b - a) > short_row;
+  const bool flagged = own_wave != nullptr && own_wave[r] && b > a;
+  bool lng = (b - a) > short_row || flagged;
   bool st = (r == 0) || ((r & 255) == 0) || lng;
   if (!st) {
     int64_t pa = rowptr[r - 1];
-    bool prev_long = (a - pa) > short_row;
+    bool prev_long = (a - pa) > short_row || (own_wave != nullptr && own_wave[r - 1] && a > pa);
     st = prev_long || (a / GM_BLOCK_NNZ != pa / GM_BLOCK_NNZ);
   }
+  const bool giant = (b - a) > giant_row && (own_wave == nullptr || flagged);
   start[r] = st ? 1 : 0;
-  ismid[r] = (lng && (b - a) <= giant_row) ? 1 : 0;
-  isgiant[r] = ((b - a) > giant_row) ? 1 : 0;
+  ismid[r] = (lng && !giant) ? 1 : 0;
+  isgiant[r] = giant ? 1 : 0;
 }
 
 // edges per kernel class of the multiply: [0] row-blocks (rows of <= short_row edges), [1] 16-rows-per-wave rows,
 // [2] one-wave-per-row rows (more than long_limit edges), [3] giant rows
 __global__ void __launch_bounds__(kT)
 k_class_edges(const int64_t* __restrict__ rowptr, int nrows, int short_row, int64_t long_limit, int giant_row,
-              unsigned long long* __restrict__ out) {
+              const unsigned char* __restrict__ own_wave, unsigned long long* __restrict__ out) {
   __shared__ unsigned long long s_c[4];
   if (threadIdx.x < 4) s_c[threadIdx.x] = 0ull;
   __syncthreads();
@@ -255,12 +260,20 @@ k_class_edges(const int64_t* __restrict__ rowptr, int nrows, int short_row, int6
   if (r < nrows) {
     const int64_t len = rowptr[r + 1] - rowptr[r];
     if (len > 0) {
-      const int cls = len <= short_row ? 0 : len > giant_row ? 3 : len > long_limit ? 2 : 1;
+      int cls = len <= short_row ? 0 : len > giant_row ? 3 : len > long_limit ? 2 : 1;
+      if (own_wave != nullptr) cls = own_wave[r] ? (len > giant_row ? 3 : 2) : (len <= short_row ? 0 : 1);
       atomicAdd(&s_c[cls], (unsigned long long)len);
     }
   }
   __syncthreads();
   if (threadIdx.x < 4 && s_c[threadIdx.x]) atomicAdd(&out[threadIdx.x], s_c[threadIdx.x]);
+}
+
+// rows of more than `limit` edges in the whole graph (column tiles with row classes fixed per row)
+__global__ void __launch_bounds__(kT)
+k_own_wave_rows(const int64_t* __restrict__ rowptr, int nrows, int64_t limit, unsigned char* __restrict__ flag) {
+  int r = blockIdx.x * kT + threadIdx.x;
+  if (r < nrows) flag[r] = (rowptr[r + 1] - rowptr[r] > limit) ? 1 : 0;
 }
 
 // presence bits of the non-empty rows (bit r&31 of word r>>5)
@@ -291,12 +304,12 @@ k_last_long(const int32_t* __restrict__ mid_row, int nmid, const int64_t* __rest
 
 __global__ void __launch_bounds__(kT)
 k_mid_long_flags(const int32_t* __restrict__ mid_row, int nmid, const int64_t* __restrict__ rowptr, int64_t limit, int64_t max_len,
-                 unsigned char* __restrict__ is_long, unsigned char* __restrict__ is_rest) {
+                 const unsigned char* __restrict__ own_wave, unsigned char* __restrict__ is_long, unsigned char* __restrict__ is_rest) {
   const int i = blockIdx.x * kT + threadIdx.x;
   if (i >= nmid) return;
   const int r = mid_row[i];
   const int64_t len = rowptr[r + 1] - rowptr[r];
-  const bool keep = len <= max_len, lg = len > limit;
+  const bool keep = len <= max_len, lg = own_wave != nullptr ? own_wave[r] != 0 : len > limit;
   is_long[i] = (keep && lg) ? 1 : 0;
   is_rest[i] = (keep && !lg) ? 1 : 0;
 }
@@ -313,12 +326,12 @@ k_giant_extent(const int32_t* __restrict__ giant_row, int ngiant, const int64_t*
 // a segment is a row-block iff its first row is short and it holds at least one edge
 __global__ void __launch_bounds__(kT)
 k_seg_flags(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ seg_row, int nseg, int short_row,
-            unsigned char* __restrict__ isblk) {
+            const unsigned char* __restrict__ own_wave, unsigned char* __restrict__ isblk) {
   int i = blockIdx.x * kT + threadIdx.x;
   if (i >= nseg) return;
   int r0 = seg_row[i], r1 = seg_row[i + 1];
   int64_t n = rowptr[r1] - rowptr[r0];
-  bool longrow = (r1 - r0 == 1) && n > short_row;
+  bool longrow = (r1 - r0 == 1) && (n > short_row || (own_wave != nullptr && own_wave[r0]));
   isblk[i] = (!longrow && n > 0) ? 1 : 0;
 }
 
@@ -346,12 +359,12 @@ static int bits_for(uint32_t maxval) {
 // out = [entries of mid_row whose row has more than long_limit edges][the others], both in list order,
 // keeping only rows of at most max_len edges; *n_long / *n_total = sizes
 static int partition_mid(const int32_t* mid_row, int nmid, const int64_t* rowptr, int64_t long_limit, int64_t max_len,
-                         int32_t* out, int* n_long, unsigned int* n_total, hipStream_t s) {
+                         int32_t* out, int* n_long, unsigned int* n_total, hipStream_t s, const unsigned char* own_wave = nullptr) {
   DevBuf fl, fs, tmp, cnt;
   int rc;
   if ((rc = fl.alloc((size_t)nmid)) || (rc = fs.alloc((size_t)nmid)) || (rc = cnt.alloc(16))) return rc;
   hipLaunchKernelGGL(k_mid_long_flags, dim3(grid_for(nmid)), dim3(kT), 0, s, mid_row, nmid, rowptr, long_limit, max_len,
-                     fl.as<unsigned char>(), fs.as<unsigned char>());
+                     own_wave, fl.as<unsigned char>(), fs.as<unsigned char>());
   size_t tb = 0;
   GM_TRY_HIP(rocprim::select(nullptr, tb, mid_row, fl.as<unsigned char>(), out, cnt.as<unsigned int>(), (size_t)nmid, s));
   if ((rc = tmp.alloc(tb + 256))) return rc;
@@ -368,7 +381,7 @@ static int partition_mid(const int32_t* mid_row, int nmid, const int64_t* rowptr
 }
 
 static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* idx_sorted, unsigned long long kept,
-                      const void* d_val, hipStream_t s, CsrOwned* out, int tile_split = -1);
+                      const void* d_val, hipStream_t s, CsrOwned* out, int tile_split = -1, const unsigned char* own_wave = nullptr);
 static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* idx_sorted, unsigned long long kept,
                        const void* d_val, hipStream_t s, const CsrOwned* whole);
 
@@ -564,8 +577,9 @@ static int build_direction_local(gm_graph* g, int by_dst, int64_t nnz, const int
 // CSR arrays and work decomposition from `kept` sorted keys (row << 32 | native col) and, for the
 // edge values, the input position of every sorted edge.
 // tile_split >= 0 (whole-graph CSR of a tiled graph): also list the wave rows of at most tile_split edges.
+// own_wave != null (a column tile): row classes fixed per row, see k_row_flags.
 static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* idx_sorted, unsigned long long kept,
-                      const void* d_val, hipStream_t s, CsrOwned* out, int tile_split) {
+                      const void* d_val, hipStream_t s, CsrOwned* out, int tile_split, const unsigned char* own_wave) {
   const int short_row = g_short_row;
   const gm_graph_desc_t& D = g->desc;
   const int nrows = D.row_hi - D.row_lo;
@@ -624,7 +638,7 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
   unsigned int nseg = 0, nblk = 0, nmid = 0, ngiant = 0;
   if (nrows > 0) {
     hipLaunchKernelGGL(k_row_flags, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr.as<int64_t>(), nrows, short_row,
-                       giant_row, f0.as<unsigned char>(), f1.as<unsigned char>(), f2.as<unsigned char>());
+                       giant_row, own_wave, f0.as<unsigned char>(), f1.as<unsigned char>(), f2.as<unsigned char>());
     GM_TRY_HIP(hipGetLastError());
     rocprim::counting_iterator<int32_t> ids(0);
     size_t tb = 0;
@@ -648,7 +662,7 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
     // row-blocks = the segments that hold short rows with at least one edge
     if ((rc = blkl.alloc((size_t)(nseg + 1) * 4))) return rc;
     hipLaunchKernelGGL(k_seg_flags, dim3(grid_for(nseg)), dim3(kT), 0, s, rowptr.as<int64_t>(), seg.as<int32_t>(),
-                       (int)nseg, short_row, f0.as<unsigned char>());
+                       (int)nseg, short_row, own_wave, f0.as<unsigned char>());
     GM_TRY_HIP(rocprim::select(tmp.p, tb, ids, f0.as<unsigned char>(), blkl.as<int32_t>(), cnt.as<unsigned int>() + 3,
                                (size_t)nseg, s));
     GM_TRY_HIP(hipMemcpyAsync(h, cnt.as<unsigned int>() + 3, 4, hipMemcpyDeviceToHost, s));
@@ -673,7 +687,7 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
       DevBuf mid2;
       if ((rc = mid2.alloc((size_t)(nrows + 1) * 4))) return rc;
       unsigned int n_all = 0;
-      if ((rc = partition_mid(mid.as<int32_t>(), (int)nmid, rowptr.as<int64_t>(), long_limit, (int64_t)1 << 62, mid2.as<int32_t>(), &nmid_long, &n_all, s))) return rc;
+      if ((rc = partition_mid(mid.as<int32_t>(), (int)nmid, rowptr.as<int64_t>(), long_limit, (int64_t)1 << 62, mid2.as<int32_t>(), &nmid_long, &n_all, s, own_wave))) return rc;
       if (tile_split >= 0) {  // the wave rows that stay untiled, same layout
         if ((rc = umid.alloc((size_t)(nmid + 1) * 4))) return rc;
         if ((rc = partition_mid(mid.as<int32_t>(), (int)nmid, rowptr.as<int64_t>(), long_limit, (int64_t)tile_split, umid.as<int32_t>(), &numid_long, &numid, s))) return rc;
@@ -698,7 +712,7 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
     GM_TRY_HIP(hipMemsetAsync(cls.p, 0, 32, s));
     if (nrows > 0)
       hipLaunchKernelGGL(k_class_edges, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr.as<int64_t>(), nrows, short_row, long_limit, giant_row,
-                         cls.as<unsigned long long>());
+                         own_wave, cls.as<unsigned long long>());
     GM_TRY_HIP(hipMemcpyAsync(h_class, cls.p, 32, hipMemcpyDeviceToHost, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
   }
@@ -781,6 +795,8 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
   v.edges_blk = (int64_t)h_class[0];
   v.edges_wave16 = (int64_t)h_class[1];
   v.edges_wave = (int64_t)h_class[2];
+  v.rows_keep_stream = own_wave != nullptr ? 1 : 0;
+  v.pad2_ = 0;
   v.hot_base = 0;
   v.hot_len = D.ndevice;
   v.hot_slices = 1;
@@ -867,6 +883,20 @@ static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t*
   for (int t = 0; t < T; t++) largest = std::max(largest, h_bounds[t + 1] - h_bounds[t]);
   DevBuf keys_t, idx_t;
   if ((rc = keys_t.alloc((size_t)largest * 8)) || (rc = idx_t.alloc((size_t)largest * 4))) return rc;
+  // Row classes fixed per row (g_own_wave_row > 0): a row of more than that many edges in the WHOLE graph is worked on
+  // by the one-wave-per-row / giant kernels in every tile, all other rows by the row-block / 16-row kernels in every
+  // tile -- the two groups then never touch the same y entry, and the engine can run them on two streams through all
+  // tiles of an iteration without joining them after every tile.
+  DevBuf own;
+  const unsigned char* own_wave = nullptr;
+  int own_limit = g_own_wave_row;
+  if (own_limit == 0) { const char* e = getenv("GRAPHMAT_OWN_WAVE_ROW"); if (e) own_limit = atoi(e); }
+  if (own_limit > 0 && nrows > 0) {
+    if ((rc = own.alloc((size_t)nrows))) return rc;
+    hipLaunchKernelGGL(k_own_wave_rows, dim3(grid_for(nrows)), dim3(kT), 0, s, (const int64_t*)whole->rowptr, nrows, (int64_t)own_limit,
+                       own.as<unsigned char>());
+    own_wave = own.as<unsigned char>();
+  }
   uint32_t* prev = nullptr;
   GM_TRY_HIP(hipMalloc((void**)&prev, (size_t)nw * 4));
   GM_TRY_HIP(hipMemsetAsync(prev, 0, (size_t)nw * 4, s));
@@ -876,7 +906,7 @@ static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t*
     if (n > 0)
       hipLaunchKernelGGL(k_tile_gather, dim3(grid_for(n)), dim3(kT), 0, s, keys_sorted, idx_sorted,
                          (const uint32_t*)pos_out.as<uint32_t>() + h_bounds[t], n, keys_t.as<uint64_t>(), idx_t.as<uint32_t>());
-    if ((rc = finish_csr(g, keys_t.as<uint64_t>(), idx_t.as<uint32_t>(), (unsigned long long)n, d_val, s, &g->out_tiles[t]))) return rc;
+    if ((rc = finish_csr(g, keys_t.as<uint64_t>(), idx_t.as<uint32_t>(), (unsigned long long)n, d_val, s, &g->out_tiles[t], -1, own_wave))) return rc;
     gm_csr_t& v = g->out_tiles[t].view;
     v.hot_base = g->tile_base[t];
     v.hot_len = g->tile_base[t + 1] - g->tile_base[t];

@@ -18,7 +18,7 @@
 
 namespace gm {
 
-extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance;
+extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance, g_own_wave_row;
 static int g_force_ordered = 0;
 
 // ---------------- PageRank (reference: src/PageRank.cpp:34-112) ----------------------------
@@ -590,6 +590,7 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "tile_balance") && value >= 0 && value <= 100400) { gm::g_tile_balance = value; return GM_OK; }
   if (key && !strcmp(key, "tile_min_row") && (value == 0 || value >= gm::g_short_row)) { gm::g_tile_min_row = value; return GM_OK; }
   if (key && !strcmp(key, "col_tiles") && value >= 0 && value <= GM_MAX_TILES) { gm::g_col_tiles = value; return GM_OK; }
+  if (key && !strcmp(key, "own_wave_row") && value >= 0) { gm::g_own_wave_row = value; return GM_OK; }
   if (key && !strcmp(key, "push_edge_permille") && value >= 0 && value <= 1000) { GraphMat::detail::push_edge_permille() = value; return GM_OK; }
   if (key && !strcmp(key, "bits_step_edges") && value >= 0) { GraphMat::detail::bits_step_edges() = value; return GM_OK; }
   if (key && !strcmp(key, "fuse_apply_send") && (value == 0 || value == 1)) { GraphMat::detail::fuse_apply_send() = value; return GM_OK; }

@@ -185,6 +185,10 @@ struct AuxStream {
   // the column-tile loop: per tile the kernels are small and each ends with a tail of a few busy waves -- overlapping the
   // one-wave-per-row kernel with the throughput-bound ones is worth 3 % at RMAT-26; untiled it costs 3-15 %)
   bool long_rows = false;
+  // keep: the passes launched next belong to a run of column-tile passes whose row classes are fixed per row
+  // (gm_csr_t.rows_keep_stream): the giant and one-wave-per-row kernels ALWAYS go to this stream, it is forked once
+  // (`forked`) and nobody waits for it until the caller joins after the last tile (`pending`)
+  bool keep = false, forked = false, pending = false;
   // defer: the giant-row passes launched next are not waited for by their launch_spmv call; whoever needs their
   // rows calls wait_join (the two-stage schedule starts them before the tail stage and joins before the head apply)
   bool defer = false;
@@ -314,20 +318,24 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
   constexpr int WPB = dev::kBlock / 64;  // rows (waves) per workgroup of k_spmv_wave
   if (A.nnz == 0) return;
   const bool defer = aux != nullptr && aux->s != nullptr && aux->defer;
-  const bool overlap = aux != nullptr && aux->s != nullptr && A.ngiant > 0 && (defer || A.nblk > 0 || A.nmid > 0);
+  const bool keep = aux != nullptr && aux->s != nullptr && aux->keep;
+  const bool overlap = aux != nullptr && aux->s != nullptr && A.ngiant > 0 && (defer || keep || A.nblk > 0 || A.nmid > 0);
   // The long wave rows (one wave each, serial in the row's length: the launch ends with a tail in which a few waves
   // finish their rows on an otherwise idle chip) go to the auxiliary stream as well, behind the giant passes, while the
   // throughput-bound row-block and 16-rows-per-wave kernels run on the main stream.
   bool long_on_aux = false;
   if constexpr (wave16_ok<U, USE_VP, RK>())
     long_on_aux = aux != nullptr && aux->s != nullptr && aux->long_rows && !defer && !(grouped && want != nullptr) && A.nmid > 0 && A.nmid_long > 0 &&
-                  (A.nblk > 0 || A.nmid > A.nmid_long) && !(debug_flags() & dev::DBG_NO_WAVE16);
+                  (keep || A.nblk > 0 || A.nmid > A.nmid_long) && !(debug_flags() & dev::DBG_NO_WAVE16);
   bool forked = false;
   auto fork_aux = [&]() {
     if (forked) return;
-    GM_HIP_OK(hipEventRecord(aux->fork, s));
-    GM_HIP_OK(hipStreamWaitEvent(aux->s, aux->fork, 0));
+    if (!(keep && aux->forked)) {
+      GM_HIP_OK(hipEventRecord(aux->fork, s));
+      GM_HIP_OK(hipStreamWaitEvent(aux->s, aux->fork, 0));
+    }
     forked = true;
+    if (keep) aux->forked = true;
   };
   if (A.ngiant > 0) {
     hipStream_t gs = s;
@@ -487,7 +495,9 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
     (*launches)++;
     if (timer && !long_on_aux) timer->mark(TAG_WAVE);
   }
-  if ((overlap && !defer) || long_on_aux) GM_HIP_OK(hipStreamWaitEvent(s, aux->join, 0));
+  if (keep) {
+    if (overlap || long_on_aux) aux->pending = true;  // (joined by the caller after the last tile)
+  } else if ((overlap && !defer) || long_on_aux) GM_HIP_OK(hipStreamWaitEvent(s, aux->join, 0));
   if (long_on_aux && timer) timer->mark(TAG_WAVE);  // the wave rows are done when both streams are
 }
 
@@ -1124,6 +1134,25 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         if (dense_x && !multi && row_bits == nullptr && rk != REDUCE_LAST && dev::stageable<T>::value && !(debug_flags() & dev::DBG_NO_TILES))
           gm_graph_tiles(g, GM_DIR_OUT, &ntile);
         if (ntile > 1) {
+          // Tiles whose row classes are fixed per row (gm_csr_t.rows_keep_stream): the giant / one-wave-per-row kernels
+          // and the row-block / 16-row kernels never touch the same y entry, so the auxiliary stream is forked once --
+          // before the untiled pass -- and joined once after the last tile instead of after every tile, where the main
+          // stream used to wait 70-120 us per tile for the tail of the one-wave-per-row kernel.
+          bool keep_streams = aux.s != nullptr && !use_vp && (rk == REDUCE_ORDERED || rk == REDUCE_F32_ADD) && std::is_trivially_copyable<U>::value &&
+                              (sizeof(U) == 4 || sizeof(U) == 8) && !rk_unverified &&
+                              !(debug_flags() & (dev::DBG_NO_WAVE16 | dev::DBG_LONG_ON_MAIN | dev::DBG_NO_OVERLAP));
+          for (int t = 0; t < ntile && keep_streams; t++) {
+            gm_csr_t At;
+            const uint32_t* prev = nullptr;
+            if (gm_graph_tile(g, GM_DIR_OUT, t, &At, &prev) != GM_OK || !At.rows_keep_stream) keep_streams = false;
+          }
+          if (keep_streams) {
+            aux.keep = true;
+            aux.pending = false;
+            GM_HIP_OK(hipEventRecord(aux.fork, s));  // x is complete here: the auxiliary stream may start on tile 0 during the untiled pass
+            GM_HIP_OK(hipStreamWaitEvent(aux.s, aux.fork, 0));
+            aux.forked = true;
+          }
           gm_csr_t As = Aout;  // the rows that are not tiled: row-blocks and the shorter wave rows
           As.mid_row = Aout.umid_row; As.nmid = Aout.numid; As.nmid_long = Aout.numid_long; As.ngiant = 0; As.ngchunk = 0;
           if (Aout.tile_min_row == 0) { As.nblk = 0; As.nmid = 0; }  // every row is tiled
@@ -1143,6 +1172,10 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
             else launch_spmv<P, T, U, V, E, false>(g, pa, At, xq, xb, d_vp, y, pb, tacc, s, &st.spmv_launches, &timer, &aux, rk);
           }
           aux.long_rows = false;
+          if (aux.keep) {
+            if (aux.pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
+            aux.keep = aux.forked = aux.pending = false;
+          }
           // (a probed strategy is cross-checked against the ordered fold of the WHOLE rows; a mismatch redoes this
           // iteration untiled with the ordered fold, which then also governs the tiled iterations that follow)
           check_probed(Aout, Aout.rowbits, nullptr, acc, ybits);
