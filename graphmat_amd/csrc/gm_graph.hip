@@ -30,7 +30,7 @@ int g_rank_by = 0;    // experiment: 0 rank vertices by total degree, 1 by out-d
 int g_tile_min_row = GM_TILE_MIN_ROW;  // rows of more than this many edges are tiled
 int g_tile_balance = 1;  // column tiles serve equally many gathers (1) or hold equally many vertices with edges (0)
 int g_long_mid = 0;  // > 0: experiment -- wave rows of more than this many edges get a wave each (0 = GM_LONG_MID rule)
-int g_own_wave_row = 0;  // column tiles: rows of more than this many edges (whole graph) keep the wave / giant kernels in every tile (0: classes per tile piece)
+int g_own_wave_row = 4096;  // column tiles: rows of more than this many edges (whole graph) keep the wave / giant kernels in every tile (0: classes per tile piece)
 int g_col_tiles = 0;  // default number of column tiles for graphs whose descriptor says 0 (0 = environment GRAPHMAT_COL_TILES, else none)
 
 constexpr int kT = 256;
@@ -966,11 +966,13 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
   if (T == 0) { const char* e = getenv("GRAPHMAT_COL_TILES"); if (e) T = atoi(e); }
   if (T == 0) {
     // automatic: tiles pay once the live part of a 4-byte message vector outgrows what the caches hold.  Measured,
-    // PageRank on RMAT with tiles that serve equally many gathers (best tile count, GTEPS against untiled): RMAT-24
-    // (34 MiB live) none; RMAT-25 (65 MiB) 4: 156 vs 154; RMAT-26 (125 MiB) 6: 159 vs 140; RMAT-27 (239 MiB) 10: 151 vs 116
-    // -- about one tile per 28 MiB on top of 1.6, from 60 MiB on
+    // PageRank on RMAT with tiles that serve equally many gathers and row classes fixed per row (g_own_wave_row; ms per
+    // iteration by tile count): RMAT-24 (34 MiB live) 1 / 3 / 4: 1.67 / 1.85 / 1.84; RMAT-25 (65 MiB) 4 / 5 / 6 / 7: 3.41 /
+    // 3.38 / 3.39 / 3.46; RMAT-26 (125 MiB) 5 / 6 / 7 / 8 / 9 / 10 / 12: 6.31 / 6.18 / 6.24 / 6.09-6.13 / 6.14 / 6.09 / 6.21;
+    // RMAT-27 (239 MiB) 10 / 12 / 14 / 16: 13.24 / 13.24 / 12.99 / 13.03 -- about one tile per 17 MiB, from 60 MiB on
+    // (with the auxiliary stream joined after every tile the optimum was fewer, larger tiles: 4 / 6 / 10)
     const double mib = (double)nz * 4.0 / 1048576.0;
-    T = mib >= 60.0 ? (int)(1.6 + mib / 28.4 + 0.5) : 1;
+    T = mib >= 60.0 ? (int)(0.6 + mib / 17.0 + 0.5) : 1;
   }
   if (T < 1 || G > 1 || nz < 2) T = 1;
   if (T > GM_MAX_TILES) T = GM_MAX_TILES;
