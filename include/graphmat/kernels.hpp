@@ -1810,15 +1810,6 @@ k_frontier_stats(const uint32_t* __restrict__ active, const int64_t* __restrict_
   if (list != nullptr) blist.init();
   unsigned long long cnt = 0, edges = 0, mx = 0;
   for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n; base += (int64_t)gridDim.x * kBlock) {
-    // (a traversal starts from one vertex: the workgroup's kBlock bits are eight words at a uniform address -- nothing
-    // set, nothing to do; 84 -> ~10 us for the 33 M live vertices of RMAT-26)
-    {
-      const int w0 = (int)(base >> 5), nw = (n + 31) >> 5;
-      uint32_t any = 0;
-#pragma unroll
-      for (int k = 0; k < kBlock / 32; k++) any |= (w0 + k < nw) ? active[w0 + k] : 0u;
-      if (any == 0u) continue;
-    }
     const int64_t i = base + threadIdx.x;
     const bool act = i < n && bit_get(active, (int)i);
     if (act) {
