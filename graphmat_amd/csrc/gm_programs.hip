@@ -594,6 +594,7 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "push_edge_permille") && value >= 0 && value <= 1000) { GraphMat::detail::push_edge_permille() = value; return GM_OK; }
   if (key && !strcmp(key, "bits_step_edges") && value >= 0) { GraphMat::detail::bits_step_edges() = value; return GM_OK; }
   if (key && !strcmp(key, "fuse_apply_send") && (value == 0 || value == 1)) { GraphMat::detail::fuse_apply_send() = value; return GM_OK; }
+  if (key && !strcmp(key, "untiled_pass_plain") && (value == 0 || value == 1)) { GraphMat::detail::untiled_pass_plain() = value; return GM_OK; }
   if (key && !strcmp(key, "last_rows_lanes") && (value == 8 || value == 16)) { GraphMat::detail::last_rows_lanes() = value; return GM_OK; }
   if (key && !strcmp(key, "sparse_step_edges") && value >= 0) { GraphMat::detail::sparse_step_edges() = value; return GM_OK; }
   if (key && !strcmp(key, "wave16_form") && value >= 0 && (value & 15) <= 5 && value < 32) { GraphMat::detail::wave16_form() = value; return GM_OK; }

@@ -101,6 +101,15 @@ inline int& fuse_apply_send() {
   return v;
 }
 
+// keep mode: the untiled short-row pass through the plain row-block kernel (1) instead of the persistent one (0).  The
+// persistent kernel's hot set is the top of tile 0 only and serves few of that pass's gathers, while its 115 KB of LDS per
+// CU slow the giant kernels of the first tile that run next to it (1.08 ms against 0.3 ms alone): RMAT-26 6.09-6.14 ->
+// 6.05-6.10 ms, the auxiliary stream's kernels 5.70 -> 5.20 ms in sum
+inline int& untiled_pass_plain() {
+  static int v = 1;
+  return v;
+}
+
 // top-down steps are taken while the active set owns less than this many thousandths of the edges
 inline int& push_edge_permille() {
   static int v = 50;
@@ -399,7 +408,9 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
       // persistent workgroups sharing a large LDS hot set, row-blocks taken by waves (kernels.hpp: k_spmv_rowwave)
       const int form = rowwave_form() & 15;
       const bool any_size = (rowwave_form() & 16) != 0;  // (tests: also for small graphs)
-      if (form > 0 && xbits == nullptr && want == nullptr && !program_row_filter<P>::enabled && (persistent_forms_pay(A) || any_size)) {
+      const bool whole_cols = A.hot_base == 0 && A.hot_len >= A.ncols;  // (not a column tile: the untiled pass of a tiled graph, or an untiled graph)
+      if (form > 0 && xbits == nullptr && want == nullptr && !program_row_filter<P>::enabled && (persistent_forms_pay(A) || any_size) &&
+          !(whole_cols && keep && untiled_pass_plain() != 0)) {
         auto persistent = [&](auto block_c, auto hot_c, int fit) {
           constexpr int BLOCK = decltype(block_c)::value, HOT = decltype(hot_c)::value;
           const int per_cu = persist_per_cu() > 0 && persist_per_cu() < fit ? persist_per_cu() : fit;
