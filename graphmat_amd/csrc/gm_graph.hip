@@ -969,10 +969,11 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     // PageRank on RMAT with tiles that serve equally many gathers and row classes fixed per row (g_own_wave_row; ms per
     // iteration by tile count): RMAT-24 (34 MiB live) 1 / 3 / 4: 1.67 / 1.85 / 1.84; RMAT-25 (65 MiB) 4 / 5 / 6 / 7: 3.41 /
     // 3.38 / 3.39 / 3.46; RMAT-26 (125 MiB) 5 / 6 / 7 / 8 / 9 / 10 / 12: 6.31 / 6.18 / 6.24 / 6.09-6.13 / 6.14 / 6.09 / 6.21;
-    // RMAT-27 (239 MiB) 10 / 12 / 14 / 16: 13.24 / 13.24 / 12.99 / 13.03 -- about one tile per 17 MiB, from 60 MiB on
+    // RMAT-27 (239 MiB) 10 / 12 / 14 / 16: 13.24 / 13.24 / 12.99 / 13.03; RMAT-25 with the persistent kernels 4 / 5 / 6 / 7 / 8:
+    // 3.18 / 3.10 / 3.15 / 3.31 / 3.31 -- about one tile per 17 MiB on top of one, from 60 MiB on
     // (with the auxiliary stream joined after every tile the optimum was fewer, larger tiles: 4 / 6 / 10)
     const double mib = (double)nz * 4.0 / 1048576.0;
-    T = mib >= 60.0 ? (int)(0.6 + mib / 17.0 + 0.5) : 1;
+    T = mib >= 60.0 ? (int)(1.0 + mib / 17.0 + 0.5) : 1;
   }
   if (T < 1 || G > 1 || nz < 2) T = 1;
   if (T > GM_MAX_TILES) T = GM_MAX_TILES;

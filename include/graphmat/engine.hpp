@@ -68,7 +68,10 @@ inline int& persist_per_cu() {
 // they pay once the message vector is far larger than the caches, i.e. where the column tiles are many.
 // Not on shards: their hot set is the first entries of EVERY slice of x (a slice lookup per gather) and they are not
 // tiled -- a shard of 8 of RMAT-26 multiplies in 1.11 ms with the plain kernels, 1.30 ms with the persistent ones.
-inline bool persistent_forms_pay(const gm_csr_t& A) { return (int64_t)A.ncols >= (48ll << 20) && A.hot_slices <= 1; }
+// (column tiles with row classes fixed per row -- the two-stream schedule -- from 24 M ids on: RMAT-25, 5 tiles, 3.39 -> 3.10 ms)
+inline bool persistent_forms_pay(const gm_csr_t& A) {
+  return A.hot_slices <= 1 && ((int64_t)A.ncols >= (48ll << 20) || ((int64_t)A.ncols >= (24ll << 20) && A.rows_keep_stream != 0));
+}
 inline int cu_count() {
   static int n = 0;
   if (n == 0) {
