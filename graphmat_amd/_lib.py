@@ -36,7 +36,7 @@ class Csr(C.Structure):
                 ("ngchunk", C.c_int32), ("giant_edges", C.c_int64), ("short_row", C.c_int32), ("nmid_long", C.c_int32),
                 ("umid_row", C.c_void_p), ("numid", C.c_int32), ("numid_long", C.c_int32), ("tile_min_row", C.c_int32),
                 ("hot_base", C.c_int32), ("hot_len", C.c_int32), ("hot_slices", C.c_int32), ("hot_stride", C.c_int32),
-                ("gchunk_state", C.c_void_p), ("edges_blk", C.c_int64), ("edges_wave16", C.c_int64), ("edges_wave", C.c_int64), ("rows_keep_stream", C.c_int32), ("pad2_", C.c_int32)]
+                ("gchunk_state", C.c_void_p), ("edges_blk", C.c_int64), ("edges_wave16", C.c_int64), ("edges_wave", C.c_int64), ("rows_keep_stream", C.c_int32), ("cold_from", C.c_int32)]
 
 
 class RunStats(C.Structure):
@@ -127,13 +127,16 @@ def lib():
     """Load the C-ABI library.  Raises (never falls back) if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(SO):
+        so = os.environ.get("GRAPHMAT_HIP_LIBRARY") or SO  # (experiments: an ablation build, graphmat_amd/build.py)
+        if so != SO:
+            print("graphmat_amd: loading %s instead of the product library" % so, flush=True)
+        if not os.path.exists(so):
             raise RuntimeError("libgraphmat_hip.so is missing: build it with `python -m graphmat_amd.build` "
                                "(hipcc, gfx950).  graphmat_amd has no CPU fallback.")
         # torch ships its own HIP runtime; import it first so this library binds to the same
         # libamdhip64 instead of bringing a second runtime into the process.
         import torch  # noqa: F401
-        L = C.CDLL(SO)
+        L = C.CDLL(so)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it
             fn.restype = res

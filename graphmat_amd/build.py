@@ -24,12 +24,18 @@ def _deps():
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = FLAGS + (["-DGRAPHMAT_ABLATION"] if os.environ.get("GRAPHMAT_ABLATION") == "1" else [])  # in-kernel ablation switches
+    ablation = os.environ.get("GRAPHMAT_ABLATION") == "1"
+    # in-kernel ablation switches: a separate library under build/ablation/ (experiments load it with
+    # GRAPHMAT_HIP_LIBRARY=...), the product library is never an ablation build
+    flags = FLAGS + (["-DGRAPHMAT_ABLATION"] if ablation else [])
+    objdir = os.path.join(ROOT, "build", "ablation") if ablation else CSRC
+    so = os.path.join(objdir, "libgraphmat_hip.so") if ablation else SO
+    os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
     deps_mtime = max(os.path.getmtime(p) for p in _deps())
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         if (not force) and os.path.exists(obj) and os.path.getmtime(obj) >= deps_mtime:
             continue
@@ -44,12 +50,12 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s" % src)
         elif verbose and out:
             sys.stderr.write(out.decode())
-    if procs or not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(o) for o in objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl", "-lrt"]
+    if procs or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(o) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs + ["-ldl", "-lrt"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return SO
+    return so
 
 
 if __name__ == "__main__":

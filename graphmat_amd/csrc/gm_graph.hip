@@ -796,7 +796,7 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
   v.edges_wave16 = (int64_t)h_class[1];
   v.edges_wave = (int64_t)h_class[2];
   v.rows_keep_stream = own_wave != nullptr ? 1 : 0;
-  v.pad2_ = 0;
+  v.cold_from = 0;
   v.hot_base = 0;
   v.hot_len = D.ndevice;
   v.hot_slices = 1;

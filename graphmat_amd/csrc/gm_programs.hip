@@ -602,6 +602,8 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "persist_per_cu") && value >= 0 && value <= 8) { GraphMat::detail::persist_per_cu() = value; return GM_OK; }
   if (key && !strcmp(key, "giant_maps") && (value == 0 || value == 1)) { GraphMat::detail::giant_maps() = value; return GM_OK; }
   if (key && !strcmp(key, "iteration_trace") && (value == 0 || value == 1)) { GraphMat::detail::iteration_trace() = value; return GM_OK; }
+  if (key && !strcmp(key, "ablate_cold_from") && value >= 0) { GraphMat::detail::ablate_cold_from() = value; return GM_OK; }
+  if (key && !strcmp(key, "ordered_giant_two_pass") && (value == 0 || value == 1)) { GraphMat::detail::ordered_giant_two_pass() = value; return GM_OK; }
   if (key && !strcmp(key, "debug_flags")) { GraphMat::detail::debug_flags() = value; return GM_OK; }
   gm::set_error("gm_set_option: unknown option");
   return GM_ERR_INVALID;

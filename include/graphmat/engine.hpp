@@ -20,7 +20,26 @@ namespace GraphMat {
 enum edge_direction { OUT_EDGES, IN_EDGES, ALL_EDGES };  // GraphProgram.h:34
 enum activity_type { ACTIVE_ONLY, ALL_VERTICES };        // GraphProgram.h:36
 
+template <class T, class U, class V, class E>
+class GraphProgram;  // include/GraphProgram.h
+
 namespace detail {
+
+// Does program P leave do_every_iteration to the base class (whose hook is empty)?  Only then may the engine compute
+// messages of iteration i+1 BEFORE the hook of iteration i has run (the fused apply + send pass, the two-stage sharded
+// schedule): the reference always runs do_every_iteration before the next send (GraphMatRuntime.h:236), and a hook
+// may change state send_message reads that no comparison of the program object's bytes can see (a pointer member's
+// target, a global).  A class-type test, evaluated at compile time: &P::do_every_iteration names the base's member
+// exactly when no class between GraphProgram and P declares one.
+template <class F>
+struct member_class_of;
+template <class C, class R, class... A>
+struct member_class_of<R (C::*)(A...)> { typedef C type; };
+template <class P>
+constexpr bool inherits_iteration_hook() {
+  typedef GraphProgram<typename P::message_type, typename P::message_reduction_type, typename P::vertex_property_type, typename P::edge_type> Base;
+  return std::is_same<typename member_class_of<decltype(&P::do_every_iteration)>::type, Base>::value;
+}
 
 #define GM_HIP_OK(expr)                                                                         \
   do {                                                                                          \
@@ -55,6 +74,11 @@ inline int& giant_maps() {
 // 20480-entry LDS hot set (large graphs: persistent_forms_pay)
 inline int& rowwave_form() {
   static int v = 4;
+  return v;
+}
+// giant rows of plain REDUCE_ORDERED programs: products by k_giant_terms + k_giant_fold_ordered (1) or one wave per row (0)
+inline int& ordered_giant_two_pass() {
+  static int v = 1;
   return v;
 }
 // persistent kernels: workgroups per CU (0 = as many as the LDS allows)
@@ -127,6 +151,13 @@ inline int& bits_step_edges() {
 // ... and entirely on lists while it owns at most this many out-edges
 inline int& sparse_step_edges() {
   static int v = 1 << 20;
+  return v;
+}
+
+// ablation builds (-DGRAPHMAT_ABLATION): columns from this device id on are not gathered by the multiply kernels (the
+// time left is what a multiply costs whose cold-column messages arrive some other way); 0 = off
+inline int& ablate_cold_from() {
+  static int v = 0;
   return v;
 }
 
@@ -324,10 +355,16 @@ constexpr bool wave16_ok() {
 
 // one multiply+reduce pass over one direction of the adjacency, strategy RK
 template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
-void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits,
+void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A_in, const T* x, const uint32_t* xbits,
                     const V* vp, U* y, uint32_t* ybits, int accumulate, hipStream_t s, int* launches, PhaseTimer* timer,
                     AuxStream* aux, const uint32_t* want = nullptr, bool grouped = false, const uint32_t* xsum = nullptr) {
   constexpr int WPB = dev::kBlock / 64;  // rows (waves) per workgroup of k_spmv_wave
+#ifdef GRAPHMAT_ABLATION
+  gm_csr_t A = A_in;
+  A.cold_from = ablate_cold_from();
+#else
+  const gm_csr_t& A = A_in;
+#endif
   if (A.nnz == 0) return;
   const bool defer = aux != nullptr && aux->s != nullptr && aux->defer;
   const bool keep = aux != nullptr && aux->s != nullptr && aux->keep;
@@ -385,9 +422,26 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A,
                          A, x, xbits, vp, y, ybits, accumulate, debug_flags(), (const U*)terms,
                          (const unsigned long long*)tpres, want, maps);
     } else {
-      hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, REDUCE_ORDERED>),
-                         dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, A.giant_row, A.ngiant, x,
-                         xbits, vp, y, ybits, accumulate, debug_flags(), want);
+      // plain ordered fold (any reduce_function): products spread over the chip by k_giant_terms, then one wave per row
+      // folds the dense products stream in stored order (kernels.hpp: k_giant_fold_ordered).  Larger reduction types keep
+      // the one-wave-per-row kernel that gathers by itself.
+      bool two_pass = false;
+      if constexpr (dev::stageable<U>::value && std::is_trivially_copyable<U>::value) {
+        void *p6 = nullptr, *p7 = nullptr;
+        if (ordered_giant_two_pass() != 0 && gm_graph_workspace(g, 6, (size_t)A.giant_edges * sizeof(U) + 64, &p6) == GM_OK &&
+            (xbits == nullptr || gm_graph_workspace(g, 14, (size_t)A.giant_edges / 8 + 64, &p7) == GM_OK)) {
+          hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa,
+                             A, x, xbits, vp, (U*)p6, (unsigned long long*)p7, debug_flags(), (dev::gchunk_state*)nullptr);
+          (*launches)++;
+          hipLaunchKernelGGL((dev::k_giant_fold_ordered<P, U, V>), dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, vp, y,
+                             ybits, accumulate, (const U*)p6, (const unsigned long long*)p7, want);
+          two_pass = true;
+        }
+      }
+      if (!two_pass)
+        hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, REDUCE_ORDERED>),
+                           dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, A.giant_row, A.ngiant, x,
+                           xbits, vp, y, ybits, accumulate, debug_flags(), want);
     }
     (*launches)++;
     if (overlap) {
@@ -733,7 +787,8 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
   // rows (the busy ones) while stage 1's messages travel.  Each row is still folded by one kernel
   // in stored order, so results are those of the plain loop below.
   const bool trace = iteration_trace() != 0;
-  if (multi && act == ALL_VERTICES && order == OUT_EDGES && iterations > 0 && !(debug_flags() & dev::DBG_NO_PIPELINE) && !trace) {
+  if (multi && act == ALL_VERTICES && order == OUT_EDGES && iterations > 0 && !(debug_flags() & dev::DBG_NO_PIPELINE) && !trace &&
+      inherits_iteration_hook<P>()) {  // (the stages send iteration i+1's messages before the hook of iteration i could run)
     void* x2v = nullptr;
     size_t x2_bytes = 0;
     int x2_ext = 0;
@@ -822,17 +877,7 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         stage(pa, Ah, 0, rs, more, early_giants);
         if (more && gm_graph_exchange(g, GM_XCHG_WAIT, xnext, (int64_t)sizeof(T), nullptr, nullptr) != 0) fail("message exchange wait failed");
         if (n_live < n) GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
-        gp->do_every_iteration(it);
-        if (more) {
-          // the stages sent the next iteration's messages with the program as it was BEFORE do_every_iteration
-          // (GraphMatRuntime.h:236 runs it before the next send): a program that changed sends again, all rows at once
-          const dev::ProgArg<P> pa_next = dev::make_prog_arg(gp);
-          if (memcmp(pa_next.b, pa.b, sizeof(pa.b)) != 0) {
-            hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa_next, (const V*)d_vp,
-                               (const uint32_t*)nullptr, xnext, xbits, n_live, desc.row_lo);
-            if (gm_graph_exchange(g, GM_XCHG_MESSAGES, xnext, (int64_t)sizeof(T), xbits, nullptr) != 0) fail("message exchange callback failed");
-          }
-        }
+        gp->do_every_iteration(it);  // (the base class's empty hook: this schedule is only taken by programs that do not override it)
         T* t = xcur; xcur = xnext; xnext = t;
       }
       hipLaunchKernelGGL(dev::k_fill_u32, dim3(grid_for(nwords)), dim3(dev::kBlock), 0, s, d_active, (int64_t)nwords, 0xffffffffu);
@@ -1230,8 +1275,11 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         hipLaunchKernelGGL((dev::k_apply<P, U, V, true>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y, apply_bits,
                            d_vp, d_active, n_live, d_changed, Asrc.rowptr, d_striped, d_want, build_list ? d_list : (int32_t*)nullptr,
                            build_list ? d_count : (unsigned int*)nullptr);
-      else if (dense_x && !lazy_send && !trace && fuse_apply_send() != 0 && !(iterations > 0 && it + 1 >= iterations)) {
-        // another iteration follows (or may follow): its messages come out of the same pass
+      else if (inherits_iteration_hook<P>() && dense_x && !lazy_send && !trace && fuse_apply_send() != 0 && iterations > 0 && it + 1 < iterations) {
+        // another iteration follows: its messages come out of the same pass.  Only for programs without a
+        // do_every_iteration of their own (nothing can change what send_message reads between the two iterations), and
+        // only in fixed-count runs: until convergence the last iteration is not known in advance, and a fused pass there
+        // would leave x holding messages of an iteration that never runs (the reference's px would not)
         hipLaunchKernelGGL((dev::k_apply_send<P, T, U, V>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y, apply_bits,
                            d_vp, d_active, n_live, d_changed, d_want, x, xbits, desc.row_lo);
         x_presend = true;

@@ -545,7 +545,7 @@ k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32
 #pragma unroll
     for (int j = 0; j < PER; j++) {
       m[j] = raw_t();
-      if (c[j] >= 0 && !(dbg & DBG_SKIP_GATHER)) m[j] = reinterpret_cast<const raw_t*>(x)[c[j]];
+      if (c[j] >= 0 && !(dbg & DBG_SKIP_GATHER) && !(GM_ABL(1) && A.cold_from > 0 && c[j] >= A.cold_from)) m[j] = reinterpret_cast<const raw_t*>(x)[c[j]];
     }
 #pragma unroll
     for (int j = 0; j < PER; j++) {
@@ -679,7 +679,11 @@ struct HotSet {
   const T* s_hot;
   int base, nhot, NS, per, stride;
   float inv_stride;
+  int cold_from;  // (ablation builds: columns from here on are read from LDS instead of being gathered)
   __device__ __forceinline__ T get(const T* __restrict__ x, int c) const {
+#ifdef GRAPHMAT_ABLATION
+    if (cold_from > 0 && c >= cold_from) return s_hot[c & 4095];
+#endif
     if (NS == 1) {
       const unsigned rel = (unsigned)(c - base);
       return rel < (unsigned)nhot ? s_hot[rel] : x[c];
@@ -697,6 +701,7 @@ template <class T, int HOT, int BLOCK>
 __device__ __forceinline__ HotSet<T> hot_load(const gm_csr_t& A, const T* __restrict__ x, T* s_hot) {
   HotSet<T> h;
   h.s_hot = s_hot;
+  h.cold_from = A.cold_from;
   h.base = A.hot_base;
   h.NS = A.hot_slices > 1 ? A.hot_slices : 1;
   h.stride = A.hot_stride;
@@ -814,7 +819,7 @@ __device__ __forceinline__ void wave_row(const P& p, const gm_csr_t& A, const in
 #pragma unroll
     for (int u = 0; u < D; u++) {
       if (c[u] >= 0 && !dense && !bit_get(xbits, c[u])) c[u] = -1;
-      if (c[u] >= 0 && !(dbg & DBG_SKIP_GATHER)) m[u] = x[c[u]];
+      if (c[u] >= 0 && !(dbg & DBG_SKIP_GATHER) && !(GM_ABL(1) && A.cold_from > 0 && c[u] >= A.cold_from)) m[u] = x[c[u]];
     }
 #pragma unroll
     for (int u = 0; u < D; u++) cn[u] = load_col(e0 + 64 * (D + u) + lane);
@@ -851,7 +856,7 @@ __device__ __forceinline__ void wave_row(const P& p, const gm_csr_t& A, const in
         // refill slot u: gathers of chunk i+D, column ids of chunk i+2D
         c[u] = cn[u];
         if (c[u] >= 0 && !dense && !bit_get(xbits, c[u])) c[u] = -1;
-        if (c[u] >= 0 && !(dbg & DBG_SKIP_GATHER)) m[u] = x[c[u]];
+        if (c[u] >= 0 && !(dbg & DBG_SKIP_GATHER) && !(GM_ABL(1) && A.cold_from > 0 && c[u] >= A.cold_from)) m[u] = x[c[u]];
         cn[u] = load_col(cb + 64 * 2 * D + lane);
       }
     }
@@ -1378,7 +1383,7 @@ k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t
   T m[PER];
 #pragma unroll
   for (int j = 0; j < PER; j++)
-    if (c[j] >= 0) { if (dbg & DBG_SKIP_GATHER) memset(&m[j], 0, sizeof(T)); else m[j] = x[c[j]]; }
+    if (c[j] >= 0) { if ((dbg & DBG_SKIP_GATHER) || (GM_ABL(1) && A.cold_from > 0 && c[j] >= A.cold_from)) memset(&m[j], 0, sizeof(T)); else m[j] = x[c[j]]; }
   // the exact replay spread over the chip (see gchunk_state): with a hint of the binade S will be in, the piece's
   // products are also composed into one ulp-map here, where they are in registers anyway
   constexpr bool kMaps = std::is_same<U, float>::value;
@@ -1441,6 +1446,88 @@ k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t
       st.dod = tot.dod;
       state[blockIdx.x] = st;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// giant rows, pass 2 for plain REDUCE_ORDERED programs (any reduce_function: the default for a program that declares no
+// trait, i.e. every unchanged application): the products k_giant_terms left in the scratch stream are folded strictly
+// in stored order, one wave per row.  What is left to the single wave is only the chain of reduce_function calls:
+// the gathers and process_message calls were spread over the chip by pass 1 (one wave walking the 200 K edges of
+// RMAT-22's hub row itself is bound by the gathers it can keep in flight: ~1.5 ms per pass), the products arrive as a
+// dense, coalesced stream that is loaded one chunk ahead, staged in the wave's LDS strip, and lane 0 folds the chunk out
+// of LDS -- the LDS reads pipeline under the dependent reduce calls, so an edge costs one reduce_function issue
+// (~4-5 cycles) instead of a v_readlane plus the call in wave_row.
+template <class P, class U, class V>
+__global__ void __launch_bounds__(kBlock)
+k_giant_fold_ordered(ProgArg<P> pa, gm_csr_t A, const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate,
+                     const U* __restrict__ terms, const unsigned long long* __restrict__ tpres, const uint32_t* __restrict__ want) {
+  static_assert(stageable<U>::value, "products of at most 8 bytes");
+  constexpr int PER = 8, CH = PER * 64;
+  __shared__ __attribute__((aligned(16))) U s_t[kBlock / 64][CH];
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= A.ngiant) return;
+  const int row = A.giant_row[w];
+  if (!row_wanted(p, vp, want, row)) return;
+  const int64_t deg = A.rowptr[row + 1] - A.rowptr[row];
+  const int64_t t0 = A.gterm_off[w];  // multiple of 64
+  U* st = s_t[threadIdx.x >> 6];
+  bool has = false;
+  U acc;
+  if (lane == 0 && (accumulate & ACC_READ_PREV) && bit_get(ybits, row)) { acc = y[row]; has = true; }
+  U cur[PER], nxt[PER];
+  unsigned long long pm[PER], pmn[PER];
+  auto load = [&](int64_t base, U (&r)[PER], unsigned long long (&m)[PER]) {
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const int64_t k0 = base + (int64_t)j * 64;  // wave-uniform
+      const int64_t left = deg - k0;
+      unsigned long long mask = left >= 64 ? ~0ull : (left > 0 ? ((1ull << left) - 1ull) : 0ull);
+      if (tpres != nullptr && mask) mask &= tpres[(t0 + k0) >> 6];
+      m[j] = mask;
+      if (k0 + lane < deg) r[j] = terms[t0 + k0 + lane];
+    }
+  };
+  load(0, cur, pm);
+  for (int64_t base = 0; base < deg; base += CH) {
+#pragma unroll
+    for (int j = 0; j < PER; j++) st[j * 64 + lane] = cur[j];
+    __builtin_amdgcn_wave_barrier();
+    if (base + CH < deg) load(base + CH, nxt, pmn);  // in flight during the fold below
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < PER; j++) {
+        unsigned long long mask = pm[j];
+        const U* t = st + j * 64;
+        if (mask == ~0ull) {
+          int k = 0;
+          if (!has) { acc = t[0]; has = true; k = 1; }
+          for (; k + 8 <= 64; k += 8) {
+            U v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = t[k + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p.P::reduce_function(acc, v[u]);
+          }
+          for (; k < 64; k++) { U v = t[k]; p.P::reduce_function(acc, v); }
+        } else {
+          while (mask) {
+            const int k = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            U v = t[k];
+            if (has) p.P::reduce_function(acc, v); else { acc = v; has = true; }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < PER; j++) { cur[j] = nxt[j]; pm[j] = pmn[j]; }
+  }
+  if (lane == 0 && has) {
+    y[row] = acc;
+    if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
   }
 }
 

@@ -199,7 +199,8 @@ typedef struct {
   int64_t edges_wave16;       /*   to short_row edges), 16-rows-per-wave rows, one-wave-per-row rows (nmid_long), and -- the */
   int64_t edges_wave;         /*   rest of nnz -- giant rows                                                                */
   int32_t rows_keep_stream;   /* a column tile built with row classes fixed per ROW: a row is a one-wave-per-row / giant row in    */
-  int32_t pad2_;              /*   every tile or in none, so those kernels and the others never share a y entry within an iteration */
+  int32_t cold_from;          /*   every tile or in none, so those kernels and the others never share a y entry within an iteration.
+                                 cold_from: ablation builds only (0 otherwise) -- columns >= cold_from are not gathered            */
 } gm_csr_t;
 
 #define GM_GIANT_CHUNK 4096 /* edges per piece of the parallel giant-row pass */

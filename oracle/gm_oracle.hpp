@@ -67,7 +67,11 @@ struct Vec {
   std::vector<T> value;
   std::vector<uint32_t> bits;
   explicit Vec(int n_ = 0) : n(n_), value(n_), bits((n_ + 31) / 32, 0u) {}
-  void clear() { std::fill(bits.begin(), bits.end(), 0u); }
+  void clear() {  // (parallel: this is also the CPU baseline bench.py times; the result is that of a serial fill)
+    const int64_t nw = (int64_t)bits.size();
+#pragma omp parallel for
+    for (int64_t w = 0; w < nw; w++) bits[w] = 0u;
+  }
   void set_all(const T& v) {  // DenseSegment.h:617-640: exactly n bits set
     for (int i = 0; i < n; i++) { value[i] = v; bv_set(bits, i); }
   }
@@ -254,11 +258,19 @@ struct Graph {
     active.assign((nvertices + 31) / 32, 0u);
   }
   int to_native0(int v1) const { return vertex_to_native(v1, nparts, nvertices) - 1; }
-  void set_all_active() {  // Graph.h:263-266
-    std::fill(active.begin(), active.end(), 0u);
-    for (int i = 0; i < nvertices; i++) bv_set(active, i);
+  void set_all_active() {  // Graph.h:263-266: exactly nvertices bits set (word-wise and parallel: also the timed CPU baseline)
+    const int64_t nw = (int64_t)active.size();
+#pragma omp parallel for
+    for (int64_t w = 0; w < nw; w++) {
+      const int64_t rem = (int64_t)nvertices - w * 32;
+      active[w] = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+    }
   }
-  void set_all_inactive() { std::fill(active.begin(), active.end(), 0u); }  // Graph.h:268-280
+  void set_all_inactive() {  // Graph.h:268-280
+    const int64_t nw = (int64_t)active.size();
+#pragma omp parallel for
+    for (int64_t w = 0; w < nw; w++) active[w] = 0u;
+  }
   void set_active(int v1) { bv_set(active, to_native0(v1)); }               // Graph.h:283-286
   void set_vertexproperty(int v1, const V& val) { vp[to_native0(v1)] = val; }  // Graph.h:312-316
   V get_vertexproperty(int v1) const { return vp[to_native0(v1)]; }            // Graph.h:358-364

@@ -219,6 +219,30 @@ int gmo_num_threads(void) {
   return 1;
 #endif
 }
+// STREAM-style triad a[i] = b[i] + 3 c[i] over three arrays of n doubles (first touched by the threads that walk them), `reps`
+// passes: GB/s of the 24 n bytes a pass moves.  bench.py's cpu_baseline reports it next to the PageRank probe so that
+// "more threads do not help" can be read against what the host's memory system delivers at that thread count.
+double gmo_stream_triad_gbs(long long n, int reps) {
+  double* a = (double*)malloc((size_t)n * 8);
+  double* b = (double*)malloc((size_t)n * 8);
+  double* c = (double*)malloc((size_t)n * 8);
+  if (!a || !b || !c) { free(a); free(b); free(c); return 0.0; }
+#pragma omp parallel for schedule(static)
+  for (long long i = 0; i < n; i++) { a[i] = 0.0; b[i] = 1.0; c[i] = 2.0; }
+  double best = 0.0;
+  for (int r = 0; r < reps; r++) {
+    const double t0 = omp_get_wtime();
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < n; i++) a[i] = b[i] + 3.0 * c[i];
+    const double dt = omp_get_wtime() - t0;
+    const double gbs = 24.0 * (double)n / dt * 1e-9;
+    if (gbs > best) best = gbs;
+  }
+  volatile double sink = a[n / 2];
+  (void)sink;
+  free(a); free(b); free(c);
+  return best;
+}
 void gmo_set_num_threads(int n) {
 #ifdef _OPENMP
   omp_set_num_threads(n);

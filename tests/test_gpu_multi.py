@@ -92,6 +92,31 @@ def test_native_exchange_several_ranks_over_shared_memory(world):
     assert out.returncode == 0 and "MULTI_OK" in text and "native-rccl" in text, text[-3000:]
 
 
+def test_missing_stream_wait_is_caught():
+    """Negative control for the multi-rank tests.  The shared-memory stand-in for librccl is stream-ordered (its collectives only
+    enqueue copies, reductions and a spinning rendezvous kernel on the stream they are handed), so the ordering between
+    gm_dist.hip's side stream and the run stream is really exercised: with ONE hipStreamWaitEvent of the two-stage
+    schedule left out (GRAPHMAT_DEBUG_DROP_WAIT=1: the run stream no longer waits for the side stream's all-gathers
+    before it copies the parts into x) a 3-rank PageRank must differ from the oracle.  A blocking transport would let
+    this bug pass."""
+    from graphmat_amd import build
+    build.build()
+    from oracle import binding
+    binding.build()
+    env = dict(os.environ, GM_BACKEND="gloo", GM_SCALE="16", GM_EXCHANGE="native", GRAPHMAT_RCCL_LIBRARY=_shm_lib(), GM_NEGATIVE="1",
+               GRAPHMAT_DEBUG_DROP_WAIT="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "multi_check.py")]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env, cwd=ROOT)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "NEGATIVE_CAUGHT" in text, text[-3000:]
+    # ... and with the dependency in place the same run equals the oracle (the positive tests above at scale 13 / 14)
+    env.pop("GRAPHMAT_DEBUG_DROP_WAIT")
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env, cwd=ROOT)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "NEGATIVE_MISSED" in text, text[-3000:]
+
+
 def test_bench_two_ranks_distributed_build_and_native_exchange():
     """bench.py as the driver launches it at N > 1 (torch.distributed.run, one rank per process), on this 1-GPU box with
     gloo for torch.distributed and the shared-memory stand-in for librccl for the library's own communicator: every rank generates

@@ -62,6 +62,16 @@ def main():
     ok = True
     pr, deg, it = g.pagerank(8)  # fixed count, ALL_VERTICES: the overlapped two-stage schedule
     opr, oit, _ = og.pagerank(8)
+    if os.environ.get("GM_NEGATIVE") == "1":
+        # negative control (GRAPHMAT_DEBUG_DROP_WAIT=1: gm_dist.hip leaves out the run stream's wait for the side stream's
+        # all-gathers): with a stream-ordered transport the two-stage schedule must now read messages that have not arrived
+        bad = int((pr.view(np.uint32) != opr.view(np.uint32)).sum())
+        flag = torch.tensor([bad], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            print("NEGATIVE_CAUGHT" if int(flag) > 0 else "NEGATIVE_MISSED", "world=%d parts=%d differing values=%d" % (world, ex.parts, int(flag)), flush=True)
+        dist.destroy_process_group()
+        sys.exit(0)
     ok &= bool((deg == og.degree()).all()) and it == oit and bool((pr.view(np.uint32) == opr.view(np.uint32)).all())
     staged = ex.parts
     ok &= staged == 2 * 7  # two parts per iteration but the last
