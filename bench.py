@@ -355,6 +355,7 @@ def main():
     ap.add_argument("--native-layout", action="store_true", help="device order = native order (single GPU; for A/B)")
     ap.add_argument("--tile-min-row", type=int, default=-1, help="experiment: rows of more than this many edges are tiled (0 = all rows)")
     ap.add_argument("--col-tiles", type=int, default=-1, help="column tiles of the OUT adjacency (-1 = default for the scale, 1 = none)")
+    ap.add_argument("--graph", choices=("rmat", "uniform"), default="rmat", help="rmat = the metric's input; uniform = every vertex with edge-factor out-edges to uniformly drawn destinations (the reference's test/generator.h:73-105 shape): policy robustness runs")
     ap.add_argument("--lib-option", action="append", default=[], metavar="KEY=VALUE", help="gm_set_option(KEY, VALUE) before the graph is built (experiments)")
     ap.add_argument("--debug-flags", type=int, default=0, help="ablation only (results become invalid): 1 skip fold, 2 skip gathers")
     args = ap.parse_args()
@@ -426,8 +427,11 @@ def main():
     nparts = args.ref_threads * 16
 
     def build_graph(local):
-        nv_, src_, dst_, _ = api.rmat_on_device(args.scale, args.edge_factor, args.seed, weights=False, device=local_rank,
-                                                part=((rank, world) if local else None))
+        if args.graph == "uniform":
+            nv_, src_, dst_, _ = api.uniform_on_device(args.scale, args.edge_factor, args.seed, device=local_rank, part=((rank, world) if local else None))
+        else:
+            nv_, src_, dst_, _ = api.rmat_on_device(args.scale, args.edge_factor, args.seed, weights=False, device=local_rank,
+                                                    part=((rank, world) if local else None))
         # device order chosen by the library: degree-ranked, dealt over the `world` shards
         g_ = api.Graph(nv_, src_, dst_, None, ref_threads=args.ref_threads, device=local_rank, keep_values=False,
                        layout=(_lib.GM_LAYOUT_NATIVE if args.native_layout else _lib.GM_LAYOUT_DEGREE), nshards=world, shard=rank,
@@ -706,12 +710,14 @@ def main():
                                    "x one gather per edge; whole iteration against the same ceiling: %.4f" % (GATHER_CEILING / 1e9, (E / world / GATHER_CEILING) / (ms_per_step * 1e-3)))
     iter_bytes = 4 * E + 48 * nv
     out = {
-        "metric": "GTEPS (edges/s) per iter + achieved HBM GB/s, PageRank RMAT-%d" % args.scale,
+        "metric": "GTEPS (edges/s) per iter + achieved HBM GB/s, PageRank %s-%d" % ("RMAT" if args.graph == "rmat" else "uniform", args.scale),
         "value": round(gteps, 3), "unit": "GTEPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "PageRank (alpha=0.3, fp32, fixed iteration count) on RMAT scale-%d, a/b/c=.57/.19/.19, "
-                               "edge factor %d, seed %d, duplicates and self loops kept" % (args.scale, args.edge_factor, args.seed),
+        "config": {"workload": ("PageRank (alpha=0.3, fp32, fixed iteration count) on RMAT scale-%d, a/b/c=.57/.19/.19, "
+                                "edge factor %d, seed %d, duplicates and self loops kept" % (args.scale, args.edge_factor, args.seed)) if args.graph == "rmat" else
+                               ("PageRank (alpha=0.3, fp32, fixed iteration count) on a UNIFORM random graph (NOT the metric's input: policy robustness run), 2^%d "
+                                "vertices with %d out-edges each to uniformly drawn destinations, seed %d" % (args.scale, args.edge_factor, args.seed)),
                    "V": nv, "E": E, "parallelism": "1d-rows x%d" % world, "exchange": ((("native exchange (gm_dist.hip) over %s, " % ("%s [GRAPHMAT_RCCL_LIBRARY, not RCCL]" % os.path.basename(os.environ["GRAPHMAT_RCCL_LIBRARY"]) if os.environ.get("GRAPHMAT_RCCL_LIBRARY") else "RCCL"))
                                                                               if native else "torch.distributed callback, ") if world > 1 else "") +
                                                                             ("two-stage overlapped all-gather" if overlapped else

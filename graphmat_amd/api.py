@@ -296,6 +296,27 @@ def copy_to_device(dev_ptr, host_array):
         raise RuntimeError("hipMemcpy failed: %d" % rc)
 
 
+def uniform_on_device(scale, edge_factor=16, seed=1, device=0, part=None):
+    """A uniform random graph generated in HBM: V = 2^scale vertices with exactly `edge_factor` out-edges each to
+    uniformly drawn destinations (the shape of the reference's generate_random_edgelist, test/generator.h:73-105; at
+    this size a row's destinations are distinct with probability 1 - 2e-6 per row, repeated draws are kept like RMAT's
+    duplicate edges).  torch's device generator, seeded: reproducible on one GPU type, not bit-identical to numpy.
+    part=(i, n): the i-th of n consecutive chunks of the edge list."""
+    dev = torch.device("cuda", device)
+    nv = 1 << scale
+    total = edge_factor * nv
+    first, ne = 0, total
+    if part is not None:
+        i, n = part
+        first = total * i // n
+        ne = total * (i + 1) // n - first
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed) * 1000003 + first)
+    src = (torch.arange(first, first + ne, dtype=torch.int64, device=dev) // edge_factor + 1).to(torch.int32)
+    dst = torch.randint(1, nv + 1, (ne,), dtype=torch.int32, device=dev, generator=gen)
+    return nv, src, dst, None
+
+
 def rmat_on_device(scale, edge_factor=16, seed=1, weights=False, device=0, part=None):
     """RMAT edges generated in HBM (bit-identical to generators.rmat_edges).
     part=(i, n): only the i-th of n consecutive chunks of the edge list (a rank's part of a distributed build)."""

@@ -316,6 +316,101 @@ k_sgd_multiply(gm_csr_t A, const float* __restrict__ x, const float* __restrict_
   }
 }
 
+// ---- the dot products on the matrix cores (option "sgd_mfma"; NOT the default: sums are within 1e-6 of the reference's,
+// not its bits) --------------------------------------------------------------------------------------------------------
+// What a matrix core can do for this path at all: per edge the work is ONE K-term dot product of a gathered row with the
+// row's own vector -- no operand is shared between the edges of different rows, and at a ratings density of 1e-4 a
+// 32 x 32 (rows x columns) block of the matrix holds 0.1 ratings, so there is no dense tile to multiply.  The one
+// mapping that wastes little is v_mfma_f32_4x4x1_16b_f32: 16 independent 4 x 4 outer products per instruction, lane
+// l = 4 b + i supplying A_b[i] and B_b[i].  With A_b[i] = x_row(edge 4 b + i)[k] and B_b[j] = v[k] for every j, the
+// accumulator D_b[i][j] of 128 consecutive instructions (k ascending: the reference's order of the terms) is the dot
+// product of edge 4 b + i, four times over (j): 64 edges per wave advance one term per instruction, 1/4 of the unit's
+// flops useful, against 16 of 64 lanes busy in the vector form of phase A.  That needs 64-edge tiles: one wave per
+// workgroup with a 33 KB LDS tile (64 rows x (K + 1) floats: lane = row at a common k is bank-conflict free) and the next
+// tile's 64 rows (32 float4 registers per lane) in flight meanwhile -- the same bytes in flight per CU as the vector form.
+// Measured against it in profiles/r04_sgd_mfma.md.
+constexpr int kSgdMTile = 64;
+typedef float gm_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int K>
+__global__ void __launch_bounds__(64)
+k_sgd_multiply_mfma(gm_csr_t A, const float* __restrict__ x, const float* __restrict__ vp, float* __restrict__ y,
+                    const uint32_t* __restrict__ prev_bits, int accumulate) {
+  static_assert(K == 128, "K = 128");
+  constexpr int PER = K / 64;        // components per lane in phase B
+  constexpr int LPR = K / 4;         // lanes that cover one x row with a float4 each
+  constexpr int RPL = 64 / LPR;      // rows per load instruction (2)
+  constexpr int NLD = kSgdMTile / RPL;  // load instructions per tile (32)
+  constexpr int XS = K + 1;
+  __shared__ float s_v[K];
+  __shared__ float s_x[kSgdMTile][XS];
+  const int lane = threadIdx.x;
+  const int row = blockIdx.x;
+  if (row >= A.nrows) return;
+  const int64_t e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
+  if (e1 == e0) return;
+  const float* vrow = vp + (int64_t)row * (K + 1);
+#pragma unroll
+  for (int j = 0; j < PER; j++) s_v[lane + 64 * j] = vrow[lane + 64 * j];
+  bool has = accumulate && ((prev_bits[row >> 5] >> (row & 31)) & 1u);
+  float acc[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++) acc[j] = has ? y[(int64_t)row * K + lane + 64 * j] : 0.f;
+  const int* vals = (const int*)A.vals;
+  const int sub = lane / LPR, part = lane % LPR;
+  int col = 0, rating = 0;
+  float4 q[NLD];
+  auto fetch = [&](int64_t base) {
+    const int n = (int)((e1 - base) < kSgdMTile ? (e1 - base) : kSgdMTile);
+    col = 0;
+    rating = 0;
+    if (lane < n) {
+      col = __builtin_nontemporal_load(A.colidx + base + lane);
+      rating = __builtin_nontemporal_load(vals + base + lane);
+    }
+#pragma unroll
+    for (int r = 0; r < NLD; r++) {
+      const int e = r * RPL + sub;
+      const int c = __shfl(col, e);
+      q[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < n) q[r] = *reinterpret_cast<const float4*>(x + (int64_t)c * K + 4 * part);
+    }
+  };
+  fetch(e0);
+  for (int64_t base = e0; base < e1; base += kSgdMTile) {
+    const int n = (int)((e1 - base) < kSgdMTile ? (e1 - base) : kSgdMTile);
+    const int my_rating = rating;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < NLD; r++) {
+      float* d = &s_x[r * RPL + sub][4 * part];
+      d[0] = q[r].x; d[1] = q[r].y; d[2] = q[r].z; d[3] = q[r].w;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (base + kSgdMTile < e1) fetch(base + kSgdMTile);
+    // phase A on the matrix cores: lane = edge; D_b[i][j] += x_{4b+i}[k] * v[k], k ascending
+    gm_f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 16
+    for (int k = 0; k < K; k++) d4 = __builtin_amdgcn_mfma_f32_4x4x1f32(s_x[lane][k], s_v[k], d4, 0, 0, 0);
+    // lane 4 b + j holds D_b[0..3][j]: edge `lane` = 4 b + (lane & 3) is row lane & 3 of its block
+    const int i3 = lane & 3;
+    const float est = i3 == 0 ? d4.x : i3 == 1 ? d4.y : i3 == 2 ? d4.z : d4.w;
+    const float err = lane < n ? (float)my_rating - est : 0.f;
+    // phase B: lane = K/64 components, the tile's edges in stored order
+    for (int e = 0; e < n; e++) {
+      const float ee = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(err), e));
+#pragma unroll
+      for (int j = 0; j < PER; j++) {
+        const float r = s_x[e][lane + 64 * j] * ee;
+        acc[j] = has ? acc[j] + r : r;
+      }
+      has = true;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PER; j++) y[(int64_t)row * K + lane + 64 * j] = acc[j];
+}
+
 template <int K>
 __global__ void __launch_bounds__(kSgdBlock)
 k_sgd_apply(const float* __restrict__ y, const uint32_t* __restrict__ bits, float* __restrict__ vp, int n, float lambda,
@@ -332,6 +427,8 @@ k_rmse_apply(const float* __restrict__ y1, const uint32_t* __restrict__ bits, fl
   const int v = blockIdx.x * kSgdBlock + threadIdx.x;
   if (v < n && ((bits[v >> 5] >> (v & 31)) & 1u)) vp[(int64_t)v * stride + stride - 1] = y1[v];  // sqerr field
 }
+
+int g_sgd_mfma = 0;  // gm_set_option("sgd_mfma", 1): the dot products of K = 128 fp32 SGD on the matrix cores (k_sgd_multiply_mfma)
 
 // fixed iteration count; sharded graphs exchange x once per iteration
 template <int K>
@@ -354,10 +451,22 @@ int run_sgd_wide(gm_graph_t* g, float* d_latent, float lambda, float step, int i
     hipLaunchKernelGGL((k_sgd_send<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)d_latent,
                        (float*)px + (size_t)d.row_lo * K, n);
     if ((rc = sgd_exchange(g, (float*)px, K, s))) return rc;
-    hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3(wgrid), dim3(kSgdMulBlock), 0, s, g->out.view, (const float*)px,
-                       (const float*)d_latent, (float*)py, (const uint32_t*)nullptr, 0);
-    hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3(wgrid), dim3(kSgdMulBlock), 0, s, g->in.view, (const float*)px,
-                       (const float*)d_latent, (float*)py, (const uint32_t*)g->out.rowbits, 1);
+    bool mfma = false;
+    if constexpr (K == 128) {
+      if (g_sgd_mfma) {
+        hipLaunchKernelGGL((k_sgd_multiply_mfma<K>), dim3(n), dim3(64), 0, s, g->out.view, (const float*)px, (const float*)d_latent, (float*)py,
+                           (const uint32_t*)nullptr, 0);
+        hipLaunchKernelGGL((k_sgd_multiply_mfma<K>), dim3(n), dim3(64), 0, s, g->in.view, (const float*)px, (const float*)d_latent, (float*)py,
+                           (const uint32_t*)g->out.rowbits, 1);
+        mfma = true;
+      }
+    }
+    if (!mfma) {
+      hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3(wgrid), dim3(kSgdMulBlock), 0, s, g->out.view, (const float*)px,
+                         (const float*)d_latent, (float*)py, (const uint32_t*)nullptr, 0);
+      hipLaunchKernelGGL((k_sgd_multiply<K, 0>), dim3(wgrid), dim3(kSgdMulBlock), 0, s, g->in.view, (const float*)px,
+                         (const float*)d_latent, (float*)py, (const uint32_t*)g->out.rowbits, 1);
+    }
     hipLaunchKernelGGL((k_sgd_apply<K>), dim3(egrid), dim3(kSgdBlock), 0, s, (const float*)py,
                        (const uint32_t*)g->rowbits_all, d_latent, n, lambda, step);
   }
@@ -581,6 +690,7 @@ extern "C" {
 
 int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "force_ordered")) { gm::g_force_ordered = value; return GM_OK; }
+  if (key && !strcmp(key, "sgd_mfma") && (value == 0 || value == 1)) { gm::g_sgd_mfma = value; return GM_OK; }
   if (key && !strcmp(key, "short_row") && value >= 1 && value <= GM_BLOCK_NNZ) { gm::g_short_row = value; return GM_OK; }
   if (key && !strcmp(key, "giant_row") && value >= 64) { gm::g_giant_row = value; return GM_OK; }
   if (key && !strcmp(key, "rank_cap") && value >= 0) { gm::g_rank_cap = value; return GM_OK; }
@@ -603,6 +713,7 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "giant_maps") && (value == 0 || value == 1)) { GraphMat::detail::giant_maps() = value; return GM_OK; }
   if (key && !strcmp(key, "iteration_trace") && (value == 0 || value == 1)) { GraphMat::detail::iteration_trace() = value; return GM_OK; }
   if (key && !strcmp(key, "ablate_cold_from") && value >= 0) { GraphMat::detail::ablate_cold_from() = value; return GM_OK; }
+  if (key && !strcmp(key, "ablate_cold_short") && value >= 0) { GraphMat::detail::ablate_cold_short() = value; return GM_OK; }
   if (key && !strcmp(key, "ordered_giant_two_pass") && (value == 0 || value == 1)) { GraphMat::detail::ordered_giant_two_pass() = value; return GM_OK; }
   if (key && !strcmp(key, "debug_flags")) { GraphMat::detail::debug_flags() = value; return GM_OK; }
   gm::set_error("gm_set_option: unknown option");

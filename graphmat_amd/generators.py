@@ -31,6 +31,31 @@ def chain_edges(n):
     return n, (i + 1).astype(np.int32), ((i + 1) % n + 1).astype(np.int32), np.ones(n, np.int32)
 
 
+def uniform_out_regular_edges(n, k, seed=1):
+    """Every vertex has exactly k out-edges to k DISTINCT destinations drawn uniformly from all n vertices: the shape of
+    the reference's own random test graphs (test/generator.h:73-105, generate_random_edgelist(n, avg_nnz_per_row): per
+    source k draws, a draw that repeats one of the row's earlier destinations is redrawn).  No skew at all: the
+    opposite end of the spectrum from RMAT for everything that ranks vertices by degree.  1-based ids, values 1."""
+    rng = np.random.default_rng(seed)
+    k = min(k, n)
+    dst = rng.integers(0, n, size=(n, k), dtype=np.int64)
+    while True:  # redraw repeated destinations inside a row
+        srt = np.sort(dst, axis=1)
+        rows = np.nonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1))[0]
+        if rows.size == 0:
+            break
+        for r in rows:
+            seen = set()
+            for j in range(k):
+                v = int(dst[r, j])
+                while v in seen:
+                    v = int(rng.integers(0, n))
+                seen.add(v)
+                dst[r, j] = v
+    src = np.repeat(np.arange(1, n + 1, dtype=np.int64), k)
+    return n, src.astype(np.int32), (dst.reshape(-1) + 1).astype(np.int32), np.ones(n * k, np.int32)
+
+
 def splitmix64(z):
     z = np.asarray(z, dtype=np.uint64)
     with np.errstate(over="ignore"):

@@ -160,6 +160,11 @@ inline int& ablate_cold_from() {
   static int v = 0;
   return v;
 }
+// ... and in the untiled short-row pass of a tiled graph: columns from this position INSIDE THEIR TILE on; 0 = off
+inline int& ablate_cold_short() {
+  static int v = 0;
+  return v;
+}
 
 // HIP-event phase timer: every mark closes an interval that is charged to `tag`.
 enum { TAG_START = 0, TAG_SEND = 1, TAG_ROWBLOCK = 2, TAG_WAVE = 3, TAG_GIANT = 4, TAG_APPLY = 5 };
@@ -361,7 +366,37 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A_
   constexpr int WPB = dev::kBlock / 64;  // rows (waves) per workgroup of k_spmv_wave
 #ifdef GRAPHMAT_ABLATION
   gm_csr_t A = A_in;
-  A.cold_from = ablate_cold_from();
+  {
+    int ntile = 1;
+    gm_graph_tiles(g, GM_DIR_OUT, &ntile);
+    const bool whole = A.hot_base == 0 && A.hot_len >= A.ncols;
+    A.cold_from = (whole && ntile > 1) ? -ablate_cold_short() : ablate_cold_from();
+    static std::vector<const void*> seen;
+    bool first = true;
+    for (const void* q : seen) first = first && q != (const void*)A.colidx;
+    if (first && A.cold_from != 0) {
+      seen.push_back((const void*)A.colidx);
+      if (ntile > 1) {
+        int base[GM_MAX_TILES + 1] = {0};
+        for (int t = 0; t < ntile; t++) {
+          gm_csr_t At;
+          const uint32_t* prev = nullptr;
+          if (gm_graph_tile(g, GM_DIR_OUT, t, &At, &prev) == GM_OK) base[t] = At.hot_base;
+        }
+        GM_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(dev::g_abl_tile_base), base, sizeof(base)));
+        GM_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(dev::g_abl_ntiles), &ntile, sizeof(int)));
+      }
+      unsigned long long* d_n = nullptr;
+      unsigned long long h_n = 0;
+      GM_HIP_OK(hipMalloc(&d_n, 8));
+      GM_HIP_OK(hipMemset(d_n, 0, 8));
+      hipLaunchKernelGGL(dev::k_abl_count, dim3(4096), dim3(256), 0, s, A.colidx, (int64_t)A.nnz, A.cold_from, A.hot_base, d_n);
+      GM_HIP_OK(hipMemcpyAsync(&h_n, d_n, 8, hipMemcpyDeviceToHost, s));
+      GM_HIP_OK(hipStreamSynchronize(s));
+      GM_HIP_OK(hipFree(d_n));
+      printf("GraphMat(HIP) ablation: view base %d len %d: %lld edges, %llu cold (cold_from %d)\n", A.hot_base, A.hot_len, (long long)A.nnz, h_n, A.cold_from);
+    }
+  }
 #else
   const gm_csr_t& A = A_in;
 #endif

@@ -108,6 +108,32 @@ inline ProgArg<P> make_prog_arg(const P* p) {
 // data would otherwise keep evicting the re-used lines of the message vector from the L2s
 __device__ __forceinline__ int stream_load(const int32_t* __restrict__ p) { return __builtin_nontemporal_load(p); }
 
+#ifdef GRAPHMAT_ABLATION
+// ablation builds only: "cold" columns are not gathered.  A.cold_from > 0: columns whose position inside the adjacency's
+// column slice (c - A.hot_base) is at least that; < 0: columns whose position inside THEIR column tile is at least
+// -A.cold_from (the untiled short-row pass of a tiled graph: tile bases from g_abl_tile_base).
+static __device__ int g_abl_tile_base[GM_MAX_TILES + 1];
+static __device__ int g_abl_ntiles;
+__device__ __forceinline__ bool abl_cold(int c, int cold_from, int base) {
+  if (cold_from > 0) return c - base >= cold_from;
+  if (cold_from < 0) {
+    int b = 0;
+    for (int t = 0; t < g_abl_ntiles; t++) if (c >= g_abl_tile_base[t]) b = g_abl_tile_base[t];
+    return c - b >= -cold_from;
+  }
+  return false;
+}
+static __global__ void k_abl_count(const int32_t* __restrict__ colidx, int64_t nnz, int cold_from, int base, unsigned long long* out) {
+  unsigned long long n = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) n += abl_cold(colidx[i], cold_from, base) ? 1 : 0;
+  for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(out, n);
+}
+#define GM_ABL_COLD(c, A) abl_cold((c), (A).cold_from, (A).hot_base)
+#else
+#define GM_ABL_COLD(c, A) false
+#endif
+
 __device__ __forceinline__ bool bit_get(const uint32_t* __restrict__ bits, int i) {
   return (bits[i >> 5] >> (i & 31)) & 1u;
 }
@@ -545,7 +571,7 @@ k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32
 #pragma unroll
     for (int j = 0; j < PER; j++) {
       m[j] = raw_t();
-      if (c[j] >= 0 && !(dbg & DBG_SKIP_GATHER) && !(GM_ABL(1) && A.cold_from > 0 && c[j] >= A.cold_from)) m[j] = reinterpret_cast<const raw_t*>(x)[c[j]];
+      if (c[j] >= 0 && !(dbg & DBG_SKIP_GATHER) && !GM_ABL_COLD(c[j], A)) m[j] = reinterpret_cast<const raw_t*>(x)[c[j]];
     }
 #pragma unroll
     for (int j = 0; j < PER; j++) {
@@ -682,7 +708,7 @@ struct HotSet {
   int cold_from;  // (ablation builds: columns from here on are read from LDS instead of being gathered)
   __device__ __forceinline__ T get(const T* __restrict__ x, int c) const {
 #ifdef GRAPHMAT_ABLATION
-    if (cold_from > 0 && c >= cold_from) return s_hot[c & 4095];
+    if (abl_cold(c, cold_from, base)) return s_hot[c & 4095];
 #endif
     if (NS == 1) {
       const unsigned rel = (unsigned)(c - base);
@@ -819,7 +845,7 @@ __device__ __forceinline__ void wave_row(const P& p, const gm_csr_t& A, const in
 #pragma unroll
     for (int u = 0; u < D; u++) {
       if (c[u] >= 0 && !dense && !bit_get(xbits, c[u])) c[u] = -1;
-      if (c[u] >= 0 && !(dbg & DBG_SKIP_GATHER) && !(GM_ABL(1) && A.cold_from > 0 && c[u] >= A.cold_from)) m[u] = x[c[u]];
+      if (c[u] >= 0 && !(dbg & DBG_SKIP_GATHER) && !GM_ABL_COLD(c[u], A)) m[u] = x[c[u]];
     }
 #pragma unroll
     for (int u = 0; u < D; u++) cn[u] = load_col(e0 + 64 * (D + u) + lane);
@@ -856,7 +882,7 @@ __device__ __forceinline__ void wave_row(const P& p, const gm_csr_t& A, const in
         // refill slot u: gathers of chunk i+D, column ids of chunk i+2D
         c[u] = cn[u];
         if (c[u] >= 0 && !dense && !bit_get(xbits, c[u])) c[u] = -1;
-        if (c[u] >= 0 && !(dbg & DBG_SKIP_GATHER) && !(GM_ABL(1) && A.cold_from > 0 && c[u] >= A.cold_from)) m[u] = x[c[u]];
+        if (c[u] >= 0 && !(dbg & DBG_SKIP_GATHER) && !GM_ABL_COLD(c[u], A)) m[u] = x[c[u]];
         cn[u] = load_col(cb + 64 * 2 * D + lane);
       }
     }
@@ -1383,7 +1409,7 @@ k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t
   T m[PER];
 #pragma unroll
   for (int j = 0; j < PER; j++)
-    if (c[j] >= 0) { if ((dbg & DBG_SKIP_GATHER) || (GM_ABL(1) && A.cold_from > 0 && c[j] >= A.cold_from)) memset(&m[j], 0, sizeof(T)); else m[j] = x[c[j]]; }
+    if (c[j] >= 0) { if ((dbg & DBG_SKIP_GATHER) || GM_ABL_COLD(c[j], A)) memset(&m[j], 0, sizeof(T)); else m[j] = x[c[j]]; }
   // the exact replay spread over the chip (see gchunk_state): with a hint of the binade S will be in, the piece's
   // products are also composed into one ulp-map here, where they are in registers anyway
   constexpr bool kMaps = std::is_same<U, float>::value;

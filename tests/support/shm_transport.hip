@@ -61,6 +61,7 @@ struct State {
   unsigned long long timeout_ticks = 0;
   hipEvent_t last_op = nullptr;        // recorded behind the most recently issued collective
   bool have_last = false;
+  hipStream_t last_stream = nullptr;   // ... and the stream it was issued on
   std::string name;
 };
 State g;
@@ -154,6 +155,7 @@ ncclResult_t begin_op(hipStream_t s) {
 ncclResult_t end_op(hipStream_t s) {
   TRY(hipEventRecord(g.last_op, s));
   g.have_last = true;
+  g.last_stream = s;
   return ncclSuccess;
 }
 ncclResult_t rendezvous(hipStream_t s) {
@@ -183,8 +185,9 @@ ncclResult_t all_reduce_32(const void* send, void* recv, size_t count, int op, i
 ncclResult_t run_group() {
   const int n = g.nranks, r = g.rank;
   const size_t box = (g.data_bytes / (size_t)n) & ~(size_t)63;
-  if (g_group.empty()) return ncclSuccess;
-  hipStream_t s = g_group[0].s;
+  // (a rank with nothing to send or receive in this group -- the ends of a ring pipeline -- still takes part in the
+  // group's two rendezvous: the others count on its arrivals.  It has no stream of its own to say: the last one used.)
+  hipStream_t s = g_group.empty() ? g.last_stream : g_group[0].s;
   for (const P2P& op : g_group)
     if (op.s != s) { fprintf(stderr, "shm_transport: the operations of one group must share a stream\n"); g_group.clear(); return ncclInvalidArgument; }
   TRYN(begin_op(s));

@@ -125,6 +125,27 @@ def test_pagerank_bit_exact_rmat(env, scale, threads, layout):
     api._lib.lib().gm_set_option(b"force_ordered", 0)
 
 
+def test_uniform_random_graph_against_oracle(env):
+    """A graph without any skew -- every vertex has exactly 16 out-edges to uniformly drawn distinct destinations, the
+    shape of the reference's own random test graphs (test/generator.h:73-105) -- where ranking vertices by degree buys
+    nothing: PageRank (fixed count, forced column tiles too), BFS and SSSP must still equal the oracle bit for bit."""
+    api, ob = env
+    nv, s, d, v = gen.uniform_out_regular_edges(1 << 16, 16, seed=9)
+    og = ob.OracleGraph(nv, s, d, v, 2)
+    opr, oit, _ = og.pagerank(8)
+    for tiles in (0, 3):
+        g = api.Graph(nv, s, d, v, ref_threads=2, col_tiles=tiles)
+        pr, deg, it = g.pagerank(8)
+        assert (deg == og.degree()).all() and (deg == 16).all()
+        assert it == oit == 8 and (f32bits(pr) == f32bits(opr)).all(), "tiles=%d" % tiles
+    depth, parent, itb = g.bfs(3)
+    od, op, oitb, _ = og.bfs(3)
+    assert itb == oitb and (depth == od).all() and (parent == op).all()
+    dist, its = g.sssp(3)
+    odist, oits = og.sssp(3)
+    assert its == oits and (dist == odist).all()
+
+
 def test_pagerank_until_convergence(env):
     api, ob = env
     nv, s, d, v = gen.rmat_edges(12, 16, seed=5)
