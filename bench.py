@@ -614,6 +614,50 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # N > 1 diagnostics (after the timed region, not part of `value`): the same schedule once more with an exchange that
+    # moves NOTHING -- what the shards' kernels alone take (results are garbage, a scratch state is used) -- so that
+    # exchange_ms_exposed = measured iteration - compute-only iteration is what the collectives add on the critical
+    # path; plus the bytes a rank contributes / receives per iteration and the per-phase times of this rank.
+    multi_diag = None
+    if world > 1 and ex is not None:
+        try:
+            xc0 = gdist.exchange_counters(g) if native else (ex.calls, ex.parts, 0)
+
+            def nothing(ctx, kind, ptr, elt, bits, flag):
+                return 0
+            cb0 = _lib.EXCHANGE_FN(nothing)
+            _lib.check(L.gm_graph_set_exchange(g.h, cb0, None))
+            scratch = st.clone()
+            g.enable_timing(False)
+            g.run_pagerank(scratch, 2)
+            dist.barrier()
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            g.run_pagerank(scratch, args.steps)
+            torch.cuda.synchronize()
+            tc = time.perf_counter() - tc
+            tct = torch.tensor([tc], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tct, op=dist.ReduceOp.MAX)
+            compute_ms = float(tct.item()) * 1e3 / args.steps
+            del scratch
+            if native:
+                _lib.check(L.gm_graph_use_rccl(g.h))
+            else:
+                _lib.check(L.gm_graph_set_exchange(g.h, cb, None))
+            live = int(g.xchg_rows)
+            multi_diag = {"compute_only_ms_per_step": round(compute_ms, 4),
+                          "exchange_ms_exposed": round(dt * 1e3 / args.steps - compute_ms, 4),
+                          "bytes_sent_per_rank_per_step": live * 4, "bytes_received_per_rank_per_step": live * 4 * (world - 1),
+                          "exchange_calls_total": int(xc0[0]), "overlapped_parts_total": int(xc0[1]),
+                          "native_bytes_contributed_total": int(xc0[2]) if native else None,
+                          "phase_ms_per_step_rank0": {"send_and_exchange_enqueue": round(stats["send_ms"] / args.steps, 4),
+                                                      "rowblock": round(stats["rowblock_ms"] / args.steps, 4), "wave": round(stats["wave_ms"] / args.steps, 4),
+                                                      "giant_aux_stream": round(stats["giant_ms"] / args.steps, 4), "apply": round(stats["apply_ms"] / args.steps, 4)},
+                          "note": "compute_only = the same schedule with an exchange callback that moves nothing (max over ranks); exposed = measured - compute_only"}
+            log(rank, "N=%d diagnostics: %.3f ms/step measured, %.3f ms/step compute only => %.3f ms of exchange exposed; %d bytes sent and %d received per rank and step"
+                % (world, dt * 1e3 / args.steps, compute_ms, dt * 1e3 / args.steps - compute_ms, live * 4, live * 4 * (world - 1)))
+        except Exception as e:  # pragma: no cover
+            multi_diag = {"error": repr(e)}
 
     ms_per_step = dt * 1e3 / args.steps
     gteps = E * args.steps / dt / 1e9
@@ -735,6 +779,8 @@ def main():
         "iter_hbm_frac": round(iter_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4),
         "roofline": roof,
     }
+    if multi_diag is not None:
+        out["multi_gpu"] = multi_diag
     if args.debug_flags & ~(128 | 64 | 32 | 16):  # flags that only choose between exact strategies keep the result valid
         out["INVALID_ablation_debug_flags"] = args.debug_flags
     if rank == 0 and world == 1 and args.cpu_scale > 0:

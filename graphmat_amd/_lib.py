@@ -46,6 +46,12 @@ class RunStats(C.Structure):
                 ("wave_launches", C.c_int32), ("giant_launches", C.c_int32), ("sparse_exchanges", C.c_int32)]
 
 
+class EngineOptions(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("debug_flags", "wave16_form", "rowwave_form", "persist_per_cu", "giant_maps", "ordered_giant_two_pass",
+                                         "fuse_apply_send", "untiled_pass_plain", "last_rows_lanes", "push_edge_permille", "bits_step_edges",
+                                         "sparse_step_edges", "iteration_trace", "ablate_cold_from", "ablate_cold_short")] + [("reserved_", C.c_int32 * 17)]
+
+
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int))
 
 # name -> (restype, argtypes); every symbol include/graphmat_hip.h declares
@@ -100,6 +106,9 @@ SIGNATURES = {
     "gm_run_sgd_bipartite": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                                        C.POINTER(C.c_int), _P]),
     "gm_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "gm_graph_engine_options": (C.c_int, [_P, C.POINTER(EngineOptions)]),
+    "gm_graph_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "gm_reset_options": (C.c_int, []),
     "gm_graph_enable_timing": (C.c_int, [_P, C.c_int]),
     "gm_graph_last_stats": (C.c_int, [_P, C.POINTER(RunStats)]),
     "gm_graph_workspace": (C.c_int, [_P, C.c_int, C.c_size_t, C.POINTER(_P)]),

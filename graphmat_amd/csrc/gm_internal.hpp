@@ -92,6 +92,9 @@ struct gm_graph {
   int xcaps;                    // GM_XCAP_* of the installed exchange
   void* native_xchg;
   hipStream_t run_stream;       // the stream of the run in progress (gm_graph_set_run_stream): collectives are enqueued on it
+  // engine options this graph overrides (gm_graph_set_option); bit i of opt_set = field i of gm_engine_options_t
+  gm_engine_options_t opt;
+  uint32_t opt_set;
 };
 namespace gm {
 void free_native_exchange(gm_graph* g);

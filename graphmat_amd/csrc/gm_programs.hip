@@ -688,7 +688,90 @@ void warm_program_kernels(void* d_scratch256) {
 
 extern "C" {
 
+// ---- engine options (graphmat_hip.h: gm_engine_options_t): process defaults + per-graph overrides --------------------
+namespace gm {
+struct EngineKey { const char* name; int index; int def, lo, hi; };  // index = position of the field in gm_engine_options_t
+static const EngineKey kEngineKeys[] = {
+  {"debug_flags", 0, 0, 0, 0x7fffffff},
+  {"wave16_form", 1, 2, 0, 31},
+  {"rowwave_form", 2, 4, 0, 31},
+  {"persist_per_cu", 3, 0, 0, 8},
+  {"giant_maps", 4, 1, 0, 1},
+  {"ordered_giant_two_pass", 5, 1, 0, 1},
+  {"fuse_apply_send", 6, 1, 0, 1},
+  {"untiled_pass_plain", 7, 1, 0, 1},
+  {"last_rows_lanes", 8, 8, 8, 16},
+  {"push_edge_permille", 9, 50, 0, 1000},
+  {"bits_step_edges", 10, 2 << 20, 0, 0x7fffffff},
+  {"sparse_step_edges", 11, 1 << 20, 0, 0x7fffffff},
+  {"iteration_trace", 12, 0, 0, 1},
+  {"ablate_cold_from", 13, 0, 0, 0x7fffffff},
+  {"ablate_cold_short", 14, 0, 0, 0x7fffffff},
+};
+static_assert(offsetof(gm_engine_options_t, ablate_cold_short) == 14 * sizeof(int32_t), "kEngineKeys follows the field order");
+static bool engine_value_ok(const EngineKey& k, int v) {
+  if (v < k.lo || v > k.hi) return false;
+  if (!strcmp(k.name, "wave16_form")) return (v & 15) <= 5;
+  if (!strcmp(k.name, "rowwave_form")) return (v & 15) <= 4;
+  if (!strcmp(k.name, "last_rows_lanes")) return v == 8 || v == 16;
+  return true;
+}
+static gm_engine_options_t engine_documented_defaults() {
+  gm_engine_options_t o;
+  memset(&o, 0, sizeof(o));
+  for (const EngineKey& k : kEngineKeys) ((int32_t*)&o)[k.index] = k.def;
+  const char* tr = getenv("GRAPHMAT_ITERATION_TRACE");
+  if (tr && tr[0] == '1') o.iteration_trace = 1;
+  return o;
+}
+static gm_engine_options_t& engine_defaults() {
+  static gm_engine_options_t o = engine_documented_defaults();
+  return o;
+}
+static const EngineKey* engine_key(const char* key) {
+  if (!key) return nullptr;
+  for (const EngineKey& k : kEngineKeys)
+    if (!strcmp(k.name, key)) return &k;
+  return nullptr;
+}
+}  // namespace gm
+
+int gm_graph_engine_options(const gm_graph_t* g, gm_engine_options_t* out) {
+  if (!out) { gm::set_error("gm_graph_engine_options: null argument"); return GM_ERR_INVALID; }
+  *out = gm::engine_defaults();
+  if (g)
+    for (const gm::EngineKey& k : gm::kEngineKeys)
+      if ((g->opt_set >> k.index) & 1u) ((int32_t*)out)[k.index] = ((const int32_t*)&g->opt)[k.index];
+  return GM_OK;
+}
+int gm_graph_set_option(gm_graph_t* g, const char* key, int value) {
+  const gm::EngineKey* k = gm::engine_key(key);
+  if (!g || !k || !gm::engine_value_ok(*k, value)) { gm::set_error("gm_graph_set_option: unknown engine option or value out of range"); return GM_ERR_INVALID; }
+  ((int32_t*)&g->opt)[k->index] = value;
+  g->opt_set |= 1u << k->index;
+  return GM_OK;
+}
+int gm_reset_options(void) {
+  gm::engine_defaults() = gm::engine_documented_defaults();
+  gm::g_force_ordered = 0;
+  gm::g_sgd_mfma = 0;
+  gm::g_short_row = GM_SHORT_ROW;
+  gm::g_giant_row = 0;
+  gm::g_rank_cap = 0;
+  gm::g_rank_by = 0;
+  gm::g_tile_min_row = GM_TILE_MIN_ROW;
+  gm::g_tile_balance = 1;
+  gm::g_long_mid = 0;
+  gm::g_own_wave_row = 4096;
+  gm::g_col_tiles = 0;
+  return GM_OK;
+}
 int gm_set_option(const char* key, int value) {
+  if (const gm::EngineKey* k = gm::engine_key(key)) {
+    if (!gm::engine_value_ok(*k, value)) { gm::set_error("gm_set_option: value out of range"); return GM_ERR_INVALID; }
+    ((int32_t*)&gm::engine_defaults())[k->index] = value;
+    return GM_OK;
+  }
   if (key && !strcmp(key, "force_ordered")) { gm::g_force_ordered = value; return GM_OK; }
   if (key && !strcmp(key, "sgd_mfma") && (value == 0 || value == 1)) { gm::g_sgd_mfma = value; return GM_OK; }
   if (key && !strcmp(key, "short_row") && value >= 1 && value <= GM_BLOCK_NNZ) { gm::g_short_row = value; return GM_OK; }
@@ -701,21 +784,6 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "tile_min_row") && (value == 0 || value >= gm::g_short_row)) { gm::g_tile_min_row = value; return GM_OK; }
   if (key && !strcmp(key, "col_tiles") && value >= 0 && value <= GM_MAX_TILES) { gm::g_col_tiles = value; return GM_OK; }
   if (key && !strcmp(key, "own_wave_row") && value >= 0) { gm::g_own_wave_row = value; return GM_OK; }
-  if (key && !strcmp(key, "push_edge_permille") && value >= 0 && value <= 1000) { GraphMat::detail::push_edge_permille() = value; return GM_OK; }
-  if (key && !strcmp(key, "bits_step_edges") && value >= 0) { GraphMat::detail::bits_step_edges() = value; return GM_OK; }
-  if (key && !strcmp(key, "fuse_apply_send") && (value == 0 || value == 1)) { GraphMat::detail::fuse_apply_send() = value; return GM_OK; }
-  if (key && !strcmp(key, "untiled_pass_plain") && (value == 0 || value == 1)) { GraphMat::detail::untiled_pass_plain() = value; return GM_OK; }
-  if (key && !strcmp(key, "last_rows_lanes") && (value == 8 || value == 16)) { GraphMat::detail::last_rows_lanes() = value; return GM_OK; }
-  if (key && !strcmp(key, "sparse_step_edges") && value >= 0) { GraphMat::detail::sparse_step_edges() = value; return GM_OK; }
-  if (key && !strcmp(key, "wave16_form") && value >= 0 && (value & 15) <= 5 && value < 32) { GraphMat::detail::wave16_form() = value; return GM_OK; }
-  if (key && !strcmp(key, "rowwave_form") && value >= 0 && (value & 15) <= 4 && value < 32) { GraphMat::detail::rowwave_form() = value; return GM_OK; }
-  if (key && !strcmp(key, "persist_per_cu") && value >= 0 && value <= 8) { GraphMat::detail::persist_per_cu() = value; return GM_OK; }
-  if (key && !strcmp(key, "giant_maps") && (value == 0 || value == 1)) { GraphMat::detail::giant_maps() = value; return GM_OK; }
-  if (key && !strcmp(key, "iteration_trace") && (value == 0 || value == 1)) { GraphMat::detail::iteration_trace() = value; return GM_OK; }
-  if (key && !strcmp(key, "ablate_cold_from") && value >= 0) { GraphMat::detail::ablate_cold_from() = value; return GM_OK; }
-  if (key && !strcmp(key, "ablate_cold_short") && value >= 0) { GraphMat::detail::ablate_cold_short() = value; return GM_OK; }
-  if (key && !strcmp(key, "ordered_giant_two_pass") && (value == 0 || value == 1)) { GraphMat::detail::ordered_giant_two_pass() = value; return GM_OK; }
-  if (key && !strcmp(key, "debug_flags")) { GraphMat::detail::debug_flags() = value; return GM_OK; }
   gm::set_error("gm_set_option: unknown option");
   return GM_ERR_INVALID;
 }

@@ -99,7 +99,7 @@ void run_graph_program(
 #endif
 
 #ifdef __TIMING
-  detail::iteration_trace() = 1;  // the reference's per-iteration lines (:150-248)
+  gm_graph_set_option(g.A, "iteration_trace", 1);  // the reference's per-iteration lines (:150-248)
 #endif
   int it = detail::run_on_device<Prog, T, U, V, E>(
       gp, g.A, gp->getOrder(), gp->getActivity(), gp->getProcessMessageRequiresVertexprop(),

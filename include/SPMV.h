@@ -41,12 +41,11 @@ void spmv_pass(Graph<V, E>& G, const Prog* gp, int dir, XV* x, YV* y, int accumu
   int launches = 0;
   const T* xv = (const T*)x->segment->value;
   U* yv = (U*)y->segment->value;
-  if (gp->getProcessMessageRequiresVertexprop())
-    launch_spmv<Prog, T, U, V, E, true>(G.A, pa, c, xv, x->segment->bit_vector, (const V*)G.vertexproperty->segment->value,
-                                        yv, y->segment->bit_vector, accumulate, 0, &launches, nullptr, nullptr, reduce_kind_of<Prog, U>(gp));
-  else
-    launch_spmv<Prog, T, U, V, E, false>(G.A, pa, c, xv, x->segment->bit_vector, (const V*)G.vertexproperty->segment->value,
-                                         yv, y->segment->bit_vector, accumulate, 0, &launches, nullptr, nullptr, reduce_kind_of<Prog, U>(gp));
+  gm_engine_options_t opt;
+  gm_graph_engine_options(G.A, &opt);
+  const Launch L{G.A, (hipStream_t)0, opt, &launches, nullptr, nullptr};
+  launch_spmv_vp<Prog, T, U, V, E>(gp->getProcessMessageRequiresVertexprop(), L, pa, c, xv, (const uint32_t*)x->segment->bit_vector,
+                                   (const V*)G.vertexproperty->segment->value, yv, y->segment->bit_vector, accumulate, reduce_kind_of<Prog, U>(gp));
   GM_HIP_OK(hipStreamSynchronize(0));
   y->segment->device_modified();
 }

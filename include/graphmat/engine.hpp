@@ -53,39 +53,11 @@ constexpr bool inherits_iteration_hook() {
 
 inline int grid_for(int64_t n) { return (int)((n + dev::kBlock - 1) / dev::kBlock); }
 
-// ablation switches for the multiply+reduce kernels (dev::DBG_*); 0 in production
-inline int& debug_flags() {
-  static int f = 0;
-  return f;
-}
+// The options of a run (which exact strategy, which kernel form, ablation switches) are NOT state of this header: they
+// live in the library, as process defaults (gm_set_option) that a graph may override (gm_graph_set_option), and a run
+// reads them once through gm_graph_engine_options (graphmat_hip.h: gm_engine_options_t documents every field).  An
+// application binary that instantiates this header and the library therefore always agree on them.
 
-// form of the 16-rows-per-wave kernel: 0 = one workgroup per 64 rows with an 8192-entry LDS hot set;
-// 2 = persistent workgroups of 1024 threads with a 22528-entry hot set (large graphs: persistent_forms_pay)
-inline int& wave16_form() {
-  static int v = 2;  // (RMAT-26, with rowwave_form 4: 6.89 -> 6.65 ms per iteration; each alone -0.03 / -0.13 ms)
-  return v;
-}
-// giant rows of float sums: precomputed chunk maps (the multi-workgroup exact replay; 0 = one workgroup walks the row)
-inline int& giant_maps() {
-  static int v = 1;
-  return v;
-}
-// row-blocks: 0 = one workgroup per block (k_spmv_rowblock); 4 = waves of persistent 1024-thread workgroups sharing a
-// 20480-entry LDS hot set (large graphs: persistent_forms_pay)
-inline int& rowwave_form() {
-  static int v = 4;
-  return v;
-}
-// giant rows of plain REDUCE_ORDERED programs: products by k_giant_terms + k_giant_fold_ordered (1) or one wave per row (0)
-inline int& ordered_giant_two_pass() {
-  static int v = 1;
-  return v;
-}
-// persistent kernels: workgroups per CU (0 = as many as the LDS allows)
-inline int& persist_per_cu() {
-  static int v = 0;
-  return v;
-}
 // Persistent workgroups with a large LDS hot set (k_spmv_rowwave, k_spmv_wave16p) trade occupancy -- and LDS the
 // auxiliary stream's kernels would use next to them -- for fewer L2 requests.  Measured on RMAT, PageRank, both forms on
 // against both off: scale 22 +1.7 %, 24 -0.6 %, 25 -3.5 %, 26 +3.5 %, 27 +5.1 % (profiles/r03_persistent_kernels.md):
@@ -107,64 +79,11 @@ inline int cu_count() {
   return n;
 }
 
-// per-iteration trace in the reference's own words (include/GraphMatRuntime.h:150-248 under __TIMING): phase times and
-// "Iteration %d :: %f msec :: updated %d vertices :: changed %d vertices".  The host synchronises after every phase, so
-// this is a diagnostic mode (set by run_graph_program in -D__TIMING builds, gm_set_option("iteration_trace", 1), or
-// GRAPHMAT_ITERATION_TRACE=1).
-inline int& iteration_trace() {
-  static int v = (getenv("GRAPHMAT_ITERATION_TRACE") && getenv("GRAPHMAT_ITERATION_TRACE")[0] == '1') ? 1 : 0;
-  return v;
-}
 
-// a=b programs, rows of more than GM_SHORT_ROW edges under a row filter (kernels.hpp: group_rows_last): lanes per row
-inline int& last_rows_lanes() {
-  static int v = 8;
-  return v;
-}
-
-// fused apply + send (kernels.hpp: k_apply_send) for ALL_VERTICES programs (single GPU, and the plain loop of sharded runs): 1 = on
-inline int& fuse_apply_send() {
-  static int v = 1;
-  return v;
-}
-
-// keep mode: the untiled short-row pass through the plain row-block kernel (1) instead of the persistent one (0).  The
-// persistent kernel's hot set is the top of tile 0 only and serves few of that pass's gathers, while its 115 KB of LDS per
-// CU slow the giant kernels of the first tile that run next to it (1.08 ms against 0.3 ms alone): RMAT-26 6.09-6.14 ->
-// 6.05-6.10 ms, the auxiliary stream's kernels 5.70 -> 5.20 ms in sum
-inline int& untiled_pass_plain() {
-  static int v = 1;
-  return v;
-}
-
-// top-down steps are taken while the active set owns less than this many thousandths of the edges
-inline int& push_edge_permille() {
-  static int v = 50;
-  return v;
-}
-
-// ... an active set too large to list bids from its bitmap while it owns at most this many out-edges
-inline int& bits_step_edges() {
-  static int v = 2 << 20;  // (measured on RMAT-26: 0.25-1 M edges over 0.25-0.9 M vertices: 0.35 -> 0.1 ms; 6 M edges over 4.9 M: a loss)
-  return v;
-}
-// ... and entirely on lists while it owns at most this many out-edges
-inline int& sparse_step_edges() {
-  static int v = 1 << 20;
-  return v;
-}
-
-// ablation builds (-DGRAPHMAT_ABLATION): columns from this device id on are not gathered by the multiply kernels (the
-// time left is what a multiply costs whose cold-column messages arrive some other way); 0 = off
-inline int& ablate_cold_from() {
-  static int v = 0;
-  return v;
-}
-// ... and in the untiled short-row pass of a tiled graph: columns from this position INSIDE THEIR TILE on; 0 = off
-inline int& ablate_cold_short() {
-  static int v = 0;
-  return v;
-}
+// (per-iteration trace in the reference's own words -- include/GraphMatRuntime.h:150-248 under __TIMING: phase times and
+// "Iteration %d :: %f msec :: updated %d vertices :: changed %d vertices" -- is the option iteration_trace: the host
+// synchronises after every phase, so it is a diagnostic mode, set by run_graph_program in -D__TIMING builds or by
+// GRAPHMAT_ITERATION_TRACE=1.)
 
 // HIP-event phase timer: every mark closes an interval that is charged to `tag`.
 enum { TAG_START = 0, TAG_SEND = 1, TAG_ROWBLOCK = 2, TAG_WAVE = 3, TAG_GIANT = 4, TAG_APPLY = 5 };
@@ -358,19 +277,35 @@ constexpr bool wave16_ok() {
          (sizeof(U) == 4 || sizeof(U) == 8);
 }
 
+// what a multiply pass is launched with: the graph (scratch, tiles), the run's stream, the options of this run, and where to
+// account launches and phase times; `aux` = the auxiliary stream's state or null
+struct Launch {
+  gm_graph_t* g;
+  hipStream_t s;
+  const gm_engine_options_t& opt;
+  int* launches;
+  PhaseTimer* timer;
+  AuxStream* aux;
+};
+
 // one multiply+reduce pass over one direction of the adjacency, strategy RK
 template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
-void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A_in, const T* x, const uint32_t* xbits,
-                    const V* vp, U* y, uint32_t* ybits, int accumulate, hipStream_t s, int* launches, PhaseTimer* timer,
-                    AuxStream* aux, const uint32_t* want = nullptr, bool grouped = false, const uint32_t* xsum = nullptr) {
+void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& A_in, const T* x, const uint32_t* xbits,
+                    const V* vp, U* y, uint32_t* ybits, int accumulate, const uint32_t* want = nullptr, bool grouped = false,
+                    const uint32_t* xsum = nullptr) {
   constexpr int WPB = dev::kBlock / 64;  // rows (waves) per workgroup of k_spmv_wave
+  gm_graph_t* const g = L.g;
+  const hipStream_t s = L.s;
+  int* const launches = L.launches;
+  PhaseTimer* const timer = L.timer;
+  AuxStream* const aux = L.aux;
 #ifdef GRAPHMAT_ABLATION
   gm_csr_t A = A_in;
   {
     int ntile = 1;
     gm_graph_tiles(g, GM_DIR_OUT, &ntile);
     const bool whole = A.hot_base == 0 && A.hot_len >= A.ncols;
-    A.cold_from = (whole && ntile > 1) ? -ablate_cold_short() : ablate_cold_from();
+    A.cold_from = (whole && ntile > 1) ? -L.opt.ablate_cold_short : L.opt.ablate_cold_from;
     static std::vector<const void*> seen;
     bool first = true;
     for (const void* q : seen) first = first && q != (const void*)A.colidx;
@@ -410,7 +345,7 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A_
   bool long_on_aux = false;
   if constexpr (wave16_ok<U, USE_VP, RK>())
     long_on_aux = aux != nullptr && aux->s != nullptr && aux->long_rows && !defer && !(grouped && want != nullptr) && A.nmid > 0 && A.nmid_long > 0 &&
-                  (keep || A.nblk > 0 || A.nmid > A.nmid_long) && !(debug_flags() & dev::DBG_NO_WAVE16);
+                  (keep || A.nblk > 0 || A.nmid > A.nmid_long) && !(L.opt.debug_flags & dev::DBG_NO_WAVE16);
   bool forked = false;
   auto fork_aux = [&]() {
     if (forked) return;
@@ -447,14 +382,14 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A_
         // piece maps (kernels.hpp: gchunk_state): the exact replay of a giant row spread over the whole chip, its serial
         // part limited to the binade crossings.  float sums over a dense x only.
         if constexpr (std::is_same<U, float>::value) {
-          if (xbits == nullptr && want == nullptr && giant_maps() != 0) maps = (dev::gchunk_state*)A.gchunk_state;
+          if (xbits == nullptr && want == nullptr && L.opt.giant_maps != 0) maps = (dev::gchunk_state*)A.gchunk_state;
         }
         hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa,
-                           A, x, xbits, vp, terms, tpres, debug_flags(), maps);
+                           A, x, xbits, vp, terms, tpres, L.opt.debug_flags, maps);
         (*launches)++;
       }
       hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa,
-                         A, x, xbits, vp, y, ybits, accumulate, debug_flags(), (const U*)terms,
+                         A, x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, (const U*)terms,
                          (const unsigned long long*)tpres, want, maps);
     } else {
       // plain ordered fold (any reduce_function): products spread over the chip by k_giant_terms, then one wave per row
@@ -463,10 +398,10 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A_
       bool two_pass = false;
       if constexpr (dev::stageable<U>::value && std::is_trivially_copyable<U>::value) {
         void *p6 = nullptr, *p7 = nullptr;
-        if (ordered_giant_two_pass() != 0 && gm_graph_workspace(g, 6, (size_t)A.giant_edges * sizeof(U) + 64, &p6) == GM_OK &&
+        if (L.opt.ordered_giant_two_pass != 0 && gm_graph_workspace(g, 6, (size_t)A.giant_edges * sizeof(U) + 64, &p6) == GM_OK &&
             (xbits == nullptr || gm_graph_workspace(g, 14, (size_t)A.giant_edges / 8 + 64, &p7) == GM_OK)) {
           hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa,
-                             A, x, xbits, vp, (U*)p6, (unsigned long long*)p7, debug_flags(), (dev::gchunk_state*)nullptr);
+                             A, x, xbits, vp, (U*)p6, (unsigned long long*)p7, L.opt.debug_flags, (dev::gchunk_state*)nullptr);
           (*launches)++;
           hipLaunchKernelGGL((dev::k_giant_fold_ordered<P, U, V>), dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, vp, y,
                              ybits, accumulate, (const U*)p6, (const unsigned long long*)p7, want);
@@ -476,7 +411,7 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A_
       if (!two_pass)
         hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, REDUCE_ORDERED>),
                            dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, A.giant_row, A.ngiant, x,
-                           xbits, vp, y, ybits, accumulate, debug_flags(), want);
+                           xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want);
     }
     (*launches)++;
     if (overlap) {
@@ -490,7 +425,7 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A_
     // a=b: one lane per row over the whole row range (short rows pick themselves by their length)
     if constexpr (RK == REDUCE_LAST) {
       hipLaunchKernelGGL((dev::k_spmv_short_last<P, T, U, V, E, USE_VP>), dim3(grid_for(A.nrows)), dim3(dev::kBlock), 0, s,
-                         pa, A, x, xbits, vp, y, ybits, accumulate, debug_flags(), want, xsum);
+                         pa, A, x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want, xsum);
       (*launches)++;
       if (timer) timer->mark(TAG_ROWBLOCK);
     }
@@ -498,14 +433,14 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A_
     bool done = false;
     if constexpr (!USE_VP && sizeof(T) == 4 && sizeof(U) == 4 && RK != REDUCE_LAST && std::is_trivially_copyable<T>::value) {
       // persistent workgroups sharing a large LDS hot set, row-blocks taken by waves (kernels.hpp: k_spmv_rowwave)
-      const int form = rowwave_form() & 15;
-      const bool any_size = (rowwave_form() & 16) != 0;  // (tests: also for small graphs)
+      const int form = L.opt.rowwave_form & 15;
+      const bool any_size = (L.opt.rowwave_form & 16) != 0;  // (tests: also for small graphs)
       const bool whole_cols = A.hot_base == 0 && A.hot_len >= A.ncols;  // (not a column tile: the untiled pass of a tiled graph, or an untiled graph)
       if (form > 0 && xbits == nullptr && want == nullptr && !program_row_filter<P>::enabled && (persistent_forms_pay(A) || any_size) &&
-          !(whole_cols && keep && untiled_pass_plain() != 0)) {
+          !(whole_cols && keep && L.opt.untiled_pass_plain != 0)) {
         auto persistent = [&](auto block_c, auto hot_c, int fit) {
           constexpr int BLOCK = decltype(block_c)::value, HOT = decltype(hot_c)::value;
-          const int per_cu = persist_per_cu() > 0 && persist_per_cu() < fit ? persist_per_cu() : fit;
+          const int per_cu = L.opt.persist_per_cu > 0 && L.opt.persist_per_cu < fit ? L.opt.persist_per_cu : fit;
           int grid = cu_count() * per_cu;
           const int need = (A.nblk + BLOCK / 64 - 1) / (BLOCK / 64);
           if (grid > need) grid = need;
@@ -520,10 +455,10 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A_
     if (done) {
     } else if (xbits == nullptr)
       hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP, true, RK>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A,
-                         x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
+                         x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want);
     else
       hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP, false, RK>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A,
-                         x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
+                         x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want);
     (*launches)++;
     if (timer) timer->mark(TAG_ROWBLOCK);
   }
@@ -534,18 +469,18 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A_
       // slot of the chip, side by side each takes twice as long -- RMAT-26, first bottom-up level: 1.55 against 1.52 ms)
       bool done = false;
       if constexpr (RK == REDUCE_LAST) {
-        if (last_rows_lanes() == 16) {
+        if (L.opt.last_rows_lanes == 16) {
           hipLaunchKernelGGL((dev::k_spmv_wave_grouped<P, T, U, V, E, USE_VP, RK, 16>), dim3((groups + WPB - 1) / WPB),
                              dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
-                             debug_flags(), want, xsum);
+                             L.opt.debug_flags, want, xsum);
           done = true;
         }
       }
       if (!done)
         hipLaunchKernelGGL((dev::k_spmv_wave_grouped<P, T, U, V, E, USE_VP, RK>), dim3((groups + WPB - 1) / WPB),
                            dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
-                           debug_flags(), want, xsum);
-    } else if (wave16_ok<U, USE_VP, RK>() && !(debug_flags() & dev::DBG_NO_WAVE16)) {
+                           L.opt.debug_flags, want, xsum);
+    } else if (wave16_ok<U, USE_VP, RK>() && !(L.opt.debug_flags & dev::DBG_NO_WAVE16)) {
       if constexpr (wave16_ok<U, USE_VP, RK>()) {
         // ordered folds: the long rows at the head of the list get a wave each, the rest are folded 16 to a wave
         const int nlong = A.nmid_long < A.nmid ? A.nmid_long : A.nmid;
@@ -563,7 +498,7 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A_
             if (timer) timer->aux_mark(ls);
           }
           hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, RK>), dim3((nlong + WPB - 1) / WPB), dim3(dev::kBlock), 0, ls,
-                             pa, A, A.mid_row, nlong, x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
+                             pa, A, A.mid_row, nlong, x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want);
           if (long_on_aux) {
             if (timer) timer->aux_mark(ls);
             GM_HIP_OK(hipEventRecord(aux->join, ls));  // (re-recorded behind the giant passes' record: the wait below sees this one)
@@ -574,27 +509,27 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A_
         // in profiles/r03_persistent_kernels.md)
         bool done = false;
         if constexpr (sizeof(T) == 4 && sizeof(U) == 4) {
-          const int form = persistent_forms_pay(A) || (wave16_form() & 16) ? (wave16_form() & 15) : 0;
+          const int form = persistent_forms_pay(A) || (L.opt.wave16_form & 16) ? (L.opt.wave16_form & 15) : 0;
           if (rest > 0 && form == 2) {
             constexpr int BLOCK = 1024, HOT = 22528;
             int grid = cu_count();
             const int need = (groups + BLOCK / 64 - 1) / (BLOCK / 64);
             if (grid > need) grid = need;
             hipLaunchKernelGGL((dev::k_spmv_wave16p<P, T, U, V, E, BLOCK, HOT>), dim3(grid), dim3(BLOCK), 0, s, pa, A, A.mid_row + nlong, rest,
-                               x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
+                               x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want);
             done = true;
           }
         }
         if (!done && rest > 0) {
           constexpr int W16 = dev::kWave16Block / 64;
           hipLaunchKernelGGL((dev::k_spmv_wave16<P, T, U, V, E>), dim3((groups + W16 - 1) / W16), dim3(dev::kWave16Block), 0, s, pa, A,
-                             A.mid_row + nlong, rest, x, xbits, vp, y, ybits, accumulate, debug_flags(), want);
+                             A.mid_row + nlong, rest, x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want);
         }
       }
     } else
       hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, RK>), dim3((A.nmid + WPB - 1) / WPB),
                          dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
-                         debug_flags(), want);
+                         L.opt.debug_flags, want);
     (*launches)++;
     if (timer && !long_on_aux) timer->mark(TAG_WAVE);
   }
@@ -606,238 +541,337 @@ void launch_spmv_rk(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A_
 
 // rk: REDUCE_* chosen for this run.  Programs with a declared kind only instantiate that one.
 template <class P, class T, class U, class V, class E, bool USE_VP>
-void launch_spmv(gm_graph_t* g, const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits,
-                 const V* vp, U* y, uint32_t* ybits, int accumulate, hipStream_t s, int* launches,
-                 PhaseTimer* timer = nullptr, AuxStream* aux = nullptr, int rk = REDUCE_ORDERED, const uint32_t* want = nullptr,
-                 bool grouped = false, const uint32_t* xsum = nullptr) {
+void launch_spmv(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits, const V* vp, U* y,
+                 uint32_t* ybits, int accumulate, int rk = REDUCE_ORDERED, const uint32_t* want = nullptr, bool grouped = false,
+                 const uint32_t* xsum = nullptr) {
   if constexpr ((int)program_traits<P>::reduce != (int)REDUCE_AUTO) {
-    launch_spmv_rk<P, T, U, V, E, USE_VP, (int)program_traits<P>::reduce>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s,
-                                                                          launches, timer, aux, want, grouped, xsum);
+    launch_spmv_rk<P, T, U, V, E, USE_VP, (int)program_traits<P>::reduce>(L, pa, A, x, xbits, vp, y, ybits, accumulate, want, grouped, xsum);
   } else {
     if constexpr (std::is_same<U, float>::value) {
       if (rk == REDUCE_F32_ADD) {
-        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_F32_ADD>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped, xsum);
+        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_F32_ADD>(L, pa, A, x, xbits, vp, y, ybits, accumulate, want, grouped, xsum);
         return;
       }
     }
     if constexpr (std::is_trivially_copyable<U>::value && sizeof(U) <= 8) {
       if (rk == REDUCE_LAST) {
-        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_LAST>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped, xsum);
+        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_LAST>(L, pa, A, x, xbits, vp, y, ybits, accumulate, want, grouped, xsum);
         return;
       }
       if (rk == REDUCE_COMMUTATIVE) {
-        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_COMMUTATIVE>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped, xsum);
+        launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_COMMUTATIVE>(L, pa, A, x, xbits, vp, y, ybits, accumulate, want, grouped, xsum);
         return;
       }
     }
-    launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_ORDERED>(g, pa, A, x, xbits, vp, y, ybits, accumulate, s, launches, timer, aux, want, grouped, xsum);
+    launch_spmv_rk<P, T, U, V, E, USE_VP, REDUCE_ORDERED>(L, pa, A, x, xbits, vp, y, ybits, accumulate, want, grouped, xsum);
   }
 }
-
-// The iteration loop.  d_vp / d_active cover the shard's rows in native order.
-// x/xbits are global-size scratch, y/ybits shard-size scratch.  Returns iterations done.
+// ... with the 2- / 3-operand form chosen at run time (GraphProgram::process_message_requires_vertexprop, SPMV.h:67-71)
 template <class P, class T, class U, class V, class E>
-int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act, bool use_vp, V* d_vp,
-                  uint32_t* d_active, T* x, uint32_t* xbits, U* y, uint32_t* ybits, int iterations, hipStream_t s) {
-  const bool verbose = getenv("GRAPHMAT_VERBOSE") != nullptr;
+void launch_spmv_vp(bool use_vp, const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& A, const T* x, const uint32_t* xbits, const V* vp,
+                    U* y, uint32_t* ybits, int accumulate, int rk = REDUCE_ORDERED, const uint32_t* want = nullptr, bool grouped = false,
+                    const uint32_t* xsum = nullptr) {
+  if (use_vp) launch_spmv<P, T, U, V, E, true>(L, pa, A, x, xbits, vp, y, ybits, accumulate, rk, want, grouped, xsum);
+  else launch_spmv<P, T, U, V, E, false>(L, pa, A, x, xbits, vp, y, ybits, accumulate, rk, want, grouped, xsum);
+}
+
+// ---- the iteration loop ---------------------------------------------------------------------------------------------
+// One run of run_graph_program (GraphMatRuntime.h:93-279) on the device.  The state of a run lives in a Run object;
+// what an iteration does is one of four SCHEDULES, each a member function that enqueues its kernels on the run's stream:
+//   step_bits_push / step_list_push   top-down steps for small active sets (a=b and exact commutative programs)
+//   step_pull                         send (or exchange) -> multiply (plain, column-tiled on two streams, or a
+//                                     top-down bid pass over a larger active set) -> apply
+//   run_two_stage                     the whole fixed-count loop of a sharded ALL_VERTICES run: tail rows, then head
+//                                     rows, each multiplied / applied / sent while the other part's messages travel
+// d_vp / d_active cover the shard's rows in device order; x / xbits are global-size scratch, y / ybits shard-size scratch.
+template <class P, class T, class U, class V, class E>
+class Run {
+ public:
+  Run(P* gp_, gm_graph_t* g_, edge_direction order_, activity_type act_, bool use_vp_, V* d_vp_, uint32_t* d_active_, T* x_, uint32_t* xbits_,
+      U* y_, uint32_t* ybits_, int iterations_, hipStream_t s_)
+      : gp(gp_), g(g_), order(order_), act(act_), use_vp(use_vp_), d_vp(d_vp_), d_active(d_active_), x(x_), xbits(xbits_), y(y_), ybits(ybits_),
+        iterations(iterations_), s(s_), timer(false, s_) {}
+
+  // Returns iterations done.
+  int go() {
+    setup();
+    int it = -1;
+    if (two_stage_applies()) it = run_two_stage();
+    if (it < 0) it = run_loop();
+    return it;
+  }
+
+ private:
+  static constexpr bool kSparseT = std::is_trivially_copyable<T>::value && sizeof(T) <= 8;
+  typedef dev::sparse_entry<typename std::conditional<kSparseT, T, int>::type> xentry_t;
+
+  // ---- what the caller handed over -------------------------------------------------------------------------------
+  P* gp;
+  gm_graph_t* g;
+  edge_direction order;
+  activity_type act;
+  bool use_vp;
+  V* d_vp;
+  uint32_t* d_active;
+  T* x;
+  uint32_t* xbits;
+  U* y;
+  uint32_t* ybits;
+  int iterations;
+  hipStream_t s;
+
+  // ---- the run's fixed facts (setup) -------------------------------------------------------------------------------
+  gm_engine_options_t opt;  // (gm_graph_engine_options: process defaults overlaid with the graph's own)
+  bool verbose = false, trace = false;
   struct timeval tv0;
-  gettimeofday(&tv0, 0);
-  auto tick = [&](const char* what, int k) {  // GRAPHMAT_VERBOSE=1: host-side timeline of one run
+  gm_graph_desc_t desc;
+  gm_csr_t Aout, Ain, Asrc;
+  int n = 0, nwords = 0, n_live = 0;
+  bool multi = false;
+  int rk = REDUCE_ORDERED;
+  bool rk_unverified = false;  // a probed strategy still to be cross-checked on the device (k_check_rows)
+  bool can_push = false, xsparse_ok = false, lazy_send = false;
+  const int32_t *dev_of_native = nullptr, *native_of_dev = nullptr;
+  xentry_t* d_gather = nullptr;
+  unsigned long long* d_best = nullptr;
+  int32_t* d_list = nullptr;
+  int32_t* d_touched = nullptr;
+  unsigned int* d_off = nullptr;
+  uint32_t* d_want = nullptr;  // row-filter bits (program_row_filter), kept current by k_apply
+  void* flag_v = nullptr;      // 4096 bytes: [2] list counter, [3] touched counter, [4..9] frontier stats, [127] changed flag, [128..] striped stats
+  int* d_changed = nullptr;
+  unsigned int *d_count = nullptr, *d_tcount = nullptr;
+  unsigned long long *d_stats = nullptr, *d_striped = nullptr;
+  static constexpr size_t striped_bytes = (size_t)dev::kStatSlots * 4 * sizeof(unsigned long long);
+  int* h_changed = nullptr;  // pinned mirror of flag_v
+  unsigned long long *h_stats = nullptr, *h_striped = nullptr;
+  int stats_grid = 1;
+  bool grouped_waves = true;
+
+  // ---- what changes from iteration to iteration ------------------------------------------------------------------
+  unsigned long long frontier_v = 0, frontier_e = 0, frontier_maxdeg = 0;
+  int xs_max = 0, xs_total = 0;  // largest / total number of active vertices per shard (from the last GM_XCHG_STATE)
+  bool list_ready = false;       // d_list holds exactly the current active set
+  bool listed = false;           // the step just run wrote the list of its changed vertices
+  bool x_presend = false;        // x already holds the next iteration's messages (fused apply + send)
+  gm_run_stats_t st;
+  PhaseTimer timer;
+  AuxStream aux;
+  struct timeval tr_iter, tr_last;
+  long long tr_updated = -1;
+
+  Launch launch_ctx() { return Launch{g, s, opt, &st.spmv_launches, &timer, &aux}; }
+  static void die(const char* what) {
+    printf("GraphMat(HIP): %s\n", what);
+    exit(1);
+  }
+  void tick(const char* what, int k) {  // GRAPHMAT_VERBOSE=1: host-side timeline of one run
     if (!verbose) return;
     (void)hipStreamSynchronize(s);
     struct timeval tv1;
     gettimeofday(&tv1, 0);
     printf("GraphMat(HIP): +%9.3f ms  %s %d\n", (tv1.tv_sec - tv0.tv_sec) * 1e3 + (tv1.tv_usec - tv0.tv_usec) * 1e-3, what, k);
-  };
-  gm_graph_desc_t desc;
-  gm_graph_desc(g, &desc);
-  gm_csr_t Aout, Ain;
-  memset(&Aout, 0, sizeof(Aout));
-  memset(&Ain, 0, sizeof(Ain));
-  if (order != IN_EDGES && gm_graph_csr(g, GM_DIR_OUT, &Aout) != GM_OK) {
-    printf("GraphMat(HIP): program needs OUT_EDGES adjacency (GM_DIR_OUT) which this graph was built without\n");
-    exit(1);
   }
-  if (order != OUT_EDGES && gm_graph_csr(g, GM_DIR_IN, &Ain) != GM_OK) {
-    printf("GraphMat(HIP): program needs IN_EDGES adjacency (GM_DIR_IN) which this graph was built without\n");
-    exit(1);
+  void lap(const char* label) {  // trace mode: host clock per phase (the reference's __TIMING lines)
+    if (!trace) return;
+    (void)hipStreamSynchronize(s);
+    if (aux.s) (void)hipStreamSynchronize(aux.s);
+    struct timeval now;
+    gettimeofday(&now, 0);
+    if (label) printf("%s = %.3f ms \n", label, (now.tv_sec - tr_last.tv_sec) * 1e3 + (now.tv_usec - tr_last.tv_usec) * 1e-3);
+    tr_last = now;
   }
-  const int n = desc.row_hi - desc.row_lo;
-  const int nwords = (n + 31) / 32;
-  const bool multi = gm_graph_has_exchange(g) != 0;
-  gm_graph_set_run_stream(g, (gm_stream_t)s);  // a native (RCCL) exchange enqueues its collectives here
-  const int n_live = (desc.xchg_rows > 0 && desc.xchg_rows < n && (desc.xchg_rows & 63) == 0) ? desc.xchg_rows : n;
-
-  // top-down steps for small active sets (kernels.hpp: k_push_*): REDUCE_LAST programs over
-  // OUT_EDGES, running until convergence (the host already syncs once per iteration), unsharded,
-  // when the by-source adjacency is available.  (A frontier-guided pull for the other reduction
-  // kinds -- mark the rows that have an active in-neighbour, multiply only those -- was tried and
-  // dropped: on RMAT graphs an active set of any size reaches most busy rows, and the extra passes
-  // plus the per-iteration statistics made SSSP 7.0 -> 13 ms on RMAT-22.)
-  bool can_push = false;
-  gm_csr_t Asrc;
-  memset(&Asrc, 0, sizeof(Asrc));
-  const int32_t *dev_of_native = nullptr, *native_of_dev = nullptr;
-  int rk = reduce_kind_of<P, U>(gp);
-  // a strategy the program did not declare but the probe inferred is cross-checked on the device against the
-  // ordered fold the first time a pull multiply runs (k_check_rows); a disagreement falls back to the ordered fold
-  bool rk_unverified = (int)program_traits<P>::reduce == (int)REDUCE_AUTO && rk != REDUCE_ORDERED && !getenv("GRAPHMAT_NO_PROBE_CHECK");
-  tick("reduce_function probed", rk);
-  if (verbose) printf("GraphMat(HIP): reduce strategy %d (0 ordered, 1 commutative, 2 last, 3 float add)\n", rk);
-  // (REDUCE_COMMUTATIVE programs with a 4-byte reduction type take the list-based steps too, folding with
-  // compare-and-swap: k_push_combine)
-  const bool comm_push = rk == REDUCE_COMMUTATIVE && sizeof(U) == 4 && std::is_trivially_copyable<U>::value;
-  can_push = (rk == REDUCE_LAST || comm_push) && order == OUT_EDGES && act == ACTIVE_ONLY && iterations <= 0 && !multi &&
-             !(debug_flags() & dev::DBG_NO_PUSH) && gm_graph_csr(g, GM_DIR_IN, &Asrc) == GM_OK && desc.row_lo == 0 &&
-             desc.row_hi == desc.ndevice;
-  if (can_push) gm_graph_maps(g, &dev_of_native, &native_of_dev);
-  // Sharded ACTIVE_ONLY programs running until convergence exchange a SMALL active set as (device id,
-  // message) lists instead of all-gathering the whole dense x (graphmat_hip.h: GM_XCHG_STATE / GM_XCHG_GATHER;
-  // the reference compresses sparse segments before sending them, DenseSegment.h:532-538,665-700)
-  constexpr bool kSparseT = std::is_trivially_copyable<T>::value && sizeof(T) <= 8;
-  bool xsparse_ok = kSparseT && multi && act == ACTIVE_ONLY && iterations <= 0 && (gm_graph_exchange_caps(g) & GM_XCAP_SPARSE) &&
-                    !(debug_flags() & dev::DBG_NO_SPARSE_XCHG);
-  if (xsparse_ok && Asrc.rowptr == nullptr) (void)gm_graph_csr(g, GM_DIR_IN, &Asrc);  // out-degrees for the statistics, when available
-  typedef dev::sparse_entry<typename std::conditional<kSparseT, T, int>::type> xentry_t;
-  xentry_t* d_gather = nullptr;
-  int xs_max = 0, xs_total = 0;  // largest / total number of active vertices per shard (from the last GM_XCHG_STATE)
-  // a=b programs consume one message per row: unsharded, they evaluate it on demand from the sender's
-  // vertex property (kernels.hpp: message_of) and the send pass disappears; the presence bits of x
-  // are the active bits themselves
-  bool lazy_send = rk == REDUCE_LAST && sizeof(U) <= 8 && std::is_trivially_copyable<U>::value && !multi &&
-                         act == ACTIVE_ONLY && order == OUT_EDGES && desc.row_lo == 0 && desc.row_hi == desc.ndevice &&
-                         !(debug_flags() & dev::DBG_NO_LAZY_SEND);
-  if (verbose && lazy_send) printf("GraphMat(HIP): messages are evaluated on demand (no send pass)\n");
-  unsigned long long* d_best = nullptr;
-  int32_t* d_list = nullptr;
-  int32_t* d_touched = nullptr;
-  unsigned int* d_off = nullptr;
-  bool list_ready = false;  // d_list holds exactly the current active set
-  bool listed = false;      // the step just run wrote the list of its changed vertices
-  unsigned long long* h_stats = nullptr;  // pinned: [0] changed flag (as int), [2],[3] frontier vertices / out-edges
-
-  void* flag_v = nullptr;
-  gm_graph_workspace(g, 0, 4096, &flag_v);
-  // words: [2] list counter, [3] touched counter, [4..9] frontier stats (3 x u64), [127] changed flag -- directly in front of
-  // the striped statistics, so that one memset clears and one copy fetches "flag + statistics" (every call the host makes
-  // between two short levels of a traversal shows up as idle time on the GPU)
-  int* d_changed = (int*)flag_v + 127;
-  unsigned int* d_count = (unsigned int*)flag_v + 2;   // entries of d_list (the active set, when it is small)
-  unsigned int* d_tcount = (unsigned int*)flag_v + 3;  // entries of d_touched (destinations bid for in a top-down step)
-  unsigned long long* d_stats = (unsigned long long*)flag_v + 2;  // byte offset 16
-  unsigned long long* d_striped = (unsigned long long*)flag_v + 64;  // byte offset 512: kStatSlots x 4 u64 (k_apply)
-  const size_t striped_bytes = (size_t)dev::kStatSlots * 4 * sizeof(unsigned long long);
-  void *res_stream = nullptr, *res_fork = nullptr, *res_join = nullptr, *res_pinned = nullptr;
-  if (gm_graph_run_resources(g, &res_stream, &res_fork, &res_join, &res_pinned) != GM_OK) {
-    printf("GraphMat(HIP): %s\n", gm_last_error());
-    exit(1);
+  long long count_bits(const uint32_t* bits, int nbits) {
+    int64_t c = 0;
+    if (bits == nullptr || nbits <= 0) return 0;
+    if (gm_popcount_bits(bits, (int64_t)nbits, &c, (gm_stream_t)s) != GM_OK) return -1;
+    return (long long)c;
   }
-  int* h_changed = (int*)res_pinned + 127;  // (the pinned mirror has the layout of flag_v)
-  h_stats = (unsigned long long*)res_pinned;
-  unsigned long long* h_striped = (unsigned long long*)res_pinned + 64;
-  unsigned long long frontier_v = 0, frontier_e = 0, frontier_maxdeg = 0;
-  const int stats_grid = grid_for(n) < 2048 ? grid_for(n) : 2048;
-  const bool xsparse_candidate = xsparse_ok;  // (the same on every shard: program, run mode and exchange capabilities)
-  if (xsparse_ok) {
-    void* pg = nullptr;
-    if (gm_graph_workspace(g, GM_WS_GATHER, (size_t)desc.nshards * dev::kSparseListCap * sizeof(xentry_t) + 256, &pg) == GM_OK) d_gather = (xentry_t*)pg;
-    else xsparse_ok = false;  // (an adopted buffer that is too small: dense exchanges only)
+  void send_all(const dev::ProgArg<P>& pa, const uint32_t* active_bits, T* into) {  // x = send_message(vp) over the live rows
+    hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp, active_bits, into, xbits, n_live,
+                       desc.row_lo);
   }
-  if (can_push || xsparse_ok) {
-    void *pb = nullptr, *pl = nullptr, *pt = nullptr;
-    if (gm_graph_workspace(g, 7, (size_t)n * 4 + 1024 + ((size_t)dev::kSparseListCap + 64 + dev::kSparseListCap / dev::kBlock + 64) * 4, &pl) != GM_OK ||
-        (can_push && (gm_graph_workspace(g, 6, (size_t)n * 8 + 64, &pb) != GM_OK || gm_graph_workspace(g, 10, (size_t)n * 4 + 1024, &pt) != GM_OK))) {
-      can_push = false;
-      xsparse_ok = false;
-    } else {
-      d_best = (unsigned long long*)pb;
-      d_list = (int32_t*)pl;
-      d_off = (unsigned int*)((char*)pl + ((size_t)n * 4 + 1024) / 256 * 256);  // piece offsets of the listed sources
-      d_touched = (int32_t*)pt;
-      // (rows past n_live have no in-edge: nobody ever bids for them -- at RMAT-26 that halves a 537 MB memset)
-      if (can_push) GM_HIP_OK(hipMemsetAsync(d_best, 0, (size_t)n_live * 8, s));
-      GM_HIP_OK(hipMemsetAsync(d_stats, 0, 24, s));
-      GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
-      hipLaunchKernelGGL(dev::k_frontier_stats, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active,
-                         Asrc.rowptr, n, d_stats, d_list, d_count);
-      GM_HIP_OK(hipMemcpyAsync(h_stats + 2, d_stats, 24, hipMemcpyDeviceToHost, s));
-      GM_HIP_OK(hipStreamSynchronize(s));
-      frontier_v = h_stats[2];
-      frontier_e = h_stats[3];
-      frontier_maxdeg = h_stats[4];
-      list_ready = frontier_v <= (unsigned long long)dev::kSparseListCap;  // listed by the same pass
-    }
+  void fill_active() {
+    hipLaunchKernelGGL(dev::k_fill_u32, dim3(grid_for(nwords)), dim3(dev::kBlock), 0, s, d_active, (int64_t)nwords, 0xffffffffu);
   }
-  auto exchange_state = [&](int* converged) {  // flag AND + active-set sizes over the shards
+  void exchange_state(int* converged) {  // flag AND + active-set sizes over the shards
     int hf[4] = {*converged, frontier_v > 0x7fffffffull ? 0x7fffffff : (int)frontier_v, 0, 0};
-    if (gm_graph_exchange(g, GM_XCHG_STATE, nullptr, 0, nullptr, hf) != 0) {
-      printf("GraphMat(HIP): state exchange failed\n");
-      exit(1);
-    }
+    if (gm_graph_exchange(g, GM_XCHG_STATE, nullptr, 0, nullptr, hf) != 0) die("state exchange failed");
     *converged = hf[0];
     xs_max = hf[1];
     xs_total = hf[2];
-  };
-  if (xsparse_candidate) {
-    // a shard that had to give up the sparse exchange (a workspace it could not get) takes the others with it: from here
-    // on the shards must issue the same collectives (MIN over the shards of "still possible here")
-    int still = xsparse_ok ? 1 : 0;
-    gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &still);
-    if (!still) xsparse_ok = false;
   }
-  if (xsparse_ok) {
-    int dummy = 0;
-    exchange_state(&dummy);
+  // piece offsets of the listed sources (kernels.hpp: k_piece_*); the per-workgroup bases live behind them
+  void piece_offsets(int nf) {
+    const int nb = grid_for(nf);
+    unsigned int* d_base = d_off + dev::kSparseListCap + 64;
+    hipLaunchKernelGGL(dev::k_piece_count, dim3(nb), dim3(dev::kBlock), 0, s, Asrc, (const int32_t*)d_list, nf, d_base);
+    hipLaunchKernelGGL(dev::k_piece_block_scan, dim3(1), dim3(dev::kBlock), 0, s, d_base, nb);
+    hipLaunchKernelGGL(dev::k_piece_offsets, dim3(nb), dim3(dev::kBlock), 0, s, Asrc, (const int32_t*)d_list, nf, (const unsigned int*)d_base, d_off);
   }
-
-  if (act == ALL_VERTICES) {  // GraphMatRuntime.h:121-123 g.setAllActive()
-    hipLaunchKernelGGL(dev::k_fill_u32, dim3(grid_for(nwords)), dim3(dev::kBlock), 0, s, d_active, (int64_t)nwords,
-                       0xffffffffu);
-  }
-  gm_run_stats_t st;
-  memset(&st, 0, sizeof(st));
-  PhaseTimer timer(gm_graph_timing_enabled(g) != 0, s);
-  AuxStream aux;
-  tick("first frontier counted", (int)frontier_v);
-  if (!(debug_flags() & dev::DBG_NO_OVERLAP)) {
-    aux.attach(res_stream, res_fork, res_join);
+  void list_active_set() {  // d_list = the current active set (when no step left it behind)
+    if (list_ready) return;
+    GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
+    hipLaunchKernelGGL(dev::k_frontier_list, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active, n, d_list, d_count);
   }
 
-  // row-filter bits (program_row_filter): one pass over the vertex properties now, kept current by k_apply
-  uint32_t* d_want = nullptr;
-  if constexpr (program_row_filter<P>::enabled) {
-    void* pw = nullptr;
-    if (gm_graph_workspace(g, 8, ((size_t)(n + 31) / 32 + 2) * 4, &pw) == GM_OK) {
-      d_want = (uint32_t*)pw;
-      dev::ProgArg<P> pa0 = dev::make_prog_arg(gp);
-      // (rows past n_live have no edges: no kernel ever looks at their bit)
-      hipLaunchKernelGGL((dev::k_want_init<P, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa0, (const V*)d_vp, n_live, d_want);
+  // ---- set-up: adjacency views, strategy, scratch --------------------------------------------------------------------
+  void setup() {
+    verbose = getenv("GRAPHMAT_VERBOSE") != nullptr;
+    gettimeofday(&tv0, 0);
+    if (gm_graph_engine_options(g, &opt) != GM_OK) die(gm_last_error());
+    trace = opt.iteration_trace != 0;
+    gm_graph_desc(g, &desc);
+    memset(&Aout, 0, sizeof(Aout));
+    memset(&Ain, 0, sizeof(Ain));
+    memset(&Asrc, 0, sizeof(Asrc));
+    memset(&st, 0, sizeof(st));
+    if (order != IN_EDGES && gm_graph_csr(g, GM_DIR_OUT, &Aout) != GM_OK)
+      die("program needs OUT_EDGES adjacency (GM_DIR_OUT) which this graph was built without");
+    if (order != OUT_EDGES && gm_graph_csr(g, GM_DIR_IN, &Ain) != GM_OK)
+      die("program needs IN_EDGES adjacency (GM_DIR_IN) which this graph was built without");
+    n = desc.row_hi - desc.row_lo;
+    nwords = (n + 31) / 32;
+    multi = gm_graph_has_exchange(g) != 0;
+    gm_graph_set_run_stream(g, (gm_stream_t)s);  // a native (RCCL) exchange enqueues its collectives here
+    n_live = (desc.xchg_rows > 0 && desc.xchg_rows < n && (desc.xchg_rows & 63) == 0) ? desc.xchg_rows : n;
+
+    rk = reduce_kind_of<P, U>(gp);
+    // a strategy the program did not declare but the probe inferred is cross-checked on the device against the
+    // ordered fold the first time a pull multiply runs (k_check_rows); a disagreement falls back to the ordered fold
+    rk_unverified = (int)program_traits<P>::reduce == (int)REDUCE_AUTO && rk != REDUCE_ORDERED && !getenv("GRAPHMAT_NO_PROBE_CHECK");
+    tick("reduce_function probed", rk);
+    if (verbose) printf("GraphMat(HIP): reduce strategy %d (0 ordered, 1 commutative, 2 last, 3 float add)\n", rk);
+    // Top-down steps for small active sets (kernels.hpp: k_push_*): REDUCE_LAST programs over OUT_EDGES, running until
+    // convergence (the host already syncs once per iteration), unsharded, when the by-source adjacency is available;
+    // REDUCE_COMMUTATIVE programs with a 4-byte reduction type take the list-based steps too, folding with
+    // compare-and-swap (k_push_combine).  (A frontier-guided pull for the other reduction kinds -- mark the rows that
+    // have an active in-neighbour, multiply only those -- was tried and dropped: on RMAT graphs an active set of any size
+    // reaches most busy rows, and the extra passes plus the per-iteration statistics made SSSP 7.0 -> 13 ms on RMAT-22.)
+    const bool comm_push = rk == REDUCE_COMMUTATIVE && sizeof(U) == 4 && std::is_trivially_copyable<U>::value;
+    can_push = (rk == REDUCE_LAST || comm_push) && order == OUT_EDGES && act == ACTIVE_ONLY && iterations <= 0 && !multi &&
+               !(opt.debug_flags & dev::DBG_NO_PUSH) && gm_graph_csr(g, GM_DIR_IN, &Asrc) == GM_OK && desc.row_lo == 0 && desc.row_hi == desc.ndevice;
+    if (can_push) gm_graph_maps(g, &dev_of_native, &native_of_dev);
+    // Sharded ACTIVE_ONLY programs running until convergence exchange a SMALL active set as (device id, message) lists
+    // instead of all-gathering the whole dense x (graphmat_hip.h: GM_XCHG_STATE / GM_XCHG_GATHER; the reference
+    // compresses sparse segments before sending them, DenseSegment.h:532-538,665-700)
+    xsparse_ok = kSparseT && multi && act == ACTIVE_ONLY && iterations <= 0 && (gm_graph_exchange_caps(g) & GM_XCAP_SPARSE) &&
+                 !(opt.debug_flags & dev::DBG_NO_SPARSE_XCHG);
+    if (xsparse_ok && Asrc.rowptr == nullptr) (void)gm_graph_csr(g, GM_DIR_IN, &Asrc);  // out-degrees for the statistics, when available
+    // a=b programs consume one message per row: unsharded, they evaluate it on demand from the sender's vertex property
+    // (kernels.hpp: message_of) and the send pass disappears; the presence bits of x are the active bits themselves
+    lazy_send = rk == REDUCE_LAST && sizeof(U) <= 8 && std::is_trivially_copyable<U>::value && !multi && act == ACTIVE_ONLY && order == OUT_EDGES &&
+                desc.row_lo == 0 && desc.row_hi == desc.ndevice && !(opt.debug_flags & dev::DBG_NO_LAZY_SEND);
+    if (verbose && lazy_send) printf("GraphMat(HIP): messages are evaluated on demand (no send pass)\n");
+
+    gm_graph_workspace(g, 0, 4096, &flag_v);
+    // (the changed flag sits directly in front of the striped statistics, so that one memset clears and one copy fetches
+    // "flag + statistics": every call the host makes between two short levels of a traversal shows up as idle time on the GPU)
+    d_changed = (int*)flag_v + 127;
+    d_count = (unsigned int*)flag_v + 2;   // entries of d_list (the active set, when it is small)
+    d_tcount = (unsigned int*)flag_v + 3;  // entries of d_touched (destinations bid for in a top-down step)
+    d_stats = (unsigned long long*)flag_v + 2;    // byte offset 16
+    d_striped = (unsigned long long*)flag_v + 64;  // byte offset 512: kStatSlots x 4 u64 (k_apply)
+    void *res_stream = nullptr, *res_fork = nullptr, *res_join = nullptr, *res_pinned = nullptr;
+    if (gm_graph_run_resources(g, &res_stream, &res_fork, &res_join, &res_pinned) != GM_OK) die(gm_last_error());
+    h_changed = (int*)res_pinned + 127;  // (the pinned mirror has the layout of flag_v)
+    h_stats = (unsigned long long*)res_pinned;
+    h_striped = (unsigned long long*)res_pinned + 64;
+    stats_grid = grid_for(n) < 2048 ? grid_for(n) : 2048;
+    const bool xsparse_candidate = xsparse_ok;  // (the same on every shard: program, run mode and exchange capabilities)
+    if (xsparse_ok) {
+      void* pg = nullptr;
+      if (gm_graph_workspace(g, GM_WS_GATHER, (size_t)desc.nshards * dev::kSparseListCap * sizeof(xentry_t) + 256, &pg) == GM_OK) d_gather = (xentry_t*)pg;
+      else xsparse_ok = false;  // (an adopted buffer that is too small: dense exchanges only)
     }
+    if (can_push || xsparse_ok) {
+      void *pb = nullptr, *pl = nullptr, *pt = nullptr;
+      if (gm_graph_workspace(g, 7, (size_t)n * 4 + 1024 + ((size_t)dev::kSparseListCap + 64 + dev::kSparseListCap / dev::kBlock + 64) * 4, &pl) != GM_OK ||
+          (can_push && (gm_graph_workspace(g, 6, (size_t)n * 8 + 64, &pb) != GM_OK || gm_graph_workspace(g, 10, (size_t)n * 4 + 1024, &pt) != GM_OK))) {
+        can_push = false;
+        xsparse_ok = false;
+      } else {
+        d_best = (unsigned long long*)pb;
+        d_list = (int32_t*)pl;
+        d_off = (unsigned int*)((char*)pl + ((size_t)n * 4 + 1024) / 256 * 256);  // piece offsets of the listed sources
+        d_touched = (int32_t*)pt;
+        // (rows past n_live have no in-edge: nobody ever bids for them -- at RMAT-26 that halves a 537 MB memset)
+        if (can_push) GM_HIP_OK(hipMemsetAsync(d_best, 0, (size_t)n_live * 8, s));
+        GM_HIP_OK(hipMemsetAsync(d_stats, 0, 24, s));
+        GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
+        hipLaunchKernelGGL(dev::k_frontier_stats, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active, Asrc.rowptr, n, d_stats, d_list,
+                           d_count);
+        GM_HIP_OK(hipMemcpyAsync(h_stats + 2, d_stats, 24, hipMemcpyDeviceToHost, s));
+        GM_HIP_OK(hipStreamSynchronize(s));
+        frontier_v = h_stats[2];
+        frontier_e = h_stats[3];
+        frontier_maxdeg = h_stats[4];
+        list_ready = frontier_v <= (unsigned long long)dev::kSparseListCap;  // listed by the same pass
+      }
+    }
+    if (xsparse_candidate) {
+      // a shard that had to give up the sparse exchange (a workspace it could not get) takes the others with it: from here
+      // on the shards must issue the same collectives (MIN over the shards of "still possible here")
+      int still = xsparse_ok ? 1 : 0;
+      gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &still);
+      if (!still) xsparse_ok = false;
+    }
+    if (xsparse_ok) {
+      int dummy = 0;
+      exchange_state(&dummy);
+    }
+    if (act == ALL_VERTICES) fill_active();  // GraphMatRuntime.h:121-123 g.setAllActive()
+    timer = PhaseTimer(gm_graph_timing_enabled(g) != 0, s);
+    tick("first frontier counted", (int)frontier_v);
+    if (!(opt.debug_flags & dev::DBG_NO_OVERLAP)) aux.attach(res_stream, res_fork, res_join);
+    // row-filter bits (program_row_filter): one pass over the vertex properties now, kept current by k_apply
+    if constexpr (program_row_filter<P>::enabled) {
+      void* pw = nullptr;
+      if (gm_graph_workspace(g, 8, ((size_t)(n + 31) / 32 + 2) * 4, &pw) == GM_OK) {
+        d_want = (uint32_t*)pw;
+        dev::ProgArg<P> pa0 = dev::make_prog_arg(gp);
+        // (rows past n_live have no edges: no kernel ever looks at their bit)
+        hipLaunchKernelGGL((dev::k_want_init<P, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa0, (const V*)d_vp, n_live, d_want);
+      }
+    }
+    grouped_waves = !(opt.debug_flags & dev::DBG_NO_GROUPED);
   }
-  const bool grouped_waves = !(debug_flags() & dev::DBG_NO_GROUPED);
 
-  // ---- overlapped two-stage schedule for sharded fixed-count ALL_VERTICES / OUT_EDGES runs ------
-  // (graphmat_hip.h: GM_XCHG_PART).  Stage 1 multiplies, applies and sends the TAIL rows (most of
-  // the rows, a third of the edges) and starts their exchange; stage 2 does the same for the HEAD
-  // rows (the busy ones) while stage 1's messages travel.  Each row is still folded by one kernel
-  // in stored order, so results are those of the plain loop below.
-  const bool trace = iteration_trace() != 0;
-  if (multi && act == ALL_VERTICES && order == OUT_EDGES && iterations > 0 && !(debug_flags() & dev::DBG_NO_PIPELINE) && !trace &&
-      inherits_iteration_hook<P>()) {  // (the stages send iteration i+1's messages before the hook of iteration i could run)
+  void finish(int it) {
+    GM_HIP_OK(hipStreamSynchronize(s));
+    tick("loop done", it);
+    aux.finish();
+    st.iterations = it;
+    timer.finish(&st);
+    gm_graph_record_stats(g, &st);
+    tick("teardown done", 0);
+  }
+
+  // ---- schedule: the overlapped two-stage loop of sharded fixed-count ALL_VERTICES / OUT_EDGES runs ------------------------
+  // (graphmat_hip.h: GM_XCHG_PART).  Stage 1 multiplies, applies and sends the TAIL rows (most of the rows, a third of
+  // the edges) and starts their exchange; stage 2 does the same for the HEAD rows (the busy ones) while stage 1's
+  // messages travel.  Each row is still folded by one kernel in stored order, so results are those of the plain loop.
+  // The stages send iteration i+1's messages before the hook of iteration i could run: only for programs that leave
+  // do_every_iteration to the base class.
+  bool two_stage_applies() const {
+    return multi && act == ALL_VERTICES && order == OUT_EDGES && iterations > 0 && !(opt.debug_flags & dev::DBG_NO_PIPELINE) && !trace &&
+           inherits_iteration_hook<P>();
+  }
+  // returns the iterations done, or -1 when the shards could not agree on a split (the caller runs the plain loop)
+  int run_two_stage() {
     void* x2v = nullptr;
     size_t x2_bytes = 0;
     int x2_ext = 0;
     int32_t rs = 0, bs = 0, ms = 0;
-    // every shard must use the same split (the parts are the same rows of every slice): take the
-    // largest of the shards' own choices, then check that it suits everybody
     bool staged = false;
-    // the second message buffer: adopted from the caller (callback exchange: the collective library must know
-    // it), or simply the library's own when the exchange is native
-    bool have_x2 = gm_graph_workspace_info(g, 9, &x2v, &x2_bytes, &x2_ext) == GM_OK && x2_ext && x2v != nullptr &&
-                   x2_bytes >= (size_t)desc.ndevice * sizeof(T);
+    // the second message buffer: adopted from the caller (callback exchange: the collective library must know it), or
+    // simply the library's own when the exchange is native
+    bool have_x2 = gm_graph_workspace_info(g, 9, &x2v, &x2_bytes, &x2_ext) == GM_OK && x2_ext && x2v != nullptr && x2_bytes >= (size_t)desc.ndevice * sizeof(T);
     if (!have_x2 && gm_graph_exchange_is_native(g))
       have_x2 = gm_graph_workspace(g, 9, (size_t)desc.ndevice * sizeof(T) + 64, &x2v) == GM_OK && x2v != nullptr;
     if (have_x2) {
+      // every shard must use the same split (the parts are the same rows of every slice): take the largest of the shards'
+      // own choices, then check that it suits everybody
       int64_t agreed = 0;
       if (gm_graph_note_get(g, 0, &agreed) == GM_OK) {  // note 0: the split the shards agreed on in an earlier run (0 = none)
         rs = (int32_t)agreed;
@@ -852,532 +886,468 @@ int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act,
         gm_graph_note_set(g, 0, staged ? (int64_t)rs : 0);
       }
     }
-    if (staged) {
-      if (verbose) printf("GraphMat(HIP): two-stage schedule, head rows [0,%d) tail rows [%d,%d)\n", rs, rs, n_live);
-      T* xcur = x;
-      T* xnext = (T*)x2v;
-      gm_csr_t At = Aout, Ah = Aout;
-      At.blk_seg += bs; At.nblk -= bs; At.mid_row += ms; At.nmid -= ms; At.ngiant = 0; At.ngchunk = 0;
-      At.nmid_long = Aout.nmid_long > ms ? Aout.nmid_long - ms : 0;
-      Ah.nblk = bs; Ah.nmid = ms;
-      Ah.nmid_long = Aout.nmid_long < ms ? Aout.nmid_long : ms;
-      // The giant rows belong to the head, but their serial chains are the longest thing in a shard's iteration (the
-      // hub row does not shrink with the number of shards): they start on the auxiliary stream before the TAIL stage
-      // and are joined only before the head rows are applied, so they overlap both stages' multiplies.
-      gm_csr_t Ag = Aout;
-      Ag.nblk = 0; Ag.nmid = 0; Ag.nmid_long = 0;
-      const bool early_giants = Aout.ngiant > 0 && aux.s != nullptr && !(debug_flags() & dev::DBG_LATE_GIANTS);
-      if (early_giants) { Ah.ngiant = 0; Ah.ngchunk = 0; }
-      auto fail = [&](const char* what) { printf("GraphMat(HIP): %s\n", what); exit(1); };
-      auto multiply = [&](const dev::ProgArg<P>& pa, const gm_csr_t& A) {
-        if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, A, xcur, nullptr, d_vp, y, ybits, dev::ACC_STATIC_BITS, s, &st.spmv_launches, &timer, &aux, rk);
-        else launch_spmv<P, T, U, V, E, false>(g, pa, A, xcur, nullptr, d_vp, y, ybits, dev::ACC_STATIC_BITS, s, &st.spmv_launches, &timer, &aux, rk);
-      };
-      auto stage = [&](const dev::ProgArg<P>& pa, const gm_csr_t& A, int r0, int r1, bool more, bool join_giants) {
-        multiply(pa, A);
-        if (join_giants) aux.wait_join(s);
-        const int cnt = r1 - r0;
-        const int ag = grid_for(cnt) < dev::kApplyMaxBlocks ? grid_for(cnt) : dev::kApplyMaxBlocks;
-        hipLaunchKernelGGL((dev::k_apply<P, U, V, false>), dim3(ag), dim3(dev::kBlock), 0, s, pa, (const U*)(y + r0), Aout.rowbits + r0 / 32,
-                           d_vp + r0, d_active + r0 / 32, cnt, d_changed, (const int64_t*)nullptr, (unsigned long long*)nullptr,
-                           (uint32_t*)nullptr);
-        timer.mark(TAG_APPLY);
-        if (more) {
-          hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(cnt)), dim3(dev::kBlock), 0, s, pa, (const V*)(d_vp + r0),
-                             (const uint32_t*)nullptr, xnext, xbits, cnt, desc.row_lo + r0);
-          int part[2] = {r0, cnt};
-          if (gm_graph_exchange(g, GM_XCHG_PART, xnext, (int64_t)sizeof(T), nullptr, part) != 0) fail("partial message exchange failed");
-          timer.mark(TAG_SEND);
-        }
-      };
-      int it = 0;
-      {
-        dev::ProgArg<P> pa = dev::make_prog_arg(gp);
-        timer.mark(TAG_START);
-        hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
-                           (const uint32_t*)nullptr, xcur, xbits, n_live, desc.row_lo);
-        if (gm_graph_exchange(g, GM_XCHG_MESSAGES, xcur, (int64_t)sizeof(T), xbits, nullptr) != 0) fail("message exchange callback failed");
+    if (!staged) return -1;
+    if (verbose) printf("GraphMat(HIP): two-stage schedule, head rows [0,%d) tail rows [%d,%d)\n", rs, rs, n_live);
+    T* xcur = x;
+    T* xnext = (T*)x2v;
+    gm_csr_t At = Aout, Ah = Aout;
+    At.blk_seg += bs; At.nblk -= bs; At.mid_row += ms; At.nmid -= ms; At.ngiant = 0; At.ngchunk = 0;
+    At.nmid_long = Aout.nmid_long > ms ? Aout.nmid_long - ms : 0;
+    Ah.nblk = bs; Ah.nmid = ms;
+    Ah.nmid_long = Aout.nmid_long < ms ? Aout.nmid_long : ms;
+    // The giant rows belong to the head, but their serial chains are the longest thing in a shard's iteration (the hub row
+    // does not shrink with the number of shards): they start on the auxiliary stream before the TAIL stage and are joined
+    // only before the head rows are applied, so they overlap both stages' multiplies.
+    gm_csr_t Ag = Aout;
+    Ag.nblk = 0; Ag.nmid = 0; Ag.nmid_long = 0;
+    const bool early_giants = Aout.ngiant > 0 && aux.s != nullptr && !(opt.debug_flags & dev::DBG_LATE_GIANTS);
+    if (early_giants) { Ah.ngiant = 0; Ah.ngchunk = 0; }
+    const Launch L = launch_ctx();
+    auto multiply = [&](const dev::ProgArg<P>& pa, const gm_csr_t& A) {
+      launch_spmv_vp<P, T, U, V, E>(use_vp, L, pa, A, (const T*)xcur, (const uint32_t*)nullptr, (const V*)d_vp, y, ybits, dev::ACC_STATIC_BITS, rk);
+    };
+    // per-stage times (send + exchange start, multiply, apply) come out of the phase timer; what the exchange adds on top
+    // is visible as the difference between this schedule's wall clock and tools/shard_emulation.py's do-nothing exchange
+    auto stage = [&](const dev::ProgArg<P>& pa, const gm_csr_t& A, int r0, int r1, bool more, bool join_giants) {
+      multiply(pa, A);
+      if (join_giants) aux.wait_join(s);
+      const int cnt = r1 - r0;
+      const int ag = grid_for(cnt) < dev::kApplyMaxBlocks ? grid_for(cnt) : dev::kApplyMaxBlocks;
+      hipLaunchKernelGGL((dev::k_apply<P, U, V, false>), dim3(ag), dim3(dev::kBlock), 0, s, pa, (const U*)(y + r0), Aout.rowbits + r0 / 32, d_vp + r0,
+                         d_active + r0 / 32, cnt, d_changed, (const int64_t*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr);
+      timer.mark(TAG_APPLY);
+      if (more) {
+        hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(cnt)), dim3(dev::kBlock), 0, s, pa, (const V*)(d_vp + r0), (const uint32_t*)nullptr, xnext,
+                           xbits, cnt, desc.row_lo + r0);
+        int part[2] = {r0, cnt};
+        if (gm_graph_exchange(g, GM_XCHG_PART, xnext, (int64_t)sizeof(T), nullptr, part) != 0) die("partial message exchange failed");
         timer.mark(TAG_SEND);
       }
-      for (; it < iterations; it++) {
-        dev::ProgArg<P> pa = dev::make_prog_arg(gp);
-        const bool more = it + 1 < iterations;
-        timer.mark(TAG_START);
-        if (early_giants) {
-          aux.defer = true;
-          multiply(pa, Ag);
-          aux.defer = false;
-        }
-        stage(pa, At, rs, n_live, more, false);
-        stage(pa, Ah, 0, rs, more, early_giants);
-        if (more && gm_graph_exchange(g, GM_XCHG_WAIT, xnext, (int64_t)sizeof(T), nullptr, nullptr) != 0) fail("message exchange wait failed");
-        if (n_live < n) GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
-        gp->do_every_iteration(it);  // (the base class's empty hook: this schedule is only taken by programs that do not override it)
-        T* t = xcur; xcur = xnext; xnext = t;
-      }
-      hipLaunchKernelGGL(dev::k_fill_u32, dim3(grid_for(nwords)), dim3(dev::kBlock), 0, s, d_active, (int64_t)nwords, 0xffffffffu);
-      GM_HIP_OK(hipStreamSynchronize(s));
-      aux.finish();
-      st.iterations = it;
-      timer.finish(&st);
-      gm_graph_record_stats(g, &st);
-      return it;
+    };
+    int it = 0;
+    {
+      dev::ProgArg<P> pa = dev::make_prog_arg(gp);
+      timer.mark(TAG_START);
+      send_all(pa, nullptr, xcur);
+      if (gm_graph_exchange(g, GM_XCHG_MESSAGES, xcur, (int64_t)sizeof(T), xbits, nullptr) != 0) die("message exchange callback failed");
+      timer.mark(TAG_SEND);
     }
+    for (; it < iterations; it++) {
+      dev::ProgArg<P> pa = dev::make_prog_arg(gp);
+      const bool more = it + 1 < iterations;
+      timer.mark(TAG_START);
+      if (early_giants) {
+        aux.defer = true;
+        multiply(pa, Ag);
+        aux.defer = false;
+      }
+      stage(pa, At, rs, n_live, more, false);
+      stage(pa, Ah, 0, rs, more, early_giants);
+      if (more && gm_graph_exchange(g, GM_XCHG_WAIT, xnext, (int64_t)sizeof(T), nullptr, nullptr) != 0) die("message exchange wait failed");
+      if (n_live < n) GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
+      gp->do_every_iteration(it);  // (the base class's empty hook: this schedule is only taken by programs that do not override it)
+      T* t = xcur; xcur = xnext; xnext = t;
+    }
+    fill_active();
+    finish(it);
+    return it;
   }
 
-  // piece offsets of the listed sources (kernels.hpp: k_piece_*); the per-workgroup bases live behind them
-  auto piece_offsets = [&](int nf) {
-    const int nb = grid_for(nf);
-    unsigned int* d_base = d_off + dev::kSparseListCap + 64;
-    hipLaunchKernelGGL(dev::k_piece_count, dim3(nb), dim3(dev::kBlock), 0, s, Asrc, (const int32_t*)d_list, nf, d_base);
-    hipLaunchKernelGGL(dev::k_piece_block_scan, dim3(1), dim3(dev::kBlock), 0, s, d_base, nb);
-    hipLaunchKernelGGL(dev::k_piece_offsets, dim3(nb), dim3(dev::kBlock), 0, s, Asrc, (const int32_t*)d_list, nf,
-                       (const unsigned int*)d_base, d_off);
-  };
-
-  int it = 0;
-  // fused apply + send: the messages of the next iteration written by this iteration's apply pass, and the program
-  // object they were computed with (they are used only if do_every_iteration leaves it unchanged)
-  bool x_presend = false;
-  dev::ProgArg<P> presend_pa = dev::make_prog_arg(gp);
-  tick("setup done", 0);
-  // trace mode: host clock per phase, counts per iteration (the reference's __TIMING lines)
-  struct timeval tr_iter, tr_last;
-  auto lap = [&](const char* label) {
-    if (!trace) return;
-    (void)hipStreamSynchronize(s);
-    if (aux.s) (void)hipStreamSynchronize(aux.s);
-    struct timeval now;
-    gettimeofday(&now, 0);
-    if (label) printf("%s = %.3f ms \n", label, (now.tv_sec - tr_last.tv_sec) * 1e3 + (now.tv_usec - tr_last.tv_usec) * 1e-3);
-    tr_last = now;
-  };
-  auto count_bits = [&](const uint32_t* bits, int nbits) -> long long {
-    int64_t c = 0;
-    if (bits == nullptr || nbits <= 0) return 0;
-    if (gm_popcount_bits(bits, (int64_t)nbits, &c, (gm_stream_t)s) != GM_OK) return -1;
-    return (long long)c;
-  };
-  while (true) {
-    tick("iteration", it);
-    if (trace) { (void)hipStreamSynchronize(s); gettimeofday(&tr_iter, 0); tr_last = tr_iter; }
-    long long tr_updated = -1;
-    if (verbose && can_push) printf("GraphMat(HIP):   active set: %llu vertices, %llu out-edges (max %llu)\n", frontier_v, frontier_e, frontier_maxdeg);
-    dev::ProgArg<P> pa = dev::make_prog_arg(gp);  // re-captured every iteration (do_every_iteration may change it)
-    // Clear(&x) / Clear(&y) (:139-140): x presence words are fully rewritten by send.  With
-    // every x entry present (ALL_VERTICES) y's presence is the static set of non-empty rows.
-    const bool static_bits = (act == ALL_VERTICES);
-    const T* xq = lazy_send ? (const T*)nullptr : (const T*)x;  // what the multiply side reads messages from (may change below)
-    const bool want_stats = (can_push || xsparse_ok) && iterations <= 0;
-    // the changed flag and, for steered runs, the striped statistics behind it (k_apply / k_push_finish add to them)
-    GM_HIP_OK(hipMemsetAsync(d_changed, 0, want_stats ? sizeof(int) + striped_bytes : sizeof(int), s));
-    timer.mark(TAG_START);
-    const bool dense_x = (act == ALL_VERTICES);
-    // this iteration's x travels as lists when every shard's active set is small: fewer bytes than the dense
-    // slices (entry = id + message against one message per live row) and within the list capacity
-    const bool xsp = xsparse_ok && xs_max <= dev::kSparseListCap &&
-                     (unsigned long long)xs_max * sizeof(xentry_t) * 2ull < (unsigned long long)n_live * sizeof(T);
-    // top-down step for small active sets only: few sources and few out-edges
-    const bool push = can_push && frontier_v > 0 && frontier_v <= (unsigned long long)dev::kSparseListCap &&
-                      frontier_e * 1000ull < (unsigned long long)Aout.nnz * (unsigned long long)push_edge_permille();
-    // ... and among those, active sets with few out-edges run entirely on lists (nothing scans all vertices)
-    const bool sparse = push && frontier_e <= (unsigned long long)sparse_step_edges();
-    const bool dense_push = push && !sparse && rk == REDUCE_LAST;
-    // ... and an active set too large to list whose vertices own only a few out-edges each (the late levels of a
-    // traversal: 10^5..10^6 vertices of degree ~1) bids straight from the active bitmap, one lane per vertex
-    const bool bits_push = can_push && !push && rk == REDUCE_LAST && frontier_v > (unsigned long long)dev::kSparseListCap &&
-                           frontier_e <= (unsigned long long)bits_step_edges() && frontier_maxdeg <= 64ull;
-    if (bits_push) {
-      hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
-                         (const uint32_t*)d_active, x, xbits, n_live, desc.row_lo);
-      timer.mark(TAG_SEND);
-      lap("Send message time");
-      GM_HIP_OK(hipMemsetAsync(d_tcount, 0, 4, s));
-      const int bgrid = grid_for(n_live) < 4096 ? grid_for(n_live) : 4096;
-      hipLaunchKernelGGL(dev::k_push_bid_bits, dim3(bgrid), dim3(dev::kBlock), 0, s, Asrc, (const uint32_t*)d_active, n_live,
-                         native_of_dev, d_best, (const uint32_t*)d_want, d_touched, d_tcount);
-      timer.mark(TAG_WAVE);
-      lap("SPMV time");
-      if (trace) {
-        unsigned int tc = 0;
-        GM_HIP_OK(hipMemcpy(&tc, d_tcount, 4, hipMemcpyDeviceToHost));
-        tr_updated = (long long)tc;
-      }
-      GM_HIP_OK(hipMemsetAsync(d_active, 0, (size_t)nwords * 4, s));
-      GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
-      const unsigned long long bound = frontier_e < (unsigned long long)n ? frontier_e : (unsigned long long)n;
-      if (bound > 0) {
-        if (use_vp)
-          hipLaunchKernelGGL((dev::k_push_finish<P, T, U, V, E, true, false>), dim3(grid_for((int64_t)bound)), dim3(dev::kBlock), 0, s, pa, Asrc,
-                             (const T*)x, dev_of_native, d_vp, d_best, (const int32_t*)d_touched, (const unsigned int*)d_tcount, d_active,
-                             d_changed, d_striped, d_want, d_list, d_count);
-        else
-          hipLaunchKernelGGL((dev::k_push_finish<P, T, U, V, E, false, false>), dim3(grid_for((int64_t)bound)), dim3(dev::kBlock), 0, s, pa, Asrc,
-                             (const T*)x, dev_of_native, d_vp, d_best, (const int32_t*)d_touched, (const unsigned int*)d_tcount, d_active,
-                             d_changed, d_striped, d_want, d_list, d_count);
-      }
-      st.spmv_launches += 2;
-      listed = true;
-      timer.mark(TAG_APPLY);
-      lap("Apply time");
-    } else if (sparse) {
-      // ---- sparse top-down step ----
-      if (!list_ready) {
-        GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
-        hipLaunchKernelGGL(dev::k_frontier_list, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active, n,
-                           d_list, d_count);
-      }
-      const int nf = (int)frontier_v;
-      // The messages of the listed vertices are always materialised here, also for programs that
-      // otherwise evaluate them on demand: k_push_finish applies while other lanes still fetch
-      // messages, so an on-demand send_message(vp[u]) could read a vertex property that this very
-      // step is rewriting (any a=b program whose active vertices can change again).  The list is
-      // small (<= kSparseListCap vertices), so this costs microseconds.
-      hipLaunchKernelGGL((dev::k_send_list<P, T, V>), dim3(grid_for(nf)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
-                         (const int32_t*)d_list, nf, x, desc.row_lo);
-      timer.mark(TAG_SEND);
-      lap("Send message time");
-      GM_HIP_OK(hipMemsetAsync(d_tcount, 0, 4, s));
-      const unsigned pieces = (unsigned)(frontier_e / dev::kPieceEdges + frontier_v);  // upper bound of the pieces
-      piece_offsets(nf);
-      if (rk == REDUCE_LAST) {
-        hipLaunchKernelGGL(dev::k_push_bid, dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc,
-                           (const int32_t*)d_list, nf, (const unsigned int*)d_off, native_of_dev, d_best, (const uint32_t*)d_want,
-                           d_touched, d_tcount);
+  // ---- schedule: top-down step straight from the active bitmap ---------------------------------------------------------
+  // an active set too large to list whose vertices own only a few out-edges each (the late levels of a traversal:
+  // 10^5..10^6 vertices of degree ~1): one lane per vertex bids for its destinations
+  void step_bits_push(const dev::ProgArg<P>& pa) {
+    send_all(pa, (const uint32_t*)d_active, x);
+    timer.mark(TAG_SEND);
+    lap("Send message time");
+    GM_HIP_OK(hipMemsetAsync(d_tcount, 0, 4, s));
+    const int bgrid = grid_for(n_live) < 4096 ? grid_for(n_live) : 4096;
+    hipLaunchKernelGGL(dev::k_push_bid_bits, dim3(bgrid), dim3(dev::kBlock), 0, s, Asrc, (const uint32_t*)d_active, n_live, native_of_dev, d_best,
+                       (const uint32_t*)d_want, d_touched, d_tcount);
+    timer.mark(TAG_WAVE);
+    lap("SPMV time");
+    finish_push(pa, false);
+  }
+  // the bids of a top-down step are in d_best / d_touched: rewrite the active vector and the list, apply the winners
+  void finish_push(const dev::ProgArg<P>& pa, bool combined) {
+    if (trace) {  // vertices that received a message = destinations first touched by this step
+      unsigned int tc = 0;
+      GM_HIP_OK(hipMemcpy(&tc, d_tcount, 4, hipMemcpyDeviceToHost));
+      tr_updated = (long long)tc;
+    }
+    GM_HIP_OK(hipMemsetAsync(d_active, 0, (size_t)nwords * 4, s));
+    GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
+    const unsigned long long bound = frontier_e < (unsigned long long)n ? frontier_e : (unsigned long long)n;
+    if (bound > 0) {
+      auto finish_k = [&](auto use_vp_c, auto combined_c) {
+        hipLaunchKernelGGL((dev::k_push_finish<P, T, U, V, E, decltype(use_vp_c)::value, decltype(combined_c)::value>), dim3(grid_for((int64_t)bound)),
+                           dim3(dev::kBlock), 0, s, pa, Asrc, (const T*)x, dev_of_native, d_vp, d_best, (const int32_t*)d_touched,
+                           (const unsigned int*)d_tcount, d_active, d_changed, d_striped, d_want, d_list, d_count);
+      };
+      if (!combined) {
+        if (use_vp) finish_k(std::true_type(), std::false_type()); else finish_k(std::false_type(), std::false_type());
       } else {
         if constexpr (sizeof(U) == 4 && std::is_trivially_copyable<U>::value) {
-          if (use_vp)
-            hipLaunchKernelGGL((dev::k_push_combine<P, T, U, V, E, true>), dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, pa,
-                               Asrc, (const int32_t*)d_list, nf, (const unsigned int*)d_off, (const T*)x, (const V*)d_vp, d_best,
-                               (const uint32_t*)d_want, d_touched, d_tcount);
-          else
-            hipLaunchKernelGGL((dev::k_push_combine<P, T, U, V, E, false>), dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, pa,
-                               Asrc, (const int32_t*)d_list, nf, (const unsigned int*)d_off, (const T*)x, (const V*)d_vp, d_best,
-                               (const uint32_t*)d_want, d_touched, d_tcount);
+          if (use_vp) finish_k(std::true_type(), std::true_type()); else finish_k(std::false_type(), std::true_type());
         }
       }
-      timer.mark(TAG_WAVE);
-      lap("SPMV time");
-      if (trace) {  // vertices that received a message = destinations first touched by this step
-        unsigned int tc = 0;
-        GM_HIP_OK(hipMemcpy(&tc, d_tcount, 4, hipMemcpyDeviceToHost));
-        tr_updated = (long long)tc;
-      }
-      // the active set has been consumed: rewrite the active vector and the list for the next step
-      GM_HIP_OK(hipMemsetAsync(d_active, 0, (size_t)nwords * 4, s));
-      GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
-      const unsigned long long bound = frontier_e < (unsigned long long)n ? frontier_e : (unsigned long long)n;
-      if (bound > 0) {
-        auto finish = [&](auto use_vp_c, auto combined_c) {
-          hipLaunchKernelGGL((dev::k_push_finish<P, T, U, V, E, decltype(use_vp_c)::value, decltype(combined_c)::value>),
-                             dim3(grid_for((int64_t)bound)), dim3(dev::kBlock), 0, s, pa, Asrc, (const T*)x, dev_of_native, d_vp, d_best,
-                             (const int32_t*)d_touched, (const unsigned int*)d_tcount, d_active, d_changed, d_striped, d_want, d_list,
-                             d_count);
-        };
-        if (rk == REDUCE_LAST) {
-          if (use_vp) finish(std::true_type(), std::false_type()); else finish(std::false_type(), std::false_type());
-        } else {
-          if (use_vp) finish(std::true_type(), std::true_type()); else finish(std::false_type(), std::true_type());
-        }
-      }
-      st.spmv_launches += 2;
-      listed = true;
-      timer.mark(TAG_APPLY);
-      lap("Apply time");
+    }
+    st.spmv_launches += 2;
+    listed = true;
+    timer.mark(TAG_APPLY);
+    lap("Apply time");
+  }
+
+  // ---- schedule: top-down step entirely on lists (few sources, few out-edges: nothing scans all vertices) ---------------------
+  void step_list_push(const dev::ProgArg<P>& pa) {
+    list_active_set();
+    const int nf = (int)frontier_v;
+    // The messages of the listed vertices are always materialised here, also for programs that otherwise evaluate them on
+    // demand: k_push_finish applies while other lanes still fetch messages, so an on-demand send_message(vp[u]) could read
+    // a vertex property that this very step is rewriting (any a=b program whose active vertices can change again).  The
+    // list is small (<= kSparseListCap vertices), so this costs microseconds.
+    hipLaunchKernelGGL((dev::k_send_list<P, T, V>), dim3(grid_for(nf)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp, (const int32_t*)d_list, nf, x,
+                       desc.row_lo);
+    timer.mark(TAG_SEND);
+    lap("Send message time");
+    GM_HIP_OK(hipMemsetAsync(d_tcount, 0, 4, s));
+    const unsigned pieces = (unsigned)(frontier_e / dev::kPieceEdges + frontier_v);  // upper bound of the pieces
+    piece_offsets(nf);
+    if (rk == REDUCE_LAST) {
+      hipLaunchKernelGGL(dev::k_push_bid, dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc, (const int32_t*)d_list, nf,
+                         (const unsigned int*)d_off, native_of_dev, d_best, (const uint32_t*)d_want, d_touched, d_tcount);
     } else {
-      // Clear(&x) / Clear(&y) (:139-140): x presence words are fully rewritten by send.  With
-      // every x entry present (ALL_VERTICES) y's presence is the static set of non-empty rows.
-      if (!static_bits) GM_HIP_OK(hipMemsetAsync(ybits, 0, (size_t)nwords * 4, s));
-      // send (:145).  Rows past n_live have no edge in either direction (degree-ranked order puts
-      // them at the tail): nobody reads their messages and they never receive one
-      if (xsp) {
-        if constexpr (kSparseT) {
-          // sparse exchange: messages of the listed active vertices only, as (device id, message) entries
-          if (!list_ready) {
-            GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
-            hipLaunchKernelGGL(dev::k_frontier_list, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active, n,
-                               d_list, d_count);
-          }
-          const int nf = (int)frontier_v;
-          const int cap = xs_max > 0 ? (xs_max + 63) / 64 * 64 : 64;
-          GM_HIP_OK(hipMemsetAsync(xbits, 0, ((size_t)(desc.ndevice + 31) / 32) * 4, s));
-          if (nf > 0)
-            hipLaunchKernelGGL((dev::k_send_list<P, T, V>), dim3(grid_for(nf)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
-                               (const int32_t*)d_list, nf, x, desc.row_lo);
-          hipLaunchKernelGGL((dev::k_pack_frontier<T>), dim3(grid_for(cap)), dim3(dev::kBlock), 0, s, (const int32_t*)d_list, nf,
-                             (const T*)x, desc.row_lo, d_gather + (size_t)desc.shard * cap, cap);
-          int hf[2] = {cap, 0};
-          if (gm_graph_exchange(g, GM_XCHG_GATHER, d_gather, (int64_t)sizeof(xentry_t), nullptr, hf) != 0) {
-            printf("GraphMat(HIP): sparse message exchange failed\n");
-            exit(1);
-          }
-          const int64_t nall = (int64_t)desc.nshards * cap;
-          hipLaunchKernelGGL((dev::k_unpack_frontier<T>), dim3(grid_for(nall)), dim3(dev::kBlock), 0, s, (const xentry_t*)d_gather, nall, x, xbits);
-          if (verbose) printf("GraphMat(HIP):   sparse exchange: %d active here, at most %d per shard, %zu bytes sent instead of %zu\n", nf, xs_max,
-                              (size_t)cap * sizeof(xentry_t), (size_t)n_live * sizeof(T) + (size_t)n_live / 8);
-          st.sparse_exchanges++;
-        }
-      } else {
-        const bool presend_valid = x_presend && memcmp(presend_pa.b, pa.b, sizeof(pa.b)) == 0;
-        x_presend = false;
-        if (!lazy_send && !presend_valid)
-          hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
-                             dense_x ? (const uint32_t*)nullptr : (const uint32_t*)d_active, x, xbits, n_live, desc.row_lo);
-        if (multi) {
-          if (gm_graph_exchange(g, GM_XCHG_MESSAGES, x, (int64_t)sizeof(T), xbits, nullptr) != 0) {
-            printf("GraphMat(HIP): message exchange callback failed\n");
-            exit(1);
-          }
-        }
-      }
-      timer.mark(TAG_SEND);
-      lap("Send message time");
-      // multiply + reduce (:160-176)
-      const uint32_t* xb = dense_x ? nullptr : (lazy_send ? (const uint32_t*)d_active : (const uint32_t*)xbits);  // (may change below)
-      const uint32_t* apply_bits = ybits;
-      // Cross-check of a probed strategy after the first pass of a pull multiply over adjacency A whose results
-      // (presence bits yb) are in y: giant rows, the first wave rows and a strided sample of all rows are folded
-      // again in order.  On a mismatch the pass is redone with the ordered fold, which also governs the rest of the run.
-      auto check_probed = [&](const gm_csr_t& A, const uint32_t* yb, const uint32_t* rowfilter, int acc_flags, uint32_t* yb_write) {
-        if (!rk_unverified || (acc_flags & dev::ACC_READ_PREV)) return;
-        rk_unverified = false;
-        unsigned int* d_mis = (unsigned int*)flag_v + 700;
-        GM_HIP_OK(hipMemsetAsync(d_mis, 0, 4, s));
-        const T* xc = xq;
-        const uint32_t* xbc = xb;
-        if (lazy_send) {  // the ordered fold reads materialised messages: write them once for the check
-          hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp,
-                             dense_x ? (const uint32_t*)nullptr : (const uint32_t*)d_active, x, xbits, n_live, desc.row_lo);
-          xc = x;
-          xbc = dense_x ? nullptr : (const uint32_t*)xbits;
-        }
-        auto sample = [&](const int32_t* rows, int cnt, int stride) {
-          if (cnt <= 0) return;
-          const int grid = (cnt + dev::kBlock / 64 - 1) / (dev::kBlock / 64);
-          if constexpr ((int)program_traits<P>::reduce != (int)REDUCE_AUTO) return;  // (declared strategies are never checked)
-          else if (use_vp)
-            hipLaunchKernelGGL((dev::k_check_rows<P, T, U, V, E, true>), dim3(grid), dim3(dev::kBlock), 0, s, pa, A, rows, cnt, stride, xc, xbc,
-                               (const V*)d_vp, (const U*)y, yb, rowfilter, d_mis);
-          else
-            hipLaunchKernelGGL((dev::k_check_rows<P, T, U, V, E, false>), dim3(grid), dim3(dev::kBlock), 0, s, pa, A, rows, cnt, stride, xc, xbc,
-                               (const V*)d_vp, (const U*)y, yb, rowfilter, d_mis);
-        };
-        sample(A.giant_row, A.ngiant, 0);
-        sample(A.mid_row, A.nmid < 2048 ? A.nmid : 2048, 0);
-        const int live_rows = n_live < A.nrows ? n_live : A.nrows;
-        const int stride = live_rows > 2048 ? live_rows / 2048 : 1;
-        sample(nullptr, live_rows / stride, stride);
-        unsigned int mis = 0;
-        GM_HIP_OK(hipMemcpyAsync(&mis, d_mis, 4, hipMemcpyDeviceToHost, s));
-        GM_HIP_OK(hipStreamSynchronize(s));
-        if (verbose) printf("GraphMat(HIP):   probed reduce strategy %d cross-checked against the ordered fold: %u mismatching rows\n", rk, mis);
-        if (mis == 0) return;
-        printf("GraphMat(HIP): warning: reduce_function matched strategy %d on the probe's operands but not on this run's data (%u sampled "
-               "rows differ from the ordered fold); using the ordered fold.  Declare GraphMat::program_traits<YourProgram>::reduce to choose explicitly.\n", rk, mis);
-        rk = REDUCE_ORDERED;
-        can_push = false;
-        if (lazy_send) {  // the ordered kernels read materialised messages (written above for the check)
-          lazy_send = false;
-          xq = x;
-          xb = dense_x ? nullptr : (const uint32_t*)xbits;
-        }
-        if (!(acc_flags & dev::ACC_STATIC_BITS)) GM_HIP_OK(hipMemsetAsync(yb_write, 0, (size_t)nwords * 4, s));
-        if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, A, xq, xb, d_vp, y, yb_write, acc_flags, s, &st.spmv_launches, &timer, &aux, rk, rowfilter);
-        else launch_spmv<P, T, U, V, E, false>(g, pa, A, xq, xb, d_vp, y, yb_write, acc_flags, s, &st.spmv_launches, &timer, &aux, rk, rowfilter);
-      };
-      const uint32_t* row_bits = d_want;  // which rows the multiply works on
-      if (dense_push) {
-        // top-down step over a larger active set: bids, then one pass over all vertices picks the winners
-        if (!list_ready) {
-          GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
-          hipLaunchKernelGGL(dev::k_frontier_list, dim3(stats_grid), dim3(dev::kBlock), 0, s, (const uint32_t*)d_active, n,
-                             d_list, d_count);
-        }
-        const unsigned pieces = (unsigned)(frontier_e / dev::kPieceEdges + frontier_v);
-        piece_offsets((int)frontier_v);
-        hipLaunchKernelGGL(dev::k_push_bid, dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc,
-                           (const int32_t*)d_list, (int)frontier_v, (const unsigned int*)d_off, native_of_dev, d_best,
-                           (const uint32_t*)d_want, (int32_t*)nullptr, (unsigned int*)nullptr);
+      if constexpr (sizeof(U) == 4 && std::is_trivially_copyable<U>::value) {
         if (use_vp)
-          hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, true>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, Asrc,
-                             xq, dev_of_native, (const V*)d_vp, d_best, y, ybits, n_live);  // (only live rows can have been bid for)
+          hipLaunchKernelGGL((dev::k_push_combine<P, T, U, V, E, true>), dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, pa, Asrc,
+                             (const int32_t*)d_list, nf, (const unsigned int*)d_off, (const T*)x, (const V*)d_vp, d_best, (const uint32_t*)d_want, d_touched,
+                             d_tcount);
         else
-          hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, false>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, Asrc,
-                             xq, dev_of_native, (const V*)d_vp, d_best, y, ybits, n_live);
-        st.spmv_launches += 2;
-        timer.mark(TAG_WAVE);
-      } else if (order == OUT_EDGES || order == ALL_EDGES) {
-        const int acc = static_bits ? dev::ACC_STATIC_BITS : 0;
-        // sparse active set of an a=b program: a 64:1 summary of the presence bits for the short-row kernel
-        const uint32_t* xsum = nullptr;
-        const unsigned long long present_x = xsparse_ok ? (unsigned long long)xs_total : frontier_v;  // entries of x that are present
-        if (want_stats && rk == REDUCE_LAST && xb != nullptr && present_x * 512ull < (unsigned long long)n_live * (unsigned long long)desc.nshards) {
-          void* ps = nullptr;
-          const int xwords = (desc.ndevice + 31) / 32;  // x (and its presence bits) cover every shard's rows
-          const int nsum = (xwords / 2 + 31) / 32 + 1;
-          if (gm_graph_workspace(g, 11, (size_t)nsum * 4 + 64, &ps) == GM_OK) {
-            hipLaunchKernelGGL(dev::k_bits_summary, dim3(grid_for(nsum)), dim3(dev::kBlock), 0, s, xb, xwords, (uint32_t*)ps, nsum);
-            xsum = (const uint32_t*)ps;
-          }
-        }
-        // Column tiles (graphmat_hip.h: gm_graph_tile): with every x entry present and an ordered or
-        // commutative fold, the rows of more than GM_SHORT_ROW edges are multiplied tile by tile -- each
-        // pass gathers from one slice of x and continues the row's fold from the value y holds -- and
-        // only the short rows take the untiled row-blocks.  Same fold order, same bits.
-        int ntile = 1;
-        if (dense_x && !multi && row_bits == nullptr && rk != REDUCE_LAST && dev::stageable<T>::value && !(debug_flags() & dev::DBG_NO_TILES))
-          gm_graph_tiles(g, GM_DIR_OUT, &ntile);
-        if (ntile > 1) {
-          // Tiles whose row classes are fixed per row (gm_csr_t.rows_keep_stream): the giant / one-wave-per-row kernels
-          // and the row-block / 16-row kernels never touch the same y entry, so the auxiliary stream is forked once --
-          // before the untiled pass -- and joined once after the last tile instead of after every tile, where the main
-          // stream used to wait 70-120 us per tile for the tail of the one-wave-per-row kernel.
-          bool keep_streams = aux.s != nullptr && !use_vp && (rk == REDUCE_ORDERED || rk == REDUCE_F32_ADD) && std::is_trivially_copyable<U>::value &&
-                              (sizeof(U) == 4 || sizeof(U) == 8) && !rk_unverified &&
-                              !(debug_flags() & (dev::DBG_NO_WAVE16 | dev::DBG_LONG_ON_MAIN | dev::DBG_NO_OVERLAP));
-          for (int t = 0; t < ntile && keep_streams; t++) {
-            gm_csr_t At;
-            const uint32_t* prev = nullptr;
-            if (gm_graph_tile(g, GM_DIR_OUT, t, &At, &prev) != GM_OK || !At.rows_keep_stream) keep_streams = false;
-          }
-          if (keep_streams) {
-            aux.keep = true;
-            aux.pending = false;
-            GM_HIP_OK(hipEventRecord(aux.fork, s));  // x is complete here: the auxiliary stream may start on tile 0 during the untiled pass
-            GM_HIP_OK(hipStreamWaitEvent(aux.s, aux.fork, 0));
-            aux.forked = true;
-          }
-          gm_csr_t As = Aout;  // the rows that are not tiled: row-blocks and the shorter wave rows
-          As.mid_row = Aout.umid_row; As.nmid = Aout.numid; As.nmid_long = Aout.numid_long; As.ngiant = 0; As.ngchunk = 0;
-          if (Aout.tile_min_row == 0) { As.nblk = 0; As.nmid = 0; }  // every row is tiled
-          if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, As, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk);
-          else launch_spmv<P, T, U, V, E, false>(g, pa, As, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk);
-          // (running this untiled pass on a stream of its own next to the tile passes -- its rows are no tile's rows --
-          // was measured too: 7.06 -> 7.03 ms at RMAT-26, not worth a third stream)
-          aux.long_rows = !(debug_flags() & dev::DBG_LONG_ON_MAIN);
-          for (int t = 0; t < ntile; t++) {
-            gm_csr_t At;
-            const uint32_t* prev = nullptr;
-            if (gm_graph_tile(g, GM_DIR_OUT, t, &At, &prev) != GM_OK) { printf("GraphMat(HIP): %s\n", gm_last_error()); exit(1); }
-            // y's presence bits are static (dense x): `prev` says which rows already carry a value
-            uint32_t* pb = const_cast<uint32_t*>(prev);
-            const int tacc = dev::ACC_STATIC_BITS | dev::ACC_READ_PREV;
-            if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, At, xq, xb, d_vp, y, pb, tacc, s, &st.spmv_launches, &timer, &aux, rk);
-            else launch_spmv<P, T, U, V, E, false>(g, pa, At, xq, xb, d_vp, y, pb, tacc, s, &st.spmv_launches, &timer, &aux, rk);
-          }
-          aux.long_rows = false;
-          if (aux.keep) {
-            if (aux.pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
-            aux.keep = aux.forked = aux.pending = false;
-          }
-          // (a probed strategy is cross-checked against the ordered fold of the WHOLE rows; a mismatch redoes this
-          // iteration untiled with the ordered fold, which then also governs the tiled iterations that follow)
-          check_probed(Aout, Aout.rowbits, nullptr, acc, ybits);
-        } else {
-          if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves, xsum);
-          else launch_spmv<P, T, U, V, E, false>(g, pa, Aout, xq, xb, d_vp, y, ybits, acc, s, &st.spmv_launches, &timer, &aux, rk, row_bits, grouped_waves, xsum);
-          check_probed(Aout, static_bits ? Aout.rowbits : (const uint32_t*)ybits, row_bits, acc, ybits);
-        }
-        if (static_bits) apply_bits = Aout.rowbits;
+          hipLaunchKernelGGL((dev::k_push_combine<P, T, U, V, E, false>), dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, pa, Asrc,
+                             (const int32_t*)d_list, nf, (const unsigned int*)d_off, (const T*)x, (const V*)d_vp, d_best, (const uint32_t*)d_want, d_touched,
+                             d_tcount);
       }
-      if (!dense_push && (order == IN_EDGES || order == ALL_EDGES)) {
-        int acc = (order == ALL_EDGES) ? dev::ACC_READ_PREV : 0;
-        uint32_t* yb = ybits;
-        if (static_bits) {
-          acc |= dev::ACC_STATIC_BITS;
-          yb = const_cast<uint32_t*>(Aout.rowbits);  // only read (presence of the OUT pass's results)
-          apply_bits = Ain.rowbits;
-          if (order == ALL_EDGES && gm_graph_rowbits_all(g, &apply_bits) != GM_OK) { printf("%s\n", gm_last_error()); exit(1); }
-        }
-        if (use_vp) launch_spmv<P, T, U, V, E, true>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
-        else launch_spmv<P, T, U, V, E, false>(g, pa, Ain, x, xb, d_vp, y, yb, acc, s, &st.spmv_launches, &timer, &aux, rk, d_want, grouped_waves);
-        if (order == IN_EDGES) check_probed(Ain, static_bits ? Ain.rowbits : (const uint32_t*)ybits, d_want, acc, ybits);
-      }
-      lap("SPMV time");
-      if (trace) tr_updated = count_bits(apply_bits, n_live);  // y.getNNZ(): rows that received a message
-      // setAllInactive (:184) + apply (:195-225): the active vector is rewritten by k_apply
-      // (when top-down steps are possible the kernel also sizes and lists the next active set)
-      // the changed vertices are also listed when the next active set is bound to be small: it cannot
-      // have more vertices than the current one has out-edges.  (If it turns out small without having
-      // been listed, a k_frontier_list pass builds the list when it is needed.)
-      const bool build_list = want_stats && frontier_e <= (4ull << 20);
-      if (want_stats) GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
-      listed = build_list;
-      // (a workgroup that lists changed vertices ends with one global atomic: fewer, longer-running workgroups then)
-      const int apply_cap = build_list ? dev::kApplyMaxBlocks / 4 : dev::kApplyMaxBlocks;
-      const int apply_grid = grid_for(n_live) < apply_cap ? grid_for(n_live) : apply_cap;
-      if (want_stats)
-        hipLaunchKernelGGL((dev::k_apply<P, U, V, true>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y, apply_bits,
-                           d_vp, d_active, n_live, d_changed, Asrc.rowptr, d_striped, d_want, build_list ? d_list : (int32_t*)nullptr,
-                           build_list ? d_count : (unsigned int*)nullptr);
-      else if (inherits_iteration_hook<P>() && dense_x && !lazy_send && !trace && fuse_apply_send() != 0 && iterations > 0 && it + 1 < iterations) {
-        // another iteration follows: its messages come out of the same pass.  Only for programs without a
-        // do_every_iteration of their own (nothing can change what send_message reads between the two iterations), and
-        // only in fixed-count runs: until convergence the last iteration is not known in advance, and a fused pass there
-        // would leave x holding messages of an iteration that never runs (the reference's px would not)
-        hipLaunchKernelGGL((dev::k_apply_send<P, T, U, V>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y, apply_bits,
-                           d_vp, d_active, n_live, d_changed, d_want, x, xbits, desc.row_lo);
-        x_presend = true;
-        presend_pa = pa;
-      } else
-        hipLaunchKernelGGL((dev::k_apply<P, U, V, false>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y, apply_bits,
-                           d_vp, d_active, n_live, d_changed, (const int64_t*)nullptr, (unsigned long long*)nullptr, d_want,
-                           (int32_t*)nullptr, (unsigned int*)nullptr);
-      if (n_live < n && it == 0)  // setAllInactive for the rows k_apply does not visit (they have no edges: once clear, nothing sets them again)
-        GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
-      timer.mark(TAG_APPLY);
-      lap("Apply time");
     }
-    int converged = 0;
-    if (iterations <= 0) {  // the flag only matters when running until convergence (:257-259)
-      // the flag and, behind it, the size of the next active set (written by k_apply): one copy
-      GM_HIP_OK(hipMemcpyAsync(h_changed, d_changed, want_stats ? sizeof(int) + striped_bytes : sizeof(int), hipMemcpyDeviceToHost, s));
-      GM_HIP_OK(hipStreamSynchronize(s));
-      if (want_stats) {
-        frontier_v = frontier_e = frontier_maxdeg = 0;
-        for (int k = 0; k < dev::kStatSlots; k++) {
-          frontier_v += h_striped[4 * k];
-          frontier_e += h_striped[4 * k + 1];
-          frontier_maxdeg = h_striped[4 * k + 2] > frontier_maxdeg ? h_striped[4 * k + 2] : frontier_maxdeg;
-        }
-        list_ready = listed && frontier_v <= (unsigned long long)dev::kSparseListCap;  // k_apply / k_push_finish listed it
-      }
-      converged = (*h_changed == 0) ? 1 : 0;
-      if (xsparse_ok) exchange_state(&converged);  // the flag and the shards' active-set sizes in one step
-      else if (multi) gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &converged);  // :226 Allreduce(LAND)
-    }
-    gp->do_every_iteration(it);  // :236
-    if (trace) {
-      lap("Do every iteration time");
-      const long long changed = count_bits(d_active, n);  // g.active->getNNZ() before ALL_VERTICES re-activates (:248-252)
-      (void)hipStreamSynchronize(s);
-      struct timeval now;
-      gettimeofday(&now, 0);
-      printf("Iteration %d :: %f msec :: updated %lld vertices :: changed %lld vertices \n", it,
-             (now.tv_sec - tr_iter.tv_sec) * 1e3 + (now.tv_usec - tr_iter.tv_usec) * 1e-3, tr_updated, changed);
-    }
-    if (act == ALL_VERTICES && iterations > 0 && it + 1 == iterations) {
-      // last iteration of a fixed-count run: leave the graph all-active (:250-252)
-      hipLaunchKernelGGL(dev::k_fill_u32, dim3(grid_for(nwords)), dim3(dev::kBlock), 0, s, d_active, (int64_t)nwords,
-                         0xffffffffu);
-    }
-    it++;
-    if (it == iterations) break;
-    if (iterations <= 0 && converged == 1) {
-      if (act == ALL_VERTICES)
-        hipLaunchKernelGGL(dev::k_fill_u32, dim3(grid_for(nwords)), dim3(dev::kBlock), 0, s, d_active,
-                           (int64_t)nwords, 0xffffffffu);
-      break;
+    timer.mark(TAG_WAVE);
+    lap("SPMV time");
+    finish_push(pa, rk != REDUCE_LAST);
+  }
+
+  // ---- schedule: the pull step (send -> multiply -> apply) ---------------------------------------------------------------
+  // what this iteration's multiply reads messages from (a probed strategy that fails its cross-check changes them)
+  const T* xq = nullptr;
+  const uint32_t* xb = nullptr;
+
+  // sparse exchange: messages of the listed active vertices only, as (device id, message) entries
+  void send_sparse(const dev::ProgArg<P>& pa) {
+    if constexpr (kSparseT) {
+      list_active_set();
+      const int nf = (int)frontier_v;
+      const int cap = xs_max > 0 ? (xs_max + 63) / 64 * 64 : 64;
+      GM_HIP_OK(hipMemsetAsync(xbits, 0, ((size_t)(desc.ndevice + 31) / 32) * 4, s));
+      if (nf > 0)
+        hipLaunchKernelGGL((dev::k_send_list<P, T, V>), dim3(grid_for(nf)), dim3(dev::kBlock), 0, s, pa, (const V*)d_vp, (const int32_t*)d_list, nf, x,
+                           desc.row_lo);
+      hipLaunchKernelGGL((dev::k_pack_frontier<T>), dim3(grid_for(cap)), dim3(dev::kBlock), 0, s, (const int32_t*)d_list, nf, (const T*)x, desc.row_lo,
+                         d_gather + (size_t)desc.shard * cap, cap);
+      int hf[2] = {cap, 0};
+      if (gm_graph_exchange(g, GM_XCHG_GATHER, d_gather, (int64_t)sizeof(xentry_t), nullptr, hf) != 0) die("sparse message exchange failed");
+      const int64_t nall = (int64_t)desc.nshards * cap;
+      hipLaunchKernelGGL((dev::k_unpack_frontier<T>), dim3(grid_for(nall)), dim3(dev::kBlock), 0, s, (const xentry_t*)d_gather, nall, x, xbits);
+      if (verbose)
+        printf("GraphMat(HIP):   sparse exchange: %d active here, at most %d per shard, %zu bytes sent instead of %zu\n", nf, xs_max,
+               (size_t)cap * sizeof(xentry_t), (size_t)n_live * sizeof(T) + (size_t)n_live / 8);
+      st.sparse_exchanges++;
     }
   }
-  GM_HIP_OK(hipStreamSynchronize(s));
-  tick("loop done", it);
-  aux.finish();
-  st.iterations = it;
-  timer.finish(&st);
-  gm_graph_record_stats(g, &st);
-  tick("teardown done", 0);
-  return it;
+
+  // Cross-check of a probed strategy after the first pass of a pull multiply over adjacency A whose results (presence bits
+  // yb) are in y: giant rows, the first wave rows and a strided sample of all rows are folded again in order.  On a
+  // mismatch the pass is redone with the ordered fold, which also governs the rest of the run.
+  void check_probed(const dev::ProgArg<P>& pa, const gm_csr_t& A, const uint32_t* yb, const uint32_t* rowfilter, int acc_flags, uint32_t* yb_write,
+                    bool dense_x) {
+    if (!rk_unverified || (acc_flags & dev::ACC_READ_PREV)) return;
+    rk_unverified = false;
+    unsigned int* d_mis = (unsigned int*)flag_v + 700;
+    GM_HIP_OK(hipMemsetAsync(d_mis, 0, 4, s));
+    const T* xc = xq;
+    const uint32_t* xbc = xb;
+    if (lazy_send) {  // the ordered fold reads materialised messages: write them once for the check
+      send_all(pa, dense_x ? (const uint32_t*)nullptr : (const uint32_t*)d_active, x);
+      xc = x;
+      xbc = dense_x ? nullptr : (const uint32_t*)xbits;
+    }
+    auto sample = [&](const int32_t* rows, int cnt, int stride) {
+      if (cnt <= 0) return;
+      const int grid = (cnt + dev::kBlock / 64 - 1) / (dev::kBlock / 64);
+      if constexpr ((int)program_traits<P>::reduce != (int)REDUCE_AUTO) return;  // (declared strategies are never checked)
+      else if (use_vp)
+        hipLaunchKernelGGL((dev::k_check_rows<P, T, U, V, E, true>), dim3(grid), dim3(dev::kBlock), 0, s, pa, A, rows, cnt, stride, xc, xbc, (const V*)d_vp,
+                           (const U*)y, yb, rowfilter, d_mis);
+      else
+        hipLaunchKernelGGL((dev::k_check_rows<P, T, U, V, E, false>), dim3(grid), dim3(dev::kBlock), 0, s, pa, A, rows, cnt, stride, xc, xbc, (const V*)d_vp,
+                           (const U*)y, yb, rowfilter, d_mis);
+    };
+    sample(A.giant_row, A.ngiant, 0);
+    sample(A.mid_row, A.nmid < 2048 ? A.nmid : 2048, 0);
+    const int live_rows = n_live < A.nrows ? n_live : A.nrows;
+    const int stride = live_rows > 2048 ? live_rows / 2048 : 1;
+    sample(nullptr, live_rows / stride, stride);
+    unsigned int mis = 0;
+    GM_HIP_OK(hipMemcpyAsync(&mis, d_mis, 4, hipMemcpyDeviceToHost, s));
+    GM_HIP_OK(hipStreamSynchronize(s));
+    if (verbose) printf("GraphMat(HIP):   probed reduce strategy %d cross-checked against the ordered fold: %u mismatching rows\n", rk, mis);
+    if (mis == 0) return;
+    printf("GraphMat(HIP): warning: reduce_function matched strategy %d on the probe's operands but not on this run's data (%u sampled "
+           "rows differ from the ordered fold); using the ordered fold.  Declare GraphMat::program_traits<YourProgram>::reduce to choose explicitly.\n", rk, mis);
+    rk = REDUCE_ORDERED;
+    can_push = false;
+    if (lazy_send) {  // the ordered kernels read materialised messages (written above for the check)
+      lazy_send = false;
+      xq = x;
+      xb = dense_x ? nullptr : (const uint32_t*)xbits;
+    }
+    if (!(acc_flags & dev::ACC_STATIC_BITS)) GM_HIP_OK(hipMemsetAsync(yb_write, 0, (size_t)nwords * 4, s));
+    launch_spmv_vp<P, T, U, V, E>(use_vp, launch_ctx(), pa, A, xq, xb, (const V*)d_vp, y, yb_write, acc_flags, rk, rowfilter);
+  }
+
+  // the OUT adjacency tile by tile on two streams (graphmat_hip.h: gm_graph_tile).  With every x entry present and an
+  // ordered or commutative fold, the rows of more than tile_min_row edges are multiplied tile by tile -- each pass gathers
+  // from one slice of x and continues the row's fold from the value y holds -- and only the short rows take the
+  // untiled row-blocks.  Same fold order, same bits.
+  void multiply_out_tiled(const dev::ProgArg<P>& pa, int ntile, int acc) {
+    const Launch L = launch_ctx();
+    // Tiles whose row classes are fixed per row (gm_csr_t.rows_keep_stream): the giant / one-wave-per-row kernels and the
+    // row-block / 16-row kernels never touch the same y entry, so the auxiliary stream is forked once -- before the untiled
+    // pass -- and joined once after the last tile instead of after every tile, where the main stream used to wait 70-120 us
+    // per tile for the tail of the one-wave-per-row kernel.
+    bool keep_streams = aux.s != nullptr && !use_vp && (rk == REDUCE_ORDERED || rk == REDUCE_F32_ADD) && std::is_trivially_copyable<U>::value &&
+                        (sizeof(U) == 4 || sizeof(U) == 8) && !rk_unverified &&
+                        !(opt.debug_flags & (dev::DBG_NO_WAVE16 | dev::DBG_LONG_ON_MAIN | dev::DBG_NO_OVERLAP));
+    for (int t = 0; t < ntile && keep_streams; t++) {
+      gm_csr_t At;
+      const uint32_t* prev = nullptr;
+      if (gm_graph_tile(g, GM_DIR_OUT, t, &At, &prev) != GM_OK || !At.rows_keep_stream) keep_streams = false;
+    }
+    if (keep_streams) {
+      aux.keep = true;
+      aux.pending = false;
+      GM_HIP_OK(hipEventRecord(aux.fork, s));  // x is complete here: the auxiliary stream may start on tile 0 during the untiled pass
+      GM_HIP_OK(hipStreamWaitEvent(aux.s, aux.fork, 0));
+      aux.forked = true;
+    }
+    gm_csr_t As = Aout;  // the rows that are not tiled: row-blocks and the shorter wave rows
+    As.mid_row = Aout.umid_row; As.nmid = Aout.numid; As.nmid_long = Aout.numid_long; As.ngiant = 0; As.ngchunk = 0;
+    if (Aout.tile_min_row == 0) { As.nblk = 0; As.nmid = 0; }  // every row is tiled
+    launch_spmv_vp<P, T, U, V, E>(use_vp, L, pa, As, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
+    // (running this untiled pass on a stream of its own next to the tile passes -- its rows are no tile's rows -- was
+    // measured too: 7.06 -> 7.03 ms at RMAT-26, not worth a third stream)
+    aux.long_rows = !(opt.debug_flags & dev::DBG_LONG_ON_MAIN);
+    for (int t = 0; t < ntile; t++) {
+      gm_csr_t At;
+      const uint32_t* prev = nullptr;
+      if (gm_graph_tile(g, GM_DIR_OUT, t, &At, &prev) != GM_OK) die(gm_last_error());
+      // y's presence bits are static (dense x): `prev` says which rows already carry a value
+      launch_spmv_vp<P, T, U, V, E>(use_vp, L, pa, At, xq, xb, (const V*)d_vp, y, const_cast<uint32_t*>(prev), dev::ACC_STATIC_BITS | dev::ACC_READ_PREV, rk);
+    }
+    aux.long_rows = false;
+    if (aux.keep) {
+      if (aux.pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
+      aux.keep = aux.forked = aux.pending = false;
+    }
+    // (a probed strategy is cross-checked against the ordered fold of the WHOLE rows; a mismatch redoes this iteration
+    // untiled with the ordered fold, which then also governs the tiled iterations that follow)
+    check_probed(pa, Aout, Aout.rowbits, nullptr, acc, ybits, true);
+  }
+
+  // top-down step over a larger active set inside the pull step: bids, then one pass over all vertices picks the winners
+  void multiply_dense_push(const dev::ProgArg<P>& pa) {
+    list_active_set();
+    const unsigned pieces = (unsigned)(frontier_e / dev::kPieceEdges + frontier_v);
+    piece_offsets((int)frontier_v);
+    hipLaunchKernelGGL(dev::k_push_bid, dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc, (const int32_t*)d_list, (int)frontier_v,
+                       (const unsigned int*)d_off, native_of_dev, d_best, (const uint32_t*)d_want, (int32_t*)nullptr, (unsigned int*)nullptr);
+    if (use_vp)
+      hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, true>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, Asrc, xq, dev_of_native,
+                         (const V*)d_vp, d_best, y, ybits, n_live);  // (only live rows can have been bid for)
+    else
+      hipLaunchKernelGGL((dev::k_push_resolve<P, T, U, V, E, false>), dim3(grid_for(n_live)), dim3(dev::kBlock), 0, s, pa, Asrc, xq, dev_of_native,
+                         (const V*)d_vp, d_best, y, ybits, n_live);
+    st.spmv_launches += 2;
+    timer.mark(TAG_WAVE);
+  }
+
+  void step_pull(const dev::ProgArg<P>& pa, int it, bool xsp, bool dense_push, bool want_stats) {
+    // Clear(&x) / Clear(&y) (:139-140): x presence words are fully rewritten by send.  With every x entry present
+    // (ALL_VERTICES) y's presence is the static set of non-empty rows.
+    const bool static_bits = (act == ALL_VERTICES);
+    const bool dense_x = (act == ALL_VERTICES);
+    if (!static_bits) GM_HIP_OK(hipMemsetAsync(ybits, 0, (size_t)nwords * 4, s));
+    // send (:145).  Rows past n_live have no edge in either direction (degree-ranked order puts them at the tail): nobody
+    // reads their messages and they never receive one
+    if (xsp) {
+      send_sparse(pa);
+    } else {
+      const bool presend_valid = x_presend;  // (only ever set for programs that cannot change between the iterations)
+      x_presend = false;
+      if (!lazy_send && !presend_valid) send_all(pa, dense_x ? (const uint32_t*)nullptr : (const uint32_t*)d_active, x);
+      if (multi && gm_graph_exchange(g, GM_XCHG_MESSAGES, x, (int64_t)sizeof(T), xbits, nullptr) != 0) die("message exchange callback failed");
+    }
+    timer.mark(TAG_SEND);
+    lap("Send message time");
+    // multiply + reduce (:160-176)
+    xq = lazy_send ? (const T*)nullptr : (const T*)x;
+    xb = dense_x ? nullptr : (lazy_send ? (const uint32_t*)d_active : (const uint32_t*)xbits);
+    const uint32_t* apply_bits = ybits;
+    const uint32_t* row_bits = d_want;  // which rows the multiply works on
+    if (dense_push) {
+      multiply_dense_push(pa);
+    } else if (order == OUT_EDGES || order == ALL_EDGES) {
+      const int acc = static_bits ? dev::ACC_STATIC_BITS : 0;
+      // sparse active set of an a=b program: a 64:1 summary of the presence bits for the short-row kernel
+      const uint32_t* xsum = nullptr;
+      const unsigned long long present_x = xsparse_ok ? (unsigned long long)xs_total : frontier_v;  // entries of x that are present
+      if (want_stats && rk == REDUCE_LAST && xb != nullptr && present_x * 512ull < (unsigned long long)n_live * (unsigned long long)desc.nshards) {
+        void* ps = nullptr;
+        const int xwords = (desc.ndevice + 31) / 32;  // x (and its presence bits) cover every shard's rows
+        const int nsum = (xwords / 2 + 31) / 32 + 1;
+        if (gm_graph_workspace(g, 11, (size_t)nsum * 4 + 64, &ps) == GM_OK) {
+          hipLaunchKernelGGL(dev::k_bits_summary, dim3(grid_for(nsum)), dim3(dev::kBlock), 0, s, xb, xwords, (uint32_t*)ps, nsum);
+          xsum = (const uint32_t*)ps;
+        }
+      }
+      int ntile = 1;
+      if (dense_x && !multi && row_bits == nullptr && rk != REDUCE_LAST && dev::stageable<T>::value && !(opt.debug_flags & dev::DBG_NO_TILES))
+        gm_graph_tiles(g, GM_DIR_OUT, &ntile);
+      if (ntile > 1) {
+        multiply_out_tiled(pa, ntile, acc);
+      } else {
+        launch_spmv_vp<P, T, U, V, E>(use_vp, launch_ctx(), pa, Aout, xq, xb, (const V*)d_vp, y, ybits, acc, rk, row_bits, grouped_waves, xsum);
+        check_probed(pa, Aout, static_bits ? Aout.rowbits : (const uint32_t*)ybits, row_bits, acc, ybits, dense_x);
+      }
+      if (static_bits) apply_bits = Aout.rowbits;
+    }
+    if (!dense_push && (order == IN_EDGES || order == ALL_EDGES)) {
+      int acc = (order == ALL_EDGES) ? dev::ACC_READ_PREV : 0;
+      uint32_t* yb = ybits;
+      if (static_bits) {
+        acc |= dev::ACC_STATIC_BITS;
+        yb = const_cast<uint32_t*>(Aout.rowbits);  // only read (presence of the OUT pass's results)
+        apply_bits = Ain.rowbits;
+        if (order == ALL_EDGES && gm_graph_rowbits_all(g, &apply_bits) != GM_OK) die(gm_last_error());
+      }
+      launch_spmv_vp<P, T, U, V, E>(use_vp, launch_ctx(), pa, Ain, (const T*)x, xb, (const V*)d_vp, y, yb, acc, rk, (const uint32_t*)d_want, grouped_waves);
+      if (order == IN_EDGES) check_probed(pa, Ain, static_bits ? Ain.rowbits : (const uint32_t*)ybits, d_want, acc, ybits, dense_x);
+    }
+    lap("SPMV time");
+    if (trace) tr_updated = count_bits(apply_bits, n_live);  // y.getNNZ(): rows that received a message
+    // setAllInactive (:184) + apply (:195-225): the active vector is rewritten by k_apply (when top-down steps are
+    // possible the kernel also sizes and lists the next active set).  The changed vertices are also listed when the next
+    // active set is bound to be small: it cannot have more vertices than the current one has out-edges.  (If it turns
+    // out small without having been listed, a k_frontier_list pass builds the list when it is needed.)
+    const bool build_list = want_stats && frontier_e <= (4ull << 20);
+    if (want_stats) GM_HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
+    listed = build_list;
+    // (a workgroup that lists changed vertices ends with one global atomic: fewer, longer-running workgroups then)
+    const int apply_cap = build_list ? dev::kApplyMaxBlocks / 4 : dev::kApplyMaxBlocks;
+    const int apply_grid = grid_for(n_live) < apply_cap ? grid_for(n_live) : apply_cap;
+    if (want_stats)
+      hipLaunchKernelGGL((dev::k_apply<P, U, V, true>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y, apply_bits, d_vp, d_active, n_live,
+                         d_changed, Asrc.rowptr, d_striped, d_want, build_list ? d_list : (int32_t*)nullptr, build_list ? d_count : (unsigned int*)nullptr);
+    else if (inherits_iteration_hook<P>() && dense_x && !lazy_send && !trace && opt.fuse_apply_send != 0 && iterations > 0 && it + 1 < iterations) {
+      // another iteration follows: its messages come out of the same pass.  Only for programs without a do_every_iteration
+      // of their own (nothing can change what send_message reads between the two iterations), and only in fixed-count
+      // runs: until convergence the last iteration is not known in advance, and a fused pass there would leave x holding
+      // messages of an iteration that never runs (the reference's px would not)
+      hipLaunchKernelGGL((dev::k_apply_send<P, T, U, V>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y, apply_bits, d_vp, d_active, n_live,
+                         d_changed, d_want, x, xbits, desc.row_lo);
+      x_presend = true;
+    } else
+      hipLaunchKernelGGL((dev::k_apply<P, U, V, false>), dim3(apply_grid), dim3(dev::kBlock), 0, s, pa, (const U*)y, apply_bits, d_vp, d_active, n_live,
+                         d_changed, (const int64_t*)nullptr, (unsigned long long*)nullptr, d_want, (int32_t*)nullptr, (unsigned int*)nullptr);
+    if (n_live < n && it == 0)  // setAllInactive for the rows k_apply does not visit (they have no edges: once clear, nothing sets them again)
+      GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
+    timer.mark(TAG_APPLY);
+    lap("Apply time");
+  }
+
+  // ---- the loop (GraphMatRuntime.h:136-261) ----------------------------------------------------------------------------
+  int run_loop() {
+    int it = 0;
+    tick("setup done", 0);
+    while (true) {
+      tick("iteration", it);
+      if (trace) { (void)hipStreamSynchronize(s); gettimeofday(&tr_iter, 0); tr_last = tr_iter; }
+      tr_updated = -1;
+      if (verbose && can_push) printf("GraphMat(HIP):   active set: %llu vertices, %llu out-edges (max %llu)\n", frontier_v, frontier_e, frontier_maxdeg);
+      dev::ProgArg<P> pa = dev::make_prog_arg(gp);  // re-captured every iteration (do_every_iteration may change it)
+      const bool want_stats = (can_push || xsparse_ok) && iterations <= 0;
+      // the changed flag and, for steered runs, the striped statistics behind it (k_apply / k_push_finish add to them)
+      GM_HIP_OK(hipMemsetAsync(d_changed, 0, want_stats ? sizeof(int) + striped_bytes : sizeof(int), s));
+      timer.mark(TAG_START);
+      // this iteration's x travels as lists when every shard's active set is small: fewer bytes than the dense slices
+      // (entry = id + message against one message per live row) and within the list capacity
+      const bool xsp = xsparse_ok && xs_max <= dev::kSparseListCap &&
+                       (unsigned long long)xs_max * sizeof(xentry_t) * 2ull < (unsigned long long)n_live * sizeof(T);
+      // top-down step for small active sets only: few sources and few out-edges
+      const bool push = can_push && frontier_v > 0 && frontier_v <= (unsigned long long)dev::kSparseListCap &&
+                        frontier_e * 1000ull < (unsigned long long)Aout.nnz * (unsigned long long)opt.push_edge_permille;
+      // ... and among those, active sets with few out-edges run entirely on lists (nothing scans all vertices)
+      const bool sparse = push && frontier_e <= (unsigned long long)opt.sparse_step_edges;
+      const bool dense_push = push && !sparse && rk == REDUCE_LAST;
+      // ... and an active set too large to list whose vertices own only a few out-edges each bids straight from the bitmap
+      const bool bits_push = can_push && !push && rk == REDUCE_LAST && frontier_v > (unsigned long long)dev::kSparseListCap &&
+                             frontier_e <= (unsigned long long)opt.bits_step_edges && frontier_maxdeg <= 64ull;
+      if (bits_push) step_bits_push(pa);
+      else if (sparse) step_list_push(pa);
+      else step_pull(pa, it, xsp, dense_push, want_stats);
+
+      int converged = 0;
+      if (iterations <= 0) {  // the flag only matters when running until convergence (:257-259)
+        // the flag and, behind it, the size of the next active set (written by k_apply): one copy
+        GM_HIP_OK(hipMemcpyAsync(h_changed, d_changed, want_stats ? sizeof(int) + striped_bytes : sizeof(int), hipMemcpyDeviceToHost, s));
+        GM_HIP_OK(hipStreamSynchronize(s));
+        if (want_stats) {
+          frontier_v = frontier_e = frontier_maxdeg = 0;
+          for (int k = 0; k < dev::kStatSlots; k++) {
+            frontier_v += h_striped[4 * k];
+            frontier_e += h_striped[4 * k + 1];
+            frontier_maxdeg = h_striped[4 * k + 2] > frontier_maxdeg ? h_striped[4 * k + 2] : frontier_maxdeg;
+          }
+          list_ready = listed && frontier_v <= (unsigned long long)dev::kSparseListCap;  // k_apply / k_push_finish listed it
+        }
+        converged = (*h_changed == 0) ? 1 : 0;
+        if (xsparse_ok) exchange_state(&converged);  // the flag and the shards' active-set sizes in one step
+        else if (multi) gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &converged);  // :226 Allreduce(LAND)
+      }
+      gp->do_every_iteration(it);  // :236
+      if (trace) {
+        lap("Do every iteration time");
+        const long long changed = count_bits(d_active, n);  // g.active->getNNZ() before ALL_VERTICES re-activates (:248-252)
+        (void)hipStreamSynchronize(s);
+        struct timeval now;
+        gettimeofday(&now, 0);
+        printf("Iteration %d :: %f msec :: updated %lld vertices :: changed %lld vertices \n", it,
+               (now.tv_sec - tr_iter.tv_sec) * 1e3 + (now.tv_usec - tr_iter.tv_usec) * 1e-3, tr_updated, changed);
+      }
+      const bool last_fixed = iterations > 0 && it + 1 == iterations;
+      const bool done = last_fixed || (iterations <= 0 && converged == 1);
+      it++;
+      if (done) {
+        if (act == ALL_VERTICES) fill_active();  // leave the graph all-active (:250-252)
+        break;
+      }
+    }
+    finish(it);
+    return it;
+  }
+};
+
+template <class P, class T, class U, class V, class E>
+int run_on_device(P* gp, gm_graph_t* g, edge_direction order, activity_type act, bool use_vp, V* d_vp, uint32_t* d_active, T* x, uint32_t* xbits, U* y,
+                  uint32_t* ybits, int iterations, hipStream_t s) {
+  Run<P, T, U, V, E> run(gp, g, order, act, use_vp, d_vp, d_active, x, xbits, y, ybits, iterations, s);
+  return run.go();
 }
 
 }  // namespace detail

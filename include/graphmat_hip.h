@@ -414,8 +414,50 @@ int gm_run_sgd_bipartite(gm_graph_t* g, void* d_latent, int K, int real_bytes, c
  * instead of the exact parallel replay (A/B check; results are bit-identical).  Graph-build experiments (read when a
  * graph is created): "short_row", "giant_row", "rank_by", "rank_cap", "col_tiles", "tile_min_row", "long_mid" (wave rows
  * of more than this many edges get a wave each instead of sharing one 16 to a wave; 0 = GM_LONG_MID rule), "tile_balance"
- * (1: column tiles serve equally many gathers, the default; 0: they hold equally many vertices with edges). */
+ * (1: column tiles serve equally many gathers, the default; 0: they hold equally many vertices with edges); "sgd_mfma"
+ * (0/1: the dot products of K = 128 fp32 SGD on the matrix cores, within 1e-6 of the vector form instead of its bits).
+ * Every field of gm_engine_options_t below is also a key: gm_set_option then sets the PROCESS default, which a graph
+ * uses unless gm_graph_set_option gave it a value of its own. */
 int gm_set_option(const char* key, int value);
+
+/* ---- engine options: how run_graph_program's iteration loop (include/graphmat/engine.hpp) schedules its kernels.
+ * None of them changes a result; they choose between exact strategies (experiments, A/B tests, ablations).  The
+ * engine reads them once per run through gm_graph_engine_options: the process defaults (gm_set_option) overlaid with
+ * the graph's own values (gm_graph_set_option) -- no state lives in the header layer, so an application binary and
+ * the library always agree. */
+typedef struct {
+  int32_t debug_flags;            /* dev::DBG_* of kernels.hpp: 16 no auxiliary stream, 32 no top-down steps, 64 no grouped wave rows, 128 no two-stage
+                                     sharded schedule, 256 no on-demand messages, 512 no 16-rows-per-wave kernel, 1024 no column tiles, 2048 dense
+                                     exchanges only, 4096 giant rows start with the head stage, 8192 long wave rows on the main stream; 1-8 are
+                                     in-kernel ablations that exist in -DGRAPHMAT_ABLATION builds only.  Default 0 */
+  int32_t wave16_form;            /* 16-rows-per-wave kernel: 0 = one workgroup per 64 rows with an 8192-entry LDS hot set; 2 = persistent 1024-thread
+                                     workgroups with a 22528-entry hot set where that pays (large unsharded graphs); +16 = on graphs of any size.  Default 2 */
+  int32_t rowwave_form;           /* row-blocks: 0 = one workgroup per block (k_spmv_rowblock); 4 = waves of persistent 1024-thread workgroups sharing a
+                                     20480-entry LDS hot set where that pays; +16 = on graphs of any size.  Default 4 */
+  int32_t persist_per_cu;         /* persistent kernels: workgroups per CU (0 = as many as the LDS allows).  Default 0 */
+  int32_t giant_maps;             /* giant rows of float sums: 1 = the exact replay spread over many workgroups (per-piece ulp-maps), 0 = one workgroup
+                                     walks the row.  Default 1 */
+  int32_t ordered_giant_two_pass; /* giant rows of plain ordered folds: 1 = products by k_giant_terms, then k_giant_fold_ordered; 0 = one wave per row
+                                     gathering by itself.  Default 1 */
+  int32_t fuse_apply_send;        /* 1 = apply of iteration i and send of iteration i+1 in one pass (fixed-count ALL_VERTICES programs that leave
+                                     do_every_iteration to the base class).  Default 1 */
+  int32_t untiled_pass_plain;     /* tiled graphs: the untiled short-row pass through the plain row-block kernel (1) or the persistent one (0).  Default 1 */
+  int32_t last_rows_lanes;        /* a=b programs under a row filter: lanes per row of the grouped wave kernel (8 or 16).  Default 8 */
+  int32_t push_edge_permille;     /* top-down steps while the active set owns less than this many thousandths of the edges.  Default 50 */
+  int32_t bits_step_edges;        /* an active set too large to list bids from its bitmap while it owns at most this many out-edges.  Default 2097152 */
+  int32_t sparse_step_edges;      /* ... and runs entirely on lists while it owns at most this many.  Default 1048576 */
+  int32_t iteration_trace;        /* 1 = the reference's __TIMING lines per iteration (host synchronises after every phase).  Default 0, or 1 when the
+                                     environment has GRAPHMAT_ITERATION_TRACE=1 */
+  int32_t ablate_cold_from;       /* -DGRAPHMAT_ABLATION builds only (profiles/r04_cold_column_ablation.md); 0 */
+  int32_t ablate_cold_short;      /* -DGRAPHMAT_ABLATION builds only; 0 */
+  int32_t reserved_[17];
+} gm_engine_options_t;
+/* the options a run on `g` uses (g may be NULL: the process defaults) */
+int gm_graph_engine_options(const gm_graph_t* g, gm_engine_options_t* out);
+/* an engine option for this graph only (key = a field name of gm_engine_options_t) */
+int gm_graph_set_option(gm_graph_t* g, const char* key, int value);
+/* every option of gm_set_option back to its documented default (tests call it from a fixture finaliser); graphs keep their own values */
+int gm_reset_options(void);
 
 /* ---- timing of the last gm_run_* call on this graph -------------------------------------
  * HIP-event times (ms) summed over iterations; kernel launches counted. */

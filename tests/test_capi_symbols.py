@@ -166,3 +166,20 @@ def test_launch_detection_from_the_environment(lib):
     out = subprocess.run([sys.executable, "-c", code], env=dict(base, GRAPHMAT_NRANKS="2", GRAPHMAT_RANK="5"), stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT, timeout=120)
     assert b"RESULT 1 " in out.stdout, out.stdout[-500:]
+
+
+def test_engine_options_defaults_overrides_and_reset(lib):
+    """gm_engine_options_t: process defaults (gm_set_option), reset (gm_reset_options); no graph and no GPU involved."""
+    import ctypes as C
+    from graphmat_amd import _lib
+    o = _lib.EngineOptions()
+    assert lib.gm_graph_engine_options(None, C.byref(o)) == 0
+    assert (o.debug_flags, o.wave16_form, o.rowwave_form, o.giant_maps, o.ordered_giant_two_pass, o.fuse_apply_send) == (0, 2, 4, 1, 1, 1)
+    assert (o.untiled_pass_plain, o.last_rows_lanes, o.push_edge_permille, o.bits_step_edges, o.sparse_step_edges) == (1, 8, 50, 2 << 20, 1 << 20)
+    assert lib.gm_set_option(b"debug_flags", 128) == 0 and lib.gm_set_option(b"wave16_form", 16 + 2) == 0
+    assert lib.gm_set_option(b"wave16_form", 7) != 0 and lib.gm_set_option(b"last_rows_lanes", 12) != 0  # out of range: refused
+    assert lib.gm_graph_engine_options(None, C.byref(o)) == 0 and (o.debug_flags, o.wave16_form) == (128, 18)
+    assert lib.gm_graph_set_option(None, b"debug_flags", 1) != 0  # needs a graph
+    assert lib.gm_reset_options() == 0
+    assert lib.gm_graph_engine_options(None, C.byref(o)) == 0 and (o.debug_flags, o.wave16_form) == (0, 2)
+    assert lib.gm_graph_engine_options(None, None) != 0
