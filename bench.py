@@ -724,7 +724,9 @@ def main():
                     traffic_note = "profiles/pmc_traffic.json was measured on other kernel sources: not quoted"
             except Exception:
                 traffic = None
-        big = nv >= (48 << 20)  # engine.hpp: persistent_forms_pay
+        # engine.hpp: persistent_forms_pay -- unsharded graphs from 48 M device ids on, tiled ones (row classes fixed per row) from 24 M on
+        ndev = int(g.ndevice)
+        big = world == 1 and (ndev >= (48 << 20) or (ndev >= (24 << 20) and int(g.col_tiles) > 1))
         kname = {"k_spmv_wave": "k_spmv_wave16+k_spmv_wave", "multiply": ("k_spmv_rowblock/k_spmv_rowwave+k_spmv_wave16p+k_spmv_wave" if big else "k_spmv_rowblock+k_spmv_wave16+k_spmv_wave") +
                  (" over %d column tiles" % int(g.col_tiles) if tiled else "")}.get(name, name)
         roof = {"bound": "hbm", "kernel": kname + "<PageRank>", "achieved": round(ach, 1),

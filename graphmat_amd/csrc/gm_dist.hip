@@ -479,14 +479,40 @@ int gm_dist_init_from_env(int* rank_out, int* nranks_out) {
     if (!ok) { (void)unlink(tmp.c_str()); gm::set_error("gm_dist_init_from_env: cannot write %s", tmp.c_str()); return GM_ERR_IO; }
     if (rename(tmp.c_str(), path.c_str()) != 0) { (void)unlink(tmp.c_str()); gm::set_error("gm_dist_init_from_env: cannot publish %s", path.c_str()); return GM_ERR_IO; }
   } else {
+    // A file written within 2 s of this rank's own start is this launch's for sure.  An OLDER one (but inside the 120 s
+    // window) may be rank 0 having started early -- or the leftover of a launch that crashed a moment ago under the same
+    // key, which this launch's rank 0 is about to unlink and replace: such a candidate is only accepted after the file
+    // has stayed the same (inode and time stamp) for 5 more seconds; a replacement that shows up meanwhile is judged afresh.
     bool got = false;
-    for (int tries = 0; tries < 60000 && !got; tries++) {  // up to ~60 s
+    bool have_cand = false;
+    int64_t cand_written = 0, cand_since_ms = 0;
+    unsigned long long cand_ino = 0;
+    char cand_id[GM_DIST_ID_BYTES];
+    for (int64_t waited_ms = 0; waited_ms < 65000 && !got; waited_ms++) {  // up to ~65 s
       const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW);
       if (fd >= 0) {
         Header h;
-        got = read(fd, &h, sizeof(h)) == (ssize_t)sizeof(h) && memcmp(h.magic, "GMRDV01", 8) == 0 && h.nranks == nranks &&
-              h.written_at >= (int64_t)started - 120 && read(fd, id, sizeof(id)) == (ssize_t)sizeof(id);
+        struct stat sb;
+        char buf[GM_DIST_ID_BYTES];
+        const bool valid = fstat(fd, &sb) == 0 && read(fd, &h, sizeof(h)) == (ssize_t)sizeof(h) && memcmp(h.magic, "GMRDV01", 8) == 0 && h.nranks == nranks &&
+                           h.written_at >= (int64_t)started - 120 && read(fd, buf, sizeof(buf)) == (ssize_t)sizeof(buf);
         (void)close(fd);
+        if (valid) {
+          if (h.written_at >= (int64_t)started - 2) {
+            memcpy(id, buf, sizeof(id));
+            got = true;
+          } else if (!have_cand || cand_ino != (unsigned long long)sb.st_ino || cand_written != h.written_at) {
+            have_cand = true;
+            cand_ino = (unsigned long long)sb.st_ino;
+            cand_written = h.written_at;
+            cand_since_ms = waited_ms;
+            memcpy(cand_id, buf, sizeof(cand_id));
+          }
+        }
+      }
+      if (!got && have_cand && waited_ms - cand_since_ms >= 5000) {
+        memcpy(id, cand_id, sizeof(id));
+        got = true;
       }
       if (!got) usleep(1000);
     }

@@ -519,6 +519,11 @@ k_rows_unpack(const float* __restrict__ in, const int32_t* __restrict__ flags, c
   if (c == 0 && flags[r]) atomicOr(&bits[row >> 5], 1u << (row & 31));
 }
 
+__global__ void __launch_bounds__(kSgdBlock) k_rows_in_range(const int32_t* __restrict__ rows, int nlist, int n, unsigned int* __restrict__ bad) {
+  const int i = blockIdx.x * kSgdBlock + threadIdx.x;
+  if (i < nlist && (rows[i] < 0 || rows[i] >= n)) atomicAdd(bad, 1u);
+}
+
 template <int K>
 int run_sgd_bipartite(gm_graph_t* g, float* d_latent, const int32_t* d_item_rows, int nitems, int blocks, float lambda, float step,
                       int iterations, int* iters_done, hipStream_t s) {
@@ -534,7 +539,7 @@ int run_sgd_bipartite(gm_graph_t* g, float* d_latent, const int32_t* d_item_rows
   if ((rc = gm_graph_workspace(g, 1, (size_t)d.ndevice * K * 4 + 64, &px))) return rc;
   if ((rc = gm_graph_workspace(g, 3, (size_t)n * K * 4 + 64, &py))) return rc;
   if ((rc = gm_graph_workspace(g, 6, (size_t)nitems * (K + 1) * 4 + 256, &pk))) return rc;  // packed item sums + their flags
-  if ((rc = gm_graph_workspace(g, 4, nw * 4 * 2, &pb))) return rc;                            // presence bits: received / applied
+  if ((rc = gm_graph_workspace(g, 4, nw * 4 * 2 + 64, &pb))) return rc;                       // presence bits: received / applied (+ 64 bytes of scratch)
   float* pack = (float*)pk;
   int32_t* flags = (int32_t*)(pack + (size_t)nitems * K);
   uint32_t* got = (uint32_t*)pb;          // item rows that carry a value from the earlier ranks
@@ -545,9 +550,40 @@ int run_sgd_bipartite(gm_graph_t* g, float* d_latent, const int32_t* d_item_rows
   auto block_lo = [&](int b) { return (int)((int64_t)nitems * b / blocks); };
   gm_run_stats_t st;
   memset(&st, 0, sizeof(st));
-  hipEvent_t ev0, ev1;
-  GM_TRY_HIP(hipEventCreate(&ev0));
-  GM_TRY_HIP(hipEventCreate(&ev1));
+  // the item rows must be rows of this graph, and the ranks must agree on the item count and the number of blocks: a rank that
+  // left the ring early (or walked it with other block boundaries) would leave the others waiting in their next collective
+  {
+    unsigned int* d_chk = (unsigned int*)((char*)pb + nw * 4 * 2);  // (the 64 bytes behind the two bit vectors)
+    GM_TRY_HIP(hipMemsetAsync(d_chk, 0, 16, s));
+    hipLaunchKernelGGL(k_rows_in_range, dim3((nitems + kSgdBlock - 1) / kSgdBlock), dim3(kSgdBlock), 0, s, d_item_rows, nitems, n, d_chk);
+    unsigned int bad = 0;
+    GM_TRY_HIP(hipMemcpyAsync(&bad, d_chk, 4, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    uint32_t agree[4] = {bad ? 1u : 0u, (uint32_t)nitems, (uint32_t)blocks, (uint32_t)iterations};
+    if (nranks > 1) {
+      // sum over the ranks: [0] = ranks with a bad row; [1..3] must be nranks x this rank's own value
+      uint32_t* d_ag = (uint32_t*)d_chk + 8;
+      GM_TRY_HIP(hipMemcpyAsync(d_ag, agree, 16, hipMemcpyHostToDevice, s));
+      if ((rc = dist_all_reduce_sum_u32(d_ag, 4, s))) return rc;
+      uint32_t tot[4];
+      GM_TRY_HIP(hipMemcpyAsync(tot, d_ag, 16, hipMemcpyDeviceToHost, s));
+      GM_TRY_HIP(hipStreamSynchronize(s));
+      if (tot[1] != (uint32_t)nranks * agree[1] || tot[2] != (uint32_t)nranks * agree[2] || tot[3] != (uint32_t)nranks * agree[3]) {
+        set_error("gm_run_sgd_bipartite: the ranks disagree on nitems / blocks / iterations (this rank: %d / %d / %d)", nitems, blocks, iterations);
+        return GM_ERR_INVALID;
+      }
+      bad = tot[0];
+    }
+    if (bad) { set_error("gm_run_sgd_bipartite: d_item_rows holds a row outside [0, %d) (on this or another rank)", n); return GM_ERR_INVALID; }
+  }
+  struct Events {  // (destroyed on every exit path)
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  GM_TRY_HIP(hipEventCreate(&ev.a));
+  GM_TRY_HIP(hipEventCreate(&ev.b));
+  hipEvent_t& ev0 = ev.a;
+  hipEvent_t& ev1 = ev.b;
   GM_TRY_HIP(hipEventRecord(ev0, s));
   unsigned long long moved = 0;
   for (int it = 0; it < iterations; it++) {
@@ -598,8 +634,6 @@ int run_sgd_bipartite(gm_graph_t* g, float* d_latent, const int32_t* d_item_rows
   GM_TRY_HIP(hipEventRecord(ev1, s));
   GM_TRY_HIP(hipEventSynchronize(ev1));
   GM_TRY_HIP(hipEventElapsedTime(&st.total_ms, ev0, ev1));
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
   st.iterations = iterations;
   g->stats = st;
   g->note_val[1] = (int64_t)(iterations > 0 ? moved / (unsigned long long)iterations : 0ull);  // bytes received per iteration

@@ -913,12 +913,20 @@ class Run {
       if (join_giants) aux.wait_join(s);
       const int cnt = r1 - r0;
       const int ag = grid_for(cnt) < dev::kApplyMaxBlocks ? grid_for(cnt) : dev::kApplyMaxBlocks;
-      hipLaunchKernelGGL((dev::k_apply<P, U, V, false>), dim3(ag), dim3(dev::kBlock), 0, s, pa, (const U*)(y + r0), Aout.rowbits + r0 / 32, d_vp + r0,
-                         d_active + r0 / 32, cnt, d_changed, (const int64_t*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr);
+      // apply, and -- when another iteration follows -- this part's messages of it out of the same pass (k_apply_send:
+      // one launch and one read of the vertex properties less per stage; the program cannot change in between, see above)
+      const bool fused = more && opt.fuse_apply_send != 0;
+      if (fused)
+        hipLaunchKernelGGL((dev::k_apply_send<P, T, U, V>), dim3(ag), dim3(dev::kBlock), 0, s, pa, (const U*)(y + r0), Aout.rowbits + r0 / 32, d_vp + r0,
+                           d_active + r0 / 32, cnt, d_changed, (uint32_t*)nullptr, xnext, xbits, desc.row_lo + r0);
+      else
+        hipLaunchKernelGGL((dev::k_apply<P, U, V, false>), dim3(ag), dim3(dev::kBlock), 0, s, pa, (const U*)(y + r0), Aout.rowbits + r0 / 32, d_vp + r0,
+                           d_active + r0 / 32, cnt, d_changed, (const int64_t*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr);
       timer.mark(TAG_APPLY);
       if (more) {
-        hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(cnt)), dim3(dev::kBlock), 0, s, pa, (const V*)(d_vp + r0), (const uint32_t*)nullptr, xnext,
-                           xbits, cnt, desc.row_lo + r0);
+        if (!fused)
+          hipLaunchKernelGGL((dev::k_send<P, T, V>), dim3(grid_for(cnt)), dim3(dev::kBlock), 0, s, pa, (const V*)(d_vp + r0), (const uint32_t*)nullptr, xnext,
+                             xbits, cnt, desc.row_lo + r0);
         int part[2] = {r0, cnt};
         if (gm_graph_exchange(g, GM_XCHG_PART, xnext, (int64_t)sizeof(T), nullptr, part) != 0) die("partial message exchange failed");
         timer.mark(TAG_SEND);

@@ -1521,39 +1521,45 @@ k_giant_fold_ordered(ProgArg<P> pa, gm_csr_t A, const V* __restrict__ vp, U* __r
     for (int j = 0; j < PER; j++) st[j * 64 + lane] = cur[j];
     __builtin_amdgcn_wave_barrier();
     if (base + CH < deg) load(base + CH, nxt, pmn);  // in flight during the fold below
-    if (lane == 0) {
+    // A chunk whose 512 products are all present and whose row already carries a value (every chunk but a row's first and
+    // last, with a dense x) takes a branch-free path: wave-uniform test, then lane 0 folds 16 sub-blocks of 32 out of two
+    // register sets, the LDS reads of sub-block b + 1 issued before the 32 dependent reduce calls of sub-block b.  (With
+    // the presence tests inside the loop the compiler sinks the reads into the branches and every sub-block waits for its
+    // own reads: 15-23 cycles per edge on RMAT-22's 160 K-edge hub row.)
+    bool dense_chunk = has;
+#pragma unroll
+    for (int j = 0; j < PER; j++) dense_chunk = dense_chunk && pm[j] == ~0ull;
+    dense_chunk = __builtin_amdgcn_readfirstlane((int)dense_chunk) != 0;
+    if (dense_chunk) {
+      if (lane == 0) {
+        constexpr int SB = 32, NSB = CH / SB;
+        U ra[SB], rb[SB];
+#pragma unroll
+        for (int u = 0; u < SB; u++) ra[u] = st[u];
+#pragma unroll
+        for (int b = 0; b < NSB; b += 2) {
+#pragma unroll
+          for (int u = 0; u < SB; u++) rb[u] = st[(b + 1) * SB + u];
+#pragma unroll
+          for (int u = 0; u < SB; u++) p.P::reduce_function(acc, ra[u]);
+          if (b + 2 < NSB) {
+#pragma unroll
+            for (int u = 0; u < SB; u++) ra[u] = st[(b + 2) * SB + u];
+          }
+#pragma unroll
+          for (int u = 0; u < SB; u++) p.P::reduce_function(acc, rb[u]);
+        }
+      }
+    } else if (lane == 0) {
 #pragma unroll
       for (int j = 0; j < PER; j++) {
         unsigned long long mask = pm[j];
         const U* t = st + j * 64;
-        if (mask == ~0ull) {
-          // 64 products: two register sets of 16, the LDS reads of one in flight under the dependent reduce calls of the
-          // other (read-then-fold 8 at a time left the LDS latency exposed: 23 cycles per edge, 1.9 ms for RMAT-22's hub row)
-          U a[16], b[16];
-#pragma unroll
-          for (int u = 0; u < 16; u++) a[u] = t[u];
-#pragma unroll
-          for (int u = 0; u < 16; u++) b[u] = t[16 + u];
-          if (!has) { acc = a[0]; has = true; } else p.P::reduce_function(acc, a[0]);
-#pragma unroll
-          for (int u = 1; u < 16; u++) p.P::reduce_function(acc, a[u]);
-#pragma unroll
-          for (int u = 0; u < 16; u++) a[u] = t[32 + u];
-#pragma unroll
-          for (int u = 0; u < 16; u++) p.P::reduce_function(acc, b[u]);
-#pragma unroll
-          for (int u = 0; u < 16; u++) b[u] = t[48 + u];
-#pragma unroll
-          for (int u = 0; u < 16; u++) p.P::reduce_function(acc, a[u]);
-#pragma unroll
-          for (int u = 0; u < 16; u++) p.P::reduce_function(acc, b[u]);
-        } else {
-          while (mask) {
-            const int k = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            U v = t[k];
-            if (has) p.P::reduce_function(acc, v); else { acc = v; has = true; }
-          }
+        while (mask) {  // (a row's first or last chunk, or a sparse x: by position)
+          const int k = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          U v = t[k];
+          if (has) p.P::reduce_function(acc, v); else { acc = v; has = true; }
         }
       }
     }

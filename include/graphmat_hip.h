@@ -131,7 +131,7 @@ typedef struct {
                             each slice.  Multiple of 64; = slice size for GM_LAYOUT_NATIVE.   */
   int32_t col_tiles;     /* column tiles of the GM_DIR_OUT adjacency (see gm_graph_tile): 0 = library default
                             (gm_set_option("col_tiles"), else environment GRAPHMAT_COL_TILES, else automatic:
-                            about one tile per 28 MiB of a 4-byte message vector's live part once that reaches 60 MiB, i.e.
+                            about one tile per 17 MiB of a 4-byte message vector's live part once that reaches 60 MiB, i.e.
                             none up to RMAT-24, 5 at RMAT-25, 8 at RMAT-26, 15 at RMAT-27), 1 = none, 2..GM_MAX_TILES = that many.
                             GM_LAYOUT_DEGREE with one shard only (ignored otherwise).  Output: the number of tiles
                             built (1 = none).                                                                 */
