@@ -741,8 +741,9 @@ static const EngineKey kEngineKeys[] = {
   {"iteration_trace", 12, 0, 0, 1},
   {"ablate_cold_from", 13, 0, 0, 0x7fffffff},
   {"ablate_cold_short", 14, 0, 0, 0x7fffffff},
+  {"two_stage_head_permille", 15, 900, 100, 990},
 };
-static_assert(offsetof(gm_engine_options_t, ablate_cold_short) == 14 * sizeof(int32_t), "kEngineKeys follows the field order");
+static_assert(offsetof(gm_engine_options_t, two_stage_head_permille) == 15 * sizeof(int32_t), "kEngineKeys follows the field order");
 static bool engine_value_ok(const EngineKey& k, int v) {
   if (v < k.lo || v > k.hi) return false;
   if (!strcmp(k.name, "wave16_form")) return (v & 15) <= 5;

@@ -875,12 +875,12 @@ class Run {
       int64_t agreed = 0;
       if (gm_graph_note_get(g, 0, &agreed) == GM_OK) {  // note 0: the split the shards agreed on in an earlier run (0 = none)
         rs = (int32_t)agreed;
-        staged = rs > 0 && gm_graph_split(g, GM_DIR_OUT, 650, &rs, &bs, &ms) == GM_OK;
+        staged = rs > 0 && gm_graph_split(g, GM_DIR_OUT, opt.two_stage_head_permille, &rs, &bs, &ms) == GM_OK;
       } else {
-        int mine = (gm_graph_split(g, GM_DIR_OUT, 650, &rs, &bs, &ms) == GM_OK) ? -rs : 0;
+        int mine = (gm_graph_split(g, GM_DIR_OUT, opt.two_stage_head_permille, &rs, &bs, &ms) == GM_OK) ? -rs : 0;
         gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &mine);  // MIN of -rs = -(largest rs)
         rs = -mine;
-        int fine = (rs >= 64 && rs < n_live && gm_graph_split(g, GM_DIR_OUT, 650, &rs, &bs, &ms) == GM_OK) ? 1 : 0;
+        int fine = (rs >= 64 && rs < n_live && gm_graph_split(g, GM_DIR_OUT, opt.two_stage_head_permille, &rs, &bs, &ms) == GM_OK) ? 1 : 0;
         gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &fine);
         staged = fine == 1;
         gm_graph_note_set(g, 0, staged ? (int64_t)rs : 0);

@@ -704,6 +704,7 @@ template <class T>
 struct HotSet {
   const T* s_hot;
   int base, nhot, NS, per, stride;
+  int shift;  // log2(stride) when stride is a power of two, else -1
   float inv_stride;
   int cold_from;  // (ablation builds: columns from here on are read from LDS instead of being gathered)
   __device__ __forceinline__ T get(const T* __restrict__ x, int c) const {
@@ -714,11 +715,18 @@ struct HotSet {
       const unsigned rel = (unsigned)(c - base);
       return rel < (unsigned)nhot ? s_hot[rel] : x[c];
     }
-    // slice q of the column and its position in it (float estimate of the quotient, fixed up exactly)
-    int q = (int)((float)c * inv_stride);
-    q = q >= NS ? NS - 1 : q;
-    int pos = c - q * stride;
-    if (pos < 0) { q--; pos += stride; } else if (pos >= stride) { q++; pos -= stride; }
+    // slice q of the column and its position in it: a shift and a mask when the slices are a power of two long (2^s
+    // vertices over 2^k shards: the benchmark's case), else a float estimate of the quotient, fixed up exactly
+    int q, pos;
+    if (shift >= 0) {
+      q = c >> shift;
+      pos = c & (stride - 1);
+    } else {
+      q = (int)((float)c * inv_stride);
+      q = q >= NS ? NS - 1 : q;
+      pos = c - q * stride;
+      if (pos < 0) { q--; pos += stride; } else if (pos >= stride) { q++; pos -= stride; }
+    }
     return pos < per ? s_hot[q * per + pos] : x[c];
   }
 };
@@ -734,6 +742,7 @@ __device__ __forceinline__ HotSet<T> hot_load(const gm_csr_t& A, const T* __rest
   h.per = HOT > 1 ? ((A.hot_len < HOT / h.NS ? A.hot_len : HOT / h.NS)) : 0;  // hot entries per slice
   h.nhot = h.per * h.NS;
   h.inv_stride = h.NS > 1 ? 1.0f / (float)A.hot_stride : 0.f;
+  h.shift = (h.NS > 1 && A.hot_stride > 0 && (A.hot_stride & (A.hot_stride - 1)) == 0) ? (31 - __clz(A.hot_stride)) : -1;
   if constexpr (HOT > 1) {
     if (h.NS == 1) {
       const T* __restrict__ xhot = x + A.hot_base;
@@ -1525,7 +1534,9 @@ k_giant_fold_ordered(ProgArg<P> pa, gm_csr_t A, const V* __restrict__ vp, U* __r
     // last, with a dense x) takes a branch-free path: wave-uniform test, then lane 0 folds 16 sub-blocks of 32 out of two
     // register sets, the LDS reads of sub-block b + 1 issued before the 32 dependent reduce calls of sub-block b.  (With
     // the presence tests inside the loop the compiler sinks the reads into the branches and every sub-block waits for its
-    // own reads: 15-23 cycles per edge on RMAT-22's 160 K-edge hub row.)
+    // own reads: 15-23 cycles per edge on RMAT-22's 160 K-edge hub row.  Reading the products through a wave-uniform pointer
+    // instead -- s_load_dwordx16 into scalar registers, no LDS at all, 32 registers a set -- was also built and measured:
+    // 19 cycles per edge, scalar loads return out of order so every wait drains the prefetch as well.)
     bool dense_chunk = has;
 #pragma unroll
     for (int j = 0; j < PER; j++) dense_chunk = dense_chunk && pm[j] == ~0ull;

@@ -450,7 +450,12 @@ typedef struct {
                                      environment has GRAPHMAT_ITERATION_TRACE=1 */
   int32_t ablate_cold_from;       /* -DGRAPHMAT_ABLATION builds only (profiles/r04_cold_column_ablation.md); 0 */
   int32_t ablate_cold_short;      /* -DGRAPHMAT_ABLATION builds only; 0 */
-  int32_t reserved_[17];
+  int32_t two_stage_head_permille;/* sharded two-stage schedule: the head stage = the first rows holding at least this many thousandths of the
+                                     edges (gm_graph_split); the rest -- most of the rows -- is the tail stage whose messages travel while the head
+                                     is multiplied.  Default 900: the tail then holds (almost) only short rows, so the 16-rows-per-wave kernel is
+                                     not cut into two launches (shard of 8 of RMAT-26, compute only: 1.103 ms against 1.196 with 650 and 1.100 for
+                                     the plain loop; profiles/r04_shard_emulation_rmat26.txt) */
+  int32_t reserved_[16];
 } gm_engine_options_t;
 /* the options a run on `g` uses (g may be NULL: the process defaults) */
 int gm_graph_engine_options(const gm_graph_t* g, gm_engine_options_t* out);

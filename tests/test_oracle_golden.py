@@ -179,3 +179,30 @@ def test_mapreduce_closed_forms(threads):
     m[[0, 9, 199, 299]] = 1
     assert ob.mapreduce_double_sum(ones, m, threads) == 8
     assert ob.mapreduce_double_sum(ones, np.zeros(1000, np.uint8), threads, init=7) == 7
+
+
+def test_uniform_out_regular_graph_closed_forms():
+    """The uniform generator (the shape of the reference's test/generator.h:73-105: every vertex has exactly k out-edges to k
+    distinct destinations) and the oracle on it: the Degree pass returns k for every vertex whatever the layout, and BFS depths
+    satisfy the level property (every reached vertex other than the source has an in-neighbour one level up, none closer) --
+    independent of the oracle's fold order, so this pins the generator and the traversal, not the parents."""
+    n, k = 1 << 10, 8
+    nv, s, d, v = gen.uniform_out_regular_edges(n, k, seed=4)
+    assert nv == n and s.size == n * k and (np.bincount(s, minlength=n + 1)[1:] == k).all()
+    assert all(len(set(row)) == k for row in d.reshape(n, k))
+    for threads in (1, 3):
+        og = ob.OracleGraph(nv, s, d, v, ref_threads=threads)
+        assert (og.degree() == k).all()
+        depth, parent, it, _ = og.bfs(1)
+        assert depth[0] == 0
+        best = np.full(n + 1, np.iinfo(np.int64).max, np.int64)
+        reached = depth != MAXD
+        dsrc = np.where(reached[s - 1], depth[s - 1].astype(np.int64), np.iinfo(np.int64).max - 1)
+        np.minimum.at(best, d, dsrc + 1)
+        for vtx in range(2, n + 1):
+            if reached[vtx - 1]:
+                assert depth[vtx - 1] == best[vtx], vtx
+                p = int(parent[vtx - 1])
+                assert depth[p - 1] + 1 == depth[vtx - 1] and ((s == p) & (d == vtx)).any()
+            else:
+                assert best[vtx] >= np.iinfo(np.int64).max - 1
