@@ -80,7 +80,7 @@ def physical_cores():
         return logical, logical
 
 
-def cpu_baseline(scale, iters, rank):
+def cpu_baseline(scale, iters, rank, scale2=0):
     """The oracle (CPU restatement of the reference algorithm, OpenMP `schedule(dynamic, 1)` over the reference's row
     partitions like include/GMDP/singlenode/spmspv.h:48) timed on this box's host cores on a bounded sample
     (RMAT-<scale>, same generator and seed as the GPU run).  Two knobs, tuned like a user of the reference would tune
@@ -149,6 +149,31 @@ def cpu_baseline(scale, iters, rank):
     tot_it = 3 * per_block
     log(rank, "cpu_baseline: RMAT-%d, 3 x %d iterations %s s on %d threads (layout %d): %s GTEPS" % (
         scale, per_block, ["%.2f" % b for b in blocks], t, layout, ["%.3f" % x for x in gteps]))
+    # the same pair on a larger sample (the review asked for RMAT-24 beside RMAT-22: 16x the metric's graph does not fit the
+    # reference layout's memory, this one does): a few iterations, enough for a rate
+    second = None
+    if scale2 > scale:
+        try:
+            del og
+            best = None
+            nv2, s2, d2, _ = api.rmat_on_device(scale2, 16, 1)
+            s2 = s2.cpu().numpy()
+            d2 = d2.cpu().numpy()
+            L.gmo_set_num_threads(min(max(threads), 64))
+            t0 = time.time()
+            og2 = ob.OracleGraph(nv2, s2, d2, None, ref_threads=layout)
+            deg2 = og2.degree()
+            build2 = time.time() - t0
+            L.gmo_set_num_threads(t)
+            og2.pagerank(2, degree=deg2)
+            t0 = time.time()
+            og2.pagerank(15, degree=deg2)
+            per = (time.time() - t0) / 15
+            second = {"scale": scale2, "E": int(len(s2)), "ms_per_iteration": round(per * 1e3, 1), "gteps": round(len(s2) / per / 1e9, 3), "build_s": round(build2, 1)}
+            log(rank, "cpu_baseline: RMAT-%d with the same pair: %.1f ms/iteration = %.3f GTEPS (build %.1f s)" % (scale2, per * 1e3, second["gteps"], build2))
+            del og2, s2, d2
+        except Exception as e:  # pragma: no cover
+            second = {"scale": scale2, "error": repr(e)}
     interleave_memory(False)
     # bytes the port's multiply moves per iteration (row index + value per edge, a column entry of 12 bytes per distinct
     # (partition, column), x per column entry, y read+written per edge in cache): what its GTEPS means in GB/s
@@ -156,7 +181,7 @@ def cpu_baseline(scale, iters, rank):
                                                                   "interleaved over all NUMA nodes" if interleaved else "default policy"),
             "value": round(gteps[1], 4), "unit": "GTEPS", "cores": t, "layout_threads": layout, "kind": "port",
             "min": round(gteps[0], 4), "max": round(gteps[2], 4), "spread_rel": round((gteps[2] - gteps[0]) / gteps[1], 4),
-            "host_cores": {"logical": logical, "physical": physical}, "thread_probe": probes, "stream_triad": triad,
+            "host_cores": {"logical": logical, "physical": physical}, "thread_probe": probes, "stream_triad": triad, "larger_sample": second,
             "phase_ms_per_iteration": {"send": round(ph[0] / tot_it * 1e3, 3), "spmv": round(ph[1] / tot_it * 1e3, 3),
                                        "apply": round(ph[2] / tot_it * 1e3, 3)},
             "calibration": "none possible: the reference proper cannot be built in this image (include/GMDP/gmdp.h needs "
@@ -315,6 +340,32 @@ def extra_sgd(users, items, per_user, iters, local_rank, rank):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     finite = bool(torch.isfinite(lat).all())
+    # the dot products on the matrix cores (gm_set_option("sgd_mfma"), k_sgd_multiply_mfma): one iteration of each form from the
+    # same state -- time and largest difference; the vector form is the one that ships and the one `ms_per_iteration` times
+    mfma = None
+    try:
+        a, b = lat.clone(), lat.clone()
+        _lib.check(L.gm_run_sgd(g.h, a.data_ptr(), K, 4, 0.001, 1e-5, 1, C.byref(it), None))
+        _lib.check(L.gm_set_option(b"sgd_mfma", 1))
+        _lib.check(L.gm_run_sgd(g.h, b.data_ptr(), K, 4, 0.001, 1e-5, 1, C.byref(it), None))  # (first use of the kernel)
+        b.copy_(lat)
+        torch.cuda.synchronize()
+        tm = time.perf_counter()
+        _lib.check(L.gm_run_sgd(g.h, b.data_ptr(), K, 4, 0.001, 1e-5, 1, C.byref(it), None))
+        torch.cuda.synchronize()
+        tm = time.perf_counter() - tm
+        _lib.check(L.gm_set_option(b"sgd_mfma", 0))
+        big = a[:, :K].abs() > 1e-3
+        rel = float(((a[:, :K] - b[:, :K]).abs()[big] / a[:, :K].abs()[big]).max().item())
+        mfma = {"ms_per_iteration": round(tm * 1e3, 3), "vs_vector_form": round(tm / dt, 3), "max_rel_diff_vs_vector_form": rel,
+                "values_differing_in_some_bit": int((a[:, :K] != b[:, :K]).sum().item()), "values": int(a[:, :K].numel()),
+                "mfma_flops_per_iteration": 2 * E * K * 4 * 2, "useful_share_of_mfma_flops": 0.25,
+                "note": "v_mfma_f32_4x4x1_16b_f32, 128 per 64-edge tile, lane = edge; not the default (profiles/r04_sgd_k128.md)"}
+        log(rank, "extra sgd: matrix-core form of the dot products: %.2f ms/iteration (%.2fx the vector form), max relative difference %.2e" % (tm * 1e3, tm / dt, rel))
+        del a, b
+    except Exception as e:  # pragma: no cover
+        mfma = {"error": repr(e)}
+        L.gm_set_option(b"sgd_mfma", 0)
     balg = 2 * E * 8 + nv * K * 4 * 4          # index + rating per edge direction, x/vp read+write per vertex
     flops = 2 * E * 4 * K + 3 * K * nv
     g.close()
@@ -325,7 +376,7 @@ def extra_sgd(users, items, per_user, iters, local_rank, rank):
                         % (users, items, E), "ms_per_iteration": round(dt * 1e3, 3), "iterations_timed": iters,
             "edge_visits_per_s_e9": round(2 * E / dt / 1e9, 3), "alg_bytes": balg, "hbm_gbps": round(balg / dt / 1e9, 1),
             "hbm_frac": round(balg / dt / 1e9 / HBM_PEAK_GBPS, 4), "gather_inclusive_gbps": round(2 * E * K * 4 / dt / 1e9, 1),
-            "tflops": round(flops / dt / 1e12, 2), "result_finite": finite,
+            "tflops": round(flops / dt / 1e12, 2), "result_finite": finite, "mfma_form": mfma,
             "rows_checked": checked, "rows_bit_identical": exact, "max_rel_err": worst, "rel_tol": 1e-6,
             "rows_check": "first iteration, %d sampled item rows + %d sampled user rows recomputed from the same initial state by "
                           "an independent torch fp32 evaluation in the reference's order (bench.py sgd_sampled_rows_check)" % (nsample, nsample),
@@ -342,6 +393,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--ref-threads", type=int, default=1, help="layout parameter of the id permutation (oracle config)")
     ap.add_argument("--cpu-scale", type=int, default=22, help="RMAT scale of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-scale2", type=int, default=24, help="a second, larger cpu_baseline sample with the tuned (layout, threads) pair: 15 iterations (0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=300, help="iterations of the cpu_baseline sample (~10-15 s of CPU work)")
     ap.add_argument("--no-extra", action="store_true", help="skip the BFS (config 3) and SGD (config 5) legs of the JSON line")
     ap.add_argument("--sgd-users", type=int, default=10_000_000)
@@ -786,7 +838,7 @@ def main():
     if args.debug_flags & ~(128 | 64 | 32 | 16):  # flags that only choose between exact strategies keep the result valid
         out["INVALID_ablation_debug_flags"] = args.debug_flags
     if rank == 0 and world == 1 and args.cpu_scale > 0:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_scale, args.cpu_iters, rank)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_scale, args.cpu_iters, rank, args.cpu_scale2)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0 and world == 1 and not args.no_extra:
