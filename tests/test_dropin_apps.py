@@ -145,6 +145,45 @@ def test_own_bfs_with_row_filter_trait(golden_dir, ref):
 
 
 @pytest.mark.gpu
+def test_untraited_programs_on_a_graph_with_giant_rows():
+    """apps/untraited_programs.cpp: what an UNCHANGED application gets by default -- programs without program_traits, i.e. the
+    ordered fold for every reduce_function -- on RMAT-16 (hub rows of 13 K in-edges: giant rows, whose ordered fold runs in
+    two passes, k_giant_terms + k_giant_fold_ordered): BFS with 8-byte a = b messages over a sparse message vector, SSSP with a
+    4-byte min over hashed edge weights, and PageRank's float sum over a dense vector, each against the oracle -- depths and
+    parents, distances, out-degrees and fp32 bits of every vertex."""
+    from graphmat_amd import generators as gen
+    from graphmat_amd.mtx import write_mtx_bin
+    from oracle import binding as ob
+    ob.build()
+    exe = _need(os.path.join(OWN_APPS, "untraited_programs"))
+    nv, s, d, v = gen.rmat_edges(16, 16, seed=11, weights="hash")
+    path = "/tmp/untraited_rmat16.bin.mtx"
+    write_mtx_bin(path, nv, s, d, v)
+    text = _run(exe, path, 5, 6)
+    og = ob.OracleGraph(nv, s, d, v, ref_threads=1)
+    od, op, oit, _ = og.bfs(5)
+    got = {int(a): (int(b), int(c)) for a, b, c in re.findall(r"^bfs (\d+) (\d+) (-?\d+)$", text, flags=re.M)}
+    reached = np.where(od != 0xFFFFFFFF)[0]
+    assert len(got) == reached.size and reached.size > nv // 4
+    for i in reached:
+        assert got[i + 1] == (int(od[i]), -1 if i + 1 == 5 else int(op[i])), i + 1
+    odist, _ = og.sssp(5)
+    gots = {int(a): int(b) for a, b in re.findall(r"^sssp (\d+) (\d+)$", text, flags=re.M)}
+    rs = np.where(odist != 0xFFFFFFFF)[0]
+    assert len(gots) == rs.size
+    for i in rs:
+        assert gots[i + 1] == int(odist[i]), i + 1
+    opr, oit2, _ = og.pagerank(6)
+    odeg = og.degree()
+    gotp = re.findall(r"^pr (\d+) (\d+) ([0-9a-f]{8})$", text, flags=re.M)
+    assert len(gotp) == nv and oit2 == 6
+    bits = np.array([int(b, 16) for _, _, b in gotp], dtype=np.uint32)
+    degs = np.array([int(x) for _, x, _ in gotp], dtype=np.int64)
+    assert (degs == odeg).all()
+    assert (bits == np.ascontiguousarray(opr, np.float32).view(np.uint32)).all()
+
+
+@pytest.mark.gpu
 def test_cpp_surface_selftest():
     """apps/api_selftest.cpp: Graph<V,E> get/set, getEdgelist, applyToAll*, activity, a (mul,add)
     SpMV and chain BFS through include/*.h -- the reference's unit tests re-expressed."""
