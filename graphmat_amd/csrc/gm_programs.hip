@@ -11,6 +11,8 @@
 #include <limits.h>
 #include <math.h>
 
+#include <string>
+
 #include "GraphMatRuntime.h"
 #include "gm_internal.hpp"
 
@@ -757,6 +759,27 @@ static gm_engine_options_t engine_documented_defaults() {
   for (const EngineKey& k : kEngineKeys) ((int32_t*)&o)[k.index] = k.def;
   const char* tr = getenv("GRAPHMAT_ITERATION_TRACE");
   if (tr && tr[0] == '1') o.iteration_trace = 1;
+  // GRAPHMAT_OPTIONS="key=value,key=value": engine options for applications that cannot call gm_set_option themselves (the
+  // reference's unchanged sources); unknown keys and values out of range are reported and ignored
+  if (const char* env = getenv("GRAPHMAT_OPTIONS")) {
+    std::string all(env);
+    size_t pos = 0;
+    while (pos < all.size()) {
+      size_t end = all.find(',', pos);
+      if (end == std::string::npos) end = all.size();
+      const std::string kv = all.substr(pos, end - pos);
+      pos = end + 1;
+      const size_t eq = kv.find('=');
+      bool ok = false;
+      if (eq != std::string::npos) {
+        const std::string key = kv.substr(0, eq);
+        const int value = atoi(kv.c_str() + eq + 1);
+        for (const EngineKey& k : kEngineKeys)
+          if (key == k.name && engine_value_ok(k, value)) { ((int32_t*)&o)[k.index] = value; ok = true; }
+      }
+      if (!ok && !kv.empty()) fprintf(stderr, "GraphMat(HIP): GRAPHMAT_OPTIONS: ignoring '%s'\n", kv.c_str());
+    }
+  }
   return o;
 }
 static gm_engine_options_t& engine_defaults() {

@@ -417,7 +417,8 @@ int gm_run_sgd_bipartite(gm_graph_t* g, void* d_latent, int K, int real_bytes, c
  * (1: column tiles serve equally many gathers, the default; 0: they hold equally many vertices with edges); "sgd_mfma"
  * (0/1: the dot products of K = 128 fp32 SGD on the matrix cores, within 1e-6 of the vector form instead of its bits).
  * Every field of gm_engine_options_t below is also a key: gm_set_option then sets the PROCESS default, which a graph
- * uses unless gm_graph_set_option gave it a value of its own. */
+ * uses unless gm_graph_set_option gave it a value of its own; the environment variable GRAPHMAT_OPTIONS="key=value,..."
+ * sets such defaults for applications that cannot call this themselves (the reference's unchanged sources). */
 int gm_set_option(const char* key, int value);
 
 /* ---- engine options: how run_graph_program's iteration loop (include/graphmat/engine.hpp) schedules its kernels.

@@ -183,3 +183,19 @@ def test_engine_options_defaults_overrides_and_reset(lib):
     assert lib.gm_reset_options() == 0
     assert lib.gm_graph_engine_options(None, C.byref(o)) == 0 and (o.debug_flags, o.wave16_form) == (0, 2)
     assert lib.gm_graph_engine_options(None, None) != 0
+
+
+def test_engine_options_from_the_environment(lib):
+    """GRAPHMAT_OPTIONS="key=value,...": defaults for applications that cannot call gm_set_option (the reference's unchanged
+    sources); read when the library first needs the options, bad entries reported and ignored.  (A fresh process: the
+    library of this one has long read its environment.)"""
+    import subprocess
+    import sys
+    code = ("import ctypes as C; from graphmat_amd import _lib; L = _lib.lib(); o = _lib.EngineOptions(); "
+            "assert L.gm_graph_engine_options(None, C.byref(o)) == 0; print(o.debug_flags, o.wave16_form, o.two_stage_head_permille, o.fuse_apply_send)")
+    env = dict(os.environ, GRAPHMAT_OPTIONS="debug_flags=64,fuse_apply_send=0,two_stage_head_permille=800,wave16_form=99,nonsense=3")
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()
+    assert out.stdout.decode().split()[-4:] == ["64", "2", "800", "0"]
+    err = out.stderr.decode()
+    assert "ignoring 'wave16_form=99'" in err and "ignoring 'nonsense=3'" in err
