@@ -108,7 +108,7 @@ def cpu_baseline(scale, iters, rank, scale2=0):
         L.gmo_set_num_threads(t)
         triad.append({"threads": t, "gbps": round(L.gmo_stream_triad_gbs(1 << 26, 3), 1)})
     log(rank, "cpu_baseline: STREAM triad (3 x 512 MiB) " + ", ".join("%d thr %.0f GB/s" % (x["threads"], x["gbps"]) for x in triad))
-    best = None
+    cands = []  # one per layout: (probe seconds, threads, graph, degrees, layout) of its best thread count
     probes = []
     for layout in (4, 8, 16, 32):
         if layout > max(physical, 8):
@@ -118,7 +118,7 @@ def cpu_baseline(scale, iters, rank, scale2=0):
         og = ob.OracleGraph(nv, s, d, None, ref_threads=layout)
         deg = og.degree()
         build_s = time.time() - t0
-        kept = False
+        mine = None
         for t in threads:
             if t < layout or t > layout * 8:  # (layout threads..half the partitions)
                 continue
@@ -129,22 +129,33 @@ def cpu_baseline(scale, iters, rank, scale2=0):
             probe = (time.time() - t0) / 10
             probes.append({"layout_threads": layout, "threads": t, "ms_per_iteration": round(probe * 1e3, 2)})
             log(rank, "cpu_baseline probe: layout %d (%d partitions), %d threads: %.1f ms/iteration (build %.1f s)" % (layout, layout * 16, t, probe * 1e3, build_s))
-            if best is None or probe < best[1]:
-                best = (t, probe, og, deg, layout)
-                kept = True
-        if not kept:
-            del og
-    t, _, og, deg, layout = best
-    L.gmo_set_num_threads(t)
+            if mine is None or probe < mine[0]:
+                mine = (probe, t, og, deg, layout)
+        if mine is not None:
+            cands.append(mine)
+        del og
+    # the probes are 10 iterations each and the host is not quiet: the two best (layout, threads) pairs both run the timed
+    # blocks, and the better median is the baseline
+    cands.sort(key=lambda c: c[0])
     per_block = max(1, iters // 3)
-    blocks = []
     ph = (C.c_double * 3)()
-    L.gmo_phase_seconds(ph, 1)
-    for _ in range(3):
-        t0 = time.time()
-        og.pagerank(per_block, degree=deg)
-        blocks.append(time.time() - t0)
-    L.gmo_phase_seconds(ph, 1)
+    best = None
+    for _, t_c, og_c, deg_c, layout_c in cands[:2]:
+        L.gmo_set_num_threads(t_c)
+        blocks_c = []
+        L.gmo_phase_seconds(ph, 1)
+        for _ in range(3):
+            t0 = time.time()
+            og_c.pagerank(per_block, degree=deg_c)
+            blocks_c.append(time.time() - t0)
+        L.gmo_phase_seconds(ph, 1)
+        med = sorted(blocks_c)[1]
+        log(rank, "cpu_baseline: layout %d, %d threads: 3 x %d iterations %s s" % (layout_c, t_c, per_block, ["%.2f" % b for b in blocks_c]))
+        if best is None or med < best[0]:
+            best = (med, t_c, og_c, deg_c, layout_c, blocks_c, [ph[0], ph[1], ph[2]])
+    _, t, og, deg, layout, blocks, phs = best
+    ph[0], ph[1], ph[2] = phs
+    del cands
     gteps = sorted(len(s) * per_block / b / 1e9 for b in blocks)
     tot_it = 3 * per_block
     log(rank, "cpu_baseline: RMAT-%d, 3 x %d iterations %s s on %d threads (layout %d): %s GTEPS" % (

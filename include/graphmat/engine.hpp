@@ -1290,8 +1290,9 @@ class Run {
       if (verbose && can_push) printf("GraphMat(HIP):   active set: %llu vertices, %llu out-edges (max %llu)\n", frontier_v, frontier_e, frontier_maxdeg);
       dev::ProgArg<P> pa = dev::make_prog_arg(gp);  // re-captured every iteration (do_every_iteration may change it)
       const bool want_stats = (can_push || xsparse_ok) && iterations <= 0;
-      // the changed flag and, for steered runs, the striped statistics behind it (k_apply / k_push_finish add to them)
-      GM_HIP_OK(hipMemsetAsync(d_changed, 0, want_stats ? sizeof(int) + striped_bytes : sizeof(int), s));
+      // the changed flag and, for steered runs, the striped statistics behind it (k_apply / k_push_finish add to them);
+      // a fixed-count run never reads the flag (:254-256), so it is not cleared either: one tiny fill kernel less per iteration
+      if (iterations <= 0) GM_HIP_OK(hipMemsetAsync(d_changed, 0, want_stats ? sizeof(int) + striped_bytes : sizeof(int), s));
       timer.mark(TAG_START);
       // this iteration's x travels as lists when every shard's active set is small: fewer bytes than the dense slices
       // (entry = id + message against one message per live row) and within the list capacity
