@@ -30,6 +30,7 @@ int g_rank_by = 0;    // experiment: 0 rank vertices by total degree, 1 by out-d
 int g_tile_min_row = GM_TILE_MIN_ROW;  // rows of more than this many edges are tiled
 int g_tile_balance = 1;  // column tiles serve equally many gathers (1) or hold equally many vertices with edges (0)
 int g_long_mid = 0;  // > 0: experiment -- wave rows of more than this many edges get a wave each (0 = GM_LONG_MID rule)
+int g_sort_tile_lists = 1;  // column tiles: the wave-row lists by descending piece length (sort_rows_by_length)
 int g_own_wave_row = 4096;  // column tiles: rows of more than this many edges (whole graph) keep the wave / giant kernels in every tile (0: classes per tile piece)
 int g_col_tiles = 0;  // default number of column tiles for graphs whose descriptor says 0 (0 = environment GRAPHMAT_COL_TILES, else none)
 
@@ -380,6 +381,33 @@ static int partition_mid(const int32_t* mid_row, int nmid, const int64_t* rowptr
   return GM_OK;
 }
 
+__global__ void __launch_bounds__(kT)
+k_row_lengths(const int32_t* __restrict__ list, int n, const int64_t* __restrict__ rowptr, uint32_t* __restrict__ len) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  const int r = list[i];
+  len[i] = (uint32_t)(rowptr[r + 1] - rowptr[r]);
+}
+// list[0, n) reordered by descending row length (stable: rows of equal length keep their order).  The persistent
+// 16-rows-per-wave kernel deals consecutive 16-entry groups to its waves round robin and a group takes as many 64-edge
+// steps as its LONGEST row: in row order a column tile's pieces of neighbouring rows differ widely (RMAT-26: 77 % of the
+// 16 x 64 slots of a step hold an edge, and the waves of one launch finish between 190 and 330 us); sorted, the rows of a
+// group are equally long and every wave gets the same number of steps.
+static int sort_rows_by_length(int32_t* list, int n, const int64_t* rowptr, hipStream_t s) {
+  if (n < 2) return GM_OK;
+  DevBuf k_in, k_out, v_out, tmp;
+  int rc;
+  if ((rc = k_in.alloc((size_t)n * 4)) || (rc = k_out.alloc((size_t)n * 4)) || (rc = v_out.alloc((size_t)n * 4))) return rc;
+  hipLaunchKernelGGL(k_row_lengths, dim3(grid_for(n)), dim3(kT), 0, s, (const int32_t*)list, n, rowptr, k_in.as<uint32_t>());
+  size_t tb = 0;
+  GM_TRY_HIP(rocprim::radix_sort_pairs_desc(nullptr, tb, k_in.as<uint32_t>(), k_out.as<uint32_t>(), (const int32_t*)list, v_out.as<int32_t>(), (size_t)n, 0, 32, s));
+  if ((rc = tmp.alloc(tb + 256))) return rc;
+  GM_TRY_HIP(rocprim::radix_sort_pairs_desc(tmp.p, tb, k_in.as<uint32_t>(), k_out.as<uint32_t>(), (const int32_t*)list, v_out.as<int32_t>(), (size_t)n, 0, 32, s));
+  GM_TRY_HIP(hipMemcpyAsync(list, v_out.p, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  return GM_OK;
+}
+
 static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* idx_sorted, unsigned long long kept,
                       const void* d_val, hipStream_t s, CsrOwned* out, int tile_split = -1, const unsigned char* own_wave = nullptr);
 static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* idx_sorted, unsigned long long kept,
@@ -691,6 +719,11 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
       if (tile_split >= 0) {  // the wave rows that stay untiled, same layout
         if ((rc = umid.alloc((size_t)(nmid + 1) * 4))) return rc;
         if ((rc = partition_mid(mid.as<int32_t>(), (int)nmid, rowptr.as<int64_t>(), long_limit, (int64_t)tile_split, umid.as<int32_t>(), &numid_long, &numid, s))) return rc;
+      }
+      // a column tile's lists by descending piece length (gm_set_option("sort_tile_lists", 0): row order, for A/B runs)
+      if (own_wave != nullptr && g_sort_tile_lists != 0) {
+        if ((rc = sort_rows_by_length(mid2.as<int32_t>(), nmid_long, rowptr.as<int64_t>(), s))) return rc;
+        if ((rc = sort_rows_by_length(mid2.as<int32_t>() + nmid_long, (int)n_all - nmid_long, rowptr.as<int64_t>(), s))) return rc;
       }
       void* old = mid.release();
       mid.p = mid2.release();

@@ -20,7 +20,7 @@
 
 namespace gm {
 
-extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance, g_own_wave_row;
+extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance, g_own_wave_row, g_sort_tile_lists;
 static int g_force_ordered = 0;
 
 // ---------------- PageRank (reference: src/PageRank.cpp:34-112) ----------------------------
@@ -821,6 +821,7 @@ int gm_reset_options(void) {
   gm::g_tile_balance = 1;
   gm::g_long_mid = 0;
   gm::g_own_wave_row = 4096;
+  gm::g_sort_tile_lists = 1;
   gm::g_col_tiles = 0;
   return GM_OK;
 }
@@ -842,9 +843,20 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "tile_min_row") && (value == 0 || value >= gm::g_short_row)) { gm::g_tile_min_row = value; return GM_OK; }
   if (key && !strcmp(key, "col_tiles") && value >= 0 && value <= GM_MAX_TILES) { gm::g_col_tiles = value; return GM_OK; }
   if (key && !strcmp(key, "own_wave_row") && value >= 0) { gm::g_own_wave_row = value; return GM_OK; }
+  if (key && !strcmp(key, "sort_tile_lists") && (value == 0 || value == 1)) { gm::g_sort_tile_lists = value; return GM_OK; }
   gm::set_error("gm_set_option: unknown option");
   return GM_ERR_INVALID;
 }
+
+#ifdef GRAPHMAT_ABLATION
+// ablation builds only (not in the header): the per-wave time stamps of the persistent kernels' last launch
+extern "C" int gm_abl_wave_times(unsigned long long* out, size_t bytes) {
+  const size_t n = sizeof(GraphMat::dev::g_abl_wave_times);
+  GM_TRY_HIP(hipDeviceSynchronize());
+  GM_TRY_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(GraphMat::dev::g_abl_wave_times), bytes < n ? bytes : n));
+  return GM_OK;
+}
+#endif
 
 int gm_debug_counters(int64_t out[4]) {
   unsigned long long h[4] = {0, 0, 0, 0};

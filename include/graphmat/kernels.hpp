@@ -123,6 +123,9 @@ __device__ __forceinline__ bool abl_cold(int c, int cold_from, int base) {
   }
   return false;
 }
+// per-wave time stamps of the persistent kernels' LAST launch (tools/wave_times_probe.py): [kernel 0 = k_spmv_wave16p,
+// 1 = k_spmv_rowwave][wave of the grid][0 start, 1 hot set loaded, 2 done, 3 work items (steps / 64-row groups)], 100 MHz ticks
+static __device__ unsigned long long g_abl_wave_times[2][8192][4];
 static __global__ void k_abl_count(const int32_t* __restrict__ colidx, int64_t nnz, int cold_from, int base, unsigned long long* out) {
   unsigned long long n = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) n += abl_cold(colidx[i], cold_from, base) ? 1 : 0;
@@ -447,7 +450,7 @@ enum { ACC_READ_PREV = 1, ACC_STATIC_BITS = 2 };
 #else
 #define GM_ABL(bit) 0
 #endif
-enum { DBG_SKIP_FOLD = GM_ABL(1), DBG_SKIP_GATHER = GM_ABL(2), DBG_FIRST_CHUNK_ONLY = GM_ABL(4), DBG_NO_REPLAY = GM_ABL(8), DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64, DBG_NO_PIPELINE = 128, DBG_NO_LAZY_SEND = 256, DBG_NO_WAVE16 = 512, DBG_NO_TILES = 1024, DBG_NO_SPARSE_XCHG = 2048, DBG_LATE_GIANTS = 4096, DBG_LONG_ON_MAIN = 8192 };
+enum { DBG_SKIP_FOLD = GM_ABL(1), DBG_SKIP_GATHER = GM_ABL(2), DBG_FIRST_CHUNK_ONLY = GM_ABL(4), DBG_NO_REPLAY = GM_ABL(8), DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64, DBG_NO_PIPELINE = 128, DBG_NO_LAZY_SEND = 256, DBG_NO_WAVE16 = 512, DBG_NO_TILES = 1024, DBG_NO_SPARSE_XCHG = 2048, DBG_LATE_GIANTS = 4096, DBG_LONG_ON_MAIN = 8192, DBG_PLAIN_WAVE16 = 16384 };
 
 // presence bits of a wave's 64 consecutive rows: one atomicOr per 32-row word (not per row:
 // same-word atomics from 32 lanes serialise in the L2); nothing when the bits are static
@@ -1031,6 +1034,31 @@ __device__ __forceinline__ void wave16_group(const P& p, const gm_csr_t& A, cons
         int k = 0;
         if (!has) { acc = t[0]; has = true; k = 1; }
         for (; k < 64; k++) { U v = t[k]; p.P::reduce_function(acc, v); }
+      } else if ((mask & (mask + 1)) == 0) {
+        // the present products are the first n of the chunk (dense x: the tail of a row).  A counted loop whose LDS reads run
+        // four elements ahead of the folds: the bit-scan loop below pays an LDS round trip per product, and nearly every
+        // step has a row in its last chunk (RMAT-26 with every gather ablated: 235 -> 215 us per launch of this kernel)
+        const int n = __popcll(mask);
+        int k = 0;
+        if (!has && n > 0) { acc = t[0]; has = true; k = 1; }
+        U nx[4];
+        if (k + 4 <= n) {
+#pragma unroll
+          for (int u = 0; u < 4; u++) nx[u] = t[k + u];
+        }
+        while (k + 4 <= n) {
+          U cur[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) cur[u] = nx[u];
+          k += 4;
+          if (k + 4 <= n) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) nx[u] = t[k + u];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) p.P::reduce_function(acc, cur[u]);
+        }
+        for (; k < n; k++) { U v = t[k]; p.P::reduce_function(acc, v); }
       } else {
         while (mask) {
           const int k = __ffsll((long long)mask) - 1;
@@ -1046,6 +1074,154 @@ __device__ __forceinline__ void wave16_group(const P& p, const gm_csr_t& A, cons
     y[my_row] = acc;
     if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[my_row >> 5], 1u << (my_row & 31));
   }
+}
+
+// ---- the same fold for the case the headline runs: every x entry present, no row filter, 2-operand program, edge
+// positions that fit 32 bits, one slice of x (single GPU).  The general form above spends ~50 wave instructions per
+// 64-edge chunk (64-bit positions re-broadcast per step, a branch around every load -- which also makes the compiler wait
+// for ALL outstanding loads at every use, presence masks through LDS) and the kernel is bound by instruction issue, not
+// by the vector-memory path: with every gather replaced by an LDS read it still took 1.9 of its 2.6 ms per RMAT-26 iteration
+// (profiles/r04_instruction_diet.md).  Here the step body is branch-free -- loads are unconditional (positions clamped
+// into the row, lanes that need no gather re-read the slice's first entry, an L1 hit), so the compiler counts the
+// outstanding loads exactly -- and software-pipelined three deep: column ids of step s+2 and messages of step s+1 are in
+// flight while step s is folded; a row's metadata (row id, CSR range, running value) is loaded while the PREVIOUS group
+// is worked on (W16Meta).  Same products in the same order: bit-identical results.
+template <class U>
+struct W16Meta {
+  int row, e0, len;
+  bool has;
+  U acc;
+};
+// the row id of list entry first + lane (lanes >= G and entries past the list: -1)
+__device__ __forceinline__ int w16_row(const int32_t* __restrict__ rows, int nlist, int first, int lane) {
+  const int i = first + lane;
+  const bool ok = lane < kWaveRows && i < nlist && first >= 0;
+  const int v = rows[ok ? i : 0];
+  return ok ? v : -1;
+}
+template <class U>
+__device__ __forceinline__ W16Meta<U> w16_meta(const gm_csr_t& A, int row, const U* __restrict__ y, const uint32_t* __restrict__ ybits, int accumulate) {
+  W16Meta<U> mt;
+  const int r = row >= 0 ? row : 0;
+  const int64_t a = A.rowptr[r], b = A.rowptr[r + 1];
+  mt.row = row;
+  mt.e0 = (int)a;
+  mt.len = row >= 0 ? (int)(b - a) : 0;
+  mt.has = false;
+  if (accumulate & ACC_READ_PREV) {
+    const uint32_t w = ybits[r >> 5];
+    mt.acc = y[r];
+    mt.has = row >= 0 && ((w >> (r & 31)) & 1u);
+  }
+  return mt;
+}
+template <class P, class T, class U, class V, class E, int KSTRIDE>
+__device__ __forceinline__ void wave16_dense(const P& p, const gm_csr_t& A, const W16Meta<U>& mt, const int lane, const T* __restrict__ x,
+                                             U* __restrict__ y, uint32_t* __restrict__ ybits, const int accumulate, const int dbg,
+                                             const HotSet<T>& hot, U (*s_t)[KSTRIDE]) {
+  constexpr int G = kWaveRows;
+  int longest = mt.len;
+  for (int off = 8; off > 0; off >>= 1) {
+    const int o = __shfl_xor(longest, off, 64);
+    longest = o > longest ? o : longest;
+  }
+  longest = __builtin_amdgcn_readfirstlane(longest);
+  const int nsteps = (longest + 63) >> 6;
+  if (nsteps == 0) return;
+  bool has = mt.has;
+  U acc = mt.acc;
+  V no_vp;
+  const int last_edge = (int)(A.nnz - 1);
+  const T* __restrict__ xdummy = x + hot.base;  // (lanes without a gather of their own all read this entry: one L1-resident line)
+  int c[G];
+  T m[G];
+  auto cols = [&](int step) {  // column ids of chunk `step` of every row (-1 past the row's end)
+    const int pos = step * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+      const int lr = __builtin_amdgcn_readlane(mt.len, r);
+      int k = __builtin_amdgcn_readlane(mt.e0, r) + (pos < lr ? pos : lr - 1);
+      k = k < 0 ? 0 : (k > last_edge ? last_edge : k);
+      const int v = stream_load(&A.colidx[k]);
+      c[r] = pos < lr ? v : -1;
+    }
+  };
+  auto msgs = [&]() {  // messages of the chunk whose column ids are in c
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+      const int cc = c[r];
+      const unsigned rel = (unsigned)(cc - hot.base);
+      bool in_lds = rel < (unsigned)hot.nhot;
+      unsigned slot = rel;
+#ifdef GRAPHMAT_ABLATION
+      if (cc >= 0 && abl_cold(cc, hot.cold_from, hot.base)) { in_lds = true; slot = (unsigned)cc & 4095u; }
+      if (dbg & DBG_SKIP_GATHER) { in_lds = true; slot = 0; }
+#endif
+      const T mh = hot.s_hot[in_lds ? slot : 0u];
+      const T* __restrict__ ga = (in_lds || cc < 0) ? xdummy : x + cc;
+      const T mg = *ga;
+      m[r] = in_lds ? mh : mg;
+    }
+  };
+  cols(0);
+  msgs();
+  if (nsteps > 1) cols(1);
+  for (int step = 0; step < nsteps; step++) {
+    // products of this step into the tile (every lane writes: a lane past its row's end writes a value nobody folds)
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+      U term;
+      const int k = __builtin_amdgcn_readlane(mt.e0, r) + step * 64 + lane;  // (only programs that read edge values use it)
+      p.P::process_message(m[r], edge_at<E>(A.vals, k), no_vp, term);
+      s_t[r][lane] = term;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (step + 1 < nsteps) {
+      msgs();                            // (their column ids were requested a whole step ago)
+      if (step + 2 < nsteps) cols(step + 2);
+    }
+    if (lane < G && !(dbg & DBG_SKIP_FOLD)) {
+      int n = mt.len - step * 64;
+      n = n > 64 ? 64 : n;
+      const U* t = s_t[lane];
+      if (n == 64) {
+        int k = 0;
+        if (!has) { acc = t[0]; has = true; k = 1; }
+        for (; k < 64; k++) { U v = t[k]; p.P::reduce_function(acc, v); }
+      } else if (n > 0) {
+        int k = 0;
+        if (!has) { acc = t[0]; has = true; k = 1; }
+        U nx[4];
+        if (k + 4 <= n) {
+#pragma unroll
+          for (int u = 0; u < 4; u++) nx[u] = t[k + u];
+        }
+        while (k + 4 <= n) {
+          U cur[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) cur[u] = nx[u];
+          k += 4;
+          if (k + 4 <= n) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) nx[u] = t[k + u];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) p.P::reduce_function(acc, cur[u]);
+        }
+        for (; k < n; k++) { U v = t[k]; p.P::reduce_function(acc, v); }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane < G && mt.row >= 0 && has) {
+    y[mt.row] = acc;
+    if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[mt.row >> 5], 1u << (mt.row & 31));
+  }
+}
+// may the lean form run?  (wave-uniform)
+template <class P, class T>
+__device__ __forceinline__ bool w16_dense_ok(const gm_csr_t& A, const uint32_t* xbits, const uint32_t* want, const HotSet<T>& hot) {
+  return xbits == nullptr && want == nullptr && !program_row_filter<P>::enabled && hot.NS == 1 && A.nnz < ((int64_t)1 << 31) && A.nnz > 0;
 }
 
 template <class P, class T, class U, class V, class E>
@@ -1090,15 +1266,46 @@ k_spmv_wave16p(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int 
   __shared__ __attribute__((aligned(16))) U s_t[BLOCK / 64][G][kStride];
   __shared__ unsigned long long s_mask[BLOCK / 64][G];
   __shared__ T s_hot[HOT];
+#ifdef GRAPHMAT_ABLATION
+  const unsigned long long abl_t0 = wall_clock64();
+#endif
   const HotSet<T> hot = hot_load<T, HOT, BLOCK>(A, x, s_hot);
   __syncthreads();
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ngroups = (nlist + G - 1) / G;
   const int nwaves = gridDim.x * (BLOCK / 64);
+#ifdef GRAPHMAT_ABLATION
+  const unsigned long long abl_t1 = wall_clock64();
+  struct AblStamp {
+    unsigned long long t0, t1;
+    int w, lane;
+    __device__ ~AblStamp() {
+      if (lane == 0 && w < 8192) {
+        g_abl_wave_times[0][w][0] = t0; g_abl_wave_times[0][w][1] = t1; g_abl_wave_times[0][w][2] = wall_clock64();
+      }
+    }
+  } abl_stamp{abl_t0, abl_t1, (int)(blockIdx.x * (BLOCK / 64) + wv), lane};
+#endif
   // wave w of the grid = workgroup (w mod gridDim.x): neighbouring groups -- the list is degree-ranked, so they cost
   // about the same -- go to different CUs, and the interleaving balances the waves.  (Handing the groups out off a
   // global work counter instead was measured: 26 000 same-address atomics per launch, 6.6 -> 7.5 ms per iteration.)
+  if (w16_dense_ok<P, T>(A, xbits, want, hot) && !(dbg & DBG_PLAIN_WAVE16)) {  // (debug_flags 16384: the general form, for A/B runs)
+    // lean form: the next group's row ids are loaded two groups ahead, its CSR range and running value one group ahead
+    int g = wv * gridDim.x + blockIdx.x;
+    int row_n = w16_row(rows, nlist, g + nwaves < ngroups ? (g + nwaves) * G : -1, lane);
+    W16Meta<U> cur = w16_meta<U>(A, w16_row(rows, nlist, g < ngroups ? g * G : -1, lane), y, ybits, accumulate);
+    while (g < ngroups) {
+      const int gn = g + nwaves;
+      const int row_nn = w16_row(rows, nlist, gn + nwaves < ngroups ? (gn + nwaves) * G : -1, lane);
+      const W16Meta<U> nxt = w16_meta<U>(A, row_n, y, ybits, accumulate);
+      wave16_dense<P, T, U, V, E, kStride>(p, A, cur, lane, x, y, ybits, accumulate, dbg, hot, s_t[wv]);
+      cur = nxt;
+      row_n = row_nn;
+      g = gn;
+    }
+    return;
+  }
   for (int g = wv * gridDim.x + blockIdx.x; g < ngroups; g += nwaves)
     wave16_group<P, T, U, V, E, kStride>(p, A, rows, nlist, g * G, lane, x, xbits, vp, y, ybits, accumulate, dbg, want, hot, s_t[wv], s_mask[wv]);
 }
@@ -1121,10 +1328,25 @@ k_spmv_rowwave(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, U* __restrict
   __shared__ T s_hot[HOT > 0 ? HOT : 1];
   __shared__ T s_msg[W][kPadw];
 #define GM_WSLOT(k) ((k) + ((k) >> 5))
+#ifdef GRAPHMAT_ABLATION
+  const unsigned long long abl_t0 = wall_clock64();
+#endif
   const HotSet<T> hot = hot_load<T, HOT, BLOCK>(A, x, s_hot);
   __syncthreads();
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#ifdef GRAPHMAT_ABLATION
+  const unsigned long long abl_t1 = wall_clock64();
+  struct AblStamp {
+    unsigned long long t0, t1;
+    int w, lane;
+    __device__ ~AblStamp() {
+      if (lane == 0 && w < 8192) {
+        g_abl_wave_times[1][w][0] = t0; g_abl_wave_times[1][w][1] = t1; g_abl_wave_times[1][w][2] = wall_clock64();
+      }
+    }
+  } abl_stamp{abl_t0, abl_t1, (int)(blockIdx.x * (BLOCK / 64) + wv), lane};
+#endif
   T* sm = s_msg[wv];
   const int nwaves = gridDim.x * W;
   V no_vp;
