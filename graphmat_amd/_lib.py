@@ -39,6 +39,12 @@ class Csr(C.Structure):
                 ("gchunk_state", C.c_void_p), ("edges_blk", C.c_int64), ("edges_wave16", C.c_int64), ("edges_wave", C.c_int64), ("rows_keep_stream", C.c_int32), ("cold_from", C.c_int32)]
 
 
+class Sweep(C.Structure):
+    _fields_ = [("nrows", C.c_int32), ("nsets", C.c_int32), ("nslices", C.c_int32), ("acc_rows", C.c_int32), ("nedges", C.c_int64),
+                ("npieces", C.c_int64), ("colidx", C.c_void_p), ("piece_start", C.c_void_p), ("piece_row", C.c_void_p),
+                ("blk_first", C.c_void_p), ("slice_base", C.c_void_p), ("row_of_rank", C.c_void_p)]
+
+
 class RunStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("send_ms", C.c_float), ("spmv_ms", C.c_float), ("apply_ms", C.c_float),
                 ("total_ms", C.c_float), ("spmv_launches", C.c_int32), ("rowblock_ms", C.c_float),
@@ -49,7 +55,7 @@ class RunStats(C.Structure):
 class EngineOptions(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("debug_flags", "wave16_form", "rowwave_form", "persist_per_cu", "giant_maps", "ordered_giant_two_pass",
                                          "fuse_apply_send", "untiled_pass_plain", "last_rows_lanes", "push_edge_permille", "bits_step_edges",
-                                         "sparse_step_edges", "iteration_trace", "ablate_cold_from", "ablate_cold_short", "two_stage_head_permille")] + [("reserved_", C.c_int32 * 16)]
+                                         "sparse_step_edges", "iteration_trace", "ablate_cold_from", "ablate_cold_short", "two_stage_head_permille", "giant_stream", "sweep_form")] + [("reserved_", C.c_int32 * 14)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int))
@@ -73,6 +79,7 @@ SIGNATURES = {
     "gm_graph_destroy": (C.c_int, [_P]),
     "gm_graph_desc": (C.c_int, [_P, C.POINTER(GraphDesc)]),
     "gm_graph_csr": (C.c_int, [_P, C.c_int, C.POINTER(Csr)]),
+    "gm_graph_sweep": (C.c_int, [_P, C.POINTER(Sweep)]),
     "gm_graph_rowbits_all": (C.c_int, [_P, C.POINTER(_P)]),
     "gm_graph_tiles": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
     "gm_graph_tile": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(Csr), C.POINTER(_P)]),
@@ -122,6 +129,7 @@ SIGNATURES = {
     "gm_graph_note_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
     "gm_graph_workspace_info": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "gm_graph_run_resources": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    "gm_graph_giant_stream": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "gm_graph_record_stats": (C.c_int, [_P, C.POINTER(RunStats)]),
     "gm_reduce_sum_f64": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_double), _P]),
     "gm_reduce_sum_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_double), _P]),

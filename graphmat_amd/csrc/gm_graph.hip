@@ -30,6 +30,7 @@ int g_rank_by = 0;    // experiment: 0 rank vertices by total degree, 1 by out-d
 int g_tile_min_row = GM_TILE_MIN_ROW;  // rows of more than this many edges are tiled
 int g_tile_balance = 1;  // column tiles serve equally many gathers (1) or hold equally many vertices with edges (0)
 int g_long_mid = 0;  // > 0: experiment -- wave rows of more than this many edges get a wave each (0 = GM_LONG_MID rule)
+int g_sweep_slices = 0;  // 1: cut the device order into ntiles * k <= 64 slices and build the row-stationary sweep of the medium rows (gm_graph_sweep)
 int g_sort_tile_lists = 1;  // column tiles: the wave-row lists by descending piece length (sort_rows_by_length)
 int g_own_wave_row = 4096;  // column tiles: rows of more than this many edges (whole graph) keep the wave / giant kernels in every tile (0: classes per tile piece)
 int g_col_tiles = 0;  // default number of column tiles for graphs whose descriptor says 0 (0 = environment GRAPHMAT_COL_TILES, else none)
@@ -878,6 +879,224 @@ k_tile_gather(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ id
   idx_t[j] = idx[p];
 }
 
+// ---- gm_graph_sweep: the medium rows' edges as [set][workgroup][slice][row][native column] ------------------------------
+__global__ void __launch_bounds__(kT)
+k_sweep_medium(const int64_t* __restrict__ rowptr, int nrows, int short_row, int64_t max_len, const unsigned char* __restrict__ own_wave,
+               unsigned char* __restrict__ flag) {
+  const int r = blockIdx.x * kT + threadIdx.x;
+  if (r >= nrows) return;
+  const int64_t len = rowptr[r + 1] - rowptr[r];
+  flag[r] = (len > short_row && len <= max_len && !(own_wave != nullptr && own_wave[r])) ? 1 : 0;
+}
+__global__ void __launch_bounds__(kT) k_sweep_unflag(const int32_t* __restrict__ list, int n, unsigned char* __restrict__ flag) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i < n) flag[list[i]] = 0;
+}
+__global__ void __launch_bounds__(kT)
+k_sweep_unswept(const int32_t* __restrict__ list, int n, const unsigned char* __restrict__ swept, unsigned char* __restrict__ keep) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i < n) keep[i] = swept[list[i]] ? 0 : 1;
+}
+__global__ void __launch_bounds__(kT) k_sweep_iota(int32_t* __restrict__ a, int n) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i < n) a[i] = i;
+}
+__global__ void __launch_bounds__(kT)
+k_sweep_lens(const int32_t* __restrict__ rows, int n, const int64_t* __restrict__ rowptr, uint32_t* __restrict__ len) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i < n) len[i] = (uint32_t)(rowptr[rows[i] + 1] - rowptr[rows[i]]);
+}
+__global__ void __launch_bounds__(kT) k_sweep_widen(const uint32_t* __restrict__ a, int n, unsigned long long* __restrict__ o) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i < n) o[i] = a[i];
+}
+struct SweepSlices { int32_t b[GM_MAX_TILES + 2]; };
+// one wave per medium row (in length-rank order): its edges, keyed (virtual workgroup, slice, accumulator slot), CSR order kept
+__global__ void __launch_bounds__(kT)
+k_sweep_keys(const int32_t* __restrict__ rows_ranked, int nmed, const unsigned long long* __restrict__ off, const int64_t* __restrict__ rowptr,
+             const int32_t* __restrict__ colidx, SweepSlices sl, int nslices, int acc_rows, unsigned long long* __restrict__ key, int32_t* __restrict__ val) {
+  const int r = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
+  if (r >= nmed) return;
+  const int lane = threadIdx.x & 63;
+  const int row = rows_ranked[r];
+  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+  const unsigned wg = (unsigned)r % 256u, l = (unsigned)r / 256u;
+  const unsigned long long vw = (unsigned long long)(l / (unsigned)acc_rows) * 256ull + wg, slot = l % (unsigned)acc_rows;
+  const unsigned long long o = off[r];
+  for (int64_t e = e0 + lane; e < e1; e += 64) {
+    const int c = colidx[e];
+    int lo = 0, hi = nslices;  // largest s with sl.b[s] <= c
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sl.b[mid] <= c) lo = mid; else hi = mid; }
+    key[o + (unsigned long long)(e - e0)] = (vw << 22) | ((unsigned long long)lo << 16) | slot;
+    val[o + (unsigned long long)(e - e0)] = c;
+  }
+}
+__global__ void __launch_bounds__(kT)
+k_sweep_heads(const unsigned long long* __restrict__ key, int64_t n, uint32_t* __restrict__ head) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i < n) head[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(kT)
+k_sweep_pieces(const unsigned long long* __restrict__ key, const uint32_t* __restrict__ head, const uint32_t* __restrict__ pidx_incl, int64_t n,
+               uint32_t* __restrict__ piece_start, uint16_t* __restrict__ piece_row, int32_t* __restrict__ blk_first, int nslices) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i >= n || !head[i]) return;
+  const uint32_t p = pidx_incl[i] - 1;
+  const unsigned long long k = key[i];
+  piece_start[p] = (uint32_t)i;
+  piece_row[p] = (uint16_t)(k & 0xffffull);
+  const unsigned long long blk = k >> 16;  // vw << 6 | slice
+  if (i == 0 || (key[i - 1] >> 16) != blk) blk_first[(int64_t)(blk >> 6) * nslices + (int64_t)(blk & 63ull)] = (int32_t)p;
+}
+static void free_sweep(gm_graph* g) {
+  gm_sweep_t& S = g->sweep;
+  if (S.colidx) (void)hipFree((void*)S.colidx);
+  if (S.piece_start) (void)hipFree((void*)S.piece_start);
+  if (S.piece_row) (void)hipFree((void*)S.piece_row);
+  if (S.blk_first) (void)hipFree((void*)S.blk_first);
+  if (S.row_of_rank) (void)hipFree((void*)S.row_of_rank);
+  if (g->d_slice_base) (void)hipFree(g->d_slice_base);
+  memset(&S, 0, sizeof(S));
+  g->d_slice_base = nullptr;
+}
+static int build_sweep(gm_graph* g, const CsrOwned* whole, const unsigned char* own_wave, hipStream_t s) {
+  memset(&g->sweep, 0, sizeof(g->sweep));
+  const int TS = g->nslices;
+  const int nrows = g->desc.row_hi - g->desc.row_lo;
+  if (TS < 2 || TS > 64 || own_wave == nullptr || nrows <= 0 || whole->view.nnz >= ((int64_t)1 << 32)) return GM_OK;
+  const int64_t* rowptr = (const int64_t*)whole->rowptr;
+  const int32_t* colidx = (const int32_t*)whole->colidx;
+  int rc;
+  DevBuf flag, iota, rows, cnt, len_in, len_out, ranked, tmp;
+  if ((rc = flag.alloc((size_t)nrows)) || (rc = iota.alloc((size_t)nrows * 4)) || (rc = rows.alloc((size_t)nrows * 4)) || (rc = cnt.alloc(16))) return rc;
+  hipLaunchKernelGGL(k_sweep_medium, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr, nrows, whole->view.short_row, (int64_t)1 << 40, own_wave,
+                     flag.as<unsigned char>());
+  // (The rows of more than own_wave_row edges keep the one-wave-per-row / giant kernels tile by tile.  Sweeping them too was
+  // measured: their pieces are hundreds of edges long, one lane folds each, and the wave that gets a workgroup's 64 longest
+  // pieces holds the workgroup's slice barrier for 38 steps -- RMAT-26 12.3 ms per iteration.)
+  if (whole->view.ngiant > 0)
+    hipLaunchKernelGGL(k_sweep_unflag, dim3(grid_for(whole->view.ngiant)), dim3(kT), 0, s, (const int32_t*)whole->giant_row, whole->view.ngiant, flag.as<unsigned char>());
+  hipLaunchKernelGGL(k_sweep_iota, dim3(grid_for(nrows)), dim3(kT), 0, s, iota.as<int32_t>(), nrows);
+  size_t tb = 0;
+  GM_TRY_HIP(rocprim::select(nullptr, tb, iota.as<int32_t>(), flag.as<unsigned char>(), rows.as<int32_t>(), cnt.as<unsigned int>(), (size_t)nrows, s));
+  if ((rc = tmp.alloc(tb + 256))) return rc;
+  GM_TRY_HIP(rocprim::select(tmp.p, tb, iota.as<int32_t>(), flag.as<unsigned char>(), rows.as<int32_t>(), cnt.as<unsigned int>(), (size_t)nrows, s));
+  unsigned int nmed = 0;
+  GM_TRY_HIP(hipMemcpyAsync(&nmed, cnt.p, 4, hipMemcpyDeviceToHost, s));
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  iota.free();
+  if (nmed == 0) return GM_OK;
+  // rank by length (descending), deal the ranks over the 256 workgroups
+  if ((rc = len_in.alloc((size_t)nmed * 4)) || (rc = len_out.alloc((size_t)nmed * 4)) || (rc = ranked.alloc((size_t)nmed * 4))) return rc;
+  hipLaunchKernelGGL(k_sweep_lens, dim3(grid_for((int)nmed)), dim3(kT), 0, s, (const int32_t*)rows.as<int32_t>(), (int)nmed, rowptr, len_in.as<uint32_t>());
+  tb = 0;
+  GM_TRY_HIP(rocprim::radix_sort_pairs_desc(nullptr, tb, len_in.as<uint32_t>(), len_out.as<uint32_t>(), rows.as<int32_t>(), ranked.as<int32_t>(), (size_t)nmed, 0, 32, s));
+  if ((rc = tmp.alloc(tb + 256))) return rc;
+  GM_TRY_HIP(rocprim::radix_sort_pairs_desc(tmp.p, tb, len_in.as<uint32_t>(), len_out.as<uint32_t>(), rows.as<int32_t>(), ranked.as<int32_t>(), (size_t)nmed, 0, 32, s));
+  rows.free(); len_in.free();
+  const int per_wg = (int)((nmed + 255u) / 256u);
+  const int acc_rows = GM_SWEEP_ACC_ROWS;
+  const int nsets = (per_wg + acc_rows - 1) / acc_rows;
+  if (nsets > 16) return GM_OK;  // (the key below has 4 bits for it; 41 M medium rows)
+  // edge offsets of the ranked rows
+  DevBuf l64, off;
+  if ((rc = l64.alloc((size_t)nmed * 8)) || (rc = off.alloc((size_t)nmed * 8))) return rc;
+  {
+    hipLaunchKernelGGL(k_sweep_widen, dim3(grid_for((int)nmed)), dim3(kT), 0, s, (const uint32_t*)len_out.as<uint32_t>(), (int)nmed, l64.as<unsigned long long>());
+    tb = 0;
+    GM_TRY_HIP(rocprim::exclusive_scan(nullptr, tb, l64.as<unsigned long long>(), off.as<unsigned long long>(), 0ull, (size_t)nmed, rocprim::plus<unsigned long long>(), s));
+    if ((rc = tmp.alloc(tb + 256))) return rc;
+    GM_TRY_HIP(rocprim::exclusive_scan(tmp.p, tb, l64.as<unsigned long long>(), off.as<unsigned long long>(), 0ull, (size_t)nmed, rocprim::plus<unsigned long long>(), s));
+  }
+  unsigned long long last_off = 0;
+  uint32_t last_len = 0;
+  GM_TRY_HIP(hipMemcpyAsync(&last_off, off.as<unsigned long long>() + (nmed - 1), 8, hipMemcpyDeviceToHost, s));
+  GM_TRY_HIP(hipMemcpyAsync(&last_len, len_out.as<uint32_t>() + (nmed - 1), 4, hipMemcpyDeviceToHost, s));
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  const int64_t nedges = (int64_t)(last_off + last_len);
+  l64.free(); len_out.free();
+  if (nedges <= 0 || nedges >= ((int64_t)1 << 32)) return GM_OK;
+  DevBuf k_in, k_out, v_in, v_out;
+  if ((rc = k_in.alloc((size_t)nedges * 8)) || (rc = k_out.alloc((size_t)nedges * 8)) || (rc = v_in.alloc((size_t)nedges * 4)) || (rc = v_out.alloc((size_t)nedges * 4))) return rc;
+  SweepSlices sl;
+  memset(&sl, 0, sizeof(sl));
+  for (int t = 0; t <= TS; t++) sl.b[t] = g->slice_base[t];
+  hipLaunchKernelGGL(k_sweep_keys, dim3((nmed + (kT / 64) - 1) / (kT / 64)), dim3(kT), 0, s, (const int32_t*)ranked.as<int32_t>(), (int)nmed,
+                     (const unsigned long long*)off.as<unsigned long long>(), rowptr, colidx, sl, TS, acc_rows, k_in.as<unsigned long long>(), v_in.as<int32_t>());
+  GM_TRY_HIP(hipGetLastError());
+  off.free();
+  tb = 0;  // stable: inside (workgroup, slice, row) the edges keep their ascending native column order
+  GM_TRY_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_in.as<unsigned long long>(), k_out.as<unsigned long long>(), v_in.as<int32_t>(), v_out.as<int32_t>(), (size_t)nedges, 0, 34, s));
+  if ((rc = tmp.alloc(tb + 256))) return rc;
+  GM_TRY_HIP(rocprim::radix_sort_pairs(tmp.p, tb, k_in.as<unsigned long long>(), k_out.as<unsigned long long>(), v_in.as<int32_t>(), v_out.as<int32_t>(), (size_t)nedges, 0, 34, s));
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  k_in.free(); v_in.free(); tmp.free();
+  // pieces
+  DevBuf head, pidx;
+  if ((rc = head.alloc((size_t)nedges * 4)) || (rc = pidx.alloc((size_t)nedges * 4))) return rc;
+  hipLaunchKernelGGL(k_sweep_heads, dim3(grid_for(nedges)), dim3(kT), 0, s, (const unsigned long long*)k_out.as<unsigned long long>(), nedges, head.as<uint32_t>());
+  tb = 0;
+  GM_TRY_HIP(rocprim::inclusive_scan(nullptr, tb, head.as<uint32_t>(), pidx.as<uint32_t>(), (size_t)nedges, rocprim::plus<uint32_t>(), s));
+  if ((rc = tmp.alloc(tb + 256))) return rc;
+  GM_TRY_HIP(rocprim::inclusive_scan(tmp.p, tb, head.as<uint32_t>(), pidx.as<uint32_t>(), (size_t)nedges, rocprim::plus<uint32_t>(), s));
+  uint32_t npieces = 0;
+  GM_TRY_HIP(hipMemcpyAsync(&npieces, pidx.as<uint32_t>() + (nedges - 1), 4, hipMemcpyDeviceToHost, s));
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  const size_t nblk = (size_t)nsets * 256 * (size_t)TS;
+  DevBuf pstart, prow, bfirst, sbase;
+  if ((rc = pstart.alloc(((size_t)npieces + 1) * 4)) || (rc = prow.alloc(((size_t)npieces + 1) * 2)) || (rc = bfirst.alloc((nblk + 1) * 4)) ||
+      (rc = sbase.alloc((size_t)(GM_MAX_TILES + 2) * 4)))
+    return rc;
+  GM_TRY_HIP(hipMemsetAsync(bfirst.p, 0xff, (nblk + 1) * 4, s));
+  hipLaunchKernelGGL(k_sweep_pieces, dim3(grid_for(nedges)), dim3(kT), 0, s, (const unsigned long long*)k_out.as<unsigned long long>(), (const uint32_t*)head.as<uint32_t>(),
+                     (const uint32_t*)pidx.as<uint32_t>(), nedges, pstart.as<uint32_t>(), prow.as<uint16_t>(), bfirst.as<int32_t>(), TS);
+  const uint32_t ne32 = (uint32_t)nedges;
+  GM_TRY_HIP(hipMemcpyAsync(pstart.as<uint32_t>() + npieces, &ne32, 4, hipMemcpyHostToDevice, s));
+  {
+    std::vector<int32_t> h(nblk + 1);
+    GM_TRY_HIP(hipMemcpyAsync(h.data(), bfirst.p, (nblk + 1) * 4, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    h[nblk] = (int32_t)npieces;
+    for (int64_t b = (int64_t)nblk - 1; b >= 0; b--) if (h[b] < 0) h[b] = h[b + 1];
+    GM_TRY_HIP(hipMemcpyAsync(bfirst.p, h.data(), (nblk + 1) * 4, hipMemcpyHostToDevice, s));
+    GM_TRY_HIP(hipMemcpyAsync(sbase.p, sl.b, (size_t)(TS + 1) * 4, hipMemcpyHostToDevice, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+  }
+  // what is left of every tile's one-wave-per-row list: the pieces of rows that are NOT swept (giant rows of the whole graph
+  // whose piece in this tile is below the tile's giant limit); kept in the tile views' umid_row / numid fields
+  for (int t = 0; t < g->ntiles; t++) {
+    CsrOwned& Ct = g->out_tiles[t];
+    const int nl = Ct.view.nmid_long < Ct.view.nmid ? Ct.view.nmid_long : Ct.view.nmid;
+    Ct.view.umid_row = nullptr; Ct.view.numid = 0; Ct.view.numid_long = 0;
+    if (nl <= 0) continue;
+    DevBuf keep, outl;
+    if ((rc = keep.alloc((size_t)nl)) || (rc = outl.alloc((size_t)nl * 4))) return rc;
+    hipLaunchKernelGGL(k_sweep_unswept, dim3(grid_for(nl)), dim3(kT), 0, s, (const int32_t*)Ct.mid_row, nl, (const unsigned char*)flag.as<unsigned char>(), keep.as<unsigned char>());
+    tb = 0;
+    GM_TRY_HIP(rocprim::select(nullptr, tb, (const int32_t*)Ct.mid_row, keep.as<unsigned char>(), outl.as<int32_t>(), cnt.as<unsigned int>(), (size_t)nl, s));
+    if ((rc = tmp.alloc(tb + 256))) return rc;
+    GM_TRY_HIP(rocprim::select(tmp.p, tb, (const int32_t*)Ct.mid_row, keep.as<unsigned char>(), outl.as<int32_t>(), cnt.as<unsigned int>(), (size_t)nl, s));
+    unsigned int nk = 0;
+    GM_TRY_HIP(hipMemcpyAsync(&nk, cnt.p, 4, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    if (Ct.umid_row) (void)hipFree(Ct.umid_row);
+    Ct.umid_row = (int32_t*)outl.release();
+    Ct.view.umid_row = Ct.umid_row;
+    Ct.view.numid = (int32_t)nk;
+    Ct.view.numid_long = (int32_t)nk;
+  }
+  gm_sweep_t& S = g->sweep;
+  S.nrows = (int32_t)nmed; S.nsets = nsets; S.nslices = TS; S.acc_rows = acc_rows; S.nedges = nedges; S.npieces = (int64_t)npieces;
+  S.colidx = (const int32_t*)v_out.release();
+  S.piece_start = (const uint32_t*)pstart.release();
+  S.piece_row = (const uint16_t*)prow.release();
+  S.blk_first = (const int32_t*)bfirst.release();
+  S.row_of_rank = (const int32_t*)ranked.release();
+  g->d_slice_base = (int32_t*)sbase.release();
+  S.slice_base = g->d_slice_base;
+  return GM_OK;
+}
+
 static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* idx_sorted, unsigned long long kept,
                        const void* d_val, hipStream_t s, const CsrOwned* whole) {
   const int T = g->ntiles;
@@ -952,6 +1171,7 @@ static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t*
     }
   }
   GM_TRY_HIP(hipStreamSynchronize(s));
+  if (g_sweep_slices != 0 && (rc = build_sweep(g, whole, own_wave, s))) return rc;
   return GM_OK;
 }
 
@@ -1039,8 +1259,11 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     unsigned long long total = 0;
     GM_TRY_HIP(hipMemcpyAsync(&total, wpre.as<unsigned long long>() + nv, 8, hipMemcpyDeviceToHost, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
+    // (gm_graph_sweep: the order is cut k times finer than the tiles, a tile = k consecutive slices)
+    const int sub = g_sweep_slices != 0 ? std::max(1, GM_MAX_TILES / T) : 1;
+    const int TS = T * sub;
     hipLaunchKernelGGL(k_tile_of_ranked, dim3(grid_for(nv)), dim3(kT), 0, s, order.as<int32_t>(), nv, deg.as<uint32_t>(),
-                       wpre.as<unsigned long long>(), total, T, tk_in.as<uint8_t>());
+                       wpre.as<unsigned long long>(), total, TS, tk_in.as<uint8_t>());
     sb = 0;
     GM_TRY_HIP(rocprim::radix_sort_pairs(nullptr, sb, tk_in.as<uint8_t>(), tk_out.as<uint8_t>(), order.as<int32_t>(),
                                          order2.as<int32_t>(), (size_t)nv, 0u, 8u, s));
@@ -1049,11 +1272,13 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
                                          order2.as<int32_t>(), (size_t)nv, 0u, 8u, s));
     GM_TRY_HIP(hipMemcpyAsync(order.p, order2.p, (size_t)nv * 4, hipMemcpyDeviceToDevice, s));
     // where every tile starts in the new order (vertices without edges carry key 255 and sort to the end)
-    hipLaunchKernelGGL(k_tile_bounds, dim3(1), dim3(128), 0, s, (const uint8_t*)tk_out.p, (int64_t)nv, T, bnd.as<int64_t>());
+    hipLaunchKernelGGL(k_tile_bounds, dim3(1), dim3(128), 0, s, (const uint8_t*)tk_out.p, (int64_t)nv, TS, bnd.as<int64_t>());
     int64_t hb[GM_MAX_TILES + 2];
-    GM_TRY_HIP(hipMemcpyAsync(hb, bnd.p, (size_t)(T + 1) * 8, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipMemcpyAsync(hb, bnd.p, (size_t)(TS + 1) * 8, hipMemcpyDeviceToHost, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
-    for (int t = 0; t <= T; t++) g->tile_base[t] = (int32_t)hb[t];
+    for (int t = 0; t <= T; t++) g->tile_base[t] = (int32_t)hb[t * sub];
+    g->nslices = sub > 1 ? TS : 0;
+    for (int t = 0; t <= TS; t++) g->slice_base[t] = (int32_t)hb[t];
   }
   g->ntiles = T;
   D.col_tiles = T;
@@ -1137,6 +1362,7 @@ static void free_csr(CsrOwned* c) {
 }
 
 static void free_tiles(gm_graph* g) {
+  free_sweep(g);
   if (g->out_tiles) {
     for (int t = 0; t < g->ntiles; t++) free_csr(&g->out_tiles[t]);
     delete[] g->out_tiles;
@@ -1157,6 +1383,12 @@ extern "C" {
 int gm_graph_tiles(const gm_graph_t* g, int direction, int* ntiles) {
   if (!g || !ntiles) { gm::set_error("gm_graph_tiles: null argument"); return GM_ERR_INVALID; }
   *ntiles = (direction == GM_DIR_OUT && g->out_tiles && g->ntiles > 1) ? g->ntiles : 1;
+  return GM_OK;
+}
+
+int gm_graph_sweep(const gm_graph_t* g, gm_sweep_t* out) {
+  if (!g || !out) { gm::set_error("gm_graph_sweep: null argument"); return GM_ERR_INVALID; }
+  *out = g->sweep;
   return GM_OK;
 }
 
@@ -1323,6 +1555,17 @@ int gm_graph_run_resources(gm_graph_t* g, void** aux_stream, void** fork_event, 
   return GM_OK;
 }
 
+int gm_graph_giant_stream(gm_graph_t* g, void** stream, void** join_event) {
+  if (!g || !stream || !join_event) { gm::set_error("gm_graph_giant_stream: null argument"); return GM_ERR_INVALID; }
+  if (!g->giant_stream) {
+    GM_TRY_HIP(hipStreamCreateWithFlags(&g->giant_stream, hipStreamNonBlocking));
+    GM_TRY_HIP(hipEventCreateWithFlags(&g->giant_join, hipEventDisableTiming));
+  }
+  *stream = (void*)g->giant_stream;
+  *join_event = (void*)g->giant_join;
+  return GM_OK;
+}
+
 int gm_graph_destroy(gm_graph_t* g) {
   if (!g) return GM_OK;
   gm::free_csr(&g->out);
@@ -1340,6 +1583,11 @@ int gm_graph_destroy(gm_graph_t* g) {
     (void)hipEventDestroy(g->aux_fork);
     (void)hipEventDestroy(g->aux_join);
     (void)hipHostFree(g->pinned_flag);
+  }
+  if (g->giant_stream) {
+    (void)hipStreamSynchronize(g->giant_stream);
+    (void)hipStreamDestroy(g->giant_stream);
+    (void)hipEventDestroy(g->giant_join);
   }
   delete g;
   return GM_OK;

@@ -76,6 +76,8 @@ struct gm_graph {
   // stream / pinned-memory creation lands inside a timed run_graph_program call
   hipStream_t aux_stream;
   hipEvent_t aux_fork, aux_join;
+  hipStream_t giant_stream;  // gm_graph_giant_stream (created on first use)
+  hipEvent_t giant_join;
   void* pinned_flag;
   // small per-graph memo for the header layer (gm_graph_note_*): e.g. the row split the shards agreed on
   int64_t note_val[GM_NOTE_SLOTS];
@@ -88,6 +90,11 @@ struct gm_graph {
   int32_t nlive;                // vertices with at least one edge (they come first in the device order)
   gm::CsrOwned* out_tiles;      // [ntiles]
   uint32_t** out_tile_prev;     // [ntiles] presence bits of the rows with an edge in an earlier tile
+  // finer cut of the device order (gm_graph_sweep): nslices = ntiles * k slices, slice_base[nslices] = nlive; 0: none
+  int nslices;
+  int32_t slice_base[GM_MAX_TILES + 2];
+  gm_sweep_t sweep;             // device arrays owned by the graph (nrows = 0: not built)
+  int32_t* d_slice_base;
   // native RCCL exchange (gm_dist.hip): state behind xfn/xctx when gm_graph_use_rccl installed it
   int xcaps;                    // GM_XCAP_* of the installed exchange
   void* native_xchg;

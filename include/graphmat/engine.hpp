@@ -159,6 +159,12 @@ struct AuxStream {
   // defer: the giant-row passes launched next are not waited for by their launch_spmv call; whoever needs their
   // rows calls wait_join (the two-stage schedule starts them before the tail stage and joins before the head apply)
   bool defer = false;
+  // gs / gjoin: a stream of their own for the giant rows' passes of a tiled multiply whose medium rows are swept (engine
+  // option giant_stream; use_gs is set by the column-tile loop): their chain of small latency-bound launches then runs NEXT
+  // TO this stream's short-row and one-wave-per-row kernels; giant_pending: something was launched there since the fork
+  hipStream_t gs = nullptr;
+  hipEvent_t gjoin = nullptr;
+  bool use_gs = false, giant_pending = false;
   void wait_join(hipStream_t main) {
     if (s) (void)hipStreamWaitEvent(main, join, 0);
   }
@@ -169,6 +175,7 @@ struct AuxStream {
   }
   void finish() {
     if (s) (void)hipStreamSynchronize(s);
+    if (gs) (void)hipStreamSynchronize(gs);
   }
 };
 
@@ -286,6 +293,7 @@ struct Launch {
   int* launches;
   PhaseTimer* timer;
   AuxStream* aux;
+  bool tiled_untiled_pass = false;  // this launch is the untiled pass of a tiled multiply (set when aux is detached from it)
 };
 
 // one multiply+reduce pass over one direction of the adjacency, strategy RK
@@ -358,7 +366,10 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
   };
   if (A.ngiant > 0) {
     hipStream_t gs = s;
-    if (overlap) {
+    const bool own_stream = overlap && keep && aux->use_gs && aux->gs != nullptr;  // (forked by the caller together with the auxiliary stream)
+    if (own_stream) {
+      gs = aux->gs;
+    } else if (overlap) {
       fork_aux();
       gs = aux->s;
       if (timer) timer->aux_mark(gs);
@@ -414,7 +425,10 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
                            xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want);
     }
     (*launches)++;
-    if (overlap) {
+    if (own_stream) {
+      GM_HIP_OK(hipEventRecord(aux->gjoin, gs));
+      aux->giant_pending = true;
+    } else if (overlap) {
       if (timer) timer->aux_mark(gs);
       GM_HIP_OK(hipEventRecord(aux->join, gs));
     } else if (timer) {
@@ -437,7 +451,7 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
       const bool any_size = (L.opt.rowwave_form & 16) != 0;  // (tests: also for small graphs)
       const bool whole_cols = A.hot_base == 0 && A.hot_len >= A.ncols;  // (not a column tile: the untiled pass of a tiled graph, or an untiled graph)
       if (form > 0 && xbits == nullptr && want == nullptr && !program_row_filter<P>::enabled && (persistent_forms_pay(A) || any_size) &&
-          !(whole_cols && keep && L.opt.untiled_pass_plain != 0)) {
+          !(whole_cols && (keep || L.tiled_untiled_pass) && L.opt.untiled_pass_plain != 0)) {
         auto persistent = [&](auto block_c, auto hot_c, int fit) {
           constexpr int BLOCK = decltype(block_c)::value, HOT = decltype(hot_c)::value;
           const int per_cu = L.opt.persist_per_cu > 0 && L.opt.persist_per_cu < fit ? L.opt.persist_per_cu : fit;
@@ -823,7 +837,15 @@ class Run {
     if (act == ALL_VERTICES) fill_active();  // GraphMatRuntime.h:121-123 g.setAllActive()
     timer = PhaseTimer(gm_graph_timing_enabled(g) != 0, s);
     tick("first frontier counted", (int)frontier_v);
-    if (!(opt.debug_flags & dev::DBG_NO_OVERLAP)) aux.attach(res_stream, res_fork, res_join);
+    if (!(opt.debug_flags & dev::DBG_NO_OVERLAP)) {
+      aux.attach(res_stream, res_fork, res_join);
+      void *gst = nullptr, *gjn = nullptr;
+      gm_sweep_t sw0;
+      if (opt.giant_stream != 0 && gm_graph_sweep(g, &sw0) == GM_OK && sw0.nrows > 0 && gm_graph_giant_stream(g, &gst, &gjn) == GM_OK) {
+        aux.gs = (hipStream_t)gst;
+        aux.gjoin = (hipEvent_t)gjn;
+      }
+    }
     // row-filter bits (program_row_filter): one pass over the vertex properties now, kept current by k_apply
     if constexpr (program_row_filter<P>::enabled) {
       void* pw = nullptr;
@@ -1143,25 +1165,60 @@ class Run {
       GM_HIP_OK(hipEventRecord(aux.fork, s));  // x is complete here: the auxiliary stream may start on tile 0 during the untiled pass
       GM_HIP_OK(hipStreamWaitEvent(aux.s, aux.fork, 0));
       aux.forked = true;
+      if (aux.gs) GM_HIP_OK(hipStreamWaitEvent(aux.gs, aux.fork, 0));
+      aux.giant_pending = false;
+      aux.use_gs = false;
     }
     gm_csr_t As = Aout;  // the rows that are not tiled: row-blocks and the shorter wave rows
     As.mid_row = Aout.umid_row; As.nmid = Aout.numid; As.nmid_long = Aout.numid_long; As.ngiant = 0; As.ngchunk = 0;
     if (Aout.tile_min_row == 0) { As.nblk = 0; As.nmid = 0; }  // every row is tiled
-    launch_spmv_vp<P, T, U, V, E>(use_vp, L, pa, As, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
-    // (running this untiled pass on a stream of its own next to the tile passes -- its rows are no tile's rows -- was
-    // measured too: 7.06 -> 7.03 ms at RMAT-26, not worth a third stream)
+    // The medium rows in one row-stationary sweep over the slices (kernels.hpp: k_spmv_sweep) instead of two launches per
+    // tile.  The sweep has the main stream to itself; the untiled short-row pass and, tile by tile, the one-wave-per-row rows
+    // go to the auxiliary stream, the giant rows' chain to a stream of its own (AuxStream::gs).
+    bool swept = false;
+    if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
+      gm_sweep_t sw;
+      if (keep_streams && !use_vp && xq != nullptr && xb == nullptr && d_want == nullptr && !program_row_filter<P>::enabled && !(acc & dev::ACC_READ_PREV) &&
+          Aout.vals == nullptr && Aout.tile_min_row >= 0 && Aout.numid == 0 && gm_graph_sweep(g, &sw) == GM_OK && sw.nrows > 0 &&
+          sw.acc_rows == GM_SWEEP_ACC_ROWS) {
+        Launch La = L;  // the untiled pass next to the sweep (or in front of it: sweep_form bit 2)
+        La.aux = nullptr;
+        La.tiled_untiled_pass = true;
+        if (!(opt.sweep_form & 4)) { La.s = aux.s; La.timer = nullptr; }
+        launch_spmv_vp<P, T, U, V, E>(use_vp, La, pa, As, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
+        for (int set = 0; set < sw.nsets; set++) {
+          const int hf = opt.sweep_form & 3;
+          if (hf == 0) hipLaunchKernelGGL((dev::k_spmv_sweep<P, T, U, V, E, 18432, GM_SWEEP_ACC_ROWS>), dim3(256), dim3(1024), 0, s, pa, sw, set, xq, y);
+          else if (hf == 1) hipLaunchKernelGGL((dev::k_spmv_sweep<P, T, U, V, E, 12288, GM_SWEEP_ACC_ROWS>), dim3(256), dim3(1024), 0, s, pa, sw, set, xq, y);
+          else hipLaunchKernelGGL((dev::k_spmv_sweep<P, T, U, V, E, 8192, GM_SWEEP_ACC_ROWS>), dim3(256), dim3(1024), 0, s, pa, sw, set, xq, y);
+        }
+        st.spmv_launches += sw.nsets;
+        timer.mark(TAG_WAVE);
+        aux.use_gs = aux.gs != nullptr;
+        swept = true;
+      }
+    }
+    // (without the sweep: running the untiled pass on a stream of its own next to the tile passes -- its rows are no tile's
+    // rows -- was measured too: 7.06 -> 7.03 ms at RMAT-26, not worth a third stream)
+    if (!swept) launch_spmv_vp<P, T, U, V, E>(use_vp, L, pa, As, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
     aux.long_rows = !(opt.debug_flags & dev::DBG_LONG_ON_MAIN);
     for (int t = 0; t < ntile; t++) {
       gm_csr_t At;
       const uint32_t* prev = nullptr;
       if (gm_graph_tile(g, GM_DIR_OUT, t, &At, &prev) != GM_OK) die(gm_last_error());
+      if (swept) { At.nblk = 0; At.mid_row = At.umid_row; At.nmid = At.numid; At.nmid_long = At.numid; }  // (giant rows, and the pieces of giant rows below the tile's giant limit)
       // y's presence bits are static (dense x): `prev` says which rows already carry a value
       launch_spmv_vp<P, T, U, V, E>(use_vp, L, pa, At, xq, xb, (const V*)d_vp, y, const_cast<uint32_t*>(prev), dev::ACC_STATIC_BITS | dev::ACC_READ_PREV, rk);
     }
     aux.long_rows = false;
+    if (swept) {  // (the untiled pass ran there: joined even when no tile had a one-wave-per-row row)
+      GM_HIP_OK(hipEventRecord(aux.join, aux.s));
+      aux.pending = true;
+    }
     if (aux.keep) {
       if (aux.pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
-      aux.keep = aux.forked = aux.pending = false;
+      if (aux.giant_pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.gjoin, 0));
+      aux.keep = aux.forked = aux.pending = aux.giant_pending = aux.use_gs = false;
     }
     // (a probed strategy is cross-checked against the ordered fold of the WHOLE rows; a mismatch redoes this iteration
     // untiled with the ordered fold, which then also governs the tiled iterations that follow)

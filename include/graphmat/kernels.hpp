@@ -1420,6 +1420,117 @@ k_spmv_rowwave(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, U* __restrict
 #undef GM_WSLOT
 }
 
+// ------------------------------------------------------------------------------------
+// The medium rows of a tiled graph (GM_SHORT_ROW < edges <= own_wave_row) in ONE launch instead of two per column tile:
+// the row-stationary sweep (graphmat_hip.h: gm_sweep_t; built by gm_graph.hip: build_sweep).  Workgroup w owns the rows
+// of length rank r with r % 256 == w and keeps their running values in LDS (s_acc / s_has) from the first slice to the
+// last; the slices are native column ranges taken in ascending order, and inside a (row, slice) piece the edges are stored
+// in ascending native column order, so every row is folded exactly as the reference folds it.  All workgroups walk the
+// slices in the same order from the same start, so at any time the chip gathers from one or two slices of x (2 MB each
+// with 64 slices: L2-resident) and each workgroup has the slice's HOT busiest entries in LDS.  Per slice the waves take
+// the workgroup's pieces 64 at a time, one lane per piece, as k_spmv_rowwave takes rows: coalesced column ids in steps
+// of 512, messages staged in the wave's LDS strip, every lane folding its piece in stored order.  Prototype and
+// measurements: tools/sweep_bench.hip, profiles/r04_sweep_prototype.md (RMAT-26: 680 M edges in 2.7 ms with 64 slices
+// against 3.95 ms of tile passes).  Dense x, 2-operand programs, 4-byte messages and reductions, no edge values.
+template <class P, class T, class U, class V, class E, int HOT, int ACC>
+__global__ void __launch_bounds__(1024)
+k_spmv_sweep(ProgArg<P> pa, gm_sweep_t S, int set, const T* __restrict__ x, U* __restrict__ y) {
+  static_assert(sizeof(T) == 4 && sizeof(U) == 4, "4-byte messages and reductions");
+  constexpr int BLOCK = 1024, W = BLOCK / 64;
+  constexpr int CH = 512, PER = CH / 64;
+  constexpr int kPadw = CH + CH / 32;
+  __shared__ T s_hot[HOT];
+  __shared__ U s_acc[ACC];
+  __shared__ unsigned char s_has[ACC];
+  __shared__ T s_msg[W][kPadw];
+#define GM_WSLOT(k) ((k) + ((k) >> 5))
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int wg = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  T* sm = s_msg[wv];
+  V no_vp;
+  for (int i = threadIdx.x; i < ACC; i += BLOCK) s_has[i] = 0;
+  const int32_t* __restrict__ blk = S.blk_first + ((size_t)set * 256 + wg) * S.nslices;
+  for (int sl = 0; sl < S.nslices; sl++) {
+    const int base = S.slice_base[sl];
+    const int slen = S.slice_base[sl + 1] - base;
+    const int nhot = slen < HOT ? slen : HOT;
+    __syncthreads();  // the previous slice's folds are done: its hot set may go, the running values are in s_acc
+    for (int i = threadIdx.x; i < nhot; i += BLOCK) s_hot[i] = x[base + i];
+    __syncthreads();
+    const T* __restrict__ xdummy = x + base;
+    const int pb = blk[sl], pe = blk[sl + 1];
+    for (int p0 = pb + wv * 64; p0 < pe; p0 += W * 64) {
+      const int pi = p0 + lane;
+      uint32_t e0 = 0, e1 = 0;
+      int rl = 0;
+      if (pi < pe) { e0 = S.piece_start[pi]; e1 = S.piece_start[pi + 1]; rl = S.piece_row[pi]; }
+      const int lastl = (pe - p0 - 1) < 63 ? (pe - p0 - 1) : 63;
+      const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)e0, 0), g1 = (uint32_t)__builtin_amdgcn_readlane((int)e1, lastl);
+      bool has = s_has[rl] != 0;
+      U acc = s_acc[rl];
+      for (uint32_t c0 = g0; c0 < g1; c0 += CH) {
+        const int n = (int)((g1 - c0) < (uint32_t)CH ? (g1 - c0) : (uint32_t)CH);
+        int c[PER];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+          const int k = lane + 64 * j;
+          c[j] = stream_load(&S.colidx[c0 + (uint32_t)(k < n ? k : n - 1)]);
+        }
+        T m[PER];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {  // (branch-free: lanes whose column is in LDS re-read the slice's first entry, an L1 hit)
+          const unsigned rel = (unsigned)(c[j] - base);
+          const bool h = rel < (unsigned)nhot;
+          const T mh = s_hot[h ? rel : 0u];
+          const T* __restrict__ ga = h ? xdummy : x + c[j];
+          const T mg = *ga;
+          m[j] = h ? mh : mg;
+        }
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+          const int k = lane + 64 * j;
+          if (k < n) sm[GM_WSLOT(k)] = m[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t ka = e0 > c0 ? e0 : c0, kb = e1 < c0 + (uint32_t)n ? e1 : c0 + (uint32_t)n;
+        if (ka < kb) {
+          int k = (int)(ka - c0);
+          const int ke = (int)(kb - c0);
+          if (!has) {
+            p.P::process_message(sm[GM_WSLOT(k)], E(), no_vp, acc);
+            has = true;
+            k++;
+          }
+          for (; k + 4 <= ke; k += 4) {
+            T r[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) r[u] = sm[GM_WSLOT(k + u)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              U res;
+              p.P::process_message(r[u], E(), no_vp, res);
+              p.P::reduce_function(acc, res);
+            }
+          }
+          for (; k < ke; k++) {
+            U res;
+            p.P::process_message(sm[GM_WSLOT(k)], E(), no_vp, res);
+            p.P::reduce_function(acc, res);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (pi < pe) { s_acc[rl] = acc; s_has[rl] = has ? 1 : 0; }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ACC; i += BLOCK) {
+    const long long r = ((long long)set * ACC + i) * 256 + wg;
+    if (r < S.nrows && s_has[i]) y[S.row_of_rank[r]] = s_acc[i];
+  }
+#undef GM_WSLOT
+}
+
 // a=b programs, the wanted rows among a wave's 64 list entries: 64 / LPR rows at a time, LPR lanes each.
 // A bottom-up level is a chain of dependent loads per row (row pointers, column ids, summary bit, presence bit, the
 // winner's message) and most rows end in their last few edges, so what counts is how many rows a wave has in flight:

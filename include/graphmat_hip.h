@@ -241,6 +241,36 @@ int gm_graph_csr(const gm_graph_t* g, int direction, gm_csr_t* out);
 #define GM_MAX_TILES 64
 #define GM_TILE_MIN_ROW 64
 int gm_graph_tiles(const gm_graph_t* g, int direction, int* ntiles); /* *ntiles = 1: not tiled */
+/* ---- the row-stationary sweep of the medium rows (tiled graphs; gm_set_option("sweep_slices", 1)) ----------------
+ * The rows of GM_SHORT_ROW+1 .. own_wave_row (4096) edges -- 63 % of RMAT-26's edges -- need not go through the column
+ * tiles pass by pass.  With the option on, the device order is cut finer than the tiles (nslices = ntiles * k <= 64 slices
+ * of the native range, each serving equally many gathers, busiest vertices first inside a slice; a tile is k consecutive
+ * slices) and the library also keeps those rows' edges as [set][workgroup][slice][row][ascending native column]:
+ * workgroup w of 256 owns the rows of length rank r with r % 256 == w (at most acc_rows per launch; `nsets` launches cover
+ * all), keeps their running values in LDS and sweeps the slices in order, every workgroup at about the same slice at any
+ * time -- the chip gathers from ~2 MB of x at a time, and a row is still folded in ascending native column order
+ * (kernels.hpp: k_spmv_sweep; measured in profiles/r04_sweep_prototype.md).
+ *   piece p = the edges [piece_start[p], piece_start[p+1]) of colidx: one row's edges inside one slice;
+ *   piece_row[p] = the row's slot in its workgroup's accumulator array (rank / 256 - set * acc_rows);
+ *   blk_first[(set * 256 + w) * nslices + s] = first piece of workgroup w's rows in slice s (entry count + 1 = npieces);
+ *   row_of_rank[r] = local row id of the row of length rank r; slice_base[s] = first device id of slice s.
+ * Single shard, GM_DIR_OUT only.  nrows = 0: the graph has no such structure. */
+typedef struct {
+  int32_t nrows;      /* medium rows */
+  int32_t nsets;      /* launches */
+  int32_t nslices;
+  int32_t acc_rows;   /* rows per workgroup and launch (the LDS accumulator array's size) */
+  int64_t nedges;
+  int64_t npieces;
+  const int32_t* colidx;
+  const uint32_t* piece_start;
+  const uint16_t* piece_row;
+  const int32_t* blk_first;
+  const int32_t* slice_base; /* [nslices + 1] */
+  const int32_t* row_of_rank;
+} gm_sweep_t;
+#define GM_SWEEP_ACC_ROWS 10240
+int gm_graph_sweep(const gm_graph_t* g, gm_sweep_t* out);
 int gm_graph_tile(const gm_graph_t* g, int direction, int tile, gm_csr_t* out, const uint32_t** d_prev_bits);
 /* rowbits of GM_DIR_OUT | rowbits of GM_DIR_IN (graphs built with both directions; ALL_EDGES programs) */
 int gm_graph_rowbits_all(const gm_graph_t* g, const uint32_t** d_bits);
@@ -456,7 +486,15 @@ typedef struct {
                                      is multiplied.  Default 900: the tail then holds (almost) only short rows, so the 16-rows-per-wave kernel is
                                      not cut into two launches (shard of 8 of RMAT-26, compute only: 1.103 ms against 1.196 with 650 and 1.100 for
                                      the plain loop; profiles/r04_shard_emulation_rmat26.txt) */
-  int32_t reserved_[16];
+  int32_t giant_stream;           /* tiled multiplies with the row-stationary sweep (gm_graph_sweep): 1 = the giant rows' passes (products, then
+                                     the exact replay: a chain of small latency-bound launches) run on a stream of their own
+                                     (gm_graph_giant_stream) next to the auxiliary stream's short-row and one-wave-per-row kernels; 0 = they
+                                     share the auxiliary stream.  (Without the sweep a third stream was measured and loses:
+                                     profiles/r04_streams_and_scalar_path.md.) */
+  int32_t sweep_form;             /* the swept multiply: bits 0-1 = hot entries per slice in LDS (0: 18432, 1: 12288, 2: 8192 -- less LDS leaves room
+                                     for the other streams' workgroups on the same CU); bit 2 = 1: the untiled short-row pass stays on the main
+                                     stream in front of the sweep (0: on the auxiliary stream next to it) */
+  int32_t reserved_[14];
 } gm_engine_options_t;
 /* the options a run on `g` uses (g may be NULL: the process defaults) */
 int gm_graph_engine_options(const gm_graph_t* g, gm_engine_options_t* out);
@@ -497,6 +535,9 @@ int gm_graph_adopt_workspace(gm_graph_t* g, int slot, void* d_ptr, size_t bytes)
  * convergence flag and frontier statistics are copied there every iteration).  Returned as
  * void* so this header stays free of HIP types. */
 int gm_graph_run_resources(gm_graph_t* g, void** aux_stream, void** fork_event, void** join_event, void** pinned);
+/* A second non-blocking stream and its join event for the giant rows' passes of a tiled multiply (engine option
+ * giant_stream); created on first use, destroyed with the graph. */
+int gm_graph_giant_stream(gm_graph_t* g, void** stream, void** join_event);
 /* counters of the giant-row kernel since the last call (then reset): 16-edge groups
  * out[0] taken by the exact parallel fp32 replay, out[1] folded serially */
 int gm_debug_counters(int64_t out[4]);
