@@ -748,6 +748,12 @@ def main():
         for t in range(int(g.col_tiles)):
             ct, _ = g.tile(api.GM_DIR_OUT, t)
             by_kernel = [a + b for a, b in zip(by_kernel, class_edges(ct))]
+    # the row-stationary sweep (graphmat_hip.h gm_sweep_t): the tiles' row-block / 16-row work is done by k_spmv_sweep
+    from graphmat_amd import _lib as _gl
+    sweep = _gl.Sweep()
+    if _gl.lib().gm_graph_sweep(g.h, C.byref(sweep)) != 0 or int(g.col_tiles) <= 1:
+        sweep.nrows = 0
+    swept = int(sweep.nrows) > 0
     roof = None
     name = max(kern, key=lambda k: kern[k][0])
     ms, launches, alg_bytes = kern[name]
@@ -779,7 +785,7 @@ def main():
                 if tj.get("kernels_fingerprint") == kernels_fingerprint() and tj.get("col_tiles", {}).get("scale%d" % args.scale) == int(g.col_tiles):
                     # (large graphs run the persistent forms k_spmv_rowwave / k_spmv_wave16p instead of, or next to, the plain ones)
                     names = {"k_spmv_rowblock": ["k_spmv_rowblock", "k_spmv_rowwave"], "k_spmv_wave": ["k_spmv_wave", "k_spmv_wave16", "k_spmv_wave16p"],
-                             "multiply": ["k_spmv_rowblock", "k_spmv_rowwave", "k_spmv_wave", "k_spmv_wave16", "k_spmv_wave16p"]}.get(name, [name])
+                             "multiply": ["k_spmv_rowblock", "k_spmv_rowwave", "k_spmv_wave", "k_spmv_wave16", "k_spmv_wave16p", "k_spmv_sweep"]}.get(name, [name])
                     parts = [per.get(k + "_bytes_per_iteration") for k in names]
                     traffic = int(sum(v for v in parts if v is not None)) if any(v is not None for v in parts) else None
                     traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernels (profiles/pmc_traffic.json)"
@@ -792,6 +798,8 @@ def main():
         big = world == 1 and (ndev >= (48 << 20) or (ndev >= (24 << 20) and int(g.col_tiles) > 1))
         kname = {"k_spmv_wave": "k_spmv_wave16+k_spmv_wave", "multiply": ("k_spmv_rowblock/k_spmv_rowwave+k_spmv_wave16p+k_spmv_wave" if big else "k_spmv_rowblock+k_spmv_wave16+k_spmv_wave") +
                  (" over %d column tiles" % int(g.col_tiles) if tiled else "")}.get(name, name)
+        if swept and name == "multiply":
+            kname = "k_spmv_rowblock+k_spmv_sweep (%d slices; main stream) next to k_spmv_wave and the giant-row passes over %d column tiles (two other streams)" % (int(sweep.nslices), int(g.col_tiles))
         roof = {"bound": "hbm", "kernel": kname + "<PageRank>", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg_bytes,
@@ -801,8 +809,10 @@ def main():
                 "wave_avg_ms": round(stats["wave_ms"] / max(args.steps, 1), 4),
                 "aux_streams_avg_ms_overlapped": round(stats["giant_ms"] / max(args.steps, 1), 4),  # giant-row passes + long wave rows
                 "edges_rowblock_wave_giant": [e_short, e_mid, e_giant],
-                "edges_by_kernel": {"k_spmv_rowblock": by_kernel[0], "k_spmv_wave16": by_kernel[1], "k_spmv_wave": by_kernel[2],
-                                    "k_giant_terms+k_spmv_giant": by_kernel[3]},
+                "edges_by_kernel": ({"k_spmv_rowblock": int(c_out.edges_blk), "k_spmv_sweep": int(sweep.nedges), "k_spmv_wave": by_kernel[2],
+                                     "k_giant_terms+k_spmv_giant": by_kernel[3]} if swept else
+                                    {"k_spmv_rowblock": by_kernel[0], "k_spmv_wave16": by_kernel[1], "k_spmv_wave": by_kernel[2],
+                                     "k_giant_terms+k_spmv_giant": by_kernel[3]}),
                 "send_avg_ms": round(stats["send_ms"] / args.steps, 4),
                 "apply_avg_ms": round(stats["apply_ms"] / args.steps, 4),
                 "gather_ceiling_note": "random 4-byte gathers on this chip peak at ~200 G/s L2-resident and ~55-66 G/s over "

@@ -30,7 +30,7 @@ int g_rank_by = 0;    // experiment: 0 rank vertices by total degree, 1 by out-d
 int g_tile_min_row = GM_TILE_MIN_ROW;  // rows of more than this many edges are tiled
 int g_tile_balance = 1;  // column tiles serve equally many gathers (1) or hold equally many vertices with edges (0)
 int g_long_mid = 0;  // > 0: experiment -- wave rows of more than this many edges get a wave each (0 = GM_LONG_MID rule)
-int g_sweep_slices = 0;  // 1: cut the device order into ntiles * k <= 64 slices and build the row-stationary sweep of the medium rows (gm_graph_sweep)
+int g_sweep_slices = 1;  // 1: cut the device order into ntiles * k <= 64 slices and build the row-stationary sweep of the medium rows (gm_graph_sweep)
 int g_sort_tile_lists = 1;  // column tiles: the wave-row lists by descending piece length (sort_rows_by_length)
 int g_own_wave_row = 4096;  // column tiles: rows of more than this many edges (whole graph) keep the wave / giant kernels in every tile (0: classes per tile piece)
 int g_col_tiles = 0;  // default number of column tiles for graphs whose descriptor says 0 (0 = environment GRAPHMAT_COL_TILES, else none)
@@ -886,7 +886,7 @@ k_sweep_medium(const int64_t* __restrict__ rowptr, int nrows, int short_row, int
   const int r = blockIdx.x * kT + threadIdx.x;
   if (r >= nrows) return;
   const int64_t len = rowptr[r + 1] - rowptr[r];
-  flag[r] = (len > short_row && len <= max_len && !(own_wave != nullptr && own_wave[r])) ? 1 : 0;
+  flag[r] = (len > short_row && len <= max_len && !(own_wave != nullptr && own_wave[r])) ? 1 : 0;  // (own_wave == nullptr: every wave row)
 }
 __global__ void __launch_bounds__(kT) k_sweep_unflag(const int32_t* __restrict__ list, int n, unsigned char* __restrict__ flag) {
   const int i = blockIdx.x * kT + threadIdx.x;
@@ -914,14 +914,31 @@ struct SweepSlices { int32_t b[GM_MAX_TILES + 2]; };
 // one wave per medium row (in length-rank order): its edges, keyed (virtual workgroup, slice, accumulator slot), CSR order kept
 __global__ void __launch_bounds__(kT)
 k_sweep_keys(const int32_t* __restrict__ rows_ranked, int nmed, const unsigned long long* __restrict__ off, const int64_t* __restrict__ rowptr,
-             const int32_t* __restrict__ colidx, SweepSlices sl, int nslices, int acc_rows, unsigned long long* __restrict__ key, int32_t* __restrict__ val) {
+             const int32_t* __restrict__ colidx, SweepSlices sl, int nslices, int acc_rows, unsigned long long* __restrict__ key, int32_t* __restrict__ val,
+             int32_t* __restrict__ row_of_slot) {
   const int r = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
   if (r >= nmed) return;
   const int lane = threadIdx.x & 63;
   const int row = rows_ranked[r];
   const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
   const unsigned wg = (unsigned)r % 256u, l = (unsigned)r / 256u;
-  const unsigned long long vw = (unsigned long long)(l / (unsigned)acc_rows) * 256ull + wg, slot = l % (unsigned)acc_rows;
+  const unsigned set = l / (unsigned)acc_rows;
+  const unsigned long long vw = (unsigned long long)set * 256ull + wg;
+  // The slot: the workgroup's rows come in descending length, and a wave takes 64 consecutive pieces (= slots) of a slice at
+  // a time -- in rank order one wave would get the workgroup's 64 longest pieces.  A multiplicative permutation of the slots
+  // deals the long rows over the groups (stride ~ rows / 64, coprime to the row count).
+  const unsigned per_wg = ((unsigned)nmed - wg + 255u) / 256u;
+  const unsigned left = per_wg - set * (unsigned)acc_rows;
+  const unsigned cnt = left < (unsigned)acc_rows ? left : (unsigned)acc_rows;
+  unsigned M = (cnt / 64u) | 1u;
+  for (;;) {
+    unsigned a = M, b = cnt;
+    while (b) { const unsigned t = a % b; a = b; b = t; }
+    if (a == 1u) break;
+    M += 2u;
+  }
+  const unsigned long long slot = (unsigned long long)(((unsigned long long)(l % (unsigned)acc_rows) * M) % cnt);
+  if (lane == 0) row_of_slot[vw * (unsigned long long)acc_rows + slot] = row;
   const unsigned long long o = off[r];
   for (int64_t e = e0 + lane; e < e1; e += 64) {
     const int c = colidx[e];
@@ -963,14 +980,26 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, const unsigned char* 
   memset(&g->sweep, 0, sizeof(g->sweep));
   const int TS = g->nslices;
   const int nrows = g->desc.row_hi - g->desc.row_lo;
-  if (TS < 2 || TS > 64 || own_wave == nullptr || nrows <= 0 || whole->view.nnz >= ((int64_t)1 << 32)) return GM_OK;
+  if (TS < 2 || TS > 64) return GM_OK;
+  {  // the slices of the device order are reported even when no row ends up in the sweep (nrows = 0)
+    DevBuf sb0;
+    int rc0;
+    if ((rc0 = sb0.alloc((size_t)(GM_MAX_TILES + 2) * 4))) return rc0;
+    GM_TRY_HIP(hipMemcpyAsync(sb0.p, g->slice_base, (size_t)(TS + 1) * 4, hipMemcpyHostToDevice, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    g->d_slice_base = (int32_t*)sb0.release();
+    g->sweep.nslices = TS;
+    g->sweep.slice_base = g->d_slice_base;
+  }
+  if (own_wave == nullptr || nrows <= 0 || whole->view.nnz >= ((int64_t)1 << 32)) return GM_OK;
   const int64_t* rowptr = (const int64_t*)whole->rowptr;
   const int32_t* colidx = (const int32_t*)whole->colidx;
   int rc;
   DevBuf flag, iota, rows, cnt, len_in, len_out, ranked, tmp;
   if ((rc = flag.alloc((size_t)nrows)) || (rc = iota.alloc((size_t)nrows * 4)) || (rc = rows.alloc((size_t)nrows * 4)) || (rc = cnt.alloc(16))) return rc;
-  hipLaunchKernelGGL(k_sweep_medium, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr, nrows, whole->view.short_row, (int64_t)1 << 40, own_wave,
-                     flag.as<unsigned char>());
+  // sweep_slices 1: the rows up to own_wave_row edges; 2: every wave row that is not a giant row of the whole graph
+  hipLaunchKernelGGL(k_sweep_medium, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr, nrows, whole->view.short_row, (int64_t)1 << 40,
+                     g_sweep_slices >= 2 ? (const unsigned char*)nullptr : own_wave, flag.as<unsigned char>());
   // (The rows of more than own_wave_row edges keep the one-wave-per-row / giant kernels tile by tile.  Sweeping them too was
   // measured: their pieces are hundreds of edges long, one lane folds each, and the wave that gets a workgroup's 64 longest
   // pieces holds the workgroup's slice barrier for 38 steps -- RMAT-26 12.3 ms per iteration.)
@@ -1021,8 +1050,12 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, const unsigned char* 
   SweepSlices sl;
   memset(&sl, 0, sizeof(sl));
   for (int t = 0; t <= TS; t++) sl.b[t] = g->slice_base[t];
+  DevBuf rslot;
+  if ((rc = rslot.alloc((size_t)nsets * 256 * (size_t)acc_rows * 4))) return rc;
+  GM_TRY_HIP(hipMemsetAsync(rslot.p, 0xff, (size_t)nsets * 256 * (size_t)acc_rows * 4, s));
   hipLaunchKernelGGL(k_sweep_keys, dim3((nmed + (kT / 64) - 1) / (kT / 64)), dim3(kT), 0, s, (const int32_t*)ranked.as<int32_t>(), (int)nmed,
-                     (const unsigned long long*)off.as<unsigned long long>(), rowptr, colidx, sl, TS, acc_rows, k_in.as<unsigned long long>(), v_in.as<int32_t>());
+                     (const unsigned long long*)off.as<unsigned long long>(), rowptr, colidx, sl, TS, acc_rows, k_in.as<unsigned long long>(), v_in.as<int32_t>(),
+                     rslot.as<int32_t>());
   GM_TRY_HIP(hipGetLastError());
   off.free();
   tb = 0;  // stable: inside (workgroup, slice, row) the edges keep their ascending native column order
@@ -1043,10 +1076,8 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, const unsigned char* 
   GM_TRY_HIP(hipMemcpyAsync(&npieces, pidx.as<uint32_t>() + (nedges - 1), 4, hipMemcpyDeviceToHost, s));
   GM_TRY_HIP(hipStreamSynchronize(s));
   const size_t nblk = (size_t)nsets * 256 * (size_t)TS;
-  DevBuf pstart, prow, bfirst, sbase;
-  if ((rc = pstart.alloc(((size_t)npieces + 1) * 4)) || (rc = prow.alloc(((size_t)npieces + 1) * 2)) || (rc = bfirst.alloc((nblk + 1) * 4)) ||
-      (rc = sbase.alloc((size_t)(GM_MAX_TILES + 2) * 4)))
-    return rc;
+  DevBuf pstart, prow, bfirst;
+  if ((rc = pstart.alloc(((size_t)npieces + 1) * 4)) || (rc = prow.alloc(((size_t)npieces + 1) * 2)) || (rc = bfirst.alloc((nblk + 1) * 4))) return rc;
   GM_TRY_HIP(hipMemsetAsync(bfirst.p, 0xff, (nblk + 1) * 4, s));
   hipLaunchKernelGGL(k_sweep_pieces, dim3(grid_for(nedges)), dim3(kT), 0, s, (const unsigned long long*)k_out.as<unsigned long long>(), (const uint32_t*)head.as<uint32_t>(),
                      (const uint32_t*)pidx.as<uint32_t>(), nedges, pstart.as<uint32_t>(), prow.as<uint16_t>(), bfirst.as<int32_t>(), TS);
@@ -1059,7 +1090,6 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, const unsigned char* 
     h[nblk] = (int32_t)npieces;
     for (int64_t b = (int64_t)nblk - 1; b >= 0; b--) if (h[b] < 0) h[b] = h[b + 1];
     GM_TRY_HIP(hipMemcpyAsync(bfirst.p, h.data(), (nblk + 1) * 4, hipMemcpyHostToDevice, s));
-    GM_TRY_HIP(hipMemcpyAsync(sbase.p, sl.b, (size_t)(TS + 1) * 4, hipMemcpyHostToDevice, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
   }
   // what is left of every tile's one-wave-per-row list: the pieces of rows that are NOT swept (giant rows of the whole graph
@@ -1091,8 +1121,7 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, const unsigned char* 
   S.piece_start = (const uint32_t*)pstart.release();
   S.piece_row = (const uint16_t*)prow.release();
   S.blk_first = (const int32_t*)bfirst.release();
-  S.row_of_rank = (const int32_t*)ranked.release();
-  g->d_slice_base = (int32_t*)sbase.release();
+  S.row_of_rank = (const int32_t*)rslot.release();
   S.slice_base = g->d_slice_base;
   return GM_OK;
 }

@@ -745,7 +745,7 @@ static const EngineKey kEngineKeys[] = {
   {"ablate_cold_short", 14, 0, 0, 0x7fffffff},
   {"two_stage_head_permille", 15, 900, 100, 990},
   {"giant_stream", 16, 1, 0, 1},
-  {"sweep_form", 17, 0, 0, 7},
+  {"sweep_form", 17, 4, 0, 11},
 };
 static_assert(offsetof(gm_engine_options_t, sweep_form) == 17 * sizeof(int32_t), "kEngineKeys follows the field order");
 static bool engine_value_ok(const EngineKey& k, int v) {
@@ -824,7 +824,7 @@ int gm_reset_options(void) {
   gm::g_long_mid = 0;
   gm::g_own_wave_row = 4096;
   gm::g_sort_tile_lists = 1;
-  gm::g_sweep_slices = 0;
+  gm::g_sweep_slices = 1;
   gm::g_col_tiles = 0;
   return GM_OK;
 }
@@ -847,7 +847,7 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "col_tiles") && value >= 0 && value <= GM_MAX_TILES) { gm::g_col_tiles = value; return GM_OK; }
   if (key && !strcmp(key, "own_wave_row") && value >= 0) { gm::g_own_wave_row = value; return GM_OK; }
   if (key && !strcmp(key, "sort_tile_lists") && (value == 0 || value == 1)) { gm::g_sort_tile_lists = value; return GM_OK; }
-  if (key && !strcmp(key, "sweep_slices") && (value == 0 || value == 1)) { gm::g_sweep_slices = value; return GM_OK; }
+  if (key && !strcmp(key, "sweep_slices") && value >= 0 && value <= 2) { gm::g_sweep_slices = value; return GM_OK; }
   gm::set_error("gm_set_option: unknown option");
   return GM_ERR_INVALID;
 }

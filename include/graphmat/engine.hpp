@@ -165,6 +165,18 @@ struct AuxStream {
   hipStream_t gs = nullptr;
   hipEvent_t gjoin = nullptr;
   bool use_gs = false, giant_pending = false;
+  // A row of more than own_wave_row edges is a giant row in one tile and a one-wave-per-row row in another (the classes
+  // follow the PIECE's length), so with the giant passes on `gs` and the one-wave-per-row kernels on `s` tile t + 1 of
+  // either stream waits for tile t of the other: tile_ev[2 t] = giant passes of tile t done, [2 t + 1] = the others
+  std::vector<hipEvent_t> tile_ev;
+  hipEvent_t tile_event(int i) {
+    while ((int)tile_ev.size() <= i) {
+      hipEvent_t e = nullptr;
+      (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      tile_ev.push_back(e);
+    }
+    return tile_ev[i];
+  }
   void wait_join(hipStream_t main) {
     if (s) (void)hipStreamWaitEvent(main, join, 0);
   }
@@ -176,6 +188,8 @@ struct AuxStream {
   void finish() {
     if (s) (void)hipStreamSynchronize(s);
     if (gs) (void)hipStreamSynchronize(gs);
+    for (hipEvent_t e : tile_ev) (void)hipEventDestroy(e);
+    tile_ev.clear();
   }
 };
 
@@ -1181,11 +1195,14 @@ class Run {
       if (keep_streams && !use_vp && xq != nullptr && xb == nullptr && d_want == nullptr && !program_row_filter<P>::enabled && !(acc & dev::ACC_READ_PREV) &&
           Aout.vals == nullptr && Aout.tile_min_row >= 0 && Aout.numid == 0 && gm_graph_sweep(g, &sw) == GM_OK && sw.nrows > 0 &&
           sw.acc_rows == GM_SWEEP_ACC_ROWS) {
-        Launch La = L;  // the untiled pass next to the sweep (or in front of it: sweep_form bit 2)
+        // the untiled short-row pass: sweep_form bits 2-3 = 0: on the auxiliary stream in front of the one-wave-per-row
+        // kernels, 1: on the main stream in front of the sweep, 2: on the main stream behind it
+        Launch La = L;
         La.aux = nullptr;
         La.tiled_untiled_pass = true;
-        if (!(opt.sweep_form & 4)) { La.s = aux.s; La.timer = nullptr; }
-        launch_spmv_vp<P, T, U, V, E>(use_vp, La, pa, As, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
+        const int where = (opt.sweep_form >> 2) & 3;
+        if (where == 0) { La.s = aux.s; La.timer = nullptr; }
+        if (where != 2) launch_spmv_vp<P, T, U, V, E>(use_vp, La, pa, As, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
         for (int set = 0; set < sw.nsets; set++) {
           const int hf = opt.sweep_form & 3;
           if (hf == 0) hipLaunchKernelGGL((dev::k_spmv_sweep<P, T, U, V, E, 18432, GM_SWEEP_ACC_ROWS>), dim3(256), dim3(1024), 0, s, pa, sw, set, xq, y);
@@ -1194,6 +1211,7 @@ class Run {
         }
         st.spmv_launches += sw.nsets;
         timer.mark(TAG_WAVE);
+        if (where == 2) launch_spmv_vp<P, T, U, V, E>(use_vp, La, pa, As, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
         aux.use_gs = aux.gs != nullptr;
         swept = true;
       }
@@ -1207,8 +1225,17 @@ class Run {
       const uint32_t* prev = nullptr;
       if (gm_graph_tile(g, GM_DIR_OUT, t, &At, &prev) != GM_OK) die(gm_last_error());
       if (swept) { At.nblk = 0; At.mid_row = At.umid_row; At.nmid = At.numid; At.nmid_long = At.numid; }  // (giant rows, and the pieces of giant rows below the tile's giant limit)
+      const bool cross = swept && aux.use_gs;  // (AuxStream::tile_ev)
+      if (cross && t > 0) {
+        GM_HIP_OK(hipStreamWaitEvent(aux.gs, aux.tile_event(2 * (t - 1) + 1), 0));
+        GM_HIP_OK(hipStreamWaitEvent(aux.s, aux.tile_event(2 * (t - 1)), 0));
+      }
       // y's presence bits are static (dense x): `prev` says which rows already carry a value
       launch_spmv_vp<P, T, U, V, E>(use_vp, L, pa, At, xq, xb, (const V*)d_vp, y, const_cast<uint32_t*>(prev), dev::ACC_STATIC_BITS | dev::ACC_READ_PREV, rk);
+      if (cross && t + 1 < ntile) {
+        GM_HIP_OK(hipEventRecord(aux.tile_event(2 * t), aux.gs));
+        GM_HIP_OK(hipEventRecord(aux.tile_event(2 * t + 1), aux.s));
+      }
     }
     aux.long_rows = false;
     if (swept) {  // (the untiled pass ran there: joined even when no tile had a one-wave-per-row row)
@@ -1219,6 +1246,7 @@ class Run {
       if (aux.pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
       if (aux.giant_pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.gjoin, 0));
       aux.keep = aux.forked = aux.pending = aux.giant_pending = aux.use_gs = false;
+      if (swept) timer.mark(TAG_WAVE);  // (the multiply ends when the other streams have joined: the wait counts as multiply time, not as apply time)
     }
     // (a probed strategy is cross-checked against the ordered fold of the WHOLE rows; a mismatch redoes this iteration
     // untiled with the ordered fold, which then also governs the tiled iterations that follow)

@@ -1525,8 +1525,8 @@ k_spmv_sweep(ProgArg<P> pa, gm_sweep_t S, int set, const T* __restrict__ x, U* _
   }
   __syncthreads();
   for (int i = threadIdx.x; i < ACC; i += BLOCK) {
-    const long long r = ((long long)set * ACC + i) * 256 + wg;
-    if (r < S.nrows && s_has[i]) y[S.row_of_rank[r]] = s_acc[i];
+    const int row = S.row_of_rank[((size_t)set * 256 + wg) * ACC + i];  // (-1: no row in this slot)
+    if (row >= 0 && s_has[i]) y[row] = s_acc[i];
   }
 #undef GM_WSLOT
 }

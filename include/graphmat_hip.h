@@ -253,7 +253,9 @@ int gm_graph_tiles(const gm_graph_t* g, int direction, int* ntiles); /* *ntiles 
  *   piece p = the edges [piece_start[p], piece_start[p+1]) of colidx: one row's edges inside one slice;
  *   piece_row[p] = the row's slot in its workgroup's accumulator array (rank / 256 - set * acc_rows);
  *   blk_first[(set * 256 + w) * nslices + s] = first piece of workgroup w's rows in slice s (entry count + 1 = npieces);
- *   row_of_rank[r] = local row id of the row of length rank r; slice_base[s] = first device id of slice s.
+ *   row_of_rank[(set * 256 + w) * acc_rows + slot] = local row id of the row in that accumulator slot of workgroup w (-1: none; the
+ *   slots are a permutation of the workgroup's length ranks that deals the long rows over the 64-piece groups of a slice);
+ *   slice_base[s] = first device id of slice s.
  * Single shard, GM_DIR_OUT only.  nrows = 0: the graph has no such structure. */
 typedef struct {
   int32_t nrows;      /* medium rows */
@@ -492,8 +494,9 @@ typedef struct {
                                      share the auxiliary stream.  (Without the sweep a third stream was measured and loses:
                                      profiles/r04_streams_and_scalar_path.md.) */
   int32_t sweep_form;             /* the swept multiply: bits 0-1 = hot entries per slice in LDS (0: 18432, 1: 12288, 2: 8192 -- less LDS leaves room
-                                     for the other streams' workgroups on the same CU); bit 2 = 1: the untiled short-row pass stays on the main
-                                     stream in front of the sweep (0: on the auxiliary stream next to it) */
+                                     for the other streams' workgroups on the same CU); bits 2-3 = where the untiled short-row pass runs: 0 on the
+                                     auxiliary stream in front of the one-wave-per-row kernels, 1 on the main stream in front of the sweep, 2 on
+                                     the main stream behind it */
   int32_t reserved_[14];
 } gm_engine_options_t;
 /* the options a run on `g` uses (g may be NULL: the process defaults) */

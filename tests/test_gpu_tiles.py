@@ -61,19 +61,34 @@ def test_tile_structure(env, tile_min, tiles, threads, minrow):
     prev_rows = np.zeros(nv, bool)
     prev_native_max = None
     gathers = []
+    # the device order may be cut finer than the tiles (gm_graph_sweep: a tile = k consecutive slices)
+    import ctypes as C
+    from graphmat_amd import _lib
+    sw = _lib.Sweep()
+    assert g.L.gm_graph_sweep(g.h, C.byref(sw)) == 0
+    cuts = None
+    if sw.nslices > 0:
+        assert sw.nslices % T == 0 and sw.nslices <= 64
+        cuts = np.zeros(sw.nslices + 1, np.int32)
+        api.copy_from_device(cuts, sw.slice_base)
+        assert cuts[0] == 0 and cuts[-1] == nlive and (np.diff(cuts) >= 0).all()
     for t in range(T):
         c, prev = g.tile(api.GM_DIR_OUT, t)
         lo, hi = c.hot_base, c.hot_base + c.hot_len
         assert lo == (0 if t == 0 else last_hi) and hi <= nlive
         last_hi = hi
-        # the slice is a contiguous native range, busiest first (a tile may be empty: tiles are cut by gathers served,
-        # and one hub can outweigh a tile's share on a small graph)
-        natives = nod[lo:hi]
-        if natives.size:
-            if prev_native_max is not None:
-                assert natives.min() > prev_native_max
-            prev_native_max = natives.max()
-            assert (np.diff(deg[natives]) <= 0).all()
+        # a slice is a contiguous native range, busiest first (a slice may be empty: they are cut by gathers served,
+        # and one hub can outweigh a slice's share on a small graph)
+        k = sw.nslices // T if cuts is not None else 1
+        bounds = cuts[t * k: (t + 1) * k + 1] if cuts is not None else np.array([lo, hi])
+        assert bounds[0] == lo and bounds[-1] == hi
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            natives = nod[a:b]
+            if natives.size:
+                if prev_native_max is not None:
+                    assert natives.min() > prev_native_max
+                prev_native_max = natives.max()
+                assert (np.diff(deg[natives]) <= 0).all()
         # expected content: long rows' edges with column in [lo, hi), untiled order
         trp = np.zeros(c.nrows + 1, np.int64)
         tci = np.zeros(max(c.nnz, 1), np.int32)
@@ -239,3 +254,67 @@ def test_persistent_rowwave_forms_bit_exact(env, tile_min, form):
                 g.close()
     finally:
         L.gm_set_option(b"rowwave_form", 4)
+
+
+@pytest.mark.parametrize("scale,tiles,threads", [(13, 3, 1), (15, 4, 2), (16, 8, 1)])
+def test_row_stationary_sweep_bit_exact(env, scale, tiles, threads):
+    """The sweep of the medium rows (graphmat_hip.h gm_sweep_t, kernels.hpp k_spmv_sweep): its structure covers exactly the
+    edges of the rows it takes, every piece lies inside one slice in ascending native column order, and PageRank through it
+    (sweep_slices 1: rows up to own_wave_row edges, 2: every non-giant wave row; every placement of the other passes) has
+    the bits of the oracle and of the tile passes (sweep_slices 0)."""
+    import ctypes as C
+    api, ob = env
+    from graphmat_amd import _lib
+    L = _lib.lib()
+    nv, s, d, _ = gen.rmat_edges(scale, 16, 5)
+    og = ob.OracleGraph(nv, s, d, None, ref_threads=threads)
+    odeg = og.degree()
+    opr, _, _ = og.pagerank(6, degree=odeg)
+    for sweep, forms in ((0, (4,)), (1, (0, 1, 4, 9)), (2, (4,))):
+        for form in forms:
+            for gs in ((0, 1) if sweep == 1 and form == 4 else (1,)):
+                api._lib.check(L.gm_reset_options())
+                api._lib.check(L.gm_set_option(b"sweep_slices", sweep))
+                api._lib.check(L.gm_set_option(b"sweep_form", form))
+                api._lib.check(L.gm_set_option(b"giant_stream", gs))
+                g = api.Graph(nv, s, d, None, ref_threads=threads, keep_values=False, col_tiles=tiles)
+                assert g.col_tiles > 1
+                sw = _lib.Sweep()
+                assert L.gm_graph_sweep(g.h, C.byref(sw)) == 0
+                if sweep == 0:
+                    assert sw.nrows == 0 and sw.nslices == 0
+                else:
+                    assert sw.nrows > 0 and sw.nslices % g.col_tiles == 0 and sw.nsets == 1
+                    rp, ci, _ = g.csr_to_host(api.GM_DIR_OUT)
+                    ln = np.diff(rp)
+                    slots = np.zeros(256 * sw.acc_rows, np.int32)
+                    api.copy_from_device(slots, sw.row_of_rank)
+                    rows = slots[slots >= 0]
+                    assert len(rows) == sw.nrows == len(set(rows.tolist())) and (ln[rows] > 64).all()
+                    assert sw.nedges == int(ln[rows].sum())
+                    col = np.zeros(sw.nedges, np.int32)
+                    ps = np.zeros(sw.npieces + 1, np.uint32)
+                    pr_ = np.zeros(sw.npieces + 1, np.uint16)
+                    bf = np.zeros(256 * sw.nslices + 1, np.int32)
+                    cuts = np.zeros(sw.nslices + 1, np.int32)
+                    for a, p in ((col, sw.colidx), (ps, sw.piece_start), (pr_, sw.piece_row), (bf, sw.blk_first), (cuts, sw.slice_base)):
+                        api.copy_from_device(a, p)
+                    assert ps[0] == 0 and ps[-1] == sw.nedges and (np.diff(ps.astype(np.int64)) > 0).all()
+                    assert bf[0] == 0 and bf[-1] == sw.npieces and (np.diff(bf) >= 0).all()
+                    # every piece: one row's edges inside one slice, in the row's CSR (= ascending native column) order
+                    blk_of_piece = np.searchsorted(bf, np.arange(sw.npieces), side="right") - 1
+                    wg, sl = blk_of_piece // sw.nslices, blk_of_piece % sw.nslices
+                    taken = {}
+                    for p in np.random.default_rng(1).choice(sw.npieces, size=min(400, sw.npieces), replace=False):
+                        row = slots[wg[p] * sw.acc_rows + pr_[p]]
+                        assert row >= 0
+                        piece = col[ps[p]: ps[p + 1]]
+                        assert (piece >= cuts[sl[p]]).all() and (piece < cuts[sl[p] + 1]).all()
+                        whole = ci[rp[row]: rp[row + 1]]
+                        inside = whole[(whole >= cuts[sl[p]]) & (whole < cuts[sl[p] + 1])]
+                        assert (piece == inside).all()
+                pr, deg, it = g.pagerank(6)
+                assert (deg == odeg).all() and it == 6
+                assert (f32bits(pr) == f32bits(opr)).all(), "sweep_slices %d sweep_form %d giant_stream %d" % (sweep, form, gs)
+                g.close()
+    api._lib.check(L.gm_reset_options())
