@@ -1207,7 +1207,7 @@ class Run {
           const int hf = opt.sweep_form & 3;
           if (hf == 0) hipLaunchKernelGGL((dev::k_spmv_sweep<P, T, U, V, E, 18432, GM_SWEEP_ACC_ROWS>), dim3(256), dim3(1024), 0, s, pa, sw, set, xq, y);
           else if (hf == 1) hipLaunchKernelGGL((dev::k_spmv_sweep<P, T, U, V, E, 12288, GM_SWEEP_ACC_ROWS>), dim3(256), dim3(1024), 0, s, pa, sw, set, xq, y);
-          else hipLaunchKernelGGL((dev::k_spmv_sweep<P, T, U, V, E, 8192, GM_SWEEP_ACC_ROWS>), dim3(256), dim3(1024), 0, s, pa, sw, set, xq, y);
+          else hipLaunchKernelGGL((dev::k_spmv_sweep<P, T, U, V, E, 9728, GM_SWEEP_ACC_ROWS>), dim3(256), dim3(1024), 0, s, pa, sw, set, xq, y);
         }
         st.spmv_launches += sw.nsets;
         timer.mark(TAG_WAVE);

@@ -493,7 +493,7 @@ typedef struct {
                                      (gm_graph_giant_stream) next to the auxiliary stream's short-row and one-wave-per-row kernels; 0 = they
                                      share the auxiliary stream.  (Without the sweep a third stream was measured and loses:
                                      profiles/r04_streams_and_scalar_path.md.) */
-  int32_t sweep_form;             /* the swept multiply: bits 0-1 = hot entries per slice in LDS (0: 18432, 1: 12288, 2: 8192 -- less LDS leaves room
+  int32_t sweep_form;             /* the swept multiply: bits 0-1 = hot entries per slice in LDS (0: 18432, 1: 12288, 2: 9728 -- less LDS leaves room
                                      for the other streams' workgroups on the same CU); bits 2-3 = where the untiled short-row pass runs: 0 on the
                                      auxiliary stream in front of the one-wave-per-row kernels, 1 on the main stream in front of the sweep, 2 on
                                      the main stream behind it */
