@@ -1459,23 +1459,48 @@ k_spmv_sweep(ProgArg<P> pa, gm_sweep_t S, int set, const T* __restrict__ x, U* _
     __syncthreads();
     const T* __restrict__ xdummy = x + base;
     const int pb = blk[sl], pe = blk[sl + 1];
-    for (int p0 = pb + wv * 64; p0 < pe; p0 += W * 64) {
-      const int pi = p0 + lane;
-      uint32_t e0 = 0, e1 = 0;
-      int rl = 0;
-      if (pi < pe) { e0 = S.piece_start[pi]; e1 = S.piece_start[pi + 1]; rl = S.piece_row[pi]; }
-      const int lastl = (pe - p0 - 1) < 63 ? (pe - p0 - 1) : 63;
-      const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)e0, 0), g1 = (uint32_t)__builtin_amdgcn_readlane((int)e1, lastl);
-      bool has = s_has[rl] != 0;
-      U acc = s_acc[rl];
-      for (uint32_t c0 = g0; c0 < g1; c0 += CH) {
-        const int n = (int)((g1 - c0) < (uint32_t)CH ? (g1 - c0) : (uint32_t)CH);
-        int c[PER];
+    // The wave's groups of this slice (64 pieces each: p0, p0 + W * 64, ...) as ONE sequence of 512-edge steps: while a step's
+    // messages are gathered and folded, the column ids of the NEXT step (of this group or of the next one) and the
+    // metadata of the group after the next are already requested -- a group of ~300 edges is a single step, and without
+    // this every group paid three load latencies in a row (metadata, column ids, messages) at 16 waves per CU.
+    int p0 = pb + wv * 64;
+    if (p0 < pe) {
+      const int plast = pe - 1;
+      auto meta = [&](int q0, uint32_t& a0, uint32_t& a1, int& slot) {  // (unconditional loads, index clamped into the block)
+        const int q = q0 + lane;
+        const int qc = q < pe ? q : plast;
+        const uint32_t v0 = S.piece_start[qc], v1 = S.piece_start[qc + 1];
+        const int vr = S.piece_row[qc];
+        a0 = q < pe ? v0 : 0u;
+        a1 = q < pe ? v1 : 0u;
+        slot = q < pe ? vr : 0;
+      };
+      auto bounds = [&](int q0, uint32_t a0, uint32_t a1, uint32_t& lo, uint32_t& hi) {
+        const int ll = (pe - q0 - 1) < 63 ? (pe - q0 - 1) : 63;
+        lo = (uint32_t)__builtin_amdgcn_readlane((int)a0, 0);
+        hi = (uint32_t)__builtin_amdgcn_readlane((int)a1, ll);
+      };
+      auto cols = [&](uint32_t c0, int n, int (&cc)[PER]) {
 #pragma unroll
         for (int j = 0; j < PER; j++) {
           const int k = lane + 64 * j;
-          c[j] = stream_load(&S.colidx[c0 + (uint32_t)(k < n ? k : n - 1)]);
+          cc[j] = stream_load(&S.colidx[c0 + (uint32_t)(k < n ? k : n - 1)]);
         }
+      };
+      uint32_t e0, e1, ne0 = 0, ne1 = 0;
+      int rl, nrl = 0;
+      meta(p0, e0, e1, rl);
+      uint32_t g0, g1;
+      bounds(p0, e0, e1, g0, g1);
+      bool more_groups = p0 + W * 64 < pe;
+      if (more_groups) meta(p0 + W * 64, ne0, ne1, nrl);
+      uint32_t c0 = g0;
+      int n = (int)((g1 - c0) < (uint32_t)CH ? (g1 - c0) : (uint32_t)CH);
+      int c[PER];
+      cols(c0, n, c);
+      bool has = s_has[rl] != 0;
+      U acc = s_acc[rl];
+      while (true) {
         T m[PER];
 #pragma unroll
         for (int j = 0; j < PER; j++) {  // (branch-free: lanes whose column is in LDS re-read the slice's first entry, an L1 hit)
@@ -1486,16 +1511,28 @@ k_spmv_sweep(ProgArg<P> pa, gm_sweep_t S, int set, const T* __restrict__ x, U* _
           const T mg = *ga;
           m[j] = h ? mh : mg;
         }
+        // the next step: the rest of this group, else the first step of the next group, else none
+        const bool same = c0 + (uint32_t)CH < g1;
+        const bool any_next = same || more_groups;
+        uint32_t nc0 = c0 + (uint32_t)CH, ng0 = 0, ng1 = g1;
+        if (!same && more_groups) {
+          bounds(p0 + W * 64, ne0, ne1, ng0, ng1);
+          nc0 = ng0;
+        }
+        const int nn = (int)((ng1 - nc0) < (uint32_t)CH ? (ng1 - nc0) : (uint32_t)CH);
+        const uint32_t cur_c0 = c0;
+        const int cur_n = n;
+        if (any_next) cols(nc0, nn, c);  // (c's old values are in the gathers' address registers already)
 #pragma unroll
         for (int j = 0; j < PER; j++) {
           const int k = lane + 64 * j;
-          if (k < n) sm[GM_WSLOT(k)] = m[j];
+          if (k < cur_n) sm[GM_WSLOT(k)] = m[j];
         }
         __builtin_amdgcn_wave_barrier();
-        const uint32_t ka = e0 > c0 ? e0 : c0, kb = e1 < c0 + (uint32_t)n ? e1 : c0 + (uint32_t)n;
+        const uint32_t ka = e0 > cur_c0 ? e0 : cur_c0, kb = e1 < cur_c0 + (uint32_t)cur_n ? e1 : cur_c0 + (uint32_t)cur_n;
         if (ka < kb) {
-          int k = (int)(ka - c0);
-          const int ke = (int)(kb - c0);
+          int k = (int)(ka - cur_c0);
+          const int ke = (int)(kb - cur_c0);
           if (!has) {
             p.P::process_message(sm[GM_WSLOT(k)], E(), no_vp, acc);
             has = true;
@@ -1519,8 +1556,20 @@ k_spmv_sweep(ProgArg<P> pa, gm_sweep_t S, int set, const T* __restrict__ x, U* _
           }
         }
         __builtin_amdgcn_wave_barrier();
+        if (!same) {  // the group is done: its rows' running values go back to LDS, the next group's come out
+          if (p0 + lane < pe) { s_acc[rl] = acc; s_has[rl] = has ? 1 : 0; }
+          if (!more_groups) break;
+          p0 += W * 64;
+          e0 = ne0; e1 = ne1; rl = nrl;
+          g0 = ng0; g1 = ng1;
+          more_groups = p0 + W * 64 < pe;
+          if (more_groups) meta(p0 + W * 64, ne0, ne1, nrl);
+          has = s_has[rl] != 0;
+          acc = s_acc[rl];
+        }
+        c0 = nc0;
+        n = nn;
       }
-      if (pi < pe) { s_acc[rl] = acc; s_has[rl] = has ? 1 : 0; }
     }
   }
   __syncthreads();
