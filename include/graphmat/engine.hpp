@@ -308,6 +308,13 @@ struct Launch {
   PhaseTimer* timer;
   AuxStream* aux;
   bool tiled_untiled_pass = false;  // this launch is the untiled pass of a tiled multiply (set when aux is detached from it)
+  // Giant rows of float sums in two calls (swept tiled multiplies, giant_stream = 2): phase 1 launches only the products pass
+  // (k_giant_terms) of a tile on `terms_stream` and records `terms_done`; phase 2 launches the replay (k_spmv_giant) behind
+  // that event.  The products of all tiles then sit side by side in one scratch (terms_offset / terms_total bytes).
+  int giant_phase = 0;
+  hipStream_t terms_stream = nullptr;
+  hipEvent_t terms_done = nullptr;
+  size_t terms_offset = 0, terms_total = 0;
 };
 
 // one multiply+reduce pass over one direction of the adjacency, strategy RK
@@ -395,11 +402,12 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
       U* terms = nullptr;
       unsigned long long* tpres = nullptr;
       dev::gchunk_state* maps = nullptr;
+      const bool split = L.giant_phase != 0 && RK == REDUCE_F32_ADD && xbits == nullptr && own_stream;
       if constexpr (RK == REDUCE_F32_ADD) {
         // pass 1: products of all giant-row edges, spread over the whole chip
         void *p6 = nullptr, *p7 = nullptr;
-        gm_graph_workspace(g, 6, (size_t)A.giant_edges * sizeof(U) + 64, &p6);
-        terms = (U*)p6;
+        gm_graph_workspace(g, 6, split ? L.terms_total : (size_t)A.giant_edges * sizeof(U) + 64, &p6);
+        terms = (U*)((char*)p6 + (split ? L.terms_offset : (size_t)0));
         if (xbits != nullptr) {
           gm_graph_workspace(g, 14, (size_t)A.giant_edges / 8 + 64, &p7);  // (slot 7 holds the active-set list of sharded ACTIVE_ONLY runs)
           tpres = (unsigned long long*)p7;
@@ -409,13 +417,19 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
         if constexpr (std::is_same<U, float>::value) {
           if (xbits == nullptr && want == nullptr && L.opt.giant_maps != 0) maps = (dev::gchunk_state*)A.gchunk_state;
         }
-        hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa,
-                           A, x, xbits, vp, terms, tpres, L.opt.debug_flags, maps);
-        (*launches)++;
+        if (!split || L.giant_phase == 1) {
+          hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, split ? L.terms_stream : gs, pa,
+                             A, x, xbits, vp, terms, tpres, L.opt.debug_flags, maps);
+          (*launches)++;
+          if (split) GM_HIP_OK(hipEventRecord(L.terms_done, L.terms_stream));
+        }
       }
-      hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa,
-                         A, x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, (const U*)terms,
-                         (const unsigned long long*)tpres, want, maps);
+      if (!split || L.giant_phase == 2) {
+        if (split) GM_HIP_OK(hipStreamWaitEvent(gs, L.terms_done, 0));
+        hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa,
+                           A, x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, (const U*)terms,
+                           (const unsigned long long*)tpres, want, maps);
+      }
     } else {
       // plain ordered fold (any reduce_function): products spread over the chip by k_giant_terms, then one wave per row
       // folds the dense products stream in stored order (kernels.hpp: k_giant_fold_ordered).  Larger reduction types keep
@@ -1220,6 +1234,38 @@ class Run {
     // rows -- was measured too: 7.06 -> 7.03 ms at RMAT-26, not worth a third stream)
     if (!swept) launch_spmv_vp<P, T, U, V, E>(use_vp, L, pa, As, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
     aux.long_rows = !(opt.debug_flags & dev::DBG_LONG_ON_MAIN);
+    // giant_stream = 2 (swept multiplies of float sums): the products passes of ALL tiles first, on the auxiliary stream,
+    // into one scratch -- they depend on nothing but x -- so that the giant rows' replay chain on its own stream is not
+    // held up by them and is through before the sweep takes the CUs' registers and LDS
+    std::vector<size_t> terms_off;
+    size_t terms_total = 0;
+    const bool split_giants = swept && aux.use_gs && opt.giant_stream >= 2 && rk == REDUCE_F32_ADD && sizeof(U) == 4;
+    if (split_giants) {
+      terms_off.resize((size_t)ntile, 0);
+      for (int t = 0; t < ntile; t++) {
+        gm_csr_t At;
+        const uint32_t* prev = nullptr;
+        if (gm_graph_tile(g, GM_DIR_OUT, t, &At, &prev) != GM_OK) die(gm_last_error());
+        terms_off[(size_t)t] = terms_total;
+        terms_total += ((size_t)At.giant_edges * sizeof(U) + 255) / 256 * 256;
+      }
+      terms_total += 256;
+      for (int t = 0; t < ntile; t++) {
+        gm_csr_t At;
+        const uint32_t* prev = nullptr;
+        if (gm_graph_tile(g, GM_DIR_OUT, t, &At, &prev) != GM_OK) die(gm_last_error());
+        if (At.ngiant == 0) continue;
+        At.nblk = 0; At.nmid = 0; At.nmid_long = 0;
+        Launch Lp = L;
+        Lp.timer = nullptr;
+        Lp.giant_phase = 1;
+        Lp.terms_stream = aux.s;
+        Lp.terms_done = aux.tile_event(2 * ntile + t);
+        Lp.terms_offset = terms_off[(size_t)t];
+        Lp.terms_total = terms_total;
+        launch_spmv_vp<P, T, U, V, E>(use_vp, Lp, pa, At, xq, xb, (const V*)d_vp, y, const_cast<uint32_t*>(prev), dev::ACC_STATIC_BITS | dev::ACC_READ_PREV, rk);
+      }
+    }
     for (int t = 0; t < ntile; t++) {
       gm_csr_t At;
       const uint32_t* prev = nullptr;
@@ -1231,7 +1277,15 @@ class Run {
         GM_HIP_OK(hipStreamWaitEvent(aux.s, aux.tile_event(2 * (t - 1)), 0));
       }
       // y's presence bits are static (dense x): `prev` says which rows already carry a value
-      launch_spmv_vp<P, T, U, V, E>(use_vp, L, pa, At, xq, xb, (const V*)d_vp, y, const_cast<uint32_t*>(prev), dev::ACC_STATIC_BITS | dev::ACC_READ_PREV, rk);
+      Launch Lt = L;
+      if (split_giants && At.ngiant > 0) {
+        Lt.giant_phase = 2;
+        Lt.terms_stream = aux.s;
+        Lt.terms_done = aux.tile_event(2 * ntile + t);
+        Lt.terms_offset = terms_off[(size_t)t];
+        Lt.terms_total = terms_total;
+      }
+      launch_spmv_vp<P, T, U, V, E>(use_vp, Lt, pa, At, xq, xb, (const V*)d_vp, y, const_cast<uint32_t*>(prev), dev::ACC_STATIC_BITS | dev::ACC_READ_PREV, rk);
       if (cross && t + 1 < ntile) {
         GM_HIP_OK(hipEventRecord(aux.tile_event(2 * t), aux.gs));
         GM_HIP_OK(hipEventRecord(aux.tile_event(2 * t + 1), aux.s));

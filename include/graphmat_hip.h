@@ -490,8 +490,10 @@ typedef struct {
                                      the plain loop; profiles/r04_shard_emulation_rmat26.txt) */
   int32_t giant_stream;           /* tiled multiplies with the row-stationary sweep (gm_graph_sweep): 1 = the giant rows' passes (products, then
                                      the exact replay: a chain of small latency-bound launches) run on a stream of their own
-                                     (gm_graph_giant_stream) next to the auxiliary stream's short-row and one-wave-per-row kernels; 0 = they
-                                     share the auxiliary stream.  (Without the sweep a third stream was measured and loses:
+                                     (gm_graph_giant_stream) next to the auxiliary stream's short-row and one-wave-per-row kernels (default); 2 =
+                                     moreover the products passes (k_giant_terms) of ALL tiles run first, on the auxiliary stream (measured: the
+                                     replay chain ends 0.18 ms earlier and the short-row pass takes 0.17 ms longer: RMAT-26 5.10-5.12 against
+                                     5.09-5.16 ms); 0 = everything shares the auxiliary stream.  (Without the sweep a third stream was measured and loses:
                                      profiles/r04_streams_and_scalar_path.md.) */
   int32_t sweep_form;             /* the swept multiply: bits 0-1 = hot entries per slice in LDS (0: 18432, 1: 12288, 2: 9728 -- less LDS leaves room
                                      for the other streams' workgroups on the same CU); bits 2-3 = where the untiled short-row pass runs: 0 on the

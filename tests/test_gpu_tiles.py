@@ -272,7 +272,7 @@ def test_row_stationary_sweep_bit_exact(env, scale, tiles, threads):
     opr, _, _ = og.pagerank(6, degree=odeg)
     for sweep, forms in ((0, (4,)), (1, (0, 1, 4, 9)), (2, (4,))):
         for form in forms:
-            for gs in ((0, 1) if sweep == 1 and form == 4 else (1,)):
+            for gs in ((0, 1, 2) if sweep == 1 and form == 4 else (1,)):
                 api._lib.check(L.gm_reset_options())
                 api._lib.check(L.gm_set_option(b"sweep_slices", sweep))
                 api._lib.check(L.gm_set_option(b"sweep_form", form))
