@@ -29,8 +29,19 @@
 
 #define OK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { printf("%s:%d %s: %s\n", __FILE__, __LINE__, #e, hipGetErrorString(e_)); exit(1); } } while (0)
 
-constexpr int kWG = 256;      // workgroups = CUs
-constexpr int kBlock = 1024;  // threads per workgroup
+// (closing session of round 4: -DKWG=4096 -DKBLOCK=64 -DKACC=1024 makes every WAVE its own "workgroup" with private rows -- the per-slice
+// barrier then costs nothing and a wave never waits for another; only sensible without the LDS hot set)
+#ifndef KWG
+#define KWG 256
+#endif
+#ifndef KBLOCK
+#define KBLOCK 1024
+#endif
+#ifndef KACC
+#define KACC 10240
+#endif
+constexpr int kWG = KWG;        // workgroups (256 = CUs)
+constexpr int kBlock = KBLOCK;  // threads per workgroup
 constexpr int kMaxT = 64;
 constexpr int kRowLo = 65, kRowHi = 4096;
 
@@ -48,6 +59,10 @@ __global__ void k_iota(int32_t* __restrict__ a, int n) {
 __global__ void k_gather_deg(const int32_t* __restrict__ rows, int n, const uint32_t* __restrict__ deg, uint32_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = deg[rows[i]];
+}
+__global__ void k_every(const int32_t* __restrict__ in, int n, int step, int first, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[(size_t)i * step + first];
 }
 __global__ void k_rank_of(const int32_t* __restrict__ rows_sorted, int n, int32_t* __restrict__ rank_of) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -229,11 +244,17 @@ int main(int argc, char** argv) {
   const int scale = argc > 1 ? atoi(argv[1]) : 26;
   const int T = argc > 2 ? atoi(argv[2]) : 32;
   const int reps = argc > 3 ? atoi(argv[3]) : 5;
+  // shard emulation (round 4, closing session): only the medium rows that the degree-ranked deal gives shard `shard` of
+  // `nshards` (every nshards-th row of the length ranking) are swept, against the WHOLE message vector -- what a row shard
+  // of a multi-GPU run would sweep if its device order were (slice, degree rank) dealt over the shards
+  const int nshards = argc > 4 ? atoi(argv[4]) : 1;
+  const int shard = argc > 5 ? atoi(argv[5]) : 0;
+  if (nshards < 1 || shard < 0 || shard >= nshards) { printf("shard: 0..nshards-1\n"); return 1; }
   if (T < 1 || T > kMaxT) { printf("slices: 1..%d\n", kMaxT); return 1; }
   const int nv = 1 << scale;
   const int64_t ne = 16ll * nv;
   const int cbits = scale;  // native column id bits
-  if (8 + 6 + 16 + cbits > 64) { printf("scale too large\n"); return 1; }
+  if (13 + 6 + 16 + cbits > 64) { printf("scale too large\n"); return 1; }
   const int G = 4096;
   int32_t *src, *dst;
   OK(hipMalloc(&src, ne * 4)); OK(hipMalloc(&dst, ne * 4));
@@ -255,7 +276,7 @@ int main(int argc, char** argv) {
     OK(hipDeviceSynchronize()); OK(hipFree(tmp));
   }
   uint32_t nmed_u = 0; OK(hipMemcpy(&nmed_u, d_cnt, 4, hipMemcpyDeviceToHost));
-  const int nmed = (int)nmed_u;
+  int nmed = (int)nmed_u;
   uint32_t *rdeg, *rdeg2; int32_t* rows_sorted;
   OK(hipMalloc(&rdeg, (size_t)nmed * 4)); OK(hipMalloc(&rdeg2, (size_t)nmed * 4)); OK(hipMalloc(&rows_sorted, (size_t)nmed * 4));
   k_gather_deg<<<(nmed + 255) / 256, 256>>>(rows, nmed, deg, rdeg);
@@ -265,6 +286,14 @@ int main(int argc, char** argv) {
     void* tmp; OK(hipMalloc(&tmp, tb + 256));
     OK(rocprim::radix_sort_pairs_desc(tmp, tb, rdeg, rdeg2, rows, rows_sorted, (size_t)nmed, 0, 32, (hipStream_t)0));
     OK(hipDeviceSynchronize()); OK(hipFree(tmp));
+  }
+  if (nshards > 1) {  // keep ranks shard, shard + nshards, ...
+    const int keep = (nmed - shard + nshards - 1) / nshards;
+    int32_t* sub; OK(hipMalloc(&sub, (size_t)keep * 4));
+    k_every<<<(keep + 255) / 256, 256>>>(rows_sorted, keep, nshards, shard, sub);
+    OK(hipDeviceSynchronize());
+    rows_sorted = sub;
+    nmed = keep;
   }
   int32_t* rank_of; OK(hipMalloc(&rank_of, (size_t)nv * 4)); OK(hipMemset(rank_of, 0xff, (size_t)nv * 4));
   k_rank_of<<<(nmed + 255) / 256, 256>>>(rows_sorted, nmed, rank_of);
@@ -345,10 +374,11 @@ int main(int argc, char** argv) {
   k_fill_x<<<(nv + 255) / 256, 256>>>(x, nv);
   OK(hipMemset(y, 0, (size_t)nmed * 4));
   OK(hipDeviceSynchronize());
-  printf("RMAT-%d: %d rows of %d..%d edges, %lld edges, %u pieces (%.1f edges each), %d slices, %d rows per workgroup\n", scale, nmed, kRowLo, kRowHi, (long long)nedges, npieces,
+  if (nshards > 1) printf("shard %d of %d: ", shard, nshards);
+  printf("[%d workgroups x %d threads] RMAT-%d: %d rows of %d..%d edges, %lld edges, %u pieces (%.1f edges each), %d slices, %d rows per workgroup\n", kWG, kBlock, scale, nmed, kRowLo, kRowHi, (long long)nedges, npieces,
          (double)nedges / npieces, T, rows_per_wg);
   if (nedges >= (1ll << 32)) { printf("too many edges for 32-bit positions\n"); return 1; }
-  constexpr int ACC = 10240;
+  constexpr int ACC = KACC;
   if (rows_per_wg > ACC) { printf("rows per workgroup %d > %d\n", rows_per_wg, ACC); return 1; }
   hipEvent_t e0, e1; OK(hipEventCreate(&e0)); OK(hipEventCreate(&e1));
   auto time_it = [&](auto launch, const char* name) {
@@ -363,7 +393,9 @@ int main(int argc, char** argv) {
     }
     printf("%-44s best %.3f ms, mean %.3f ms  = %.2f ps per edge, %.1f G edges/s\n", name, best, sum / reps, best * 1e9 / nedges, nedges / best * 1e-6);
   };
-  time_it([&]() { k_sweep<18432, ACC><<<kWG, kBlock>>>(v1s, piece_start, piece_row, blk_first, slice_base, slice_len, T, x, y, nmed); }, "sweep, 18432 hot entries per slice");
+  constexpr bool kBig = KBLOCK >= 1024;  // (small workgroups: no room for hot sets; the first, verified launch is the one without)
+  if constexpr (kBig) time_it([&]() { k_sweep<18432, ACC><<<kWG, kBlock>>>(v1s, piece_start, piece_row, blk_first, slice_base, slice_len, T, x, y, nmed); }, "sweep, 18432 hot entries per slice");
+  else time_it([&]() { k_sweep<1, ACC><<<kWG, kBlock>>>(v1s, piece_start, piece_row, blk_first, slice_base, slice_len, T, x, y, nmed); }, "sweep, no hot set (small workgroups)");
   OK(hipGetLastError());
   k_reference<<<(nmed + 255) / 256, 256>>>(row_start, nmed, nedges, v2s, x, yref);
   OK(hipDeviceSynchronize());
@@ -375,7 +407,9 @@ int main(int argc, char** argv) {
     for (int i = 0; i < nmed; i++) bad += memcmp(&a[i], &b[i], 4) != 0;
     printf("against the serial fold in ascending native column order: %lld of %d rows differ (bit compare)\n", (long long)bad, nmed);
   }
-  time_it([&]() { k_sweep<8192, ACC><<<kWG, kBlock>>>(v1s, piece_start, piece_row, blk_first, slice_base, slice_len, T, x, y, nmed); }, "sweep, 8192 hot entries per slice");
+  if constexpr (kBig) time_it([&]() { k_sweep<8192, ACC><<<kWG, kBlock>>>(v1s, piece_start, piece_row, blk_first, slice_base, slice_len, T, x, y, nmed); }, "sweep, 8192 hot entries per slice");
+  if constexpr (kBig) time_it([&]() { k_sweep<4096, ACC><<<kWG, kBlock>>>(v1s, piece_start, piece_row, blk_first, slice_base, slice_len, T, x, y, nmed); }, "sweep, 4096 hot entries per slice");
+  if constexpr (KBLOCK >= 256) time_it([&]() { k_sweep<2048, ACC><<<kWG, kBlock>>>(v1s, piece_start, piece_row, blk_first, slice_base, slice_len, T, x, y, nmed); }, "sweep, 2048 hot entries per slice");
   time_it([&]() { k_sweep<1, ACC><<<kWG, kBlock>>>(v1s, piece_start, piece_row, blk_first, slice_base, slice_len, T, x, y, nmed); }, "sweep, no hot set");
   return 0;
 }
