@@ -1256,6 +1256,14 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     // (with the auxiliary stream joined after every tile the optimum was fewer, larger tiles: 4 / 6 / 10)
     const double mib = (double)nz * 4.0 / 1048576.0;
     T = mib >= 60.0 ? (int)(1.0 + mib / 17.0 + 0.5) : 1;
+    // With the row-stationary sweep (g_sweep_slices != 0; the closing session of round 4, profiles/r04_tile_counts_with_sweep.md) the
+    // tiles only cut the one-wave-per-row and giant rows -- the medium rows walk ~64 slices whatever the tile count -- and every tile
+    // is a pass of two latency-bound kernel chains: FEWER tiles win, and tiling pays from smaller graphs on because it brings the
+    // sweep with it.  ms per iteration by tile count: RMAT-23 (18 MiB) 1 / 2 / 3: 0.820 / 0.842 / 0.857; RMAT-24 (34 MiB) 1 / 2 / 3:
+    // 1.66 / 1.33 / 1.45; RMAT-25 (65 MiB) 2 / 3 / 4 / 5 / 6: 2.61 / 2.47 / 2.54 / 2.56 / 2.60; RMAT-26 (125 MiB) 2 .. 9: 5.26 / 4.84 / 4.92 /
+    // 4.99 / 5.00 / 5.09 / 5.10 / 5.12 (seeds 2 and 3: 3 tiles best as well, 4.83 / 4.81); RMAT-27 (239 MiB) 3 / 4 / 5 / 6 / 8 / 10 / 12 / 15:
+    // 11.84 / 11.20 / 11.27 / 11.15 / 11.14 / 11.30 / 11.38 / 11.49 -- two tiles from 25 MiB, three from 50 MiB, one per 40 MiB from 180 MiB on
+    if (g_sweep_slices != 0) T = mib < 25.0 ? 1 : mib < 50.0 ? 2 : mib < 180.0 ? 3 : (int)(mib / 40.0 + 0.5);
   }
   if (T < 1 || G > 1 || nz < 2) T = 1;
   if (T > GM_MAX_TILES) T = GM_MAX_TILES;

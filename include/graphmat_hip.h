@@ -131,8 +131,11 @@ typedef struct {
                             each slice.  Multiple of 64; = slice size for GM_LAYOUT_NATIVE.   */
   int32_t col_tiles;     /* column tiles of the GM_DIR_OUT adjacency (see gm_graph_tile): 0 = library default
                             (gm_set_option("col_tiles"), else environment GRAPHMAT_COL_TILES, else automatic:
-                            about one tile per 17 MiB of a 4-byte message vector's live part once that reaches 60 MiB, i.e.
-                            none up to RMAT-24, 5 at RMAT-25, 8 at RMAT-26, 15 at RMAT-27), 1 = none, 2..GM_MAX_TILES = that many.
+                            by the live part of a 4-byte message vector: two tiles from 25 MiB, three from 50 MiB, one per 40 MiB
+                            from 180 MiB on, i.e. none up to RMAT-23, 2 at RMAT-24, 3 at RMAT-25 and RMAT-26, 6 at RMAT-27 -- the
+                            medium rows are swept over ~64 slices whatever the tile count (gm_graph_sweep), tiles only cut the longer
+                            rows; with gm_set_option("sweep_slices", 0): one tile per 17 MiB once the live part reaches 60 MiB),
+                            1 = none, 2..GM_MAX_TILES = that many.
                             GM_LAYOUT_DEGREE with one shard only (ignored otherwise).  Output: the number of tiles
                             built (1 = none).                                                                 */
   int32_t edges_local;   /* 0: every rank passes the whole edge list (edges of other shards' rows are dropped).
