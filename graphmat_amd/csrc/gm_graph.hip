@@ -1205,7 +1205,7 @@ static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t*
 }
 
 // GM_LAYOUT_DEGREE: rank vertices by total degree, deal the ranks round-robin over the shards
-static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, const int32_t* d_dst, hipStream_t s) {
+static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, const int32_t* d_dst, hipStream_t s, bool keeps_values) {
   gm_graph_desc_t& D = g->desc;
   const int nv = D.nvertices, G = D.nshards;
   int S = (nv + G - 1) / G;
@@ -1263,7 +1263,12 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     // 1.66 / 1.33 / 1.45; RMAT-25 (65 MiB) 2 / 3 / 4 / 5 / 6: 2.61 / 2.47 / 2.54 / 2.56 / 2.60; RMAT-26 (125 MiB) 2 .. 9: 5.26 / 4.84 / 4.92 /
     // 4.99 / 5.00 / 5.09 / 5.10 / 5.12 (seeds 2 and 3: 3 tiles best as well, 4.83 / 4.81); RMAT-27 (239 MiB) 3 / 4 / 5 / 6 / 8 / 10 / 12 / 15:
     // 11.84 / 11.20 / 11.27 / 11.15 / 11.14 / 11.30 / 11.38 / 11.49 -- two tiles from 25 MiB, three from 50 MiB, one per 40 MiB from 180 MiB on
-    if (g_sweep_slices != 0) T = mib < 25.0 ? 1 : mib < 50.0 ? 2 : mib < 180.0 ? 3 : (int)(mib / 40.0 + 0.5);
+    // (An adjacency that keeps its edge values is not swept -- the sweep's copy of the medium rows holds column ids only -- and all
+    // its rows above 64 edges go through the tiles as before: the old rule stays for it, from 100 MiB on.  The reference's unchanged
+    // PageRank.cpp -- int edge values, ordered fold -- by tile count: RMAT-24 1 / 2 / 3 / 5: 149 / 161 / 162 / 165 ms; RMAT-25 1 / 2 / 3 / 5:
+    // 228 / 308 / 283 / 281 ms; RMAT-26 1 / 3 / 8: 641 / 582 / 506 ms.)
+    if (g_sweep_slices != 0 && !keeps_values) T = mib < 25.0 ? 1 : mib < 50.0 ? 2 : mib < 180.0 ? 3 : (int)(mib / 40.0 + 0.5);
+    else if (keeps_values && mib < 100.0) T = 1;
   }
   if (T < 1 || G > 1 || nz < 2) T = 1;
   if (T > GM_MAX_TILES) T = GM_MAX_TILES;
@@ -1543,7 +1548,7 @@ int gm_graph_create(gm_graph_t** gout, const gm_graph_desc_t* desc, int64_t nnz,
   g->desc.ndevice = desc->nvertices;
   g->desc.xchg_rows = desc->row_hi - desc->row_lo;
   g->ntiles = 1;
-  if (desc->layout == GM_LAYOUT_DEGREE) rc = gm::build_degree_layout(g, nnz, d_src, d_dst, s);
+  if (desc->layout == GM_LAYOUT_DEGREE) rc = gm::build_degree_layout(g, nnz, d_src, d_dst, s, desc->val_bytes > 0 && d_val != nullptr);
   else g->desc.col_tiles = 1;
   if (rc != GM_OK) { gm_graph_destroy(g); return rc; }
   if (desc->edges_local) {

@@ -134,7 +134,8 @@ typedef struct {
                             by the live part of a 4-byte message vector: two tiles from 25 MiB, three from 50 MiB, one per 40 MiB
                             from 180 MiB on, i.e. none up to RMAT-23, 2 at RMAT-24, 3 at RMAT-25 and RMAT-26, 6 at RMAT-27 -- the
                             medium rows are swept over ~64 slices whatever the tile count (gm_graph_sweep), tiles only cut the longer
-                            rows; with gm_set_option("sweep_slices", 0): one tile per 17 MiB once the live part reaches 60 MiB),
+                            rows; with gm_set_option("sweep_slices", 0): one tile per 17 MiB once the live part reaches 60 MiB; with
+                            edge values kept (such an adjacency is not swept): the same from 100 MiB on),
                             1 = none, 2..GM_MAX_TILES = that many.
                             GM_LAYOUT_DEGREE with one shard only (ignored otherwise).  Output: the number of tiles
                             built (1 = none).                                                                 */
