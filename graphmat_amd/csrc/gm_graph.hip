@@ -32,6 +32,7 @@ int g_tile_balance = 1;  // column tiles serve equally many gathers (1) or hold 
 int g_long_mid = 0;  // > 0: experiment -- wave rows of more than this many edges get a wave each (0 = GM_LONG_MID rule)
 int g_sweep_slices = 1;  // 1: cut the device order into ntiles * k <= 64 slices and build the row-stationary sweep of the medium rows (gm_graph_sweep)
 int g_sort_tile_lists = 1;  // column tiles: the wave-row lists by descending piece length (sort_rows_by_length)
+int g_sweep_acc_limit = GM_SWEEP_ACC_ROWS, g_sweep_long_limit = GM_SWEEP_LONG_SLOTS;  // rows per workgroup and launch of the sweep (tests force several launches with small values)
 int g_own_wave_row = 4096;  // column tiles: rows of more than this many edges (whole graph) keep the wave / giant kernels in every tile (0: classes per tile piece)
 int g_col_tiles = 0;  // default number of column tiles for graphs whose descriptor says 0 (0 = environment GRAPHMAT_COL_TILES, else none)
 
@@ -879,23 +880,16 @@ k_tile_gather(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ id
   idx_t[j] = idx[p];
 }
 
-// ---- gm_graph_sweep: the medium rows' edges as [set][workgroup][slice][row][native column] ------------------------------
+// ---- gm_graph_sweep: the rows of more than short_row edges that are not giant, laid out for kernels.hpp: k_spmv_sell ----------
+// (graphmat_hip.h: gm_sweep_t; prototype and measurements: tools/sell_bench.hip, profiles/r05_sell_prototype*.txt)
 __global__ void __launch_bounds__(kT)
-k_sweep_medium(const int64_t* __restrict__ rowptr, int nrows, int short_row, int64_t max_len, const unsigned char* __restrict__ own_wave,
-               unsigned char* __restrict__ flag) {
+k_sweep_flag(const int64_t* __restrict__ rowptr, int nrows, int short_row, unsigned char* __restrict__ flag) {
   const int r = blockIdx.x * kT + threadIdx.x;
-  if (r >= nrows) return;
-  const int64_t len = rowptr[r + 1] - rowptr[r];
-  flag[r] = (len > short_row && len <= max_len && !(own_wave != nullptr && own_wave[r])) ? 1 : 0;  // (own_wave == nullptr: every wave row)
+  if (r < nrows) flag[r] = (rowptr[r + 1] - rowptr[r] > short_row) ? 1 : 0;
 }
 __global__ void __launch_bounds__(kT) k_sweep_unflag(const int32_t* __restrict__ list, int n, unsigned char* __restrict__ flag) {
   const int i = blockIdx.x * kT + threadIdx.x;
   if (i < n) flag[list[i]] = 0;
-}
-__global__ void __launch_bounds__(kT)
-k_sweep_unswept(const int32_t* __restrict__ list, int n, const unsigned char* __restrict__ swept, unsigned char* __restrict__ keep) {
-  const int i = blockIdx.x * kT + threadIdx.x;
-  if (i < n) keep[i] = swept[list[i]] ? 0 : 1;
 }
 __global__ void __launch_bounds__(kT) k_sweep_iota(int32_t* __restrict__ a, int n) {
   const int i = blockIdx.x * kT + threadIdx.x;
@@ -910,42 +904,40 @@ __global__ void __launch_bounds__(kT) k_sweep_widen(const uint32_t* __restrict__
   const int i = blockIdx.x * kT + threadIdx.x;
   if (i < n) o[i] = a[i];
 }
-struct SweepSlices { int32_t b[GM_MAX_TILES + 2]; };
-// one wave per medium row (in length-rank order): its edges, keyed (virtual workgroup, slice, accumulator slot), CSR order kept
+// lens are sorted descending: the number of entries > limit
+__global__ void k_sweep_count_above(const uint32_t* __restrict__ len_desc, int n, uint32_t limit, unsigned int* __restrict__ out) {
+  int lo = 0, hi = n;  // first index with len <= limit
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (len_desc[mid] > limit) lo = mid + 1; else hi = mid; }
+  *out = (unsigned int)lo;
+}
+struct SweepSlices { int32_t b[GM_MAX_SLICES + 2]; };
+// one wave per swept row (in length-rank order, the long rows first): its edges, keyed (set * 256 + workgroup, slice, slot), with
+// the CSR position as the value; the row's edges keep their CSR order in the key stream (ranked offsets `off`)
 __global__ void __launch_bounds__(kT)
-k_sweep_keys(const int32_t* __restrict__ rows_ranked, int nmed, const unsigned long long* __restrict__ off, const int64_t* __restrict__ rowptr,
-             const int32_t* __restrict__ colidx, SweepSlices sl, int nslices, int acc_rows, unsigned long long* __restrict__ key, int32_t* __restrict__ val,
-             int32_t* __restrict__ row_of_slot) {
+k_sweep_keys(const int32_t* __restrict__ rows_ranked, int nswept, int nlong, int nsets, const unsigned long long* __restrict__ off,
+             const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, SweepSlices sl, int nslices, unsigned long long* __restrict__ key,
+             uint32_t* __restrict__ val, int32_t* __restrict__ row_of_slot, int32_t* __restrict__ lrow_of_slot) {
   const int r = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
-  if (r >= nmed) return;
+  if (r >= nswept) return;
   const int lane = threadIdx.x & 63;
   const int row = rows_ranked[r];
   const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
-  const unsigned wg = (unsigned)r % 256u, l = (unsigned)r / 256u;
-  const unsigned set = l / (unsigned)acc_rows;
+  const bool is_long = r < nlong;
+  const unsigned q = (unsigned)(is_long ? r : r - nlong);
+  const unsigned wg = q % 256u, l = q / 256u;
+  const unsigned set = l % (unsigned)nsets, slot = l / (unsigned)nsets;
   const unsigned long long vw = (unsigned long long)set * 256ull + wg;
-  // The slot: the workgroup's rows come in descending length, and a wave takes 64 consecutive pieces (= slots) of a slice at
-  // a time -- in rank order one wave would get the workgroup's 64 longest pieces.  A multiplicative permutation of the slots
-  // deals the long rows over the groups (stride ~ rows / 64, coprime to the row count).
-  const unsigned per_wg = ((unsigned)nmed - wg + 255u) / 256u;
-  const unsigned left = per_wg - set * (unsigned)acc_rows;
-  const unsigned cnt = left < (unsigned)acc_rows ? left : (unsigned)acc_rows;
-  unsigned M = (cnt / 64u) | 1u;
-  for (;;) {
-    unsigned a = M, b = cnt;
-    while (b) { const unsigned t = a % b; a = b; b = t; }
-    if (a == 1u) break;
-    M += 2u;
+  if (lane == 0) {
+    if (is_long) lrow_of_slot[vw * (unsigned long long)GM_SWEEP_LONG_SLOTS + slot] = row;
+    else row_of_slot[vw * (unsigned long long)GM_SWEEP_ACC_ROWS + slot] = row;
   }
-  const unsigned long long slot = (unsigned long long)(((unsigned long long)(l % (unsigned)acc_rows) * M) % cnt);
-  if (lane == 0) row_of_slot[vw * (unsigned long long)acc_rows + slot] = row;
   const unsigned long long o = off[r];
   for (int64_t e = e0 + lane; e < e1; e += 64) {
     const int c = colidx[e];
     int lo = 0, hi = nslices;  // largest s with sl.b[s] <= c
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sl.b[mid] <= c) lo = mid; else hi = mid; }
-    key[o + (unsigned long long)(e - e0)] = (vw << 22) | ((unsigned long long)lo << 16) | slot;
-    val[o + (unsigned long long)(e - e0)] = c;
+    key[o + (unsigned long long)(e - e0)] = (vw << 23) | ((unsigned long long)lo << 16) | slot;
+    val[o + (unsigned long long)(e - e0)] = (uint32_t)e;
   }
 }
 __global__ void __launch_bounds__(kT)
@@ -953,56 +945,214 @@ k_sweep_heads(const unsigned long long* __restrict__ key, int64_t n, uint32_t* _
   const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
   if (i < n) head[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
 }
+// pieces of the medium rows in (set, workgroup, slice, slot) order; rowmin[(set * 256 + w) * acc + slot] = the row's first slice
 __global__ void __launch_bounds__(kT)
 k_sweep_pieces(const unsigned long long* __restrict__ key, const uint32_t* __restrict__ head, const uint32_t* __restrict__ pidx_incl, int64_t n,
-               uint32_t* __restrict__ piece_start, uint16_t* __restrict__ piece_row, int32_t* __restrict__ blk_first, int nslices) {
+               uint32_t* __restrict__ piece_start, uint16_t* __restrict__ piece_slot, uint32_t* __restrict__ piece_blk, int32_t* __restrict__ blk_first,
+               int nslices, int* __restrict__ rowmin) {
   const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
   if (i >= n || !head[i]) return;
   const uint32_t p = pidx_incl[i] - 1;
   const unsigned long long k = key[i];
+  const unsigned slot = (unsigned)(k & 0xffffull), slice = (unsigned)((k >> 16) & 127ull);
+  const unsigned long long vw = k >> 23;
+  const uint32_t blk = (uint32_t)(vw * (unsigned long long)nslices + slice);
   piece_start[p] = (uint32_t)i;
-  piece_row[p] = (uint16_t)(k & 0xffffull);
-  const unsigned long long blk = k >> 16;  // vw << 6 | slice
-  if (i == 0 || (key[i - 1] >> 16) != blk) blk_first[(int64_t)(blk >> 6) * nslices + (int64_t)(blk & 63ull)] = (int32_t)p;
+  piece_slot[p] = (uint16_t)slot;
+  piece_blk[p] = blk;
+  if (i == 0 || (key[i - 1] >> 16) != (k >> 16)) blk_first[blk] = (int32_t)p;
+  atomicMin(&rowmin[vw * (unsigned long long)GM_SWEEP_ACC_ROWS + slot], (int)slice);
+}
+// sort key of a piece inside its block: the longest first
+__global__ void __launch_bounds__(kT)
+k_sweep_piece_keys(const uint32_t* __restrict__ piece_start, const uint32_t* __restrict__ piece_blk, uint32_t np, unsigned long long* __restrict__ pkey,
+                   uint32_t* __restrict__ pid) {
+  const uint32_t p = blockIdx.x * kT + threadIdx.x;
+  if (p >= np) return;
+  const uint32_t len = piece_start[p + 1] - piece_start[p];
+  pkey[p] = ((unsigned long long)piece_blk[p] << 16) | (unsigned long long)(0xffffu - (len > 0xffffu ? 0xffffu : len));
+  pid[p] = p;
+}
+__global__ void __launch_bounds__(kT) k_sweep_block_groups(const int32_t* __restrict__ blk_first, int nblk, uint32_t* __restrict__ ng) {
+  const int b = blockIdx.x * kT + threadIdx.x;
+  if (b < nblk) ng[b] = (uint32_t)(blk_first[b + 1] - blk_first[b] + 63) / 64u;
+}
+// group g of block b = pieces q0 .. q0 + 63 of the block's sorted order; entries = 64 x its first (longest) piece
+__global__ void __launch_bounds__(64)
+k_sweep_group_sizes(const int32_t* __restrict__ blk_first, const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ sp,
+                    const uint32_t* __restrict__ piece_start, unsigned long long* __restrict__ gsize, uint32_t* __restrict__ gq0, uint32_t* __restrict__ gblk) {
+  const int b = blockIdx.x;
+  const uint32_t g0 = grp_first[b], g1 = grp_first[b + 1];
+  for (uint32_t g = g0 + threadIdx.x; g < g1; g += 64) {
+    const uint32_t q0 = (uint32_t)blk_first[b] + (g - g0) * 64u;
+    const uint32_t p = sp[q0];
+    gsize[g] = ((unsigned long long)(piece_start[p + 1] - piece_start[p]) + 1ull) * 64ull;  // (a meta row, then the longest piece's rows)
+    gq0[g] = q0;
+    gblk[g] = (uint32_t)b;
+  }
+}
+__global__ void __launch_bounds__(kT) k_sweep_narrow(const unsigned long long* __restrict__ a, size_t n, uint32_t* __restrict__ o) {
+  const size_t i = (size_t)blockIdx.x * kT + threadIdx.x;
+  if (i < n) o[i] = (uint32_t)a[i];
+}
+// a group's entries: row 0 = the meta row (GM_SWEEP_PAD | width << 16 | first-piece flag << 15 | slot, slot 0x7fff: no piece),
+// then transposed columns: scol[gbase + (1 + k) * 64 + lane] = byte offset of the k-th column of the lane's piece, or padding
+__global__ void __launch_bounds__(kT)
+k_sweep_fill(uint32_t ngroups, const uint32_t* __restrict__ gbase, const uint32_t* __restrict__ gq0, const uint32_t* __restrict__ gblk,
+             const int32_t* __restrict__ blk_first, const uint32_t* __restrict__ sp, const uint32_t* __restrict__ piece_start,
+             const uint16_t* __restrict__ piece_slot, const uint32_t* __restrict__ pos_sorted, const int32_t* __restrict__ colidx,
+             const uint32_t* __restrict__ vals, SweepSlices sl, int nslices, const int* __restrict__ rowmin, uint32_t* __restrict__ scol,
+             uint32_t* __restrict__ sval, uint32_t* __restrict__ src_pos) {
+  for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const uint32_t b = gblk[g], q0 = gq0[g], qe = (uint32_t)blk_first[b + 1];
+    const uint32_t base = gbase[g], n = gbase[g + 1] - base;
+    const uint32_t width = (n >> 6) - 1u;
+    const uint32_t slice = b % (uint32_t)nslices, vw = b / (uint32_t)nslices;
+    const uint32_t pad = GM_SWEEP_PAD | ((uint32_t)sl.b[slice] << 2);
+    const int lane = threadIdx.x & 63;
+    const uint32_t q = q0 + lane;
+    uint32_t ps = 0, len = 0;
+    uint32_t meta = GM_SWEEP_PAD | (width << 16) | 0x7fffu;
+    if (q < qe) {
+      const uint32_t p = sp[q];
+      ps = piece_start[p];
+      len = piece_start[p + 1] - ps;
+      const unsigned slot = piece_slot[p];
+      const bool first = rowmin[(size_t)vw * GM_SWEEP_ACC_ROWS + slot] == (int)slice;
+      meta = GM_SWEEP_PAD | (width << 16) | (first ? 0x8000u : 0u) | slot;
+    }
+    for (uint32_t j = threadIdx.x; j < n; j += kT) {
+      uint32_t c = pad, v = 0u, sp_ = 0xffffffffu;
+      if (j < 64) {
+        c = meta;
+      } else {
+        const uint32_t k = (j >> 6) - 1u;
+        if (k < len) {
+          sp_ = pos_sorted[ps + k];
+          c = (uint32_t)colidx[sp_] << 2;
+          if (vals) v = vals[sp_];
+        }
+      }
+      scol[base + j] = c;
+      if (sval) sval[base + j] = v;
+      if (src_pos) src_pos[base + j] = sp_;
+    }
+  }
+}
+// contiguous ranges of a block's groups for the 16 waves (wfirst: groups; wrow: 64-entry rows of scol), balanced by rows + 1 per group; the last two waves (they fold the long
+// rows of the block first) get fold_share percent of an equal share
+__global__ void __launch_bounds__(64)
+k_sweep_wave_ranges(const uint32_t* __restrict__ grp_first, int nblk, const uint32_t* __restrict__ gbase, uint32_t* __restrict__ wfirst, uint32_t* __restrict__ wrow,
+                    int fold_share) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= nblk) return;
+  constexpr int W = 16, FW = GM_SWEEP_LONG_SLOTS / 64;
+  const uint32_t g0 = grp_first[b], g1 = grp_first[b + 1];
+  unsigned long long total = 0;
+  for (uint32_t g = g0; g < g1; g++) total += (gbase[g + 1] - gbase[g]) / 64u + 1u;
+  const unsigned long long units = (unsigned long long)(W - FW) * 100ull + (unsigned long long)FW * (unsigned)fold_share;
+  uint32_t g = g0;
+  unsigned long long acc = 0, share = 0;
+  for (int w = 0; w < W; w++) {
+    wfirst[(size_t)b * (W + 1) + w] = g;
+    wrow[(size_t)b * (W + 1) + w] = gbase[g] >> 6;
+    share += w >= W - FW ? (unsigned)fold_share : 100u;
+    const unsigned long long want = total * share / units;
+    while (g < g1 && acc + ((gbase[g + 1] - gbase[g]) / 64u + 1u + 1u) / 2u <= want) { acc += (gbase[g + 1] - gbase[g]) / 64u + 1u; g++; }
+  }
+  wfirst[(size_t)b * (W + 1) + W] = g1;
+  wrow[(size_t)b * (W + 1) + W] = gbase[g1] >> 6;
+}
+// long rows: entry e = ((set * 256 + w) * nslices + slice) * long_slots + j -> first position of that piece in the sorted keys
+__global__ void __launch_bounds__(kT)
+k_sweep_long_starts(const unsigned long long* __restrict__ key, int64_t n, int nslices, size_t nent, uint32_t* __restrict__ lps) {
+  const size_t e = (size_t)blockIdx.x * kT + threadIdx.x;
+  if (e > nent) return;
+  if (e == nent) { lps[e] = (uint32_t)n; return; }
+  const size_t b = e / GM_SWEEP_LONG_SLOTS;
+  const unsigned long long vw = b / (size_t)nslices, slice = b % (size_t)nslices, j = e % GM_SWEEP_LONG_SLOTS;
+  const unsigned long long want = (vw << 23) | (slice << 16) | j;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (key[mid] >= want) hi = mid; else lo = mid + 1; }
+  lps[e] = (uint32_t)lo;
+}
+__global__ void __launch_bounds__(kT)
+k_sweep_long_fill(const uint32_t* __restrict__ pos_sorted, int64_t n, const int32_t* __restrict__ colidx, const uint32_t* __restrict__ vals,
+                  uint32_t* __restrict__ lcol, uint32_t* __restrict__ lval) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t p = pos_sorted[i];
+  lcol[i] = (uint32_t)colidx[p] << 2;
+  if (lval) lval[i] = vals[p];
+}
+__global__ void __launch_bounds__(kT)
+k_sweep_long_max(const uint32_t* __restrict__ lps, size_t nblk, unsigned int* __restrict__ out) {
+  const size_t b = (size_t)blockIdx.x * kT + threadIdx.x;
+  if (b < nblk) atomicMax(out, lps[(b + 1) * GM_SWEEP_LONG_SLOTS] - lps[b * GM_SWEEP_LONG_SLOTS]);
+}
+// edge values rewritten in the CSR: the sweep's copies follow (gm_graph_sync_tile_vals)
+__global__ void __launch_bounds__(kT)
+k_sweep_sync_vals(const uint32_t* __restrict__ src_pos, size_t n, const uint32_t* __restrict__ vals, uint32_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * kT + threadIdx.x;
+  if (i < n && src_pos[i] != 0xffffffffu) out[i] = vals[src_pos[i]];
 }
 static void free_sweep(gm_graph* g) {
   gm_sweep_t& S = g->sweep;
-  if (S.colidx) (void)hipFree((void*)S.colidx);
-  if (S.piece_start) (void)hipFree((void*)S.piece_start);
-  if (S.piece_row) (void)hipFree((void*)S.piece_row);
-  if (S.blk_first) (void)hipFree((void*)S.blk_first);
-  if (S.row_of_rank) (void)hipFree((void*)S.row_of_rank);
+  const void* owned[] = {S.scol, S.sval, S.gbase, S.wrow, S.wfirst, S.row_of_slot, S.lcol, S.lval, S.lps, S.lrow_of_slot, S.src_pos, S.lsrc_pos};
+  for (const void* q : owned)
+    if (q) (void)hipFree((void*)q);
   if (g->d_slice_base) (void)hipFree(g->d_slice_base);
   memset(&S, 0, sizeof(S));
   g->d_slice_base = nullptr;
 }
-static int build_sweep(gm_graph* g, const CsrOwned* whole, const unsigned char* own_wave, hipStream_t s) {
+template <class K, class V>
+static int sweep_sort_pairs(K* kin, K* kout, V* vin, V* vout, size_t n, int bits, hipStream_t s) {
+  DevBuf tmp;
+  size_t tb = 0;
+  int rc;
+  GM_TRY_HIP(rocprim::radix_sort_pairs(nullptr, tb, kin, kout, vin, vout, n, 0, bits, s));
+  if ((rc = tmp.alloc(tb + 256))) return rc;
+  GM_TRY_HIP(rocprim::radix_sort_pairs(tmp.p, tb, kin, kout, vin, vout, n, 0, bits, s));
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  return GM_OK;
+}
+template <class X>
+static int sweep_excl_scan(X* in, X* out, size_t n, hipStream_t s) {
+  DevBuf tmp;
+  size_t tb = 0;
+  int rc;
+  GM_TRY_HIP(rocprim::exclusive_scan(nullptr, tb, in, out, X(0), n, rocprim::plus<X>(), s));
+  if ((rc = tmp.alloc(tb + 256))) return rc;
+  GM_TRY_HIP(rocprim::exclusive_scan(tmp.p, tb, in, out, X(0), n, rocprim::plus<X>(), s));
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  return GM_OK;
+}
+static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
   memset(&g->sweep, 0, sizeof(g->sweep));
   const int TS = g->nslices;
   const int nrows = g->desc.row_hi - g->desc.row_lo;
-  if (TS < 2 || TS > 64) return GM_OK;
+  if (TS < 2 || TS > GM_MAX_SLICES) return GM_OK;
   {  // the slices of the device order are reported even when no row ends up in the sweep (nrows = 0)
     DevBuf sb0;
     int rc0;
-    if ((rc0 = sb0.alloc((size_t)(GM_MAX_TILES + 2) * 4))) return rc0;
+    if ((rc0 = sb0.alloc((size_t)(GM_MAX_SLICES + 2) * 4))) return rc0;
     GM_TRY_HIP(hipMemcpyAsync(sb0.p, g->slice_base, (size_t)(TS + 1) * 4, hipMemcpyHostToDevice, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
     g->d_slice_base = (int32_t*)sb0.release();
     g->sweep.nslices = TS;
     g->sweep.slice_base = g->d_slice_base;
   }
-  if (own_wave == nullptr || nrows <= 0 || whole->view.nnz >= ((int64_t)1 << 32)) return GM_OK;
+  const int vb = whole->view.val_bytes;
+  if (nrows <= 0 || whole->view.nnz >= ((int64_t)1 << 32) || g->desc.ndevice >= (1 << 29) || (whole->vals != nullptr && vb != 4)) return GM_OK;
   const int64_t* rowptr = (const int64_t*)whole->rowptr;
   const int32_t* colidx = (const int32_t*)whole->colidx;
+  const uint32_t* vals = (const uint32_t*)whole->vals;
   int rc;
   DevBuf flag, iota, rows, cnt, len_in, len_out, ranked, tmp;
   if ((rc = flag.alloc((size_t)nrows)) || (rc = iota.alloc((size_t)nrows * 4)) || (rc = rows.alloc((size_t)nrows * 4)) || (rc = cnt.alloc(16))) return rc;
-  // sweep_slices 1: the rows up to own_wave_row edges; 2: every wave row that is not a giant row of the whole graph
-  hipLaunchKernelGGL(k_sweep_medium, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr, nrows, whole->view.short_row, (int64_t)1 << 40,
-                     g_sweep_slices >= 2 ? (const unsigned char*)nullptr : own_wave, flag.as<unsigned char>());
-  // (The rows of more than own_wave_row edges keep the one-wave-per-row / giant kernels tile by tile.  Sweeping them too was
-  // measured: their pieces are hundreds of edges long, one lane folds each, and the wave that gets a workgroup's 64 longest
-  // pieces holds the workgroup's slice barrier for 38 steps -- RMAT-26 12.3 ms per iteration.)
+  hipLaunchKernelGGL(k_sweep_flag, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr, nrows, whole->view.short_row, flag.as<unsigned char>());
+  // (giant rows keep their own passes -- k_giant_terms + the exact replay: a lane folding a 13 000-edge piece per slice would hold
+  // its workgroup's slice barrier for the whole multiply)
   if (whole->view.ngiant > 0)
     hipLaunchKernelGGL(k_sweep_unflag, dim3(grid_for(whole->view.ngiant)), dim3(kT), 0, s, (const int32_t*)whole->giant_row, whole->view.ngiant, flag.as<unsigned char>());
   hipLaunchKernelGGL(k_sweep_iota, dim3(grid_for(nrows)), dim3(kT), 0, s, iota.as<int32_t>(), nrows);
@@ -1010,119 +1160,181 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, const unsigned char* 
   GM_TRY_HIP(rocprim::select(nullptr, tb, iota.as<int32_t>(), flag.as<unsigned char>(), rows.as<int32_t>(), cnt.as<unsigned int>(), (size_t)nrows, s));
   if ((rc = tmp.alloc(tb + 256))) return rc;
   GM_TRY_HIP(rocprim::select(tmp.p, tb, iota.as<int32_t>(), flag.as<unsigned char>(), rows.as<int32_t>(), cnt.as<unsigned int>(), (size_t)nrows, s));
-  unsigned int nmed = 0;
-  GM_TRY_HIP(hipMemcpyAsync(&nmed, cnt.p, 4, hipMemcpyDeviceToHost, s));
+  unsigned int nswept = 0;
+  GM_TRY_HIP(hipMemcpyAsync(&nswept, cnt.p, 4, hipMemcpyDeviceToHost, s));
   GM_TRY_HIP(hipStreamSynchronize(s));
-  iota.free();
-  if (nmed == 0) return GM_OK;
-  // rank by length (descending), deal the ranks over the 256 workgroups
-  if ((rc = len_in.alloc((size_t)nmed * 4)) || (rc = len_out.alloc((size_t)nmed * 4)) || (rc = ranked.alloc((size_t)nmed * 4))) return rc;
-  hipLaunchKernelGGL(k_sweep_lens, dim3(grid_for((int)nmed)), dim3(kT), 0, s, (const int32_t*)rows.as<int32_t>(), (int)nmed, rowptr, len_in.as<uint32_t>());
+  iota.free(); flag.free();
+  if (nswept == 0) return GM_OK;
+  // rank by length (descending; stable: ties by row id), the long rows come first
+  if ((rc = len_in.alloc((size_t)nswept * 4)) || (rc = len_out.alloc((size_t)nswept * 4)) || (rc = ranked.alloc((size_t)nswept * 4))) return rc;
+  hipLaunchKernelGGL(k_sweep_lens, dim3(grid_for((int)nswept)), dim3(kT), 0, s, (const int32_t*)rows.as<int32_t>(), (int)nswept, rowptr, len_in.as<uint32_t>());
   tb = 0;
-  GM_TRY_HIP(rocprim::radix_sort_pairs_desc(nullptr, tb, len_in.as<uint32_t>(), len_out.as<uint32_t>(), rows.as<int32_t>(), ranked.as<int32_t>(), (size_t)nmed, 0, 32, s));
+  GM_TRY_HIP(rocprim::radix_sort_pairs_desc(nullptr, tb, len_in.as<uint32_t>(), len_out.as<uint32_t>(), rows.as<int32_t>(), ranked.as<int32_t>(), (size_t)nswept, 0, 32, s));
   if ((rc = tmp.alloc(tb + 256))) return rc;
-  GM_TRY_HIP(rocprim::radix_sort_pairs_desc(tmp.p, tb, len_in.as<uint32_t>(), len_out.as<uint32_t>(), rows.as<int32_t>(), ranked.as<int32_t>(), (size_t)nmed, 0, 32, s));
+  GM_TRY_HIP(rocprim::radix_sort_pairs_desc(tmp.p, tb, len_in.as<uint32_t>(), len_out.as<uint32_t>(), rows.as<int32_t>(), ranked.as<int32_t>(), (size_t)nswept, 0, 32, s));
   rows.free(); len_in.free();
-  const int per_wg = (int)((nmed + 255u) / 256u);
-  const int acc_rows = GM_SWEEP_ACC_ROWS;
-  const int nsets = (per_wg + acc_rows - 1) / acc_rows;
-  if (nsets > 16) return GM_OK;  // (the key below has 4 bits for it; 41 M medium rows)
+  const uint32_t long_limit = (uint32_t)(g_own_wave_row > 0 ? std::min(g_own_wave_row, 8191) : 4096);  // (13 bits for a group's width)
+  hipLaunchKernelGGL(k_sweep_count_above, dim3(1), dim3(1), 0, s, (const uint32_t*)len_out.as<uint32_t>(), (int)nswept, long_limit, cnt.as<unsigned int>());
+  unsigned int nlong = 0;
+  GM_TRY_HIP(hipMemcpyAsync(&nlong, cnt.p, 4, hipMemcpyDeviceToHost, s));
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  const unsigned int nmed = nswept - nlong;
+  const int per_wg_med = (int)((nmed + 255u) / 256u), per_wg_long = (int)((nlong + 255u) / 256u);
+  int nsets = std::max(1, std::max((per_wg_med + g_sweep_acc_limit - 1) / g_sweep_acc_limit, (per_wg_long + g_sweep_long_limit - 1) / g_sweep_long_limit));
+  if (nsets > 16) return GM_OK;  // (12 key bits for set * 256 + workgroup)
   // edge offsets of the ranked rows
   DevBuf l64, off;
-  if ((rc = l64.alloc((size_t)nmed * 8)) || (rc = off.alloc((size_t)nmed * 8))) return rc;
-  {
-    hipLaunchKernelGGL(k_sweep_widen, dim3(grid_for((int)nmed)), dim3(kT), 0, s, (const uint32_t*)len_out.as<uint32_t>(), (int)nmed, l64.as<unsigned long long>());
-    tb = 0;
-    GM_TRY_HIP(rocprim::exclusive_scan(nullptr, tb, l64.as<unsigned long long>(), off.as<unsigned long long>(), 0ull, (size_t)nmed, rocprim::plus<unsigned long long>(), s));
-    if ((rc = tmp.alloc(tb + 256))) return rc;
-    GM_TRY_HIP(rocprim::exclusive_scan(tmp.p, tb, l64.as<unsigned long long>(), off.as<unsigned long long>(), 0ull, (size_t)nmed, rocprim::plus<unsigned long long>(), s));
-  }
-  unsigned long long last_off = 0;
-  uint32_t last_len = 0;
-  GM_TRY_HIP(hipMemcpyAsync(&last_off, off.as<unsigned long long>() + (nmed - 1), 8, hipMemcpyDeviceToHost, s));
-  GM_TRY_HIP(hipMemcpyAsync(&last_len, len_out.as<uint32_t>() + (nmed - 1), 4, hipMemcpyDeviceToHost, s));
+  if ((rc = l64.alloc(((size_t)nswept + 1) * 8)) || (rc = off.alloc(((size_t)nswept + 1) * 8))) return rc;
+  GM_TRY_HIP(hipMemsetAsync(l64.p, 0, ((size_t)nswept + 1) * 8, s));
+  hipLaunchKernelGGL(k_sweep_widen, dim3(grid_for((int)nswept)), dim3(kT), 0, s, (const uint32_t*)len_out.as<uint32_t>(), (int)nswept, l64.as<unsigned long long>());
+  if ((rc = sweep_excl_scan(l64.as<unsigned long long>(), off.as<unsigned long long>(), (size_t)nswept + 1, s))) return rc;
+  unsigned long long tot_edges = 0, long_edges = 0;
+  GM_TRY_HIP(hipMemcpyAsync(&tot_edges, off.as<unsigned long long>() + nswept, 8, hipMemcpyDeviceToHost, s));
+  GM_TRY_HIP(hipMemcpyAsync(&long_edges, off.as<unsigned long long>() + nlong, 8, hipMemcpyDeviceToHost, s));
   GM_TRY_HIP(hipStreamSynchronize(s));
-  const int64_t nedges = (int64_t)(last_off + last_len);
   l64.free(); len_out.free();
-  if (nedges <= 0 || nedges >= ((int64_t)1 << 32)) return GM_OK;
-  DevBuf k_in, k_out, v_in, v_out;
-  if ((rc = k_in.alloc((size_t)nedges * 8)) || (rc = k_out.alloc((size_t)nedges * 8)) || (rc = v_in.alloc((size_t)nedges * 4)) || (rc = v_out.alloc((size_t)nedges * 4))) return rc;
+  const int64_t nedges_all = (int64_t)tot_edges, nedges_long = (int64_t)long_edges, nedges = nedges_all - nedges_long;
+  if (nedges_all <= 0 || nedges_all >= ((int64_t)1 << 32)) return GM_OK;
+  const size_t nvw = (size_t)nsets * 256;
+  const size_t nblk = nvw * (size_t)TS;
+  DevBuf k_in, k_out, v_in, v_out, rslot, lrslot;
+  if ((rc = k_in.alloc((size_t)nedges_all * 8)) || (rc = k_out.alloc((size_t)nedges_all * 8)) || (rc = v_in.alloc((size_t)nedges_all * 4)) ||
+      (rc = v_out.alloc((size_t)nedges_all * 4)) || (rc = rslot.alloc(nvw * GM_SWEEP_ACC_ROWS * 4)) || (rc = lrslot.alloc(nvw * GM_SWEEP_LONG_SLOTS * 4)))
+    return rc;
   SweepSlices sl;
   memset(&sl, 0, sizeof(sl));
   for (int t = 0; t <= TS; t++) sl.b[t] = g->slice_base[t];
-  DevBuf rslot;
-  if ((rc = rslot.alloc((size_t)nsets * 256 * (size_t)acc_rows * 4))) return rc;
-  GM_TRY_HIP(hipMemsetAsync(rslot.p, 0xff, (size_t)nsets * 256 * (size_t)acc_rows * 4, s));
-  hipLaunchKernelGGL(k_sweep_keys, dim3((nmed + (kT / 64) - 1) / (kT / 64)), dim3(kT), 0, s, (const int32_t*)ranked.as<int32_t>(), (int)nmed,
-                     (const unsigned long long*)off.as<unsigned long long>(), rowptr, colidx, sl, TS, acc_rows, k_in.as<unsigned long long>(), v_in.as<int32_t>(),
-                     rslot.as<int32_t>());
+  GM_TRY_HIP(hipMemsetAsync(rslot.p, 0xff, nvw * GM_SWEEP_ACC_ROWS * 4, s));
+  GM_TRY_HIP(hipMemsetAsync(lrslot.p, 0xff, nvw * GM_SWEEP_LONG_SLOTS * 4, s));
+  hipLaunchKernelGGL(k_sweep_keys, dim3((nswept + (kT / 64) - 1) / (kT / 64)), dim3(kT), 0, s, (const int32_t*)ranked.as<int32_t>(), (int)nswept, (int)nlong, nsets,
+                     (const unsigned long long*)off.as<unsigned long long>(), rowptr, colidx, sl, TS, k_in.as<unsigned long long>(), v_in.as<uint32_t>(),
+                     rslot.as<int32_t>(), lrslot.as<int32_t>());
   GM_TRY_HIP(hipGetLastError());
-  off.free();
-  tb = 0;  // stable: inside (workgroup, slice, row) the edges keep their ascending native column order
-  GM_TRY_HIP(rocprim::radix_sort_pairs(nullptr, tb, k_in.as<unsigned long long>(), k_out.as<unsigned long long>(), v_in.as<int32_t>(), v_out.as<int32_t>(), (size_t)nedges, 0, 34, s));
-  if ((rc = tmp.alloc(tb + 256))) return rc;
-  GM_TRY_HIP(rocprim::radix_sort_pairs(tmp.p, tb, k_in.as<unsigned long long>(), k_out.as<unsigned long long>(), v_in.as<int32_t>(), v_out.as<int32_t>(), (size_t)nedges, 0, 34, s));
-  GM_TRY_HIP(hipStreamSynchronize(s));
-  k_in.free(); v_in.free(); tmp.free();
-  // pieces
-  DevBuf head, pidx;
-  if ((rc = head.alloc((size_t)nedges * 4)) || (rc = pidx.alloc((size_t)nedges * 4))) return rc;
-  hipLaunchKernelGGL(k_sweep_heads, dim3(grid_for(nedges)), dim3(kT), 0, s, (const unsigned long long*)k_out.as<unsigned long long>(), nedges, head.as<uint32_t>());
-  tb = 0;
-  GM_TRY_HIP(rocprim::inclusive_scan(nullptr, tb, head.as<uint32_t>(), pidx.as<uint32_t>(), (size_t)nedges, rocprim::plus<uint32_t>(), s));
-  if ((rc = tmp.alloc(tb + 256))) return rc;
-  GM_TRY_HIP(rocprim::inclusive_scan(tmp.p, tb, head.as<uint32_t>(), pidx.as<uint32_t>(), (size_t)nedges, rocprim::plus<uint32_t>(), s));
-  uint32_t npieces = 0;
-  GM_TRY_HIP(hipMemcpyAsync(&npieces, pidx.as<uint32_t>() + (nedges - 1), 4, hipMemcpyDeviceToHost, s));
-  GM_TRY_HIP(hipStreamSynchronize(s));
-  const size_t nblk = (size_t)nsets * 256 * (size_t)TS;
-  DevBuf pstart, prow, bfirst;
-  if ((rc = pstart.alloc(((size_t)npieces + 1) * 4)) || (rc = prow.alloc(((size_t)npieces + 1) * 2)) || (rc = bfirst.alloc((nblk + 1) * 4))) return rc;
-  GM_TRY_HIP(hipMemsetAsync(bfirst.p, 0xff, (nblk + 1) * 4, s));
-  hipLaunchKernelGGL(k_sweep_pieces, dim3(grid_for(nedges)), dim3(kT), 0, s, (const unsigned long long*)k_out.as<unsigned long long>(), (const uint32_t*)head.as<uint32_t>(),
-                     (const uint32_t*)pidx.as<uint32_t>(), nedges, pstart.as<uint32_t>(), prow.as<uint16_t>(), bfirst.as<int32_t>(), TS);
-  const uint32_t ne32 = (uint32_t)nedges;
-  GM_TRY_HIP(hipMemcpyAsync(pstart.as<uint32_t>() + npieces, &ne32, 4, hipMemcpyHostToDevice, s));
-  {
-    std::vector<int32_t> h(nblk + 1);
-    GM_TRY_HIP(hipMemcpyAsync(h.data(), bfirst.p, (nblk + 1) * 4, hipMemcpyDeviceToHost, s));
-    GM_TRY_HIP(hipStreamSynchronize(s));
-    h[nblk] = (int32_t)npieces;
-    for (int64_t b = (int64_t)nblk - 1; b >= 0; b--) if (h[b] < 0) h[b] = h[b + 1];
-    GM_TRY_HIP(hipMemcpyAsync(bfirst.p, h.data(), (nblk + 1) * 4, hipMemcpyHostToDevice, s));
-    GM_TRY_HIP(hipStreamSynchronize(s));
-  }
-  // what is left of every tile's one-wave-per-row list: the pieces of rows that are NOT swept (giant rows of the whole graph
-  // whose piece in this tile is below the tile's giant limit); kept in the tile views' umid_row / numid fields
-  for (int t = 0; t < g->ntiles; t++) {
-    CsrOwned& Ct = g->out_tiles[t];
-    const int nl = Ct.view.nmid_long < Ct.view.nmid ? Ct.view.nmid_long : Ct.view.nmid;
-    Ct.view.umid_row = nullptr; Ct.view.numid = 0; Ct.view.numid_long = 0;
-    if (nl <= 0) continue;
-    DevBuf keep, outl;
-    if ((rc = keep.alloc((size_t)nl)) || (rc = outl.alloc((size_t)nl * 4))) return rc;
-    hipLaunchKernelGGL(k_sweep_unswept, dim3(grid_for(nl)), dim3(kT), 0, s, (const int32_t*)Ct.mid_row, nl, (const unsigned char*)flag.as<unsigned char>(), keep.as<unsigned char>());
-    tb = 0;
-    GM_TRY_HIP(rocprim::select(nullptr, tb, (const int32_t*)Ct.mid_row, keep.as<unsigned char>(), outl.as<int32_t>(), cnt.as<unsigned int>(), (size_t)nl, s));
-    if ((rc = tmp.alloc(tb + 256))) return rc;
-    GM_TRY_HIP(rocprim::select(tmp.p, tb, (const int32_t*)Ct.mid_row, keep.as<unsigned char>(), outl.as<int32_t>(), cnt.as<unsigned int>(), (size_t)nl, s));
-    unsigned int nk = 0;
-    GM_TRY_HIP(hipMemcpyAsync(&nk, cnt.p, 4, hipMemcpyDeviceToHost, s));
-    GM_TRY_HIP(hipStreamSynchronize(s));
-    if (Ct.umid_row) (void)hipFree(Ct.umid_row);
-    Ct.umid_row = (int32_t*)outl.release();
-    Ct.view.umid_row = Ct.umid_row;
-    Ct.view.numid = (int32_t)nk;
-    Ct.view.numid_long = (int32_t)nk;
-  }
+  off.free(); ranked.free();
+  // stable sorts: inside (set, workgroup, slice, slot) the edges keep their ascending native column order
+  const int key_bits = 23 + bits_for((uint32_t)nvw);
+  if (nedges_long > 0 && (rc = sweep_sort_pairs(k_in.as<unsigned long long>(), k_out.as<unsigned long long>(), v_in.as<uint32_t>(), v_out.as<uint32_t>(), (size_t)nedges_long, key_bits, s))) return rc;
+  if (nedges > 0 && (rc = sweep_sort_pairs(k_in.as<unsigned long long>() + nedges_long, k_out.as<unsigned long long>() + nedges_long, v_in.as<uint32_t>() + nedges_long,
+                                            v_out.as<uint32_t>() + nedges_long, (size_t)nedges, key_bits, s)))
+    return rc;
+  k_in.free(); v_in.free();
   gm_sweep_t& S = g->sweep;
-  S.nrows = (int32_t)nmed; S.nsets = nsets; S.nslices = TS; S.acc_rows = acc_rows; S.nedges = nedges; S.npieces = (int64_t)npieces;
-  S.colidx = (const int32_t*)v_out.release();
-  S.piece_start = (const uint32_t*)pstart.release();
-  S.piece_row = (const uint16_t*)prow.release();
-  S.blk_first = (const int32_t*)bfirst.release();
-  S.row_of_rank = (const int32_t*)rslot.release();
-  S.slice_base = g->d_slice_base;
+  const bool keep_pos = vals != nullptr;
+  // ---- the long rows
+  DevBuf lps, lcol, lval, lpos;
+  unsigned int max_block = 0;
+  {
+    const size_t nent = nblk * GM_SWEEP_LONG_SLOTS;
+    if ((rc = lps.alloc((nent + 1) * 4)) || (rc = lcol.alloc(((size_t)nedges_long + 64) * 4))) return rc;
+    if (vals && (rc = lval.alloc(((size_t)nedges_long + 64) * 4))) return rc;
+    hipLaunchKernelGGL(k_sweep_long_starts, dim3(grid_for((int64_t)nent + 1)), dim3(kT), 0, s, (const unsigned long long*)k_out.as<unsigned long long>(), nedges_long, TS, nent,
+                       lps.as<uint32_t>());
+    if (nedges_long > 0)
+      hipLaunchKernelGGL(k_sweep_long_fill, dim3(grid_for(nedges_long)), dim3(kT), 0, s, (const uint32_t*)v_out.as<uint32_t>(), nedges_long, colidx, vals, lcol.as<uint32_t>(),
+                         vals ? lval.as<uint32_t>() : (uint32_t*)nullptr);
+    GM_TRY_HIP(hipMemsetAsync(cnt.p, 0, 4, s));
+    hipLaunchKernelGGL(k_sweep_long_max, dim3(grid_for((int64_t)nblk)), dim3(kT), 0, s, (const uint32_t*)lps.as<uint32_t>(), nblk, cnt.as<unsigned int>());
+    GM_TRY_HIP(hipMemcpyAsync(&max_block, cnt.p, 4, hipMemcpyDeviceToHost, s));
+    if (keep_pos && nedges_long > 0) {
+      if ((rc = lpos.alloc((size_t)nedges_long * 4))) return rc;
+      GM_TRY_HIP(hipMemcpyAsync(lpos.p, v_out.p, (size_t)nedges_long * 4, hipMemcpyDeviceToDevice, s));
+    }
+    GM_TRY_HIP(hipStreamSynchronize(s));
+  }
+  // ---- the medium rows: pieces, groups of 64 pieces of similar length, transposed entries
+  DevBuf scol, sval, spos, gbase, wrow, wfirst;
+  uint32_t ngroups = 0;
+  unsigned long long nentries = 0;
+  if (nedges > 0) {
+    const unsigned long long* mkey = k_out.as<unsigned long long>() + nedges_long;
+    const uint32_t* mpos = v_out.as<uint32_t>() + nedges_long;
+    DevBuf head, pidx;
+    if ((rc = head.alloc((size_t)nedges * 4)) || (rc = pidx.alloc((size_t)nedges * 4))) return rc;
+    hipLaunchKernelGGL(k_sweep_heads, dim3(grid_for(nedges)), dim3(kT), 0, s, mkey, nedges, head.as<uint32_t>());
+    tb = 0;
+    GM_TRY_HIP(rocprim::inclusive_scan(nullptr, tb, head.as<uint32_t>(), pidx.as<uint32_t>(), (size_t)nedges, rocprim::plus<uint32_t>(), s));
+    if ((rc = tmp.alloc(tb + 256))) return rc;
+    GM_TRY_HIP(rocprim::inclusive_scan(tmp.p, tb, head.as<uint32_t>(), pidx.as<uint32_t>(), (size_t)nedges, rocprim::plus<uint32_t>(), s));
+    uint32_t npieces = 0;
+    GM_TRY_HIP(hipMemcpyAsync(&npieces, pidx.as<uint32_t>() + (nedges - 1), 4, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    DevBuf pstart, pslot16, pblk, bfirst, rowmin;
+    if ((rc = pstart.alloc(((size_t)npieces + 1) * 4)) || (rc = pslot16.alloc(((size_t)npieces + 1) * 2)) || (rc = pblk.alloc(((size_t)npieces + 1) * 4)) ||
+        (rc = bfirst.alloc((nblk + 1) * 4)) || (rc = rowmin.alloc(nvw * GM_SWEEP_ACC_ROWS * 4)))
+      return rc;
+    GM_TRY_HIP(hipMemsetAsync(bfirst.p, 0xff, (nblk + 1) * 4, s));
+    GM_TRY_HIP(hipMemsetAsync(rowmin.p, 0x7f, nvw * GM_SWEEP_ACC_ROWS * 4, s));
+    hipLaunchKernelGGL(k_sweep_pieces, dim3(grid_for(nedges)), dim3(kT), 0, s, mkey, (const uint32_t*)head.as<uint32_t>(), (const uint32_t*)pidx.as<uint32_t>(), nedges,
+                       pstart.as<uint32_t>(), pslot16.as<uint16_t>(), pblk.as<uint32_t>(), bfirst.as<int32_t>(), TS, rowmin.as<int>());
+    const uint32_t ne32 = (uint32_t)nedges;
+    GM_TRY_HIP(hipMemcpyAsync(pstart.as<uint32_t>() + npieces, &ne32, 4, hipMemcpyHostToDevice, s));
+    {
+      std::vector<int32_t> h(nblk + 1);
+      GM_TRY_HIP(hipMemcpyAsync(h.data(), bfirst.p, (nblk + 1) * 4, hipMemcpyDeviceToHost, s));
+      GM_TRY_HIP(hipStreamSynchronize(s));
+      h[nblk] = (int32_t)npieces;
+      for (int64_t b = (int64_t)nblk - 1; b >= 0; b--) if (h[b] < 0) h[b] = h[b + 1];
+      GM_TRY_HIP(hipMemcpyAsync(bfirst.p, h.data(), (nblk + 1) * 4, hipMemcpyHostToDevice, s));
+      GM_TRY_HIP(hipStreamSynchronize(s));
+    }
+    head.free(); pidx.free();
+    // the pieces of a block, longest first (stable: equal lengths keep their slot order)
+    DevBuf pk_in, pk_out, pid_in, sp;
+    if ((rc = pk_in.alloc((size_t)npieces * 8)) || (rc = pk_out.alloc((size_t)npieces * 8)) || (rc = pid_in.alloc((size_t)npieces * 4)) || (rc = sp.alloc((size_t)npieces * 4))) return rc;
+    hipLaunchKernelGGL(k_sweep_piece_keys, dim3(grid_for((int64_t)npieces)), dim3(kT), 0, s, (const uint32_t*)pstart.as<uint32_t>(), (const uint32_t*)pblk.as<uint32_t>(), npieces,
+                       pk_in.as<unsigned long long>(), pid_in.as<uint32_t>());
+    if ((rc = sweep_sort_pairs(pk_in.as<unsigned long long>(), pk_out.as<unsigned long long>(), pid_in.as<uint32_t>(), sp.as<uint32_t>(), (size_t)npieces,
+                               16 + bits_for((uint32_t)nblk), s)))
+      return rc;
+    pk_in.free(); pk_out.free(); pid_in.free(); pblk.free();
+    DevBuf ng, grp_first;
+    if ((rc = ng.alloc((nblk + 1) * 4)) || (rc = grp_first.alloc((nblk + 1) * 4))) return rc;
+    GM_TRY_HIP(hipMemsetAsync(ng.p, 0, (nblk + 1) * 4, s));
+    hipLaunchKernelGGL(k_sweep_block_groups, dim3(grid_for((int64_t)nblk)), dim3(kT), 0, s, (const int32_t*)bfirst.as<int32_t>(), (int)nblk, ng.as<uint32_t>());
+    if ((rc = sweep_excl_scan(ng.as<uint32_t>(), grp_first.as<uint32_t>(), nblk + 1, s))) return rc;
+    GM_TRY_HIP(hipMemcpyAsync(&ngroups, grp_first.as<uint32_t>() + nblk, 4, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    DevBuf gsize, gb64, gq0, gblk;
+    if ((rc = gsize.alloc(((size_t)ngroups + 1) * 8)) || (rc = gb64.alloc(((size_t)ngroups + 1) * 8)) || (rc = gq0.alloc(((size_t)ngroups + 1) * 4)) ||
+        (rc = gblk.alloc(((size_t)ngroups + 1) * 4)) || (rc = gbase.alloc(((size_t)ngroups + 1) * 4)))
+      return rc;
+    GM_TRY_HIP(hipMemsetAsync(gsize.p, 0, ((size_t)ngroups + 1) * 8, s));
+    hipLaunchKernelGGL(k_sweep_group_sizes, dim3((unsigned)nblk), dim3(64), 0, s, (const int32_t*)bfirst.as<int32_t>(), (const uint32_t*)grp_first.as<uint32_t>(),
+                       (const uint32_t*)sp.as<uint32_t>(), (const uint32_t*)pstart.as<uint32_t>(), gsize.as<unsigned long long>(), gq0.as<uint32_t>(), gblk.as<uint32_t>());
+    if ((rc = sweep_excl_scan(gsize.as<unsigned long long>(), gb64.as<unsigned long long>(), (size_t)ngroups + 1, s))) return rc;
+    GM_TRY_HIP(hipMemcpyAsync(&nentries, gb64.as<unsigned long long>() + ngroups, 8, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    if (nentries >= (1ull << 32)) return GM_OK;  // (32-bit entry positions; the graph keeps its tile passes)
+    hipLaunchKernelGGL(k_sweep_narrow, dim3(grid_for((int64_t)ngroups + 1)), dim3(kT), 0, s, (const unsigned long long*)gb64.as<unsigned long long>(), (size_t)ngroups + 1,
+                       gbase.as<uint32_t>());
+    gsize.free(); gb64.free();
+    if ((rc = scol.alloc(((size_t)nentries + 64 * 64) * 4)) || (rc = wrow.alloc(nblk * 17 * 4)) || (rc = wfirst.alloc(nblk * 17 * 4))) return rc;
+    if (vals && ((rc = sval.alloc(((size_t)nentries + 64 * 64) * 4)) || (rc = spos.alloc(((size_t)nentries + 64) * 4)))) return rc;
+    hipLaunchKernelGGL(k_sweep_fill, dim3(65536), dim3(kT), 0, s, ngroups, (const uint32_t*)gbase.as<uint32_t>(), (const uint32_t*)gq0.as<uint32_t>(),
+                       (const uint32_t*)gblk.as<uint32_t>(), (const int32_t*)bfirst.as<int32_t>(), (const uint32_t*)sp.as<uint32_t>(), (const uint32_t*)pstart.as<uint32_t>(),
+                       (const uint16_t*)pslot16.as<uint16_t>(), mpos, colidx, vals, sl, TS, (const int*)rowmin.as<int>(), scol.as<uint32_t>(),
+                       vals ? sval.as<uint32_t>() : (uint32_t*)nullptr, vals ? spos.as<uint32_t>() : (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_sweep_wave_ranges, dim3((unsigned)((nblk + 63) / 64)), dim3(64), 0, s, (const uint32_t*)grp_first.as<uint32_t>(), (int)nblk,
+                       (const uint32_t*)gbase.as<uint32_t>(), wfirst.as<uint32_t>(), wrow.as<uint32_t>(), nlong > 0 ? 50 : 100);
+    GM_TRY_HIP(hipGetLastError());
+    GM_TRY_HIP(hipStreamSynchronize(s));
+  } else {
+    // no medium row: empty blocks for every wave
+    if ((rc = gbase.alloc(64)) || (rc = wrow.alloc(nblk * 17 * 4)) || (rc = wfirst.alloc(nblk * 17 * 4)) || (rc = scol.alloc(64 * 64 * 4))) return rc;
+    GM_TRY_HIP(hipMemsetAsync(gbase.p, 0, 64, s));
+    GM_TRY_HIP(hipMemsetAsync(wfirst.p, 0, nblk * 17 * 4, s));
+    GM_TRY_HIP(hipMemsetAsync(wrow.p, 0, nblk * 17 * 4, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+  }
+  S.nrows = (int32_t)nswept; S.nrows_long = (int32_t)nlong; S.nsets = nsets; S.nslices = TS;
+  S.acc_rows = GM_SWEEP_ACC_ROWS; S.long_slots = GM_SWEEP_LONG_SLOTS; S.max_long_block = (int32_t)max_block; S.val_bytes = vals ? 4 : 0;
+  S.short_row = whole->view.short_row; S.giant_row = 0;
+  S.nedges = nedges; S.nedges_long = nedges_long; S.nentries = (int64_t)nentries; S.ngroups = (int64_t)ngroups;
+  S.scol = (const uint32_t*)scol.release(); S.sval = (const uint32_t*)sval.release(); S.gbase = (const uint32_t*)gbase.release();
+  S.wrow = (const uint32_t*)wrow.release(); S.wfirst = (const uint32_t*)wfirst.release(); S.row_of_slot = (const int32_t*)rslot.release();
+  S.lcol = (const uint32_t*)lcol.release(); S.lval = (const uint32_t*)lval.release(); S.lps = (const uint32_t*)lps.release();
+  S.lrow_of_slot = (const int32_t*)lrslot.release(); S.slice_base = g->d_slice_base;
+  S.src_pos = (const uint32_t*)spos.release(); S.lsrc_pos = (const uint32_t*)lpos.release();
   return GM_OK;
 }
 
@@ -1200,7 +1412,7 @@ static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t*
     }
   }
   GM_TRY_HIP(hipStreamSynchronize(s));
-  if (g_sweep_slices != 0 && (rc = build_sweep(g, whole, own_wave, s))) return rc;
+  if (g_sweep_slices != 0 && (rc = build_sweep(g, whole, s))) return rc;
   return GM_OK;
 }
 
@@ -1244,6 +1456,7 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
   // column tiles: contiguous NATIVE ranges; the device order becomes (tile, degree rank inside the tile),
   // vertices without edges last.  A stable sort of the ranked list by tile does it.
   int T = D.col_tiles;
+  const double mib_live = (double)nz * 4.0 / 1048576.0;
   if (T == 0) T = g_col_tiles;
   if (T == 0) { const char* e = getenv("GRAPHMAT_COL_TILES"); if (e) T = atoi(e); }
   if (T == 0) {
@@ -1267,7 +1480,9 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     // its rows above 64 edges go through the tiles as before: the old rule stays for it, from 100 MiB on.  The reference's unchanged
     // PageRank.cpp -- int edge values, ordered fold -- by tile count: RMAT-24 1 / 2 / 3 / 5: 149 / 161 / 162 / 165 ms; RMAT-25 1 / 2 / 3 / 5:
     // 228 / 308 / 283 / 281 ms; RMAT-26 1 / 3 / 8: 641 / 582 / 506 ms.)
-    if (g_sweep_slices != 0 && !keeps_values) T = mib < 25.0 ? 1 : mib < 50.0 ? 2 : mib < 180.0 ? 3 : (int)(mib / 40.0 + 0.5);
+    // (round 5: the sweep -- kernels.hpp: k_spmv_sell -- also takes the rows of more than own_wave_row edges and adjacencies that keep
+    // 4-byte edge values; the tiles are only walked by programs the sweep does not cover, and get the same count)
+    if (g_sweep_slices != 0 && (!keeps_values || D.val_bytes == 4)) T = mib < 25.0 ? 1 : mib < 50.0 ? 2 : mib < 180.0 ? 3 : (int)(mib / 40.0 + 0.5);
     else if (keeps_values && mib < 100.0) T = 1;
   }
   if (T < 1 || G > 1 || nz < 2) T = 1;
@@ -1280,7 +1495,7 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     DevBuf cnt, w, wpre, tk_in, tk_out, order2, bnd;
     if ((rc = cnt.alloc((size_t)nv * 4)) || (rc = w.alloc((size_t)(nv + 1) * 8)) || (rc = wpre.alloc((size_t)(nv + 1) * 8)) ||
         (rc = tk_in.alloc((size_t)nv)) || (rc = tk_out.alloc((size_t)nv)) || (rc = order2.alloc((size_t)nv * 4)) ||
-        (rc = bnd.alloc((size_t)(GM_MAX_TILES + 2) * 8)))
+        (rc = bnd.alloc((size_t)(GM_MAX_SLICES + 2) * 8)))
       return rc;
     GM_TRY_HIP(hipMemsetAsync(cnt.p, 0, (size_t)nv * 4, s));
     GM_TRY_HIP(hipMemsetAsync(w.p, 0, (size_t)(nv + 1) * 8, s));
@@ -1301,8 +1516,12 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     unsigned long long total = 0;
     GM_TRY_HIP(hipMemcpyAsync(&total, wpre.as<unsigned long long>() + nv, 8, hipMemcpyDeviceToHost, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
-    // (gm_graph_sweep: the order is cut k times finer than the tiles, a tile = k consecutive slices)
-    const int sub = g_sweep_slices != 0 ? std::max(1, GM_MAX_TILES / T) : 1;
+    // (gm_graph_sweep: the order is cut k times finer than the tiles, a tile = k consecutive slices; about 1.3 MiB of live
+    // messages per slice -- measured with the sweep's prototype, tools/sell_bench.hip: RMAT-26 (125 MiB) 64 / 80 / 96 / 128 slices
+    // 2.17 / 2.09 / 2.05 / 2.15 ms for the swept rows, RMAT-25 (65 MiB) 32 / 64: 1.02 / 0.94 ms, RMAT-24 (34 MiB) 16 / 32 / 64: 0.79 / 0.80 / 0.92)
+    int want_slices = g_sweep_slices >= 8 ? g_sweep_slices : (int)(mib_live / 1.3 + 0.5);
+    want_slices = std::max(16, std::min(GM_MAX_SLICES, want_slices));
+    const int sub = g_sweep_slices != 0 ? std::max(1, std::min(GM_MAX_SLICES / T, (want_slices + T / 2) / T)) : 1;
     const int TS = T * sub;
     hipLaunchKernelGGL(k_tile_of_ranked, dim3(grid_for(nv)), dim3(kT), 0, s, order.as<int32_t>(), nv, deg.as<uint32_t>(),
                        wpre.as<unsigned long long>(), total, TS, tk_in.as<uint8_t>());
@@ -1314,8 +1533,8 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
                                          order2.as<int32_t>(), (size_t)nv, 0u, 8u, s));
     GM_TRY_HIP(hipMemcpyAsync(order.p, order2.p, (size_t)nv * 4, hipMemcpyDeviceToDevice, s));
     // where every tile starts in the new order (vertices without edges carry key 255 and sort to the end)
-    hipLaunchKernelGGL(k_tile_bounds, dim3(1), dim3(128), 0, s, (const uint8_t*)tk_out.p, (int64_t)nv, TS, bnd.as<int64_t>());
-    int64_t hb[GM_MAX_TILES + 2];
+    hipLaunchKernelGGL(k_tile_bounds, dim3(1), dim3(256), 0, s, (const uint8_t*)tk_out.p, (int64_t)nv, TS, bnd.as<int64_t>());
+    int64_t hb[GM_MAX_SLICES + 2];
     GM_TRY_HIP(hipMemcpyAsync(hb, bnd.p, (size_t)(TS + 1) * 8, hipMemcpyDeviceToHost, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
     for (int t = 0; t <= T; t++) g->tile_base[t] = (int32_t)hb[t * sub];
@@ -1801,8 +2020,18 @@ int gm_graph_set_vals(gm_graph_t* g, int direction, const void* h_vals) {
 
 int gm_graph_sync_tile_vals(gm_graph_t* g, gm_stream_t stream) {
   if (!g) { gm::set_error("gm_graph_sync_tile_vals: null graph"); return GM_ERR_INVALID; }
-  if (g->ntiles <= 1 || !g->out_tiles || !g->out.present || !g->out.vals) return GM_OK;
+  if (!g->out.present || !g->out.vals) return GM_OK;
   hipStream_t s = (hipStream_t)stream;
+  {  // the sweep's copies of the values (gm_sweep_t.sval / lval), through the CSR positions its entries came from
+    const gm_sweep_t& S = g->sweep;
+    if (S.nrows > 0 && S.val_bytes == 4 && S.sval && S.src_pos && S.nentries > 0)
+      hipLaunchKernelGGL(gm::k_sweep_sync_vals, dim3(gm::grid_for(S.nentries)), dim3(gm::kT), 0, s, S.src_pos, (size_t)S.nentries, (const uint32_t*)g->out.vals,
+                         const_cast<uint32_t*>(S.sval));
+    if (S.nrows > 0 && S.val_bytes == 4 && S.lval && S.lsrc_pos && S.nedges_long > 0)
+      hipLaunchKernelGGL(gm::k_sweep_sync_vals, dim3(gm::grid_for(S.nedges_long)), dim3(gm::kT), 0, s, S.lsrc_pos, (size_t)S.nedges_long, (const uint32_t*)g->out.vals,
+                         const_cast<uint32_t*>(S.lval));
+  }
+  if (g->ntiles <= 1 || !g->out_tiles) { GM_TRY_HIP(hipGetLastError()); GM_TRY_HIP(hipStreamSynchronize(s)); return GM_OK; }
   const int nrows = g->out.view.nrows, vb = g->out.view.val_bytes;
   gm::DevBuf done;
   int rc;

@@ -92,7 +92,7 @@ struct gm_graph {
   uint32_t** out_tile_prev;     // [ntiles] presence bits of the rows with an edge in an earlier tile
   // finer cut of the device order (gm_graph_sweep): nslices = ntiles * k slices, slice_base[nslices] = nlive; 0: none
   int nslices;
-  int32_t slice_base[GM_MAX_TILES + 2];
+  int32_t slice_base[GM_MAX_SLICES + 2];
   gm_sweep_t sweep;             // device arrays owned by the graph (nrows = 0: not built)
   int32_t* d_slice_base;
   // native RCCL exchange (gm_dist.hip): state behind xfn/xctx when gm_graph_use_rccl installed it

@@ -20,7 +20,7 @@
 
 namespace gm {
 
-extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance, g_own_wave_row, g_sort_tile_lists, g_sweep_slices;
+extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance, g_own_wave_row, g_sort_tile_lists, g_sweep_slices, g_sweep_acc_limit, g_sweep_long_limit;
 static int g_force_ordered = 0;
 
 // ---------------- PageRank (reference: src/PageRank.cpp:34-112) ----------------------------
@@ -745,7 +745,7 @@ static const EngineKey kEngineKeys[] = {
   {"ablate_cold_short", 14, 0, 0, 0x7fffffff},
   {"two_stage_head_permille", 15, 900, 100, 990},
   {"giant_stream", 16, 1, 0, 2},
-  {"sweep_form", 17, 4, 0, 11},
+  {"sweep_form", 17, 0, 0, 7},
 };
 static_assert(offsetof(gm_engine_options_t, sweep_form) == 17 * sizeof(int32_t), "kEngineKeys follows the field order");
 static bool engine_value_ok(const EngineKey& k, int v) {
@@ -825,6 +825,8 @@ int gm_reset_options(void) {
   gm::g_own_wave_row = 4096;
   gm::g_sort_tile_lists = 1;
   gm::g_sweep_slices = 1;
+  gm::g_sweep_acc_limit = GM_SWEEP_ACC_ROWS;
+  gm::g_sweep_long_limit = GM_SWEEP_LONG_SLOTS;
   gm::g_col_tiles = 0;
   return GM_OK;
 }
@@ -847,7 +849,10 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "col_tiles") && value >= 0 && value <= GM_MAX_TILES) { gm::g_col_tiles = value; return GM_OK; }
   if (key && !strcmp(key, "own_wave_row") && value >= 0) { gm::g_own_wave_row = value; return GM_OK; }
   if (key && !strcmp(key, "sort_tile_lists") && (value == 0 || value == 1)) { gm::g_sort_tile_lists = value; return GM_OK; }
-  if (key && !strcmp(key, "sweep_slices") && value >= 0 && value <= 2) { gm::g_sweep_slices = value; return GM_OK; }
+  // (0: no slices, no sweep; 1: automatic slice count; 8 .. GM_MAX_SLICES: about that many slices)
+  if (key && !strcmp(key, "sweep_slices") && (value == 0 || value == 1 || (value >= 8 && value <= GM_MAX_SLICES))) { gm::g_sweep_slices = value; return GM_OK; }
+  if (key && !strcmp(key, "sweep_acc_rows") && value >= 1 && value <= GM_SWEEP_ACC_ROWS) { gm::g_sweep_acc_limit = value; return GM_OK; }
+  if (key && !strcmp(key, "sweep_long_slots") && value >= 1 && value <= GM_SWEEP_LONG_SLOTS) { gm::g_sweep_long_limit = value; return GM_OK; }
   gm::set_error("gm_set_option: unknown option");
   return GM_ERR_INVALID;
 }

@@ -867,12 +867,6 @@ class Run {
     tick("first frontier counted", (int)frontier_v);
     if (!(opt.debug_flags & dev::DBG_NO_OVERLAP)) {
       aux.attach(res_stream, res_fork, res_join);
-      void *gst = nullptr, *gjn = nullptr;
-      gm_sweep_t sw0;
-      if (opt.giant_stream != 0 && gm_graph_sweep(g, &sw0) == GM_OK && sw0.nrows > 0 && gm_graph_giant_stream(g, &gst, &gjn) == GM_OK) {
-        aux.gs = (hipStream_t)gst;
-        aux.gjoin = (hipEvent_t)gjn;
-      }
     }
     // row-filter bits (program_row_filter): one pass over the vertex properties now, kept current by k_apply
     if constexpr (program_row_filter<P>::enabled) {
@@ -1169,6 +1163,91 @@ class Run {
     launch_spmv_vp<P, T, U, V, E>(use_vp, launch_ctx(), pa, A, xq, xb, (const V*)d_vp, y, yb_write, acc_flags, rk, rowfilter);
   }
 
+  // Can this run's pull multiply of the OUT adjacency take the row-stationary sweep (graphmat_hip.h: gm_sweep_t; kernels.hpp:
+  // k_spmv_sell)?  Every x entry present, 2-operand program, 4-byte messages and reductions, edge values absent or 4 bytes and
+  // carried by the structure, no row filter, nothing accumulated from an earlier pass; the structure must hold exactly the rows
+  // the whole-graph CSR's short-row pass and giant passes leave out.
+  bool sweep_usable(int acc, gm_sweep_t* sw) {
+    if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
+      if (aux.s == nullptr || use_vp || xq == nullptr || xb != nullptr || d_want != nullptr || program_row_filter<P>::enabled || (acc & dev::ACC_READ_PREV)) return false;
+      if (!(rk == REDUCE_ORDERED || rk == REDUCE_F32_ADD || rk == REDUCE_COMMUTATIVE)) return false;
+      if (opt.debug_flags & (dev::DBG_NO_TILES | dev::DBG_NO_OVERLAP)) return false;
+      if (gm_graph_sweep(g, sw) != GM_OK || sw->nrows <= 0 || sw->acc_rows != GM_SWEEP_ACC_ROWS || sw->long_slots != GM_SWEEP_LONG_SLOTS) return false;
+      if (sw->short_row != Aout.short_row) return false;
+      if (Aout.vals != nullptr && !(sw->val_bytes == 4 && sizeof(E) == 4 && std::is_trivially_copyable<E>::value)) return false;
+      return true;
+    } else {
+      (void)acc; (void)sw;
+      return false;
+    }
+  }
+
+  // The OUT adjacency through the sweep: the giant rows' passes (products spread over the chip, then the exact replay or the
+  // ordered fold: a chain of small latency-bound launches) on the auxiliary stream from the moment x is complete, the short
+  // rows (row-blocks of the whole-graph CSR) and the sweep's launches on the main stream; joined before apply.  sweep_form:
+  // 0 = short rows in front of the sweep, 1 = on the auxiliary stream behind the giant passes (next to the sweep), 2 = behind
+  // the sweep.  The three row sets are disjoint, so no two kernels touch the same y entry.
+  void multiply_out_swept(const dev::ProgArg<P>& pa, int acc, const gm_sweep_t& sw) {
+    if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
+      const Launch L = launch_ctx();
+      aux.keep = true;
+      aux.pending = aux.giant_pending = aux.use_gs = false;
+      GM_HIP_OK(hipEventRecord(aux.fork, s));
+      GM_HIP_OK(hipStreamWaitEvent(aux.s, aux.fork, 0));
+      aux.forked = true;
+      if (Aout.ngiant > 0) {
+        gm_csr_t Ag = Aout;
+        Ag.nblk = 0; Ag.nmid = 0; Ag.nmid_long = 0;
+        launch_spmv_vp<P, T, U, V, E>(use_vp, L, pa, Ag, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
+      }
+      gm_csr_t As = Aout;  // the short rows
+      As.nmid = 0; As.nmid_long = 0; As.ngiant = 0; As.ngchunk = 0;
+      Launch La = L;
+      La.aux = nullptr;
+      La.tiled_untiled_pass = true;
+      const int where = opt.sweep_form & 3;
+      if (where == 1) { La.s = aux.s; La.timer = nullptr; }
+      auto short_rows = [&]() {
+        if (As.nblk <= 0) return;
+        launch_spmv_vp<P, T, U, V, E>(use_vp, La, pa, As, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
+        if (where == 1) { GM_HIP_OK(hipEventRecord(aux.join, aux.s)); aux.pending = true; }
+      };
+      if (where != 2) short_rows();
+      // the pool of LDS words is split between the slice's hot entries and the long rows' stage: a stage that takes the
+      // largest block in one round where that leaves most of the pool to the hot set
+      int stage = 64;
+      if (sw.nrows_long > 0) {
+        stage = (sw.max_long_block + 63) / 64 * 64;
+        if (stage > GM_SWEEP_MAX_STAGE) stage = GM_SWEEP_MAX_STAGE;
+        if (stage < 1024) stage = 1024;
+        if (opt.sweep_form & 4) stage = 1024;  // (tests: blocks staged in several rounds)
+      }
+      for (int set = 0; set < sw.nsets; set++) {
+        bool with_vals = false;
+        if constexpr (sizeof(E) == 4 && std::is_trivially_copyable<E>::value) {
+          if (Aout.vals != nullptr) {
+            hipLaunchKernelGGL((dev::k_spmv_sell<P, T, U, V, E, true>), dim3(256), dim3(1024), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base, sw.scol,
+                               sw.sval, sw.wrow, sw.row_of_slot, sw.lcol, sw.lval, sw.lps, sw.lrow_of_slot, xq, y);
+            with_vals = true;
+          }
+        }
+        if (!with_vals)
+          hipLaunchKernelGGL((dev::k_spmv_sell<P, T, U, V, E, false>), dim3(256), dim3(1024), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base, sw.scol,
+                             (const uint32_t*)nullptr, sw.wrow, sw.row_of_slot, sw.lcol, (const uint32_t*)nullptr, sw.lps, sw.lrow_of_slot, xq, y);
+      }
+      st.spmv_launches += sw.nsets;
+      timer.mark(TAG_WAVE);
+      if (where == 2) short_rows();
+      if (aux.pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
+      if (aux.giant_pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.gjoin, 0));
+      aux.keep = aux.forked = aux.pending = aux.giant_pending = aux.use_gs = false;
+      timer.mark(TAG_WAVE);  // (the multiply ends when the auxiliary stream has joined: the wait counts as multiply time)
+      check_probed(pa, Aout, Aout.rowbits, nullptr, acc, ybits, true);
+    } else {
+      (void)pa; (void)acc; (void)sw;
+    }
+  }
+
   // the OUT adjacency tile by tile on two streams (graphmat_hip.h: gm_graph_tile).  With every x entry present and an
   // ordered or commutative fold, the rows of more than tile_min_row edges are multiplied tile by tile -- each pass gathers
   // from one slice of x and continues the row's fold from the value y holds -- and only the short rows take the
@@ -1200,107 +1279,22 @@ class Run {
     gm_csr_t As = Aout;  // the rows that are not tiled: row-blocks and the shorter wave rows
     As.mid_row = Aout.umid_row; As.nmid = Aout.numid; As.nmid_long = Aout.numid_long; As.ngiant = 0; As.ngchunk = 0;
     if (Aout.tile_min_row == 0) { As.nblk = 0; As.nmid = 0; }  // every row is tiled
-    // The medium rows in one row-stationary sweep over the slices (kernels.hpp: k_spmv_sweep) instead of two launches per
-    // tile.  The sweep has the main stream to itself; the untiled short-row pass and, tile by tile, the one-wave-per-row rows
-    // go to the auxiliary stream, the giant rows' chain to a stream of its own (AuxStream::gs).
-    bool swept = false;
-    if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
-      gm_sweep_t sw;
-      if (keep_streams && !use_vp && xq != nullptr && xb == nullptr && d_want == nullptr && !program_row_filter<P>::enabled && !(acc & dev::ACC_READ_PREV) &&
-          Aout.vals == nullptr && Aout.tile_min_row >= 0 && Aout.numid == 0 && gm_graph_sweep(g, &sw) == GM_OK && sw.nrows > 0 &&
-          sw.acc_rows == GM_SWEEP_ACC_ROWS) {
-        // the untiled short-row pass: sweep_form bits 2-3 = 0: on the auxiliary stream in front of the one-wave-per-row
-        // kernels, 1: on the main stream in front of the sweep, 2: on the main stream behind it
-        Launch La = L;
-        La.aux = nullptr;
-        La.tiled_untiled_pass = true;
-        const int where = (opt.sweep_form >> 2) & 3;
-        if (where == 0) { La.s = aux.s; La.timer = nullptr; }
-        if (where != 2) launch_spmv_vp<P, T, U, V, E>(use_vp, La, pa, As, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
-        for (int set = 0; set < sw.nsets; set++) {
-          const int hf = opt.sweep_form & 3;
-          if (hf == 0) hipLaunchKernelGGL((dev::k_spmv_sweep<P, T, U, V, E, 18432, GM_SWEEP_ACC_ROWS>), dim3(256), dim3(1024), 0, s, pa, sw, set, xq, y);
-          else if (hf == 1) hipLaunchKernelGGL((dev::k_spmv_sweep<P, T, U, V, E, 12288, GM_SWEEP_ACC_ROWS>), dim3(256), dim3(1024), 0, s, pa, sw, set, xq, y);
-          else hipLaunchKernelGGL((dev::k_spmv_sweep<P, T, U, V, E, 9728, GM_SWEEP_ACC_ROWS>), dim3(256), dim3(1024), 0, s, pa, sw, set, xq, y);
-        }
-        st.spmv_launches += sw.nsets;
-        timer.mark(TAG_WAVE);
-        if (where == 2) launch_spmv_vp<P, T, U, V, E>(use_vp, La, pa, As, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
-        aux.use_gs = aux.gs != nullptr;
-        swept = true;
-      }
-    }
-    // (without the sweep: running the untiled pass on a stream of its own next to the tile passes -- its rows are no tile's
-    // rows -- was measured too: 7.06 -> 7.03 ms at RMAT-26, not worth a third stream)
-    if (!swept) launch_spmv_vp<P, T, U, V, E>(use_vp, L, pa, As, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
+    // (running the untiled pass on a stream of its own next to the tile passes -- its rows are no tile's rows -- was measured:
+    // 7.06 -> 7.03 ms at RMAT-26, not worth a third stream)
+    launch_spmv_vp<P, T, U, V, E>(use_vp, L, pa, As, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
     aux.long_rows = !(opt.debug_flags & dev::DBG_LONG_ON_MAIN);
-    // giant_stream = 2 (swept multiplies of float sums): the products passes of ALL tiles first, on the auxiliary stream,
-    // into one scratch -- they depend on nothing but x -- so that the giant rows' replay chain on its own stream is not
-    // held up by them and is through before the sweep takes the CUs' registers and LDS
-    std::vector<size_t> terms_off;
-    size_t terms_total = 0;
-    const bool split_giants = swept && aux.use_gs && opt.giant_stream >= 2 && rk == REDUCE_F32_ADD && sizeof(U) == 4;
-    if (split_giants) {
-      terms_off.resize((size_t)ntile, 0);
-      for (int t = 0; t < ntile; t++) {
-        gm_csr_t At;
-        const uint32_t* prev = nullptr;
-        if (gm_graph_tile(g, GM_DIR_OUT, t, &At, &prev) != GM_OK) die(gm_last_error());
-        terms_off[(size_t)t] = terms_total;
-        terms_total += ((size_t)At.giant_edges * sizeof(U) + 255) / 256 * 256;
-      }
-      terms_total += 256;
-      for (int t = 0; t < ntile; t++) {
-        gm_csr_t At;
-        const uint32_t* prev = nullptr;
-        if (gm_graph_tile(g, GM_DIR_OUT, t, &At, &prev) != GM_OK) die(gm_last_error());
-        if (At.ngiant == 0) continue;
-        At.nblk = 0; At.nmid = 0; At.nmid_long = 0;
-        Launch Lp = L;
-        Lp.timer = nullptr;
-        Lp.giant_phase = 1;
-        Lp.terms_stream = aux.s;
-        Lp.terms_done = aux.tile_event(2 * ntile + t);
-        Lp.terms_offset = terms_off[(size_t)t];
-        Lp.terms_total = terms_total;
-        launch_spmv_vp<P, T, U, V, E>(use_vp, Lp, pa, At, xq, xb, (const V*)d_vp, y, const_cast<uint32_t*>(prev), dev::ACC_STATIC_BITS | dev::ACC_READ_PREV, rk);
-      }
-    }
     for (int t = 0; t < ntile; t++) {
       gm_csr_t At;
       const uint32_t* prev = nullptr;
       if (gm_graph_tile(g, GM_DIR_OUT, t, &At, &prev) != GM_OK) die(gm_last_error());
-      if (swept) { At.nblk = 0; At.mid_row = At.umid_row; At.nmid = At.numid; At.nmid_long = At.numid; }  // (giant rows, and the pieces of giant rows below the tile's giant limit)
-      const bool cross = swept && aux.use_gs;  // (AuxStream::tile_ev)
-      if (cross && t > 0) {
-        GM_HIP_OK(hipStreamWaitEvent(aux.gs, aux.tile_event(2 * (t - 1) + 1), 0));
-        GM_HIP_OK(hipStreamWaitEvent(aux.s, aux.tile_event(2 * (t - 1)), 0));
-      }
       // y's presence bits are static (dense x): `prev` says which rows already carry a value
-      Launch Lt = L;
-      if (split_giants && At.ngiant > 0) {
-        Lt.giant_phase = 2;
-        Lt.terms_stream = aux.s;
-        Lt.terms_done = aux.tile_event(2 * ntile + t);
-        Lt.terms_offset = terms_off[(size_t)t];
-        Lt.terms_total = terms_total;
-      }
-      launch_spmv_vp<P, T, U, V, E>(use_vp, Lt, pa, At, xq, xb, (const V*)d_vp, y, const_cast<uint32_t*>(prev), dev::ACC_STATIC_BITS | dev::ACC_READ_PREV, rk);
-      if (cross && t + 1 < ntile) {
-        GM_HIP_OK(hipEventRecord(aux.tile_event(2 * t), aux.gs));
-        GM_HIP_OK(hipEventRecord(aux.tile_event(2 * t + 1), aux.s));
-      }
+      launch_spmv_vp<P, T, U, V, E>(use_vp, L, pa, At, xq, xb, (const V*)d_vp, y, const_cast<uint32_t*>(prev), dev::ACC_STATIC_BITS | dev::ACC_READ_PREV, rk);
     }
     aux.long_rows = false;
-    if (swept) {  // (the untiled pass ran there: joined even when no tile had a one-wave-per-row row)
-      GM_HIP_OK(hipEventRecord(aux.join, aux.s));
-      aux.pending = true;
-    }
     if (aux.keep) {
       if (aux.pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
       if (aux.giant_pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.gjoin, 0));
       aux.keep = aux.forked = aux.pending = aux.giant_pending = aux.use_gs = false;
-      if (swept) timer.mark(TAG_WAVE);  // (the multiply ends when the other streams have joined: the wait counts as multiply time, not as apply time)
     }
     // (a probed strategy is cross-checked against the ordered fold of the WHOLE rows; a mismatch redoes this iteration
     // untiled with the ordered fold, which then also governs the tiled iterations that follow)
@@ -1366,7 +1360,10 @@ class Run {
       int ntile = 1;
       if (dense_x && !multi && row_bits == nullptr && rk != REDUCE_LAST && dev::stageable<T>::value && !(opt.debug_flags & dev::DBG_NO_TILES))
         gm_graph_tiles(g, GM_DIR_OUT, &ntile);
-      if (ntile > 1) {
+      gm_sweep_t sw;
+      if (dense_x && !multi && row_bits == nullptr && sweep_usable(acc, &sw)) {
+        multiply_out_swept(pa, acc, sw);
+      } else if (ntile > 1) {
         multiply_out_tiled(pa, ntile, acc);
       } else {
         launch_spmv_vp<P, T, U, V, E>(use_vp, launch_ctx(), pa, Aout, xq, xb, (const V*)d_vp, y, ybits, acc, rk, row_bits, grouped_waves, xsum);

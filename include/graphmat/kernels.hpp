@@ -1421,163 +1421,191 @@ k_spmv_rowwave(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, U* __restrict
 }
 
 // ------------------------------------------------------------------------------------
-// The medium rows of a tiled graph (GM_SHORT_ROW < edges <= own_wave_row) in ONE launch instead of two per column tile:
-// the row-stationary sweep (graphmat_hip.h: gm_sweep_t; built by gm_graph.hip: build_sweep).  Workgroup w owns the rows
-// of length rank r with r % 256 == w and keeps their running values in LDS (s_acc / s_has) from the first slice to the
-// last; the slices are native column ranges taken in ascending order, and inside a (row, slice) piece the edges are stored
-// in ascending native column order, so every row is folded exactly as the reference folds it.  All workgroups walk the
-// slices in the same order from the same start, so at any time the chip gathers from one or two slices of x (2 MB each
-// with 64 slices: L2-resident) and each workgroup has the slice's HOT busiest entries in LDS.  Per slice the waves take
-// the workgroup's pieces 64 at a time, one lane per piece, as k_spmv_rowwave takes rows: coalesced column ids in steps
-// of 512, messages staged in the wave's LDS strip, every lane folding its piece in stored order.  Prototype and
-// measurements: tools/sweep_bench.hip, profiles/r04_sweep_prototype.md (RMAT-26: 680 M edges in 2.7 ms with 64 slices
-// against 3.95 ms of tile passes).  Dense x, 2-operand programs, 4-byte messages and reductions, no edge values.
-template <class P, class T, class U, class V, class E, int HOT, int ACC>
+// The rows of more than GM_SHORT_ROW edges that are not giant, in ONE launch per set: the row-stationary sweep over a
+// sliced-ELLPACK layout (graphmat_hip.h: gm_sweep_t; built by gm_graph.hip: build_sweep; prototype and measurements:
+// tools/sell_bench.hip, profiles/r05_sell_prototype*.txt -- RMAT-26: 876 M edges in 2.05 ms against 2.25 ms for 679 M of them
+// in round 4's CSR-ordered sweep plus 1.2 ms of one-wave-per-row tile passes for the rest).
+// Workgroup w (one per CU, 16 waves) owns the rows of length rank r % 256 == w and keeps their running values in LDS (medium
+// rows) or in registers (long rows) from the first slice to the last; slices are native column ranges taken in ascending
+// order and a (row, slice) piece holds its edges in ascending native column order, so every row is folded exactly as the
+// reference folds it.  All workgroups walk the slices in the same order from the same start: at any time the chip gathers from
+// one or two slices of x (~1.3 MB each: L2-resident), and each workgroup has the slice's busiest entries in LDS.
+//  * medium rows: a wave streams its contiguous range of the block's groups as ONE sequence of 64-entry rows -- row k of a
+//    group hands every lane the k-th edge of ITS piece (lane = piece, transposed storage): one coalesced load of byte offsets,
+//    a branch-free gather (LDS hot set or L2), process_message, and the fold under the "entry is not padding" mask; U rows per
+//    batch, the next batch's entries requested before this batch's messages are waited for; a group starts with a META row
+//    (slots, first-piece flags, width) inside the same stream, at which the lanes' running values go back to LDS and the next
+//    group's come out -- no other loads, nothing that would drain the prefetch;
+//  * long rows (few, uneven: no 64-wide groups): all waves gather the block's long-row products into the LDS stage (coalesced
+//    entries in (slot, column) order), then the last GM_SWEEP_LONG_SLOTS threads fold one piece each out of LDS while the other
+//    waves start on their groups; blocks larger than the stage take several rounds.
+// Dense x, 2-operand programs, 4-byte messages and reductions; edge values: none, or 4 bytes in the entries' positions.
+// (ABL: measurement forms instantiated by tools/sweep_lib_bench.hip only -- 1: no gathers at all, 2: every gather served from
+// LDS, 4: no long-row phase; their results are wrong by construction)
+template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL = 0>
 __global__ void __launch_bounds__(1024)
-k_spmv_sweep(ProgArg<P> pa, gm_sweep_t S, int set, const T* __restrict__ x, U* __restrict__ y) {
+k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long, const int32_t* __restrict__ slice_base, const uint32_t* __restrict__ scol,
+            const uint32_t* __restrict__ sval, const uint32_t* __restrict__ wrow, const int32_t* __restrict__ row_of_slot, const uint32_t* __restrict__ lcol,
+            const uint32_t* __restrict__ lval, const uint32_t* __restrict__ lps, const int32_t* __restrict__ lrow_of_slot, const T* __restrict__ x,
+            U* __restrict__ y) {
   static_assert(sizeof(T) == 4 && sizeof(U) == 4, "4-byte messages and reductions");
-  constexpr int BLOCK = 1024, W = BLOCK / 64;
-  constexpr int CH = 512, PER = CH / 64;
-  constexpr int kPadw = CH + CH / 32;
-  __shared__ T s_hot[HOT];
-  __shared__ U s_acc[ACC];
-  __shared__ unsigned char s_has[ACC];
-  __shared__ T s_msg[W][kPadw];
-#define GM_WSLOT(k) ((k) + ((k) >> 5))
+  constexpr int BLOCK = 1024, W = BLOCK / 64, UB = 8;
+  constexpr int ACC = GM_SWEEP_ACC_ROWS, NLP = GM_SWEEP_LONG_SLOTS;
+  constexpr int KMAX = GM_SWEEP_MAX_STAGE / BLOCK;  // entries of a staging round per thread
+  __shared__ uint32_t s_pool[GM_SWEEP_POOL];  // [hot entries of the slice | stage of the long rows' products]
+  __shared__ uint32_t s_acc[ACC];
   const P& p = *reinterpret_cast<const P*>(pa.b);
-  const int wg = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  T* sm = s_msg[wv];
+  const int wg = blockIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int HOT = GM_SWEEP_POOL - stage_words;
+  uint32_t* const s_stage = s_pool + HOT;
+  const char* __restrict__ xb = (const char*)x;
   V no_vp;
-  for (int i = threadIdx.x; i < ACC; i += BLOCK) s_has[i] = 0;
-  const int32_t* __restrict__ blk = S.blk_first + ((size_t)set * 256 + wg) * S.nslices;
-  for (int sl = 0; sl < S.nslices; sl++) {
-    const int base = S.slice_base[sl];
-    const int slen = S.slice_base[sl + 1] - base;
+  const size_t vw = (size_t)set * 256 + wg;
+  const int lj = (int)threadIdx.x - (BLOCK - NLP);  // long-row slot of this thread (the last NLP threads fold)
+  bool lhas = false;
+  U lacc;
+  auto as_t = [](uint32_t raw) { T t; __builtin_memcpy(&t, &raw, 4); return t; };
+  auto as_u = [](uint32_t raw) { U u; __builtin_memcpy(&u, &raw, 4); return u; };
+  auto raw_u = [](const U& u) { uint32_t r; __builtin_memcpy(&r, &u, 4); return r; };
+  auto as_e = [](uint32_t raw) { E e; if constexpr (HAS_VALS) __builtin_memcpy(&e, &raw, 4); else e = E(); return e; };
+  for (int sl = 0; sl < nslices; sl++) {
+    const int base = slice_base[sl];
+    const int slen = slice_base[sl + 1] - base;
     const int nhot = slen < HOT ? slen : HOT;
-    __syncthreads();  // the previous slice's folds are done: its hot set may go, the running values are in s_acc
-    for (int i = threadIdx.x; i < nhot; i += BLOCK) s_hot[i] = x[base + i];
+    const uint32_t base4 = (uint32_t)base << 2, nhot4 = (uint32_t)nhot << 2;
+    __syncthreads();  // the previous slice's folds are done: its hot set and stage may go, the running values are in s_acc
+    for (int i = threadIdx.x; i < nhot; i += BLOCK) s_pool[i] = ((const uint32_t*)x)[base + i];
     __syncthreads();
-    const T* __restrict__ xdummy = x + base;
-    const int pb = blk[sl], pe = blk[sl + 1];
-    // The wave's groups of this slice (64 pieces each: p0, p0 + W * 64, ...) as ONE sequence of 512-edge steps: while a step's
-    // messages are gathered and folded, the column ids of the NEXT step (of this group or of the next one) and the
-    // metadata of the group after the next are already requested -- a group of ~300 edges is a single step, and without
-    // this every group paid three load latencies in a row (metadata, column ids, messages) at 16 waves per CU.
-    int p0 = pb + wv * 64;
-    if (p0 < pe) {
-      const int plast = pe - 1;
-      auto meta = [&](int q0, uint32_t& a0, uint32_t& a1, int& slot) {  // (unconditional loads, index clamped into the block)
-        const int q = q0 + lane;
-        const int qc = q < pe ? q : plast;
-        const uint32_t v0 = S.piece_start[qc], v1 = S.piece_start[qc + 1];
-        const int vr = S.piece_row[qc];
-        a0 = q < pe ? v0 : 0u;
-        a1 = q < pe ? v1 : 0u;
-        slot = q < pe ? vr : 0;
-      };
-      auto bounds = [&](int q0, uint32_t a0, uint32_t a1, uint32_t& lo, uint32_t& hi) {
-        const int ll = (pe - q0 - 1) < 63 ? (pe - q0 - 1) : 63;
-        lo = (uint32_t)__builtin_amdgcn_readlane((int)a0, 0);
-        hi = (uint32_t)__builtin_amdgcn_readlane((int)a1, ll);
-      };
-      auto cols = [&](uint32_t c0, int n, int (&cc)[PER]) {
+    auto gather = [&](uint32_t c4) {  // (branch-free: lanes whose column is in LDS re-read the slice's first entry, an L1 hit)
+      const uint32_t rel4 = c4 - base4;
+      if constexpr ((ABL & 3) == 1) return c4;
+      if constexpr ((ABL & 3) == 2) return *(const uint32_t*)((const char*)s_pool + (nhot4 ? (rel4 % nhot4) & ~3u : 0u));
+      const bool h = rel4 < nhot4;
+      const uint32_t mh = *(const uint32_t*)((const char*)s_pool + (h ? rel4 : 0u));
+      const uint32_t mg = *(const uint32_t*)(xb + (h ? base4 : c4));
+      return h ? mh : mg;
+    };
+    const size_t blk = vw * (size_t)nslices + (size_t)sl;
+    if (nrows_long > 0 && !(ABL & 4)) {
+      const size_t eb = blk * NLP;
+      const uint32_t l0 = lps[eb], l1 = lps[eb + NLP];
+      uint32_t ps = 0, pe = 0;
+      if (lj >= 0) { ps = lps[eb + lj]; pe = lps[eb + lj + 1]; }
+      for (uint32_t c0 = l0; c0 < l1; c0 += (uint32_t)stage_words) {
+        const uint32_t n = l1 - c0 < (uint32_t)stage_words ? l1 - c0 : (uint32_t)stage_words;
+        if (c0 != l0) __syncthreads();  // the previous round is folded: the stage may be overwritten
+        // a round's entries all at once: every thread requests its (at most KMAX) entries, then their messages, then stores
+        // the products -- one chain of two latencies per round
+        uint32_t c[KMAX], ev[KMAX], m[KMAX];
 #pragma unroll
-        for (int j = 0; j < PER; j++) {
-          const int k = lane + 64 * j;
-          cc[j] = stream_load(&S.colidx[c0 + (uint32_t)(k < n ? k : n - 1)]);
-        }
-      };
-      uint32_t e0, e1, ne0 = 0, ne1 = 0;
-      int rl, nrl = 0;
-      meta(p0, e0, e1, rl);
-      uint32_t g0, g1;
-      bounds(p0, e0, e1, g0, g1);
-      bool more_groups = p0 + W * 64 < pe;
-      if (more_groups) meta(p0 + W * 64, ne0, ne1, nrl);
-      uint32_t c0 = g0;
-      int n = (int)((g1 - c0) < (uint32_t)CH ? (g1 - c0) : (uint32_t)CH);
-      int c[PER];
-      cols(c0, n, c);
-      bool has = s_has[rl] != 0;
-      U acc = s_acc[rl];
-      while (true) {
-        T m[PER];
-#pragma unroll
-        for (int j = 0; j < PER; j++) {  // (branch-free: lanes whose column is in LDS re-read the slice's first entry, an L1 hit)
-          const unsigned rel = (unsigned)(c[j] - base);
-          const bool h = rel < (unsigned)nhot;
-          const T mh = s_hot[h ? rel : 0u];
-          const T* __restrict__ ga = h ? xdummy : x + c[j];
-          const T mg = *ga;
-          m[j] = h ? mh : mg;
-        }
-        // the next step: the rest of this group, else the first step of the next group, else none
-        const bool same = c0 + (uint32_t)CH < g1;
-        const bool any_next = same || more_groups;
-        uint32_t nc0 = c0 + (uint32_t)CH, ng0 = 0, ng1 = g1;
-        if (!same && more_groups) {
-          bounds(p0 + W * 64, ne0, ne1, ng0, ng1);
-          nc0 = ng0;
-        }
-        const int nn = (int)((ng1 - nc0) < (uint32_t)CH ? (ng1 - nc0) : (uint32_t)CH);
-        const uint32_t cur_c0 = c0;
-        const int cur_n = n;
-        if (any_next) cols(nc0, nn, c);  // (c's old values are in the gathers' address registers already)
-#pragma unroll
-        for (int j = 0; j < PER; j++) {
-          const int k = lane + 64 * j;
-          if (k < cur_n) sm[GM_WSLOT(k)] = m[j];
-        }
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t ka = e0 > cur_c0 ? e0 : cur_c0, kb = e1 < cur_c0 + (uint32_t)cur_n ? e1 : cur_c0 + (uint32_t)cur_n;
-        if (ka < kb) {
-          int k = (int)(ka - cur_c0);
-          const int ke = (int)(kb - cur_c0);
-          if (!has) {
-            p.P::process_message(sm[GM_WSLOT(k)], E(), no_vp, acc);
-            has = true;
-            k++;
+        for (int j = 0; j < KMAX; j++) {
+          if ((uint32_t)(j * BLOCK) < n) {
+            const uint32_t i = (uint32_t)(j * BLOCK) + threadIdx.x;
+            const uint32_t ii = c0 + (i < n ? i : n - 1);
+            c[j] = __builtin_nontemporal_load(&lcol[ii]);
+            if constexpr (HAS_VALS) ev[j] = __builtin_nontemporal_load(&lval[ii]); else ev[j] = 0u;
           }
-          for (; k + 4 <= ke; k += 4) {
-            T r[4];
+        }
 #pragma unroll
-            for (int u = 0; u < 4; u++) r[u] = sm[GM_WSLOT(k + u)];
+        for (int j = 0; j < KMAX; j++)
+          if ((uint32_t)(j * BLOCK) < n) m[j] = gather(c[j]);
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-              U res;
-              p.P::process_message(r[u], E(), no_vp, res);
-              p.P::reduce_function(acc, res);
-            }
-          }
-          for (; k < ke; k++) {
+        for (int j = 0; j < KMAX; j++) {
+          const uint32_t i = (uint32_t)(j * BLOCK) + threadIdx.x;
+          if (i < n) {
             U res;
-            p.P::process_message(sm[GM_WSLOT(k)], E(), no_vp, res);
-            p.P::reduce_function(acc, res);
+            p.P::process_message(as_t(m[j]), as_e(ev[j]), no_vp, res);
+            s_stage[i] = raw_u(res);
           }
         }
-        __builtin_amdgcn_wave_barrier();
-        if (!same) {  // the group is done: its rows' running values go back to LDS, the next group's come out
-          if (p0 + lane < pe) { s_acc[rl] = acc; s_has[rl] = has ? 1 : 0; }
-          if (!more_groups) break;
-          p0 += W * 64;
-          e0 = ne0; e1 = ne1; rl = nrl;
-          g0 = ng0; g1 = ng1;
-          more_groups = p0 + W * 64 < pe;
-          if (more_groups) meta(p0 + W * 64, ne0, ne1, nrl);
-          has = s_has[rl] != 0;
-          acc = s_acc[rl];
+        __syncthreads();
+        if (lj >= 0) {
+          uint32_t k = ps > c0 ? ps : c0;
+          const uint32_t ke = pe < c0 + n ? pe : c0 + n;
+          if (k < ke && !lhas) { lacc = as_u(s_stage[k - c0]); lhas = true; k++; }
+          for (; k + 4 <= ke; k += 4) {
+            uint32_t r[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) r[u] = s_stage[k - c0 + u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) p.P::reduce_function(lacc, as_u(r[u]));
+          }
+          for (; k < ke; k++) p.P::reduce_function(lacc, as_u(s_stage[k - c0]));
         }
-        c0 = nc0;
-        n = nn;
       }
     }
+    // The wave's part of the block: rows [r, rend) of 64 entries each.  A group = one META row (bit 31 set in every lane;
+    // bits 0-14 the lane's accumulator slot or 0x7fff, bit 15 "the row's first piece", bits 16-28 the group's width) followed by
+    // `width` rows of column entries: the stream describes itself, the only loads are the entries, one batch ahead.
+    const uint32_t* __restrict__ wr = wrow + blk * (W + 1);
+    uint32_t r = __builtin_amdgcn_readfirstlane(wr[wv]);
+    const uint32_t rend = __builtin_amdgcn_readfirstlane(wr[wv + 1]);
+    if (r >= rend) continue;
+    uint32_t left = 0;  // rows left in the current group (0: the next row is a meta row)
+    int slot = 0x7fff;
+    U acc;
+    bool has = false;
+    uint32_t c[UB], ev[UB];
+    auto entries = [&](uint32_t r0) {
+#pragma unroll
+      for (int j = 0; j < UB; j++) {
+        const uint32_t rr = r0 + j < rend ? r0 + j : rend - 1;
+        c[j] = __builtin_nontemporal_load(&scol[(size_t)rr * 64 + lane]);
+        if constexpr (HAS_VALS) ev[j] = __builtin_nontemporal_load(&sval[(size_t)rr * 64 + lane]); else ev[j] = 0u;
+      }
+    };
+    entries(r);
+    while (r < rend) {
+      uint32_t m[UB], cc[UB], e2[UB];
+      // which rows of the batch are meta rows (wave-uniform): they are not gathered
+      uint32_t metamask = 0, l = left;
+#pragma unroll
+      for (int j = 0; j < UB; j++) {
+        if (r + j < rend) {
+          if (l == 0) { metamask |= 1u << j; l = ((uint32_t)__builtin_amdgcn_readfirstlane((int)c[j]) >> 16) & 0x1fffu; }
+          else l--;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < UB; j++) {
+        cc[j] = c[j];
+        e2[j] = ev[j];
+        m[j] = 0u;
+        if (!((metamask >> j) & 1u)) m[j] = gather(c[j] & 0x7fffffffu);
+      }
+      const uint32_t r0 = r;
+      r += UB;
+      if (r < rend) entries(r);
+#pragma unroll
+      for (int j = 0; j < UB; j++) {
+        if (r0 + j < rend) {
+          if ((metamask >> j) & 1u) {  // a new group: the previous group's running values go back to LDS, this one's come out
+            if (slot != 0x7fff) s_acc[slot] = raw_u(acc);
+            slot = (int)(cc[j] & 0x7fffu);
+            has = !(cc[j] & 0x8000u);
+            acc = as_u(slot != 0x7fff ? s_acc[slot] : 0u);
+          } else if ((int32_t)cc[j] >= 0) {
+            U res;
+            p.P::process_message(as_t(m[j]), as_e(e2[j]), no_vp, res);
+            if (has) p.P::reduce_function(acc, res);  // SPMV.h:54-59: c = a; reduce(c, b)
+            else acc = res;                           // no additive identity: the first message assigns (spmspv.h:73-77)
+            has = true;
+          }
+        }
+      }
+      left = l;
+    }
+    if (slot != 0x7fff) s_acc[slot] = raw_u(acc);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < ACC; i += BLOCK) {
-    const int row = S.row_of_rank[((size_t)set * 256 + wg) * ACC + i];  // (-1: no row in this slot)
-    if (row >= 0 && s_has[i]) y[row] = s_acc[i];
+    const int row = row_of_slot[vw * ACC + i];  // (-1: no row in this slot; every row of the sweep has edges)
+    if (row >= 0) y[row] = as_u(s_acc[i]);
   }
-#undef GM_WSLOT
+  if (lj >= 0 && nrows_long > 0) {
+    const int row = lrow_of_slot[vw * NLP + lj];
+    if (row >= 0 && lhas) y[row] = lacc;
+  }
 }
 
 // a=b programs, the wanted rows among a wave's 64 list entries: 64 / LPR rows at a time, LPR lanes each.

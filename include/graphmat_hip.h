@@ -245,37 +245,73 @@ int gm_graph_csr(const gm_graph_t* g, int direction, gm_csr_t* out);
 #define GM_MAX_TILES 64
 #define GM_TILE_MIN_ROW 64
 int gm_graph_tiles(const gm_graph_t* g, int direction, int* ntiles); /* *ntiles = 1: not tiled */
-/* ---- the row-stationary sweep of the medium rows (tiled graphs; gm_set_option("sweep_slices", 1)) ----------------
- * The rows of GM_SHORT_ROW+1 .. own_wave_row (4096) edges -- 63 % of RMAT-26's edges -- need not go through the column
- * tiles pass by pass.  With the option on, the device order is cut finer than the tiles (nslices = ntiles * k <= 64 slices
- * of the native range, each serving equally many gathers, busiest vertices first inside a slice; a tile is k consecutive
- * slices) and the library also keeps those rows' edges as [set][workgroup][slice][row][ascending native column]:
- * workgroup w of 256 owns the rows of length rank r with r % 256 == w (at most acc_rows per launch; `nsets` launches cover
- * all), keeps their running values in LDS and sweeps the slices in order, every workgroup at about the same slice at any
- * time -- the chip gathers from ~2 MB of x at a time, and a row is still folded in ascending native column order
- * (kernels.hpp: k_spmv_sweep; measured in profiles/r04_sweep_prototype.md).
- *   piece p = the edges [piece_start[p], piece_start[p+1]) of colidx: one row's edges inside one slice;
- *   piece_row[p] = the row's slot in its workgroup's accumulator array (rank / 256 - set * acc_rows);
- *   blk_first[(set * 256 + w) * nslices + s] = first piece of workgroup w's rows in slice s (entry count + 1 = npieces);
- *   row_of_rank[(set * 256 + w) * acc_rows + slot] = local row id of the row in that accumulator slot of workgroup w (-1: none; the
- *   slots are a permutation of the workgroup's length ranks that deals the long rows over the 64-piece groups of a slice);
- *   slice_base[s] = first device id of slice s.
- * Single shard, GM_DIR_OUT only.  nrows = 0: the graph has no such structure. */
+/* ---- the row-stationary sweep (sliced-ELLPACK layout; round 5) ---------------------------------------------------------
+ * Every row of the GM_DIR_OUT adjacency with more than GM_SHORT_ROW edges that is not a giant row -- 82 % of RMAT-26's edges
+ * -- is multiplied by ONE persistent kernel (kernels.hpp: k_spmv_sell) instead of tile passes.  With
+ * gm_set_option("sweep_slices", 1) (default) the device order of a large single-shard graph is cut into nslices contiguous
+ * native ranges that serve equally many gathers (busiest vertices first inside a slice; a column tile = k consecutive
+ * slices), and the library keeps those rows' edges a second time, laid out for the sweep: workgroup w of 256 owns the rows of
+ * length rank r with r % 256 == w, keeps their running values in LDS (long rows: in registers) and walks the slices in
+ * ascending order -- every workgroup at about the same slice at any time, so the chip gathers from ~1.3 MB of x at a time
+ * (L2-resident), the slice's busiest entries from LDS -- and a row is still folded in ascending native column order: slices are
+ * native ranges taken in order, and inside a (row, slice) PIECE the edges keep their CSR order.  `nsets` launches cover all
+ * rows (a workgroup holds acc_rows medium + long_slots long rows per launch: rank r -> workgroup r % 256, set (r / 256) % nsets).
+ *   MEDIUM rows (at most own_wave_row = 4096 edges): the pieces of a (set, workgroup, slice) BLOCK are sorted by length
+ *   (descending) and cut into GROUPS of 64, lane = piece.  Group g occupies scol[gbase[g] .. gbase[g + 1]): first a META row of 64
+ *   entries -- GM_SWEEP_PAD | width << 16 | first << 15 | slot: the group's width (rows that follow = its longest piece), whether
+ *   this is the lane's row's first piece (its first message is assigned, not reduced: the reference has no additive identity)
+ *   and the row's slot in the workgroup's accumulator array (0x7fff: the lane has no piece) -- then `width` rows stored
+ *   transposed, scol[gbase[g] + (1 + k) * 64 + lane] = the k-th column of the lane's piece as a BYTE offset into a 4-byte message
+ *   vector (column << 2), padded to the width with entries that carry GM_SWEEP_PAD (bit 31; the rest = the slice's first
+ *   column): one coalesced 256-byte load hands every lane the next edge of ITS piece, the fold is one instruction per 64 edges,
+ *   and the stream describes itself -- the kernel loads nothing else.  sval: the edge values in the same positions (val_bytes =
+ *   4) or NULL.  Blocks are stored in (set, workgroup, slice) order, so a block's groups are contiguous; wfirst[((set * 256 + w)
+ *   * nslices + s) * 17 + v] = first group of wave v of 16 (entry 16 = end of the block), wrow = the same as positions in scol /
+ *   64: contiguous ranges balanced by rows.  row_of_slot[(set * 256 + w) * acc_rows + slot] = local row id (-1: none).
+ *   LONG rows (more than own_wave_row edges; at most long_slots per workgroup and set): too few and too uneven for groups.
+ *   lcol (column << 2) / lval hold a block's edges in (slot, ascending native column) order, lps[((set * 256 + w) * nslices + s)
+ *   * long_slots + j] = first entry of slot j's piece (the next entry ends it; the last entry of all = nedges_long); per
+ *   slice all waves gather a block's messages into an LDS stage and the workgroup's last long_slots threads fold one piece each.
+ *   lrow_of_slot[(set * 256 + w) * long_slots + j] = local row id (-1: none).  max_long_block = edges of the largest block.
+ *   src_pos / lsrc_pos (graphs that keep edge values only): the CSR position every entry came from (0xffffffff: padding), so
+ *   that rewritten edge values can be brought over (gm_graph_sync_tile_vals).
+ * Single shard, GM_DIR_OUT only.  nrows = 0: the graph has no such structure (nslices and slice_base are valid whenever the
+ * device order was sliced). */
 typedef struct {
-  int32_t nrows;      /* medium rows */
-  int32_t nsets;      /* launches */
+  int32_t nrows;          /* swept rows: medium + long */
+  int32_t nrows_long;
+  int32_t nsets;          /* launches */
   int32_t nslices;
-  int32_t acc_rows;   /* rows per workgroup and launch (the LDS accumulator array's size) */
-  int64_t nedges;
-  int64_t npieces;
-  const int32_t* colidx;
-  const uint32_t* piece_start;
-  const uint16_t* piece_row;
-  const int32_t* blk_first;
-  const int32_t* slice_base; /* [nslices + 1] */
-  const int32_t* row_of_rank;
+  int32_t acc_rows;       /* medium-row slots per workgroup and launch (= GM_SWEEP_ACC_ROWS) */
+  int32_t long_slots;     /* long-row slots per workgroup and launch (= GM_SWEEP_LONG_SLOTS) */
+  int32_t max_long_block; /* most long-row edges of one (set, workgroup, slice) block */
+  int32_t val_bytes;      /* 0, or 4: sval / lval hold the edge values */
+  int32_t short_row;      /* the structure holds the rows of more than short_row edges ... */
+  int32_t giant_row;      /* ... and at most giant_row edges (= the whole-graph CSR's limits when it was built) */
+  int64_t nedges;         /* edges of the medium rows */
+  int64_t nedges_long;
+  int64_t nentries;       /* entries of scol (edges + padding) */
+  int64_t ngroups;
+  const uint32_t* scol;
+  const uint32_t* sval;
+  const uint32_t* gbase;  /* [ngroups + 1] */
+  const uint32_t* wrow;   /* [nsets * 256 * nslices * 17] */
+  const uint32_t* wfirst; /* [nsets * 256 * nslices * 17] */
+  const int32_t* row_of_slot;
+  const uint32_t* lcol;
+  const uint32_t* lval;
+  const uint32_t* lps;    /* [nsets * 256 * nslices * long_slots + 1] */
+  const int32_t* lrow_of_slot;
+  const int32_t* slice_base; /* [nslices + 1] first device id of every slice */
+  const uint32_t* src_pos;
+  const uint32_t* lsrc_pos;
 } gm_sweep_t;
-#define GM_SWEEP_ACC_ROWS 10240
+#define GM_MAX_SLICES 128
+#define GM_SWEEP_ACC_ROWS 10048
+#define GM_SWEEP_LONG_SLOTS 128
+#define GM_SWEEP_PAD 0x80000000u
+#define GM_SWEEP_POOL 30848      /* 4-byte LDS words shared by the slice's hot entries and the long rows' stage */
+#define GM_SWEEP_MAX_STAGE 14336 /* largest stage (words): larger blocks are staged in chunks */
 int gm_graph_sweep(const gm_graph_t* g, gm_sweep_t* out);
 int gm_graph_tile(const gm_graph_t* g, int direction, int tile, gm_csr_t* out, const uint32_t** d_prev_bits);
 /* rowbits of GM_DIR_OUT | rowbits of GM_DIR_IN (graphs built with both directions; ALL_EDGES programs) */
@@ -499,10 +535,9 @@ typedef struct {
                                      replay chain ends 0.18 ms earlier and the short-row pass takes 0.17 ms longer: RMAT-26 5.10-5.12 against
                                      5.09-5.16 ms); 0 = everything shares the auxiliary stream.  (Without the sweep a third stream was measured and loses:
                                      profiles/r04_streams_and_scalar_path.md.) */
-  int32_t sweep_form;             /* the swept multiply: bits 0-1 = hot entries per slice in LDS (0: 18432, 1: 12288, 2: 9728 -- less LDS leaves room
-                                     for the other streams' workgroups on the same CU); bits 2-3 = where the untiled short-row pass runs: 0 on the
-                                     auxiliary stream in front of the one-wave-per-row kernels, 1 on the main stream in front of the sweep, 2 on
-                                     the main stream behind it */
+  int32_t sweep_form;             /* the swept multiply (engine.hpp: multiply_out_swept): bits 0-1 = where the short rows' pass runs: 0 on the main stream
+                                     in front of the sweep (default), 1 on the auxiliary stream behind the giant rows' passes (next to the sweep),
+                                     2 on the main stream behind the sweep; bit 2 = the long rows staged in rounds of 1024 entries (tests) */
   int32_t reserved_[14];
 } gm_engine_options_t;
 /* the options a run on `g` uses (g may be NULL: the process defaults) */

@@ -68,7 +68,7 @@ def test_tile_structure(env, tile_min, tiles, threads, minrow):
     assert g.L.gm_graph_sweep(g.h, C.byref(sw)) == 0
     cuts = None
     if sw.nslices > 0:
-        assert sw.nslices % T == 0 and sw.nslices <= 64
+        assert sw.nslices % T == 0 and sw.nslices <= 128
         cuts = np.zeros(sw.nslices + 1, np.int32)
         api.copy_from_device(cuts, sw.slice_base)
         assert cuts[0] == 0 and cuts[-1] == nlive and (np.diff(cuts) >= 0).all()
@@ -256,65 +256,141 @@ def test_persistent_rowwave_forms_bit_exact(env, tile_min, form):
         L.gm_set_option(b"rowwave_form", 4)
 
 
+def _sweep_arrays(api, sw):
+    """host copies of a gm_sweep_t's arrays"""
+    nvw, T = sw.nsets * 256, sw.nslices
+    out = {}
+    def get(name, n, dt):
+        a = np.zeros(max(int(n), 1), dt)
+        ptr = getattr(sw, name)
+        if ptr and n:
+            api.copy_from_device(a[: int(n)], ptr)
+        out[name] = a
+    get("scol", sw.nentries, np.uint32); get("gbase", sw.ngroups + 1, np.uint32)
+    get("wfirst", nvw * T * 17, np.uint32); get("wrow", nvw * T * 17, np.uint32); get("row_of_slot", nvw * sw.acc_rows, np.int32)
+    get("lcol", sw.nedges_long, np.uint32); get("lps", nvw * T * sw.long_slots + 1, np.uint32); get("lrow_of_slot", nvw * sw.long_slots, np.int32)
+    get("slice_base", T + 1, np.int32)
+    if sw.val_bytes:
+        get("sval", sw.nentries, np.uint32); get("lval", sw.nedges_long, np.uint32)
+        get("src_pos", sw.nentries, np.uint32); get("lsrc_pos", sw.nedges_long, np.uint32)
+    return out
+
+
+def _check_sweep_structure(api, g, sw, keep_values, rng, own=4096):
+    """gm_sweep_t covers exactly the rows of more than 64 edges that are not giant; every piece lies inside one slice and holds
+    the row's edges of that slice in CSR (= ascending native column) order; first-piece flags, wave ranges and values are right."""
+    rp, ci, vv = g.csr_to_host(api.GM_DIR_OUT)
+    ln = np.diff(rp)
+    c = g.csr(api.GM_DIR_OUT)
+    giant = np.zeros(max(c.ngiant, 1), np.int32)
+    if c.ngiant:
+        api.copy_from_device(giant[: c.ngiant], c.giant_row)
+    A = _sweep_arrays(api, sw)
+    cuts = A["slice_base"]
+    T, NL, ACC = sw.nslices, sw.long_slots, sw.acc_rows
+    med = A["row_of_slot"][A["row_of_slot"] >= 0]
+    lng = A["lrow_of_slot"][A["lrow_of_slot"] >= 0]
+    want = set(np.nonzero(ln > 64)[0].tolist()) - set(giant[: c.ngiant].tolist())
+    assert len(med) + len(lng) == sw.nrows == len(want) and set(med.tolist()) | set(lng.tolist()) == want
+    assert len(lng) == sw.nrows_long and (ln[lng] > own).all() and (ln[med] <= own).all()
+    assert sw.nedges == int(ln[med].sum()) and sw.nedges_long == int(ln[lng].sum())
+    gb, wf = A["gbase"].astype(np.int64), A["wfirst"].reshape(-1, 17)
+    assert gb[0] == 0 and gb[-1] == sw.nentries and (np.diff(gb) >= 128).all() and (np.diff(gb) % 64 == 0).all()
+    assert (np.diff(wf, axis=1).astype(np.int64) >= 0).all() and wf[0, 0] == 0 and wf[-1, 16] == sw.ngroups and (wf[1:, 0] == wf[:-1, 16]).all()
+    assert (A["wrow"].astype(np.int64) == gb[A["wfirst"]] // 64).all()
+    # every edge exactly once: entries without the pad bit (meta rows and padding carry it); checked per piece below on a sample
+    assert int((A["scol"] >> 31 == 0).sum()) == sw.nedges
+    def row_part(row, sl):
+        whole = ci[rp[row]: rp[row + 1]]
+        sel = (whole >= cuts[sl]) & (whole < cuts[sl + 1])
+        return whole[sel], (vv[rp[row]: rp[row + 1]][sel] if vv is not None else None), np.nonzero(sel)[0] + rp[row]
+    def first_slice(row):
+        return int(np.searchsorted(cuts, ci[rp[row]: rp[row + 1]].min(), side="right") - 1)
+    blk_of_group = np.searchsorted(wf[:, 16], np.arange(sw.ngroups), side="right")
+    for gI in rng.choice(sw.ngroups, size=min(120, sw.ngroups), replace=False):
+        b = int(blk_of_group[gI]); vw, sl = b // T, b % T
+        width = int(gb[gI + 1] - gb[gI]) // 64 - 1
+        grp = A["scol"][gb[gI]: gb[gI + 1]].reshape(width + 1, 64)
+        metas, ent = grp[0], grp[1:]
+        assert (metas >> 31).all() and (((metas >> 16) & 0x1fff) == width).all()
+        lens = []
+        for lane in range(64):
+            meta = int(metas[lane]) & 0xffff
+            col = ent[:, lane]
+            if meta & 0x7fff == 0x7fff:
+                assert (col >> 31).all()
+                lens.append(0)
+                continue
+            row = int(A["row_of_slot"][vw * ACC + (meta & 0x7fff)])
+            assert row >= 0
+            n = int((col >> 31 == 0).sum())
+            assert (col[:n] >> 31 == 0).all() and (col[n:] >> 31).all() and ((col[n:] & 0x7fffffff) == (int(cuts[sl]) << 2)).all()
+            cols, vals, pos = row_part(row, sl)
+            assert n == len(cols) > 0 and ((col[:n] >> 2) == cols).all()
+            assert bool(meta & 0x8000) == (first_slice(row) == sl)
+            if keep_values:
+                assert (A["sval"][gb[gI]: gb[gI + 1]].reshape(width + 1, 64)[1: n + 1, lane] == vals.view(np.uint32)).all()
+                assert (A["src_pos"][gb[gI]: gb[gI + 1]].reshape(width + 1, 64)[1: n + 1, lane] == pos).all()
+            lens.append(n)
+        assert lens[0] == width and all(x >= y for x, y in zip(lens[:-1], lens[1:]))  # longest first, padded to the longest
+    lps = A["lps"].astype(np.int64)
+    assert lps[0] == 0 and lps[-1] == sw.nedges_long and (np.diff(lps) >= 0).all()
+    if sw.nrows_long:
+        blocks = lps[:: NL]
+        assert int(np.diff(blocks).max()) == sw.max_long_block
+        ent = np.nonzero(np.diff(lps) > 0)[0]
+        for e in rng.choice(ent, size=min(60, len(ent)), replace=False):
+            b, j = int(e) // NL, int(e) % NL; vw, sl = b // T, b % T
+            row = int(A["lrow_of_slot"][vw * NL + j])
+            cols, vals, pos = row_part(row, sl)
+            assert ((A["lcol"][lps[e]: lps[e + 1]] >> 2) == cols).all()
+            if keep_values:
+                assert (A["lval"][lps[e]: lps[e + 1]] == vals.view(np.uint32)).all() and (A["lsrc_pos"][lps[e]: lps[e + 1]] == pos).all()
+
+
 @pytest.mark.parametrize("scale,tiles,threads", [(13, 3, 1), (15, 4, 2), (16, 8, 1)])
 def test_row_stationary_sweep_bit_exact(env, scale, tiles, threads):
-    """The sweep of the medium rows (graphmat_hip.h gm_sweep_t, kernels.hpp k_spmv_sweep): its structure covers exactly the
-    edges of the rows it takes, every piece lies inside one slice in ascending native column order, and PageRank through it
-    (sweep_slices 1: rows up to own_wave_row edges, 2: every non-giant wave row; every placement of the other passes) has
-    the bits of the oracle and of the tile passes (sweep_slices 0)."""
+    """The sweep (graphmat_hip.h gm_sweep_t, kernels.hpp k_spmv_sell): its structure covers exactly the rows it takes, every piece
+    lies inside one slice in ascending native column order, and PageRank through it -- with and without edge values, several
+    launches (sets), the long rows staged in one or several rounds, every placement of the short-row pass -- has the bits of
+    the oracle, which are also those of the tile passes (sweep_slices 0)."""
     import ctypes as C
     api, ob = env
     from graphmat_amd import _lib
     L = _lib.lib()
-    nv, s, d, _ = gen.rmat_edges(scale, 16, 5)
+    nv, s, d, v = gen.rmat_edges(scale, 16, 5, weights="hash")
     og = ob.OracleGraph(nv, s, d, None, ref_threads=threads)
     odeg = og.degree()
     opr, _, _ = og.pagerank(6, degree=odeg)
-    for sweep, forms in ((0, (4,)), (1, (0, 1, 4, 9)), (2, (4,))):
-        for form in forms:
-            for gs in ((0, 1, 2) if sweep == 1 and form == 4 else (1,)):
-                api._lib.check(L.gm_reset_options())
-                api._lib.check(L.gm_set_option(b"sweep_slices", sweep))
-                api._lib.check(L.gm_set_option(b"sweep_form", form))
-                api._lib.check(L.gm_set_option(b"giant_stream", gs))
-                g = api.Graph(nv, s, d, None, ref_threads=threads, keep_values=False, col_tiles=tiles)
-                assert g.col_tiles > 1
-                sw = _lib.Sweep()
-                assert L.gm_graph_sweep(g.h, C.byref(sw)) == 0
-                if sweep == 0:
-                    assert sw.nrows == 0 and sw.nslices == 0
-                else:
-                    assert sw.nrows > 0 and sw.nslices % g.col_tiles == 0 and sw.nsets == 1
-                    rp, ci, _ = g.csr_to_host(api.GM_DIR_OUT)
-                    ln = np.diff(rp)
-                    slots = np.zeros(256 * sw.acc_rows, np.int32)
-                    api.copy_from_device(slots, sw.row_of_rank)
-                    rows = slots[slots >= 0]
-                    assert len(rows) == sw.nrows == len(set(rows.tolist())) and (ln[rows] > 64).all()
-                    assert sw.nedges == int(ln[rows].sum())
-                    col = np.zeros(sw.nedges, np.int32)
-                    ps = np.zeros(sw.npieces + 1, np.uint32)
-                    pr_ = np.zeros(sw.npieces + 1, np.uint16)
-                    bf = np.zeros(256 * sw.nslices + 1, np.int32)
-                    cuts = np.zeros(sw.nslices + 1, np.int32)
-                    for a, p in ((col, sw.colidx), (ps, sw.piece_start), (pr_, sw.piece_row), (bf, sw.blk_first), (cuts, sw.slice_base)):
-                        api.copy_from_device(a, p)
-                    assert ps[0] == 0 and ps[-1] == sw.nedges and (np.diff(ps.astype(np.int64)) > 0).all()
-                    assert bf[0] == 0 and bf[-1] == sw.npieces and (np.diff(bf) >= 0).all()
-                    # every piece: one row's edges inside one slice, in the row's CSR (= ascending native column) order
-                    blk_of_piece = np.searchsorted(bf, np.arange(sw.npieces), side="right") - 1
-                    wg, sl = blk_of_piece // sw.nslices, blk_of_piece % sw.nslices
-                    taken = {}
-                    for p in np.random.default_rng(1).choice(sw.npieces, size=min(400, sw.npieces), replace=False):
-                        row = slots[wg[p] * sw.acc_rows + pr_[p]]
-                        assert row >= 0
-                        piece = col[ps[p]: ps[p + 1]]
-                        assert (piece >= cuts[sl[p]]).all() and (piece < cuts[sl[p] + 1]).all()
-                        whole = ci[rp[row]: rp[row + 1]]
-                        inside = whole[(whole >= cuts[sl[p]]) & (whole < cuts[sl[p] + 1])]
-                        assert (piece == inside).all()
-                pr, deg, it = g.pagerank(6)
-                assert (deg == odeg).all() and it == 6
-                assert (f32bits(pr) == f32bits(opr)).all(), "sweep_slices %d sweep_form %d giant_stream %d" % (sweep, form, gs)
-                g.close()
-    api._lib.check(L.gm_reset_options())
+    rng = np.random.default_rng(1)
+    seen_sets = [1]
+    #        sweep_slices, sweep_form, keep_values, own_wave_row, acc_rows, long_slots
+    cases = [(0, 0, False, 4096, 10048, 128), (1, 0, False, 4096, 10048, 128), (1, 1, True, 4096, 10048, 128), (1, 2, False, 4096, 10048, 128),
+             (16, 0, False, 256, 10048, 128), (16, 4, True, 256, 10048, 128), (24, 5, False, 128, 3, 3), (128, 0, True, 512, 2, 128)]
+    try:
+        for slices, form, keep, own, accl, longl in cases:
+            api._lib.check(L.gm_reset_options())
+            for k_, v_ in ((b"sweep_slices", slices), (b"sweep_form", form), (b"own_wave_row", own), (b"sweep_acc_rows", accl), (b"sweep_long_slots", longl)):
+                api._lib.check(L.gm_set_option(k_, v_))
+            g = api.Graph(nv, s, d, v if keep else None, ref_threads=threads, keep_values=keep, col_tiles=tiles)
+            assert g.col_tiles > 1
+            sw = _lib.Sweep()
+            assert L.gm_graph_sweep(g.h, C.byref(sw)) == 0
+            if slices == 0:
+                assert sw.nrows == 0 and sw.nslices == 0
+            else:
+                assert sw.nrows > 0 and sw.nslices % g.col_tiles == 0 and sw.val_bytes == (4 if keep else 0)
+                nmed, nlng = sw.nrows - sw.nrows_long, sw.nrows_long
+                assert sw.nsets == max(1, -(-(-(-nmed // 256)) // accl), -(-(-(-nlng // 256)) // longl))
+                if own < 4096 and scale >= 15:
+                    assert sw.nrows_long > 0
+                seen_sets[0] = max(seen_sets[0], sw.nsets)
+                _check_sweep_structure(api, g, sw, keep, rng, own)
+            pr, deg, it = g.pagerank(6)
+            assert (deg == odeg).all() and it == 6
+            assert (f32bits(pr) == f32bits(opr)).all(), "sweep_slices %d sweep_form %d values %d own_wave_row %d" % (slices, form, keep, own)
+            g.close()
+        if scale >= 15:
+            assert seen_sets[0] > 1  # (several launches were exercised)
+    finally:
+        api._lib.check(L.gm_reset_options())

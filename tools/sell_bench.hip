@@ -127,7 +127,8 @@ __global__ void k_pieces(const unsigned long long* __restrict__ key, const uint3
   }
 }
 // sort key of a piece inside its block: longest first
-__global__ void k_piece_keys(const uint32_t* __restrict__ piece_start, uint32_t np, const int32_t* __restrict__ blk_first, int nblk, uint32_t* __restrict__ pkey, uint32_t* __restrict__ pid) {
+__global__ void k_piece_keys(const uint32_t* __restrict__ piece_start, uint32_t np, const int32_t* __restrict__ blk_first, int nblk, uint32_t* __restrict__ pkey, uint32_t* __restrict__ pid,
+                             const uint16_t* __restrict__ piece_row, int T, int* __restrict__ rowmin) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= np) return;
   int lo = 0, hi = nblk;  // largest b with blk_first[b] <= p (empty blocks share a start: take the last of them)
@@ -135,6 +136,7 @@ __global__ void k_piece_keys(const uint32_t* __restrict__ piece_start, uint32_t 
   const uint32_t len = piece_start[p + 1] - piece_start[p];
   pkey[p] = ((uint32_t)lo << 16) | (0xffffu - (len > 0xffffu ? 0xffffu : len));
   pid[p] = p;
+  atomicMin(&rowmin[(int)piece_row[p] * kWG + lo / T], lo % T);  // the first slice in which the row (rank = slot * 256 + workgroup) has an edge
 }
 __global__ void k_block_groups(const int32_t* __restrict__ blk_first, int nblk, uint32_t* __restrict__ ng) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,7 +159,7 @@ __global__ void k_group_sizes(const int32_t* __restrict__ blk_first, const uint3
 __global__ void k_fill_groups(uint32_t ngroups, const uint32_t* __restrict__ gbase, const uint32_t* __restrict__ gq0, const uint32_t* __restrict__ gblk,
                               const int32_t* __restrict__ blk_first, const uint32_t* __restrict__ sp, const uint32_t* __restrict__ piece_start,
                               const uint16_t* __restrict__ piece_row, const int32_t* __restrict__ col_sorted, const int32_t* __restrict__ slice_base, int T,
-                              uint32_t* __restrict__ scol, uint16_t* __restrict__ pslot) {
+                              uint32_t* __restrict__ scol, uint16_t* __restrict__ pslot, const int* __restrict__ rowmin) {
   for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const uint32_t b = gblk[g], q0 = gq0[g], qe = (uint32_t)blk_first[b + 1];
     const uint32_t base = gbase[g], n = gbase[g + 1] - base;
@@ -165,7 +167,11 @@ __global__ void k_fill_groups(uint32_t ngroups, const uint32_t* __restrict__ gba
     const int lane = threadIdx.x & 63;
     const uint32_t q = q0 + lane;
     uint32_t ps = 0, len = 0;
-    if (q < qe) { const uint32_t p = sp[q]; ps = piece_start[p]; len = piece_start[p + 1] - ps; if (threadIdx.x < 64) pslot[(size_t)g * 64 + lane] = piece_row[p]; }
+    if (q < qe) {
+      const uint32_t p = sp[q]; ps = piece_start[p]; len = piece_start[p + 1] - ps;
+      const int first = rowmin[(int)piece_row[p] * kWG + (int)(b / T)] == (int)(b % T);
+      if (threadIdx.x < 64) pslot[(size_t)g * 64 + lane] = (uint16_t)(piece_row[p] | (first ? 0x8000 : 0));
+    }
     else if (threadIdx.x < 64) pslot[(size_t)g * 64 + lane] = 0xffff;
     for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
       const uint32_t k = j >> 6;
@@ -173,18 +179,21 @@ __global__ void k_fill_groups(uint32_t ngroups, const uint32_t* __restrict__ gba
     }
   }
 }
-// contiguous ranges of a block's groups for the W waves, balanced by rows + 2 per group
-__global__ void k_wave_ranges(const uint32_t* __restrict__ grp_first, int nblk, const uint32_t* __restrict__ gbase, uint32_t* __restrict__ wfirst) {
+// contiguous ranges of a block's groups for the W waves, balanced by rows + 2 per group; the last fold_waves waves (they fold
+// the long rows first) get fold_share percent of an equal share
+__global__ void k_wave_ranges(const uint32_t* __restrict__ grp_first, int nblk, const uint32_t* __restrict__ gbase, uint32_t* __restrict__ wfirst, int fold_waves, int fold_share) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblk) return;
   const uint32_t g0 = grp_first[b], g1 = grp_first[b + 1];
   unsigned long long total = 0;
   for (uint32_t g = g0; g < g1; g++) total += (gbase[g + 1] - gbase[g]) / 64 + 2;
+  const unsigned long long units = (unsigned long long)(kW - fold_waves) * 100 + (unsigned long long)fold_waves * fold_share;
   uint32_t g = g0;
-  unsigned long long acc = 0;
+  unsigned long long acc = 0, share = 0;
   for (int w = 0; w < kW; w++) {
     wfirst[(size_t)b * (kW + 1) + w] = g;
-    const unsigned long long want = total * (unsigned)(w + 1) / (unsigned)kW;
+    share += w >= kW - fold_waves ? fold_share : 100;
+    const unsigned long long want = total * share / units;
     while (g < g1 && acc + ((gbase[g + 1] - gbase[g]) / 64 + 2 + 1) / 2 <= want) { acc += (gbase[g + 1] - gbase[g]) / 64 + 2; g++; }
   }
   wfirst[(size_t)b * (kW + 1) + kW] = g1;
@@ -208,23 +217,113 @@ __global__ void k_fill_x(float* __restrict__ x, int n) {
 
 // ---- the sweep over SELL groups ---------------------------------------------------------------------------------------
 // U rows of 64 entries per batch; the next batch's column entries are requested before this batch's messages are waited for.
-template <int HOT, int ACC, int U>
+// Medium rows: SELL groups (pslot: bits 0-14 accumulator slot, bit 15 = the row's first piece: its first message is assigned).
+// Long rows (optional, NLP > 0: at most NLP per workgroup, slots ACC - NLP ..): their pieces are too few and too uneven for
+// 64-wide groups, so per slice ALL waves gather the block's long-row messages into an LDS stage (coalesced column stream in
+// (slot, native column) order, no padding), and the last NLP threads of the workgroup then fold one piece each out of LDS.
+template <int HOT, int ACC, int U, int STG, int NLP, bool ASYNC = false>
 __global__ void __launch_bounds__(kBlock)
 k_sell_sweep(const uint32_t* __restrict__ scol, const uint32_t* __restrict__ gbase, const uint16_t* __restrict__ pslot, const uint32_t* __restrict__ wfirst,
-             const int32_t* __restrict__ slice_base, const int32_t* __restrict__ slice_len, int T, const float* __restrict__ x, float* __restrict__ y_by_rank, int nrows) {
+             const uint32_t* __restrict__ lcol, const uint32_t* __restrict__ lps,
+             const int32_t* __restrict__ slice_base, const int32_t* __restrict__ slice_len, int T, const float* __restrict__ x, float* __restrict__ y_by_rank, int nrows,
+             float* __restrict__ yl_by_rank, int nlong) {
   __shared__ float s_hot[HOT];
   __shared__ float s_acc[ACC];
-  __shared__ unsigned char s_has[ACC];
+  __shared__ float s_stage[STG > 0 ? STG : 1];
+  __shared__ int s_cnt;
   const int wg = blockIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < ACC; i += kBlock) s_has[i] = 0;
   const char* __restrict__ xb = (const char*)x;
+  constexpr int LB = ACC - NLP;
+  const int lj = (int)threadIdx.x - (kBlock - NLP);  // long-row slot of this thread (the last NLP threads fold)
+  bool lhas = false;
+  float lacc = 0.f;
   for (int s = 0; s < T; s++) {
     const uint32_t base4 = (uint32_t)slice_base[s] << 2;
     const int nhot = slice_len[s] < HOT ? slice_len[s] : HOT;
     const uint32_t nhot4 = (uint32_t)nhot << 2;
     __syncthreads();
     for (int i = threadIdx.x; i < nhot; i += kBlock) s_hot[i] = x[slice_base[s] + i];
+    if (ASYNC && threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
+    if constexpr (NLP > 0 && ASYNC) {
+      // every wave stages its share of the block's long-row messages and signs off on an LDS counter; only the folding
+      // waves wait for the others (the block fits the stage: checked by the host)
+      const size_t eb = (size_t)(wg * T + s) * NLP;
+      const uint32_t l0 = lps[eb], l1 = lps[eb + NLP];
+      const uint32_t n = l1 - l0, nr = (n + 63) >> 6;
+      const uint32_t ra = nr * (uint32_t)wv / kW, rb = nr * (uint32_t)(wv + 1) / kW;
+      uint32_t ps = 0, pe = 0;
+      if (lj >= 0) { ps = lps[eb + lj]; pe = lps[eb + lj + 1]; }
+      for (uint32_t r0 = ra; r0 < rb; r0 += 4) {
+        uint32_t c[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const uint32_t i = (r0 + j) * 64 + lane; c[j] = __builtin_nontemporal_load(&lcol[l0 + (i < n ? i : n - 1)]); }
+        float m[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t rel4 = c[j] - base4;
+          const bool h = rel4 < nhot4;
+          const float mh = *(const float*)((const char*)s_hot + (h ? rel4 : 0u));
+          const float mg = *(const float*)(xb + (h ? base4 : c[j]));
+          m[j] = h ? mh : mg;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const uint32_t i = (r0 + j) * 64 + lane; if (r0 + j < rb && i < n) s_stage[i] = m[j]; }
+      }
+      if (lane == 0) __hip_atomic_fetch_add(&s_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lj >= 0) {
+        while (__hip_atomic_load(&s_cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kW) __builtin_amdgcn_s_sleep(1);
+        uint32_t k = ps;
+        if (k < pe && !lhas) { lacc = s_stage[k - l0]; lhas = true; k++; }
+        for (; k + 4 <= pe; k += 4) {
+          float r[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) r[u] = s_stage[k - l0 + u];
+#pragma unroll
+          for (int u = 0; u < 4; u++) lacc += r[u];
+        }
+        for (; k < pe; k++) lacc += s_stage[k - l0];
+      }
+    } else if constexpr (NLP > 0) {
+      const size_t eb = (size_t)(wg * T + s) * NLP;
+      const uint32_t l0 = lps[eb], l1 = lps[eb + NLP];
+      uint32_t ps = 0, pe = 0;
+      if (lj >= 0) { ps = lps[eb + lj]; pe = lps[eb + lj + 1]; }
+      for (uint32_t c0 = l0; c0 < l1; c0 += STG) {
+        const uint32_t n = l1 - c0 < (uint32_t)STG ? l1 - c0 : (uint32_t)STG;
+        if (c0 != l0) __syncthreads();  // the previous chunk is folded: the stage may be overwritten
+        for (uint32_t i0 = 0; i0 < n; i0 += kBlock * 4) {
+          uint32_t c[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) { const uint32_t i = i0 + j * kBlock + threadIdx.x; c[j] = __builtin_nontemporal_load(&lcol[c0 + (i < n ? i : n - 1)]); }
+          float m[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const uint32_t rel4 = c[j] - base4;
+            const bool h = rel4 < nhot4;
+            const float mh = *(const float*)((const char*)s_hot + (h ? rel4 : 0u));
+            const float mg = *(const float*)(xb + (h ? base4 : c[j]));
+            m[j] = h ? mh : mg;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) { const uint32_t i = i0 + j * kBlock + threadIdx.x; if (i < n) s_stage[i] = m[j]; }
+        }
+        __syncthreads();
+        if (lj >= 0) {
+          uint32_t k = ps > c0 ? ps : c0;
+          const uint32_t ke = pe < c0 + n ? pe : c0 + n;
+          if (k < ke && !lhas) { lacc = s_stage[k - c0]; lhas = true; k++; }
+          for (; k + 4 <= ke; k += 4) {
+            float r[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) r[u] = s_stage[k - c0 + u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) lacc += r[u];
+          }
+          for (; k < ke; k++) lacc += s_stage[k - c0];
+        }
+      }
+    }
     const uint32_t* __restrict__ wf = wfirst + (size_t)(wg * T + s) * (kW + 1);
     uint32_t g = __builtin_amdgcn_readfirstlane(wf[wv]);
     const uint32_t gl = __builtin_amdgcn_readfirstlane(wf[wv + 1]);
@@ -234,8 +333,8 @@ k_sell_sweep(const uint32_t* __restrict__ scol, const uint32_t* __restrict__ gba
     uint32_t gend = __builtin_amdgcn_readfirstlane(gbase[g + 1] >> 6);     // end of the current group
     int slot = pslot[(size_t)g * 64 + lane];
     int nslot = g + 1 < gl ? pslot[(size_t)(g + 1) * 64 + lane] : 0xffff;
-    float acc = slot != 0xffff ? s_acc[slot] : 0.f;
-    bool has = slot != 0xffff ? s_has[slot] != 0 : false;
+    float acc = slot != 0xffff ? s_acc[slot & 0x7fff] : 0.f;
+    bool has = !(slot & 0x8000);
     uint32_t c[U];
 #pragma unroll
     for (int j = 0; j < U; j++) {
@@ -268,25 +367,44 @@ k_sell_sweep(const uint32_t* __restrict__ scol, const uint32_t* __restrict__ gba
       for (int j = 0; j < U; j++) {
         if (r0 + j < rend) {
           if (r0 + j == gend) {  // the group is done: its running values go back, the next group's come out
-            if (slot != 0xffff) { s_acc[slot] = acc; s_has[slot] = has ? 1 : 0; }
+            if (slot != 0xffff) s_acc[slot & 0x7fff] = acc;
             g++;
             gend = __builtin_amdgcn_readfirstlane(gbase[g + 1] >> 6);
             slot = nslot;
             nslot = g + 1 < gl ? pslot[(size_t)(g + 1) * 64 + lane] : 0xffff;
-            acc = slot != 0xffff ? s_acc[slot] : 0.f;
-            has = slot != 0xffff ? s_has[slot] != 0 : false;
+            acc = slot != 0xffff ? s_acc[slot & 0x7fff] : 0.f;
+            has = !(slot & 0x8000);
           }
           if (valid[j]) { acc = has ? acc + m[j] : m[j]; has = true; }
         }
       }
     }
-    if (slot != 0xffff) { s_acc[slot] = acc; s_has[slot] = has ? 1 : 0; }
+    if (slot != 0xffff) s_acc[slot & 0x7fff] = acc;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < ACC; i += kBlock) {
+  for (int i = threadIdx.x; i < LB; i += kBlock) {
     const long long rr = (long long)i * kWG + wg;
-    if (rr < nrows && s_has[i]) y_by_rank[rr] = s_acc[i];
+    if (rr < nrows) y_by_rank[rr] = s_acc[i];
   }
+  if constexpr (NLP > 0) {
+    if (lj >= 0) { const long long rr = (long long)lj * kWG + wg; if (rr < nlong && lhas) yl_by_rank[rr] = lacc; }
+  }
+}
+
+// long rows: entry e = (workgroup * T + slice) * NLP + slot -> first position in the sorted key stream
+__global__ void k_long_starts(const unsigned long long* __restrict__ key, int64_t n, int cbits, int T, int NLP, size_t nent, uint32_t* __restrict__ lps) {
+  const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (e > nent) return;
+  if (e == nent) { lps[e] = (uint32_t)n; return; }
+  const size_t b = e / NLP;
+  const unsigned long long wg = b / T, sl = b % T, j = e % NLP;
+  const unsigned long long want = (((wg << 7 | sl) << 16) | j) << cbits;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (key[mid] >= want) hi = mid; else lo = mid + 1; }
+  lps[e] = (uint32_t)lo;
+}
+__global__ void k_shift2(const int32_t* __restrict__ in, int64_t n, uint32_t* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (uint32_t)in[i] << 2;
 }
 
 // ---- short rows: lane = row, whole rows, groups of 64 rows of (nearly) equal length ------------------------------------
@@ -489,8 +607,11 @@ int main(int argc, char** argv) {
   const int scale = argc > 1 ? atoi(argv[1]) : 26;
   const int T = argc > 2 ? atoi(argv[2]) : 64;
   const int reps = argc > 3 ? atoi(argv[3]) : 5;
-  const int row_hi = argc > 4 ? atoi(argv[4]) : 4096;
+  const int row_hi = argc > 4 ? atoi(argv[4]) : 32768;   // long rows up to here are staged through LDS
   const int do_short = argc > 5 ? atoi(argv[5]) : 1;
+  const int row_mid = argc > 6 ? atoi(argv[6]) : 4096;  // medium rows (SELL groups) up to here
+  const int fold_waves = argc > 7 ? atoi(argv[7]) : 2;  // the last waves fold the long rows: they get fold_share percent of an equal share of the medium groups
+  const int fold_share = argc > 8 ? atoi(argv[8]) : 100;
   if (T < 1 || T > kMaxT) { printf("slices: 1..%d\n", kMaxT); return 1; }
   const int nv = 1 << scale;
   const int64_t ne = 16ll * nv;
@@ -535,7 +656,49 @@ int main(int argc, char** argv) {
 
   // ================= the swept rows =================
   {
-    const int nrows = rank_rows(deg, nv, kRowLo, (uint32_t)row_hi, iota, rank_of);
+    // ---- long rows (row_mid+1 .. row_hi): staged through LDS ----
+    constexpr int NLP = 128;
+    uint32_t *lcol = nullptr, *lps = nullptr;
+    uint32_t maxblk = 0;
+    float *yl = nullptr, *ylref = nullptr;
+    int nlong = 0;
+    int64_t ledges = 0;
+    if (row_hi > row_mid) {
+      nlong = rank_rows(deg, nv, (uint32_t)row_mid + 1, (uint32_t)row_hi, iota, rank_of);
+      if ((nlong + kWG - 1) / kWG > NLP) { printf("long rows per workgroup %d > %d\n", (nlong + kWG - 1) / kWG, NLP); return 1; }
+      unsigned long long *k1, *k1s, *k2, *k2s; int32_t *v, *v1s, *v2s;
+      OK(hipMalloc(&k1, ne * 8)); OK(hipMalloc(&k1s, ne * 8)); OK(hipMalloc(&k2, ne * 8)); OK(hipMalloc(&k2s, ne * 8));
+      OK(hipMalloc(&v, ne * 4)); OK(hipMalloc(&v1s, ne * 4)); OK(hipMalloc(&v2s, ne * 4));
+      k_edge_keys<<<G, 256>>>(src, dst, ne, rank_of, bound, T, dev_of, cbits, k1, v, k2);
+      unsigned long long* d_cnt; OK(hipMalloc(&d_cnt, 8)); OK(hipMemset(d_cnt, 0, 8));
+      k_count_valid<<<G, 256>>>(k1, ne, d_cnt);
+      unsigned long long nedges_u = 0; OK(hipMemcpy(&nedges_u, d_cnt, 8, hipMemcpyDeviceToHost));
+      ledges = (int64_t)nedges_u;
+      sort_pairs(k1, k1s, v, v1s, (size_t)ne, 64);
+      sort_pairs(k2, k2s, v, v2s, (size_t)ne, 64);
+      OK(hipFree(k1)); OK(hipFree(k2)); OK(hipFree(v));
+      const size_t nent = (size_t)kWG * T * NLP;
+      OK(hipMalloc(&lps, (nent + 1) * 4)); OK(hipMalloc(&lcol, ((size_t)ledges + 64) * 4));
+      k_long_starts<<<(unsigned)((nent + 1 + 255) / 256), 256>>>(k1s, ledges, cbits, T, NLP, nent, lps);
+      k_shift2<<<G, 256>>>(v1s, ledges, lcol);
+      uint32_t* row_start; OK(hipMalloc(&row_start, ((size_t)nlong + 1) * 4));
+      k_row_starts<<<G, 256>>>(k2s, ledges, cbits, row_start);
+      OK(hipMalloc(&yl, (size_t)nlong * 4)); OK(hipMalloc(&ylref, (size_t)nlong * 4));
+      k_reference<<<(nlong + 255) / 256, 256>>>(row_start, nlong, ledges, v2s, x, ylref);
+      OK(hipDeviceSynchronize());
+      OK(hipFree(k1s)); OK(hipFree(k2s)); OK(hipFree(v1s)); OK(hipFree(v2s)); OK(hipFree(row_start));
+      // the largest block (edges of one workgroup's long rows inside one slice)
+      std::vector<uint32_t> h(nent + 1);
+      OK(hipMemcpy(h.data(), lps, (nent + 1) * 4, hipMemcpyDeviceToHost));
+      uint32_t mx = 0, mxp = 0;
+      for (size_t bI = 0; bI < (size_t)kWG * T; bI++) { const uint32_t d = h[(bI + 1) * NLP] - h[bI * NLP]; mx = d > mx ? d : mx; }
+      for (size_t e = 0; e < nent; e++) { const uint32_t d = h[e + 1] - h[e]; mxp = d > mxp ? d : mxp; }
+      maxblk = mx;
+      printf("long rows %d..%d: %d rows, %lld edges; per (workgroup, slice) block %.0f edges on average, %u at most; longest piece %u\n", row_mid + 1, row_hi, nlong, (long long)ledges,
+             (double)ledges / (kWG * T), mx, mxp);
+    }
+    // ---- medium rows (kRowLo .. row_mid): SELL groups ----
+    const int nrows = rank_rows(deg, nv, kRowLo, (uint32_t)row_mid, iota, rank_of);
     const int rows_per_wg = (nrows + kWG - 1) / kWG;
     unsigned long long *k1, *k1s, *k2, *k2s; int32_t *v, *v1s, *v2s;
     OK(hipMalloc(&k1, ne * 8)); OK(hipMalloc(&k1s, ne * 8)); OK(hipMalloc(&k2, ne * 8)); OK(hipMalloc(&k2s, ne * 8));
@@ -571,8 +734,9 @@ int main(int argc, char** argv) {
     if (nedges >= (1ll << 32)) { printf("too many edges for 32-bit positions\n"); return 1; }
     // pieces sorted by (block, length descending)
     uint32_t *pkey, *pkey2, *pid, *sp;
+    int* rowmin; OK(hipMalloc(&rowmin, ((size_t)rows_per_wg * kWG + 1) * 4)); OK(hipMemset(rowmin, 0x7f, ((size_t)rows_per_wg * kWG + 1) * 4));
     OK(hipMalloc(&pkey, (size_t)npieces * 4)); OK(hipMalloc(&pkey2, (size_t)npieces * 4)); OK(hipMalloc(&pid, (size_t)npieces * 4)); OK(hipMalloc(&sp, (size_t)npieces * 4));
-    k_piece_keys<<<(npieces + 255) / 256, 256>>>(piece_start, npieces, blk_first, nblk, pkey, pid);
+    k_piece_keys<<<(npieces + 255) / 256, 256>>>(piece_start, npieces, blk_first, nblk, pkey, pid, piece_row, T, rowmin);
     sort_pairs(pkey, pkey2, pid, sp, (size_t)npieces, 32);
     OK(hipFree(pkey)); OK(hipFree(pkey2)); OK(hipFree(pid));
     uint32_t *ng, *grp_first;
@@ -585,12 +749,11 @@ int main(int argc, char** argv) {
     OK(hipMalloc(&gsize, ((size_t)ngroups + 1) * 4)); OK(hipMalloc(&gbase, ((size_t)ngroups + 1) * 4)); OK(hipMalloc(&gq0, ((size_t)ngroups + 1) * 4)); OK(hipMalloc(&gblk, ((size_t)ngroups + 1) * 4));
     OK(hipMemset(gsize, 0, ((size_t)ngroups + 1) * 4));
     k_group_sizes<<<nblk, 64>>>(blk_first, grp_first, nblk, sp, piece_start, gsize, gq0, gblk);
-    // 64-bit total first (overflow check), then the 32-bit scan
     {
       std::vector<uint32_t> hs((size_t)ngroups);
       OK(hipMemcpy(hs.data(), gsize, (size_t)ngroups * 4, hipMemcpyDeviceToHost));
       unsigned long long tot = 0; for (uint32_t gI = 0; gI < ngroups; gI++) tot += hs[gI];
-      printf("swept rows %d..%d: %d rows, %lld edges, %u pieces (%.2f edges each), %u groups, padded entries %llu (+%.2f %%), %d slices, %d rows per workgroup\n", kRowLo, row_hi, nrows,
+      printf("medium rows %d..%d: %d rows, %lld edges, %u pieces (%.2f edges each), %u groups, padded entries %llu (+%.2f %%), %d slices, %d rows per workgroup\n", kRowLo, row_mid, nrows,
              (long long)nedges, npieces, (double)nedges / npieces, ngroups, tot, 100.0 * ((double)tot / nedges - 1.0), T, rows_per_wg);
       if (tot >= (1ull << 32)) { printf("too many padded entries for 32-bit positions\n"); return 1; }
     }
@@ -598,12 +761,11 @@ int main(int argc, char** argv) {
     uint32_t total_entries = 0; OK(hipMemcpy(&total_entries, gbase + ngroups, 4, hipMemcpyDeviceToHost));
     uint32_t* scol; uint16_t* pslot;
     OK(hipMalloc(&scol, ((size_t)total_entries + 64 * 64) * 4)); OK(hipMalloc(&pslot, ((size_t)ngroups + 1) * 64 * 2));
-    k_fill_groups<<<65536, 256>>>(ngroups, gbase, gq0, gblk, blk_first, sp, piece_start, piece_row, v1s, slice_base, T, scol, pslot);
+    k_fill_groups<<<65536, 256>>>(ngroups, gbase, gq0, gblk, blk_first, sp, piece_start, piece_row, v1s, slice_base, T, scol, pslot, rowmin);
     uint32_t* wfirst; OK(hipMalloc(&wfirst, (size_t)nblk * (kW + 1) * 4));
-    k_wave_ranges<<<(nblk + 63) / 64, 64>>>(grp_first, nblk, gbase, wfirst);
+    k_wave_ranges<<<(nblk + 63) / 64, 64>>>(grp_first, nblk, gbase, wfirst, fold_waves, fold_share);
     OK(hipDeviceSynchronize());
     OK(hipFree(v1s)); OK(hipFree(sp)); OK(hipFree(piece_start)); OK(hipFree(piece_row));
-    // reference
     uint32_t* row_start; OK(hipMalloc(&row_start, ((size_t)nrows + 1) * 4));
     k_row_starts<<<G, 256>>>(k2s, nedges, cbits, row_start);
     float *y, *yref;
@@ -611,18 +773,24 @@ int main(int argc, char** argv) {
     k_reference<<<(nrows + 255) / 256, 256>>>(row_start, nrows, nedges, v2s, x, yref);
     OK(hipDeviceSynchronize());
     OK(hipFree(k2s)); OK(hipFree(v2s));
-    constexpr int ACC = 10752;
-    if (rows_per_wg > ACC) { printf("rows per workgroup %d > %d\n", rows_per_wg, ACC); return 1; }
-#define RUN(HOT, U) do { OK(hipMemset(y, 0, (size_t)nrows * 4)); \
-      time_it([&]() { k_sell_sweep<HOT, ACC, U><<<kWG, kBlock>>>(scol, gbase, pslot, wfirst, slice_base, slice_len, T, x, y, nrows); }, "SELL sweep, hot " #HOT ", batch " #U, reps, nedges); \
-      compare(y, yref, nrows, "  "); } while (0)
-    RUN(18432, 4);
-    RUN(18432, 8);
-    RUN(26624, 4);
-    RUN(26624, 8);
-    RUN(26624, 2);
-    RUN(8192, 4);
-    RUN(1, 4);
+    constexpr int ACC = 10176;
+    if (rows_per_wg > ACC - NLP) { printf("rows per workgroup %d > %d\n", rows_per_wg, ACC - NLP); return 1; }
+    const int64_t alledges = nedges + ledges;
+#define RUN(HOT, U, STG, NL, AS) do { if ((AS) && maxblk > (uint32_t)(STG)) { printf("(block of %u edges does not fit a stage of %d)\n", maxblk, (int)(STG)); break; } OK(hipMemset(y, 0, (size_t)nrows * 4)); if (nlong) OK(hipMemset(yl, 0, (size_t)nlong * 4)); \
+      if ((NL) == 0 || nlong > 0) { \
+      time_it([&]() { k_sell_sweep<HOT, ACC, U, STG, NL, AS><<<kWG, kBlock>>>(scol, gbase, pslot, wfirst, lcol, lps, slice_base, slice_len, T, x, y, nrows, yl, nlong); }, \
+              "SELL sweep, hot " #HOT ", batch " #U ", stage " #STG ", long slots " #NL ", async " #AS, reps, (NL) ? alledges : nedges); \
+      compare(y, yref, nrows, "   medium rows"); if (NL) compare(yl, ylref, nlong, "   long rows"); } } while (0)
+    RUN(26624, 8, 0, 0, false);
+    RUN(18432, 8, 0, 0, false);
+    RUN(22528, 8, 8192, 128, false);
+    RUN(22528, 8, 8192, 128, true);
+    RUN(21504, 8, 9216, 128, false);
+    RUN(21504, 8, 9216, 128, true);
+    RUN(18432, 8, 12288, 128, false);
+    RUN(18432, 8, 12288, 128, true);
+    RUN(16384, 8, 14336, 128, false);
+    RUN(16384, 8, 14336, 128, true);
 #undef RUN
     OK(hipFree(scol)); OK(hipFree(pslot)); OK(hipFree(wfirst)); OK(hipFree(gbase)); OK(hipFree(gsize)); OK(hipFree(gq0)); OK(hipFree(gblk)); OK(hipFree(y)); OK(hipFree(yref));
     OK(hipFree(row_start)); OK(hipFree(blk_first)); OK(hipFree(ng)); OK(hipFree(grp_first));
