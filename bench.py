@@ -30,7 +30,6 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-GATHER_CEILING = 238e9  # L2-resident random 4-byte gathers per second, whole chip (tools/gather_path_bench.hip, profiles/r03_gather_paths_microbench.txt)
 
 
 def log(rank, *a):
@@ -136,6 +135,14 @@ def cpu_baseline(scale, iters, rank, scale2=0):
         del og
     # the probes are 10 iterations each and the host is not quiet: the two best (layout, threads) pairs both run the timed
     # blocks, and the better median is the baseline
+    if not cands:  # (a host with very few cores: no (layout, threads) pair of the grid applies -- one small layout on all of them)
+        layout = max(1, min(4, logical))
+        L.gmo_set_num_threads(logical)
+        og = ob.OracleGraph(nv, s, d, None, ref_threads=layout)
+        deg = og.degree()
+        t0 = time.time()
+        og.pagerank(2, degree=deg)
+        cands.append(((time.time() - t0) / 2, logical, og, deg, layout))
     cands.sort(key=lambda c: c[0])
     per_block = max(1, iters // 3)
     ph = (C.c_double * 3)()
@@ -748,17 +755,26 @@ def main():
         for t in range(int(g.col_tiles)):
             ct, _ = g.tile(api.GM_DIR_OUT, t)
             by_kernel = [a + b for a, b in zip(by_kernel, class_edges(ct))]
-    # the row-stationary sweep (graphmat_hip.h gm_sweep_t): the tiles' row-block / 16-row work is done by k_spmv_sweep
+    # the row-stationary sweep (graphmat_hip.h gm_sweep_t; kernels.hpp k_spmv_sell): every row of more than 64 edges that is not
+    # giant goes through it, the short rows through the row-block kernel, the giant rows through their own passes on the auxiliary stream
     from graphmat_amd import _lib as _gl
     sweep = _gl.Sweep()
-    if _gl.lib().gm_graph_sweep(g.h, C.byref(sweep)) != 0 or int(g.col_tiles) <= 1:
+    if _gl.lib().gm_graph_sweep(g.h, C.byref(sweep)) != 0 or world > 1:
         sweep.nrows = 0
     swept = int(sweep.nrows) > 0
     roof = None
     name = max(kern, key=lambda k: kern[k][0])
     ms, launches, alg_bytes = kern[name]
-    tiled = int(g.col_tiles) > 1
-    if tiled:
+    tiled = int(g.col_tiles) > 1 and not swept
+    if swept:
+        # the dominant kernel: one launch per iteration (nsets launches timed as one unit when the rows do not fit one);
+        # algorithmic bytes = 4 B column id per edge + 8 B per row (its y entry, its slot)
+        name = "k_spmv_sell"
+        ms, launches = stats["wave_ms"], stats["wave_launches"]
+        swept_edges = int(sweep.nedges) + int(sweep.nedges_long)
+        alg_bytes = 4 * swept_edges + 8 * int(sweep.nrows)
+        by_kernel = [int(c_out.edges_blk), swept_edges, 0, int(c_out.nnz) - int(c_out.edges_blk) - swept_edges]
+    elif tiled:
         # column tiles: a row's pieces are spread over T launches of every kernel class (and per tile the long wave rows
         # overlap the other kernels on the auxiliary stream), so the unit is the whole multiply of one iteration: every
         # row-block and wave launch of its T tiles, its duration the span of the run's stream up to the join of the
@@ -785,10 +801,12 @@ def main():
                 if tj.get("kernels_fingerprint") == kernels_fingerprint() and tj.get("col_tiles", {}).get("scale%d" % args.scale) == int(g.col_tiles):
                     # (large graphs run the persistent forms k_spmv_rowwave / k_spmv_wave16p instead of, or next to, the plain ones)
                     names = {"k_spmv_rowblock": ["k_spmv_rowblock", "k_spmv_rowwave"], "k_spmv_wave": ["k_spmv_wave", "k_spmv_wave16", "k_spmv_wave16p"],
-                             "multiply": ["k_spmv_rowblock", "k_spmv_rowwave", "k_spmv_wave", "k_spmv_wave16", "k_spmv_wave16p", "k_spmv_sweep"]}.get(name, [name])
+                             "k_spmv_sell": ["k_spmv_sell"],
+                             "multiply": ["k_spmv_rowblock", "k_spmv_rowwave", "k_spmv_wave", "k_spmv_wave16", "k_spmv_wave16p"]}.get(name, [name])
                     parts = [per.get(k + "_bytes_per_iteration") for k in names]
                     traffic = int(sum(v for v in parts if v is not None)) if any(v is not None for v in parts) else None
-                    traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernels (profiles/pmc_traffic.json)"
+                    traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernels (profiles/pmc_traffic.json); calibration of the counters "
+                                    "on a pure coalesced stream and a pure random 4-byte gather: %s" % json.dumps(tj.get("calibration", "not recorded")))
                 else:
                     traffic_note = "profiles/pmc_traffic.json was measured on other kernel sources: not quoted"
             except Exception:
@@ -798,35 +816,38 @@ def main():
         big = world == 1 and (ndev >= (48 << 20) or (ndev >= (24 << 20) and int(g.col_tiles) > 1))
         kname = {"k_spmv_wave": "k_spmv_wave16+k_spmv_wave", "multiply": ("k_spmv_rowblock/k_spmv_rowwave+k_spmv_wave16p+k_spmv_wave" if big else "k_spmv_rowblock+k_spmv_wave16+k_spmv_wave") +
                  (" over %d column tiles" % int(g.col_tiles) if tiled else "")}.get(name, name)
-        if swept and name == "multiply":
-            kname = "k_spmv_rowblock+k_spmv_sweep (%d slices; main stream) next to k_spmv_wave and the giant-row passes over %d column tiles (two other streams)" % (int(sweep.nslices), int(g.col_tiles))
+        if swept:
+            kname = "k_spmv_sell (row-stationary sweep over %d slices, %d launch(es) per iteration)" % (int(sweep.nslices), int(sweep.nsets))
+        # every multiply kernel of the iteration by itself: edges x 4 B / its average time / the HBM peak.  (The giant rows'
+        # passes run on the auxiliary stream next to the row-block kernel: their time overlaps it.)
+        steps_ = max(args.steps, 1)
+        def kfrac(edges, ms_total):
+            t = ms_total / steps_
+            return {"edges": int(edges), "avg_ms": round(t, 4), "gbps": round(4 * edges / (t * 1e-3) / 1e9, 1) if t > 0 else None,
+                    "frac": round(4 * edges / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if t > 0 else None}
+        per_kernel = ({"k_spmv_rowblock (rows of up to 64 edges)": kfrac(by_kernel[0], stats["rowblock_ms"]),
+                       "k_spmv_sell (rows of 65 .. giant-limit edges)": kfrac(by_kernel[1], stats["wave_ms"]),
+                       "k_giant_terms+k_spmv_giant (auxiliary stream, overlapping the row-block kernel)": kfrac(by_kernel[3], stats["giant_ms"])} if swept else
+                      {"k_spmv_rowblock": kfrac(by_kernel[0], stats["rowblock_ms"]), "k_spmv_wave16+k_spmv_wave": kfrac(by_kernel[1] + by_kernel[2], stats["wave_ms"]),
+                       "k_giant_terms+k_spmv_giant (auxiliary stream, overlapped)": kfrac(by_kernel[3], stats["giant_ms"])})
         roof = {"bound": "hbm", "kernel": kname + "<PageRank>", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg_bytes,
                 "unit_note": ("one launch unit = all %d launches of these kernels in one iteration" % per_step) if per_step > 1 else "one launch per iteration",
                 "launches_per_iteration": per_step,
+                "per_kernel": per_kernel,
                 "rowblock_avg_ms": round(stats["rowblock_ms"] / max(args.steps, 1), 4),
                 "wave_avg_ms": round(stats["wave_ms"] / max(args.steps, 1), 4),
                 "aux_streams_avg_ms_overlapped": round(stats["giant_ms"] / max(args.steps, 1), 4),  # giant-row passes + long wave rows
                 "edges_rowblock_wave_giant": [e_short, e_mid, e_giant],
-                "edges_by_kernel": ({"k_spmv_rowblock": int(c_out.edges_blk), "k_spmv_sweep": int(sweep.nedges), "k_spmv_wave": by_kernel[2],
-                                     "k_giant_terms+k_spmv_giant": by_kernel[3]} if swept else
+                "edges_by_kernel": ({"k_spmv_rowblock": by_kernel[0], "k_spmv_sell": by_kernel[1], "k_giant_terms+k_spmv_giant": by_kernel[3]} if swept else
                                     {"k_spmv_rowblock": by_kernel[0], "k_spmv_wave16": by_kernel[1], "k_spmv_wave": by_kernel[2],
                                      "k_giant_terms+k_spmv_giant": by_kernel[3]}),
                 "send_avg_ms": round(stats["send_ms"] / args.steps, 4),
                 "apply_avg_ms": round(stats["apply_ms"] / args.steps, 4),
-                "gather_ceiling_note": "random 4-byte gathers on this chip peak at ~200 G/s L2-resident and ~55-66 G/s over "
-                                       "a 268 MB table (tools/gather_bench.hip); one gather per edge is inherent to the path"}
-        # What this formulation can attain: one 4-byte gather of x per edge, and the chip serves at most GATHER_CEILING
-        # such gathers per second even when every one hits the L2 (the per-CU vector-memory path holds ~110 requests in
-        # flight at ~250 cycles each: profiles/r03_tcp_counters_scale26.md; microbenchmark tools/gather_path_bench.hip,
-        # 1 MB table, uniform indices: 238 G/s).  attainable = the unit's algorithmic bytes / (its gathers / ceiling).
-        gathers = sum(by_kernel[:3]) if tiled or name == "multiply" else (by_kernel[0] if name == "k_spmv_rowblock" else by_kernel[1] + by_kernel[2])
-        t_min = gathers / GATHER_CEILING
-        roof["attainable"] = round(alg_bytes / t_min / 1e9, 1)
-        roof["frac_of_attainable"] = round(t_min / (avg_ms * 1e-3), 4)
-        roof["attainable_note"] = ("%.0f G gathers/s ceiling of the chip for L2-resident random 4-byte gathers (profiles/r03_gather_paths_microbench.txt) "
-                                   "x one gather per edge; whole iteration against the same ceiling: %.4f" % (GATHER_CEILING / 1e9, (E / world / GATHER_CEILING) / (ms_per_step * 1e-3)))
+                "bound_note": ("one 4-byte gather of x per edge is inherent to the path; what bounds the sweep is measured with its own phase clocks and "
+                               "measurement forms (tools/sweep_lib_bench.hip, profiles/r05_sweep_phase_clocks.md): the L1-miss path of the CUs for the gathers "
+                               "the LDS hot sets do not serve, and the per-slice latency chains")}
     iter_bytes = 4 * E + 48 * nv
     out = {
         "metric": "GTEPS (edges/s) per iter + achieved HBM GB/s, PageRank %s-%d" % ("RMAT" if args.graph == "rmat" else "uniform", args.scale),

@@ -41,7 +41,7 @@ class Csr(C.Structure):
 
 class Sweep(C.Structure):
     _fields_ = [("nrows", C.c_int32), ("nrows_long", C.c_int32), ("nsets", C.c_int32), ("nslices", C.c_int32), ("acc_rows", C.c_int32),
-                ("long_slots", C.c_int32), ("max_long_block", C.c_int32), ("val_bytes", C.c_int32), ("short_row", C.c_int32), ("giant_row", C.c_int32),
+                ("long_slots", C.c_int32), ("max_long_block", C.c_int32), ("val_bytes", C.c_int32), ("short_row", C.c_int32), ("long_row", C.c_int32),
                 ("nedges", C.c_int64), ("nedges_long", C.c_int64), ("nentries", C.c_int64), ("ngroups", C.c_int64),
                 ("scol", C.c_void_p), ("sval", C.c_void_p), ("gbase", C.c_void_p), ("wrow", C.c_void_p), ("wfirst", C.c_void_p),
                 ("row_of_slot", C.c_void_p), ("lcol", C.c_void_p), ("lval", C.c_void_p), ("lps", C.c_void_p), ("lrow_of_slot", C.c_void_p),

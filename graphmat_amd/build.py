@@ -58,5 +58,24 @@ def build(force=False, verbose=False):
     return so
 
 
+def build_hooks(verbose=False):
+    """The TEST-HOOKS variant of the library (build/hooks/libgraphmat_hip.so): the product objects with gm_dist.hip compiled
+    -DGM_TEST_HOOKS, which adds the fault injection the negative control of the multi-rank tests needs (GRAPHMAT_DEBUG_DROP_WAIT).
+    Test infrastructure: loaded only through GRAPHMAT_HIP_LIBRARY, never by the product."""
+    build(verbose=verbose)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(ROOT, "build", "hooks")
+    os.makedirs(objdir, exist_ok=True)
+    so = os.path.join(objdir, "libgraphmat_hip.so")
+    obj = os.path.join(objdir, "gm_dist.o")
+    deps_mtime = max(os.path.getmtime(p) for p in _deps())
+    if not os.path.exists(obj) or os.path.getmtime(obj) < deps_mtime:
+        subprocess.check_call([hipcc] + FLAGS + ["-DGM_TEST_HOOKS", "-c", os.path.join(CSRC, "gm_dist.hip"), "-o", obj])
+    objs = [os.path.join(CSRC, src.replace(".hip", ".o")) for src in SOURCES if src != "gm_dist.hip"] + [obj]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(o) for o in objs):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs + ["-ldl", "-lrt"])
+    return so
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -229,11 +229,16 @@ static int wait_parts(RcclExchange* X) {
   const int64_t S = g->desc.row_hi - g->desc.row_lo;
   hipStream_t s = g->run_stream;
   GM_TRY_HIP(hipEventRecord(X->arrived, X->xs));
-  // GRAPHMAT_DEBUG_DROP_WAIT=1 (tests only) leaves this dependency out: the run stream then copies the parts out of the
-  // staging buffer without waiting for the side stream's all-gathers -- the bug a blocking transport can never show and
-  // tests/test_gpu_multi.py::test_missing_stream_wait_is_caught proves the stream-ordered test transport does
+#ifdef GM_TEST_HOOKS
+  // Fault injection of the TEST-HOOKS build only (graphmat_amd/build.py: build_hooks -> build/hooks/libgraphmat_hip.so; the product
+  // library has no such switch): GRAPHMAT_DEBUG_DROP_WAIT=1 leaves this dependency out -- the run stream then copies the parts
+  // out of the staging buffer without waiting for the side stream's all-gathers, the bug a blocking transport can never show
+  // and tests/test_gpu_multi.py::test_missing_stream_wait_is_caught proves the stream-ordered test transport does
   static const bool drop_wait = getenv("GRAPHMAT_DEBUG_DROP_WAIT") != nullptr && getenv("GRAPHMAT_DEBUG_DROP_WAIT")[0] == '1';
   if (!drop_wait) GM_TRY_HIP(hipStreamWaitEvent(s, X->arrived, 0));
+#else
+  GM_TRY_HIP(hipStreamWaitEvent(s, X->arrived, 0));
+#endif
   for (const RcclExchange::Part& p : X->pending) {
     const char* st = (const char*)X->part_stage + (size_t)n * p.first * p.elt;
     GM_TRY_HIP(hipMemcpy2DAsync((char*)p.buf + (size_t)p.first * p.elt, (size_t)(S * p.elt), st, (size_t)(p.count * p.elt),

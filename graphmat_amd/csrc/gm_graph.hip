@@ -32,6 +32,9 @@ int g_tile_balance = 1;  // column tiles serve equally many gathers (1) or hold 
 int g_long_mid = 0;  // > 0: experiment -- wave rows of more than this many edges get a wave each (0 = GM_LONG_MID rule)
 int g_sweep_slices = 1;  // 1: cut the device order into ntiles * k <= 64 slices and build the row-stationary sweep of the medium rows (gm_graph_sweep)
 int g_sort_tile_lists = 1;  // column tiles: the wave-row lists by descending piece length (sort_rows_by_length)
+int g_sweep_border_factor = 4;  // the medium / long border is lowered while it exceeds this many times a wave's share of a block per slice
+int g_sweep_fold_share = 70;  // share (percent of an equal share) of a block's groups that the waves folding the long rows get
+int g_sweep_long_row = 0;  // the sweep's medium / long border (edges per row): 0 = chosen per graph (build_sweep)
 int g_sweep_acc_limit = GM_SWEEP_ACC_ROWS, g_sweep_long_limit = GM_SWEEP_LONG_SLOTS;  // rows per workgroup and launch of the sweep (tests force several launches with small values)
 int g_own_wave_row = 4096;  // column tiles: rows of more than this many edges (whole graph) keep the wave / giant kernels in every tile (0: classes per tile piece)
 int g_col_tiles = 0;  // default number of column tiles for graphs whose descriptor says 0 (0 = environment GRAPHMAT_COL_TILES, else none)
@@ -1039,14 +1042,15 @@ k_sweep_fill(uint32_t ngroups, const uint32_t* __restrict__ gbase, const uint32_
     }
   }
 }
-// contiguous ranges of a block's groups for the 16 waves (wfirst: groups; wrow: 64-entry rows of scol), balanced by rows + 1 per group; the last two waves (they fold the long
-// rows of the block first) get fold_share percent of an equal share
+// contiguous ranges of a block's groups for the 16 waves (wfirst: groups; wrow: 64-entry rows of scol), balanced by rows + 1 per group; the last waves (they fold the long
+// rows of the block first: as many waves as the workgroup's long rows need lanes) get fold_share percent of an equal share
 __global__ void __launch_bounds__(64)
 k_sweep_wave_ranges(const uint32_t* __restrict__ grp_first, int nblk, const uint32_t* __restrict__ gbase, uint32_t* __restrict__ wfirst, uint32_t* __restrict__ wrow,
-                    int fold_share) {
+                    int fold_share, int fold_waves) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= nblk) return;
-  constexpr int W = 16, FW = GM_SWEEP_LONG_SLOTS / 64;
+  constexpr int W = 16;
+  const int FW = fold_waves;
   const uint32_t g0 = grp_first[b], g1 = grp_first[b + 1];
   unsigned long long total = 0;
   for (uint32_t g = g0; g < g1; g++) total += (gbase[g + 1] - gbase[g]) / 64u + 1u;
@@ -1173,7 +1177,42 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
   if ((rc = tmp.alloc(tb + 256))) return rc;
   GM_TRY_HIP(rocprim::radix_sort_pairs_desc(tmp.p, tb, len_in.as<uint32_t>(), len_out.as<uint32_t>(), rows.as<int32_t>(), ranked.as<int32_t>(), (size_t)nswept, 0, 32, s));
   rows.free(); len_in.free();
-  const uint32_t long_limit = (uint32_t)(g_own_wave_row > 0 ? std::min(g_own_wave_row, 8191) : 4096);  // (13 bits for a group's width)
+  // The border between medium rows (64-wide groups) and long rows (staged through LDS, one lane folds a piece).  A piece is folded
+  // by ONE lane, row of entries after row: the longest medium piece of a slice is a chain that one wave has to walk while its
+  // workgroup's other waves wait at the slice barrier, so it should not exceed a wave's fair share of the block -- (medium
+  // entries per workgroup / 64) / 16 waves per slice, against ~L / nslices for a row of L edges: L <= medium edges / 262144 (phase
+  // clocks of the kernel, tools/sweep_lib_bench.hip: with the border at 4096 the slowest wave of an RMAT-26 workgroup spends
+  // 2.0 ms in its groups against 1.5 ms on average, at RMAT-24 1.2 against 0.33).  Candidates: powers of two from 256 to 4096;
+  // the long rows must fit their slots (long_slots per workgroup and launch) in as many launches as the medium rows need.
+  uint32_t long_limit = 4096;
+  if (g_sweep_long_row > 0) {
+    long_limit = (uint32_t)std::min(g_sweep_long_row, 8191);  // (13 bits for a group's width)
+  } else {
+    std::vector<uint32_t> hl(nswept);
+    GM_TRY_HIP(hipMemcpyAsync(hl.data(), len_out.p, (size_t)nswept * 4, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    // hl is descending: for a border L, the long rows are the prefix with len > L
+    auto rows_above = [&](uint32_t L) { size_t lo = 0, hi = nswept; while (lo < hi) { const size_t mid = (lo + hi) / 2; if (hl[mid] > L) lo = mid + 1; else hi = mid; } return lo; };
+    std::vector<unsigned long long> suffix((size_t)nswept + 1, 0ull);  // edges of the rows from position i on
+    for (size_t i = nswept; i-- > 0;) suffix[i] = suffix[i + 1] + hl[i];
+    // launches a border needs: the medium rows must fit the accumulator slots, the long rows theirs
+    auto sets_for = [&](uint32_t L) {
+      const size_t nl = rows_above(L), nm = (size_t)nswept - nl;
+      const size_t a = ((nm + 255) / 256 + (size_t)g_sweep_acc_limit - 1) / (size_t)g_sweep_acc_limit, b = ((nl + 255) / 256 + (size_t)g_sweep_long_limit - 1) / (size_t)g_sweep_long_limit;
+      return std::max<size_t>(1, std::max(a, b));
+    };
+    size_t fewest = ~(size_t)0;
+    for (uint32_t L = 4096; L >= 256; L >>= 1) fewest = std::min(fewest, sets_for(L));
+    long_limit = 0;
+    uint32_t smallest_ok = 4096;
+    for (uint32_t L = 4096; L >= 256; L >>= 1) {
+      if (sets_for(L) != fewest) continue;
+      smallest_ok = L;
+      const unsigned long long emed = suffix[rows_above(L)];
+      if ((unsigned long long)L * 262144ull <= emed * (unsigned long long)g_sweep_border_factor) { long_limit = L; break; }
+    }
+    if (long_limit == 0) long_limit = smallest_ok;
+  }
   hipLaunchKernelGGL(k_sweep_count_above, dim3(1), dim3(1), 0, s, (const uint32_t*)len_out.as<uint32_t>(), (int)nswept, long_limit, cnt.as<unsigned int>());
   unsigned int nlong = 0;
   GM_TRY_HIP(hipMemcpyAsync(&nlong, cnt.p, 4, hipMemcpyDeviceToHost, s));
@@ -1315,7 +1354,8 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
                        (const uint16_t*)pslot16.as<uint16_t>(), mpos, colidx, vals, sl, TS, (const int*)rowmin.as<int>(), scol.as<uint32_t>(),
                        vals ? sval.as<uint32_t>() : (uint32_t*)nullptr, vals ? spos.as<uint32_t>() : (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_sweep_wave_ranges, dim3((unsigned)((nblk + 63) / 64)), dim3(64), 0, s, (const uint32_t*)grp_first.as<uint32_t>(), (int)nblk,
-                       (const uint32_t*)gbase.as<uint32_t>(), wfirst.as<uint32_t>(), wrow.as<uint32_t>(), nlong > 0 ? 50 : 100);
+                       (const uint32_t*)gbase.as<uint32_t>(), wfirst.as<uint32_t>(), wrow.as<uint32_t>(), nlong > 0 ? g_sweep_fold_share : 100,
+                       (int)std::min(8, (((per_wg_long + nsets - 1) / nsets) + 63) / 64));
     GM_TRY_HIP(hipGetLastError());
     GM_TRY_HIP(hipStreamSynchronize(s));
   } else {
@@ -1328,7 +1368,7 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
   }
   S.nrows = (int32_t)nswept; S.nrows_long = (int32_t)nlong; S.nsets = nsets; S.nslices = TS;
   S.acc_rows = GM_SWEEP_ACC_ROWS; S.long_slots = GM_SWEEP_LONG_SLOTS; S.max_long_block = (int32_t)max_block; S.val_bytes = vals ? 4 : 0;
-  S.short_row = whole->view.short_row; S.giant_row = 0;
+  S.short_row = whole->view.short_row; S.long_row = (int32_t)long_limit;
   S.nedges = nedges; S.nedges_long = nedges_long; S.nentries = (int64_t)nentries; S.ngroups = (int64_t)ngroups;
   S.scol = (const uint32_t*)scol.release(); S.sval = (const uint32_t*)sval.release(); S.gbase = (const uint32_t*)gbase.release();
   S.wrow = (const uint32_t*)wrow.release(); S.wfirst = (const uint32_t*)wfirst.release(); S.row_of_slot = (const int32_t*)rslot.release();

@@ -20,7 +20,7 @@
 
 namespace gm {
 
-extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance, g_own_wave_row, g_sort_tile_lists, g_sweep_slices, g_sweep_acc_limit, g_sweep_long_limit;
+extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance, g_own_wave_row, g_sort_tile_lists, g_sweep_slices, g_sweep_acc_limit, g_sweep_long_limit, g_sweep_long_row, g_sweep_fold_share, g_sweep_border_factor;
 static int g_force_ordered = 0;
 
 // ---------------- PageRank (reference: src/PageRank.cpp:34-112) ----------------------------
@@ -750,6 +750,12 @@ static const EngineKey kEngineKeys[] = {
 static_assert(offsetof(gm_engine_options_t, sweep_form) == 17 * sizeof(int32_t), "kEngineKeys follows the field order");
 static bool engine_value_ok(const EngineKey& k, int v) {
   if (v < k.lo || v > k.hi) return false;
+#ifndef GRAPHMAT_ABLATION
+  // result-invalidating switches exist in -DGRAPHMAT_ABLATION builds only (build/ablation/libgraphmat_hip.so, tools/): the
+  // product library rejects them -- the in-kernel ablation bits of debug_flags (1, 2, 4, 8) and the cold-column ablation
+  if (!strcmp(k.name, "debug_flags") && (v & 15) != 0) return false;
+  if (!strncmp(k.name, "ablate_", 7)) return false;
+#endif
   if (!strcmp(k.name, "wave16_form")) return (v & 15) <= 5;
   if (!strcmp(k.name, "rowwave_form")) return (v & 15) <= 4;
   if (!strcmp(k.name, "last_rows_lanes")) return v == 8 || v == 16;
@@ -827,6 +833,9 @@ int gm_reset_options(void) {
   gm::g_sweep_slices = 1;
   gm::g_sweep_acc_limit = GM_SWEEP_ACC_ROWS;
   gm::g_sweep_long_limit = GM_SWEEP_LONG_SLOTS;
+  gm::g_sweep_long_row = 0;
+  gm::g_sweep_fold_share = 70;
+  gm::g_sweep_border_factor = 4;
   gm::g_col_tiles = 0;
   return GM_OK;
 }
@@ -852,6 +861,9 @@ int gm_set_option(const char* key, int value) {
   // (0: no slices, no sweep; 1: automatic slice count; 8 .. GM_MAX_SLICES: about that many slices)
   if (key && !strcmp(key, "sweep_slices") && (value == 0 || value == 1 || (value >= 8 && value <= GM_MAX_SLICES))) { gm::g_sweep_slices = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_acc_rows") && value >= 1 && value <= GM_SWEEP_ACC_ROWS) { gm::g_sweep_acc_limit = value; return GM_OK; }
+  if (key && !strcmp(key, "sweep_long_row") && value >= 0 && value <= 8191) { gm::g_sweep_long_row = value; return GM_OK; }
+  if (key && !strcmp(key, "sweep_border_factor") && value >= 1 && value <= 64) { gm::g_sweep_border_factor = value; return GM_OK; }
+  if (key && !strcmp(key, "sweep_fold_share") && value >= 0 && value <= 100) { gm::g_sweep_fold_share = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_long_slots") && value >= 1 && value <= GM_SWEEP_LONG_SLOTS) { gm::g_sweep_long_limit = value; return GM_OK; }
   gm::set_error("gm_set_option: unknown option");
   return GM_ERR_INVALID;

@@ -1241,7 +1241,7 @@ class Run {
       if (aux.pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
       if (aux.giant_pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.gjoin, 0));
       aux.keep = aux.forked = aux.pending = aux.giant_pending = aux.use_gs = false;
-      timer.mark(TAG_WAVE);  // (the multiply ends when the auxiliary stream has joined: the wait counts as multiply time)
+      timer.mark(TAG_GIANT);  // (the multiply ends when the auxiliary stream has joined: the wait is charged to the giant rows' passes)
       check_probed(pa, Aout, Aout.rowbits, nullptr, acc, ybits, true);
     } else {
       (void)pa; (void)acc; (void)sw;

@@ -1171,7 +1171,10 @@ __device__ __forceinline__ void wave16_dense(const P& p, const gm_csr_t& A, cons
 #pragma unroll
     for (int r = 0; r < G; r++) {
       U term;
-      const int k = __builtin_amdgcn_readlane(mt.e0, r) + step * 64 + lane;  // (only programs that read edge values use it)
+      // (only programs that read edge values use it; a lane past its row's end -- its product is never folded -- must not read
+      // past the end of the value array: the position is clamped like the column positions)
+      const int kraw = __builtin_amdgcn_readlane(mt.e0, r) + step * 64 + lane;
+      const int k = (int64_t)kraw < A.nnz ? kraw : (int)(A.nnz - 1);
       p.P::process_message(m[r], edge_at<E>(A.vals, k), no_vp, term);
       s_t[r][lane] = term;
     }
@@ -1441,7 +1444,14 @@ k_spmv_rowwave(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, U* __restrict
 //    waves start on their groups; blocks larger than the stage take several rounds.
 // Dense x, 2-operand programs, 4-byte messages and reductions; edge values: none, or 4 bytes in the entries' positions.
 // (ABL: measurement forms instantiated by tools/sweep_lib_bench.hip only -- 1: no gathers at all, 2: every gather served from
-// LDS, 4: no long-row phase; their results are wrong by construction)
+// LDS, 4: no long-row phase; their results are wrong by construction; 8: per-wave time per phase, 100 MHz ticks, into
+// g_sell_phase_ticks[wave of the grid][phase])
+#ifdef GM_SELL_PHASE_TIMES
+static __device__ unsigned long long g_sell_phase_ticks[4096][8];
+#define GM_SELL_TICK(k) do { if constexpr (ABL & 8) { const unsigned long long t_ = wall_clock64(); if (lane == 0) g_sell_phase_ticks[wg * 16 + wv][k] += t_ - tphase; tphase = t_; } } while (0)
+#else
+#define GM_SELL_TICK(k) do { } while (0)
+#endif
 template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL = 0>
 __global__ void __launch_bounds__(1024)
 k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long, const int32_t* __restrict__ slice_base, const uint32_t* __restrict__ scol,
@@ -1461,21 +1471,60 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
   const char* __restrict__ xb = (const char*)x;
   V no_vp;
   const size_t vw = (size_t)set * 256 + wg;
-  const int lj = (int)threadIdx.x - (BLOCK - NLP);  // long-row slot of this thread (the last NLP threads fold)
+  const int lj = (BLOCK - 1) - (int)threadIdx.x < NLP ? (BLOCK - 1) - (int)threadIdx.x : -1;  // long-row slot of this thread (slot 0 = the last thread: the last waves fold)
   bool lhas = false;
   U lacc;
   auto as_t = [](uint32_t raw) { T t; __builtin_memcpy(&t, &raw, 4); return t; };
   auto as_u = [](uint32_t raw) { U u; __builtin_memcpy(&u, &raw, 4); return u; };
   auto raw_u = [](const U& u) { uint32_t r; __builtin_memcpy(&r, &u, 4); return r; };
   auto as_e = [](uint32_t raw) { E e; if constexpr (HAS_VALS) __builtin_memcpy(&e, &raw, 4); else e = E(); return e; };
+  // What a slice needs from global memory besides x is requested one slice AHEAD, before the barrier that ends the previous
+  // slice: the wave's row range, its first batch of entries, the long rows' piece bounds and the first staging round's
+  // entries -- after a workgroup barrier every wave would otherwise start with two or three exposed load latencies
+  // (96 slices x ~3 us).  pc / pe: first batch, lc / le: staging round, (pr, prend): row range, (pl0, pl1, pps, ppe): long bounds.
+  uint32_t pc[UB], pe[UB], lc[KMAX], le[KMAX];
+  uint32_t pr = 0, prend = 0, pl0 = 0, pl1 = 0, pps = 0, ppe = 0;
+  auto prefetch = [&](int sl) {
+    const size_t blk = vw * (size_t)nslices + (size_t)sl;
+    const uint32_t* __restrict__ wr = wrow + blk * (W + 1);
+    pr = __builtin_amdgcn_readfirstlane(wr[wv]);
+    prend = __builtin_amdgcn_readfirstlane(wr[wv + 1]);
+#pragma unroll
+    for (int j = 0; j < UB; j++) {
+      const uint32_t rr = pr + j < prend ? pr + j : (prend > 0 ? prend - 1 : 0);
+      pc[j] = __builtin_nontemporal_load(&scol[(size_t)rr * 64 + lane]);
+      if constexpr (HAS_VALS) pe[j] = __builtin_nontemporal_load(&sval[(size_t)rr * 64 + lane]); else pe[j] = 0u;
+    }
+    if (nrows_long > 0 && !(ABL & 4)) {
+      const size_t eb = blk * NLP;
+      pl0 = lps[eb];
+      pl1 = lps[eb + NLP];
+      if (lj >= 0) { pps = lps[eb + lj]; ppe = lps[eb + lj + 1]; }
+      const uint32_t n = pl1 - pl0 < (uint32_t)stage_words ? pl1 - pl0 : (uint32_t)stage_words;
+#pragma unroll
+      for (int j = 0; j < KMAX; j++) {
+        if ((uint32_t)(j * BLOCK) < n) {
+          const uint32_t i = (uint32_t)(j * BLOCK) + threadIdx.x;
+          const uint32_t ii = pl0 + (i < n ? i : n - 1);
+          lc[j] = __builtin_nontemporal_load(&lcol[ii]);
+          if constexpr (HAS_VALS) le[j] = __builtin_nontemporal_load(&lval[ii]); else le[j] = 0u;
+        }
+      }
+    }
+  };
+  prefetch(0);
+  [[maybe_unused]] unsigned long long tphase = 0;
+  if constexpr (ABL & 8) tphase = wall_clock64();
   for (int sl = 0; sl < nslices; sl++) {
     const int base = slice_base[sl];
     const int slen = slice_base[sl + 1] - base;
     const int nhot = slen < HOT ? slen : HOT;
     const uint32_t base4 = (uint32_t)base << 2, nhot4 = (uint32_t)nhot << 2;
     __syncthreads();  // the previous slice's folds are done: its hot set and stage may go, the running values are in s_acc
+    GM_SELL_TICK(0);  // waiting for the other waves at the end of a slice
     for (int i = threadIdx.x; i < nhot; i += BLOCK) s_pool[i] = ((const uint32_t*)x)[base + i];
     __syncthreads();
+    GM_SELL_TICK(1);  // hot set
     auto gather = [&](uint32_t c4) {  // (branch-free: lanes whose column is in LDS re-read the slice's first entry, an L1 hit)
       const uint32_t rel4 = c4 - base4;
       if constexpr ((ABL & 3) == 1) return c4;
@@ -1485,43 +1534,40 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
       const uint32_t mg = *(const uint32_t*)(xb + (h ? base4 : c4));
       return h ? mh : mg;
     };
-    const size_t blk = vw * (size_t)nslices + (size_t)sl;
     if (nrows_long > 0 && !(ABL & 4)) {
-      const size_t eb = blk * NLP;
-      const uint32_t l0 = lps[eb], l1 = lps[eb + NLP];
-      uint32_t ps = 0, pe = 0;
-      if (lj >= 0) { ps = lps[eb + lj]; pe = lps[eb + lj + 1]; }
+      const uint32_t l0 = pl0, l1 = pl1, ps = pps, pe_ = ppe;
       for (uint32_t c0 = l0; c0 < l1; c0 += (uint32_t)stage_words) {
         const uint32_t n = l1 - c0 < (uint32_t)stage_words ? l1 - c0 : (uint32_t)stage_words;
-        if (c0 != l0) __syncthreads();  // the previous round is folded: the stage may be overwritten
-        // a round's entries all at once: every thread requests its (at most KMAX) entries, then their messages, then stores
-        // the products -- one chain of two latencies per round
-        uint32_t c[KMAX], ev[KMAX], m[KMAX];
+        if (c0 != l0) {
+          __syncthreads();  // the previous round is folded: the stage may be overwritten
 #pragma unroll
-        for (int j = 0; j < KMAX; j++) {
-          if ((uint32_t)(j * BLOCK) < n) {
-            const uint32_t i = (uint32_t)(j * BLOCK) + threadIdx.x;
-            const uint32_t ii = c0 + (i < n ? i : n - 1);
-            c[j] = __builtin_nontemporal_load(&lcol[ii]);
-            if constexpr (HAS_VALS) ev[j] = __builtin_nontemporal_load(&lval[ii]); else ev[j] = 0u;
+          for (int j = 0; j < KMAX; j++) {  // (later rounds: their entries are requested here)
+            if ((uint32_t)(j * BLOCK) < n) {
+              const uint32_t i = (uint32_t)(j * BLOCK) + threadIdx.x;
+              const uint32_t ii = c0 + (i < n ? i : n - 1);
+              lc[j] = __builtin_nontemporal_load(&lcol[ii]);
+              if constexpr (HAS_VALS) le[j] = __builtin_nontemporal_load(&lval[ii]); else le[j] = 0u;
+            }
           }
         }
+        uint32_t m[KMAX];
 #pragma unroll
         for (int j = 0; j < KMAX; j++)
-          if ((uint32_t)(j * BLOCK) < n) m[j] = gather(c[j]);
+          if ((uint32_t)(j * BLOCK) < n) m[j] = gather(lc[j]);
 #pragma unroll
         for (int j = 0; j < KMAX; j++) {
           const uint32_t i = (uint32_t)(j * BLOCK) + threadIdx.x;
           if (i < n) {
             U res;
-            p.P::process_message(as_t(m[j]), as_e(ev[j]), no_vp, res);
+            p.P::process_message(as_t(m[j]), as_e(le[j]), no_vp, res);
             s_stage[i] = raw_u(res);
           }
         }
         __syncthreads();
+        GM_SELL_TICK(2);  // staging
         if (lj >= 0) {
           uint32_t k = ps > c0 ? ps : c0;
-          const uint32_t ke = pe < c0 + n ? pe : c0 + n;
+          const uint32_t ke = pe_ < c0 + n ? pe_ : c0 + n;
           if (k < ke && !lhas) { lacc = as_u(s_stage[k - c0]); lhas = true; k++; }
           for (; k + 4 <= ke; k += 4) {
             uint32_t r[4];
@@ -1537,15 +1583,16 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
     // The wave's part of the block: rows [r, rend) of 64 entries each.  A group = one META row (bit 31 set in every lane;
     // bits 0-14 the lane's accumulator slot or 0x7fff, bit 15 "the row's first piece", bits 16-28 the group's width) followed by
     // `width` rows of column entries: the stream describes itself, the only loads are the entries, one batch ahead.
-    const uint32_t* __restrict__ wr = wrow + blk * (W + 1);
-    uint32_t r = __builtin_amdgcn_readfirstlane(wr[wv]);
-    const uint32_t rend = __builtin_amdgcn_readfirstlane(wr[wv + 1]);
-    if (r >= rend) continue;
+    GM_SELL_TICK(3);  // long folds (the last two waves)
+    uint32_t r = pr;
+    const uint32_t rend = prend;
     uint32_t left = 0;  // rows left in the current group (0: the next row is a meta row)
     int slot = 0x7fff;
     U acc;
     bool has = false;
     uint32_t c[UB], ev[UB];
+#pragma unroll
+    for (int j = 0; j < UB; j++) { c[j] = pc[j]; ev[j] = pe[j]; }
     auto entries = [&](uint32_t r0) {
 #pragma unroll
       for (int j = 0; j < UB; j++) {
@@ -1554,7 +1601,6 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
         if constexpr (HAS_VALS) ev[j] = __builtin_nontemporal_load(&sval[(size_t)rr * 64 + lane]); else ev[j] = 0u;
       }
     };
-    entries(r);
     while (r < rend) {
       uint32_t m[UB], cc[UB], e2[UB];
       // which rows of the batch are meta rows (wave-uniform): they are not gathered
@@ -1596,6 +1642,9 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
       left = l;
     }
     if (slot != 0x7fff) s_acc[slot] = raw_u(acc);
+    GM_SELL_TICK(4);  // groups
+    if (sl + 1 < nslices) prefetch(sl + 1);  // (in flight while this wave waits for the others at the barrier)
+    GM_SELL_TICK(5);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < ACC; i += BLOCK) {

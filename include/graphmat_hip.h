@@ -256,7 +256,8 @@ int gm_graph_tiles(const gm_graph_t* g, int direction, int* ntiles); /* *ntiles 
  * (L2-resident), the slice's busiest entries from LDS -- and a row is still folded in ascending native column order: slices are
  * native ranges taken in order, and inside a (row, slice) PIECE the edges keep their CSR order.  `nsets` launches cover all
  * rows (a workgroup holds acc_rows medium + long_slots long rows per launch: rank r -> workgroup r % 256, set (r / 256) % nsets).
- *   MEDIUM rows (at most own_wave_row = 4096 edges): the pieces of a (set, workgroup, slice) BLOCK are sorted by length
+ *   MEDIUM rows (at most long_row edges: chosen per graph so that a slice's longest piece does not exceed a wave's share of a
+ *   block -- 2048 at RMAT-26, 512 at RMAT-24; gm_set_option("sweep_long_row")): the pieces of a (set, workgroup, slice) BLOCK are sorted by length
  *   (descending) and cut into GROUPS of 64, lane = piece.  Group g occupies scol[gbase[g] .. gbase[g + 1]): first a META row of 64
  *   entries -- GM_SWEEP_PAD | width << 16 | first << 15 | slot: the group's width (rows that follow = its longest piece), whether
  *   this is the lane's row's first piece (its first message is assigned, not reduced: the reference has no additive identity)
@@ -268,7 +269,7 @@ int gm_graph_tiles(const gm_graph_t* g, int direction, int* ntiles); /* *ntiles 
  *   4) or NULL.  Blocks are stored in (set, workgroup, slice) order, so a block's groups are contiguous; wfirst[((set * 256 + w)
  *   * nslices + s) * 17 + v] = first group of wave v of 16 (entry 16 = end of the block), wrow = the same as positions in scol /
  *   64: contiguous ranges balanced by rows.  row_of_slot[(set * 256 + w) * acc_rows + slot] = local row id (-1: none).
- *   LONG rows (more than own_wave_row edges; at most long_slots per workgroup and set): too few and too uneven for groups.
+ *   LONG rows (more than long_row edges; at most long_slots per workgroup and set): too few and too uneven for groups.
  *   lcol (column << 2) / lval hold a block's edges in (slot, ascending native column) order, lps[((set * 256 + w) * nslices + s)
  *   * long_slots + j] = first entry of slot j's piece (the next entry ends it; the last entry of all = nedges_long); per
  *   slice all waves gather a block's messages into an LDS stage and the workgroup's last long_slots threads fold one piece each.
@@ -287,7 +288,7 @@ typedef struct {
   int32_t max_long_block; /* most long-row edges of one (set, workgroup, slice) block */
   int32_t val_bytes;      /* 0, or 4: sval / lval hold the edge values */
   int32_t short_row;      /* the structure holds the rows of more than short_row edges ... */
-  int32_t giant_row;      /* ... and at most giant_row edges (= the whole-graph CSR's limits when it was built) */
+  int32_t long_row;       /* ... that are not giant; those of more than long_row edges are the LONG rows */
   int64_t nedges;         /* edges of the medium rows */
   int64_t nedges_long;
   int64_t nentries;       /* entries of scol (edges + padding) */
@@ -308,7 +309,7 @@ typedef struct {
 } gm_sweep_t;
 #define GM_MAX_SLICES 128
 #define GM_SWEEP_ACC_ROWS 10048
-#define GM_SWEEP_LONG_SLOTS 128
+#define GM_SWEEP_LONG_SLOTS 512
 #define GM_SWEEP_PAD 0x80000000u
 #define GM_SWEEP_POOL 30848      /* 4-byte LDS words shared by the slice's hot entries and the long rows' stage */
 #define GM_SWEEP_MAX_STAGE 14336 /* largest stage (words): larger blocks are staged in chunks */

@@ -5,6 +5,7 @@
 // through ctypes.  Per-vertex arrays cross this API in ORIGINAL vertex order
 // (index v-1 for the 1-based vertex id v of the .mtx file); the permutation to
 // the reference's native order happens inside, as in include/Graph.h:312-364.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -222,6 +223,13 @@ int gmo_num_threads(void) {
 // STREAM-style triad a[i] = b[i] + 3 c[i] over three arrays of n doubles (first touched by the threads that walk them), `reps`
 // passes: GB/s of the 24 n bytes a pass moves.  bench.py's cpu_baseline reports it next to the PageRank probe so that
 // "more threads do not help" can be read against what the host's memory system delivers at that thread count.
+static double gmo_now_s() {
+#ifdef _OPENMP
+  return omp_get_wtime();
+#else
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+#endif
+}
 double gmo_stream_triad_gbs(long long n, int reps) {
   double* a = (double*)malloc((size_t)n * 8);
   double* b = (double*)malloc((size_t)n * 8);
@@ -231,10 +239,10 @@ double gmo_stream_triad_gbs(long long n, int reps) {
   for (long long i = 0; i < n; i++) { a[i] = 0.0; b[i] = 1.0; c[i] = 2.0; }
   double best = 0.0;
   for (int r = 0; r < reps; r++) {
-    const double t0 = omp_get_wtime();
+    const double t0 = gmo_now_s();
 #pragma omp parallel for schedule(static)
     for (long long i = 0; i < n; i++) a[i] = b[i] + 3.0 * c[i];
-    const double dt = omp_get_wtime() - t0;
+    const double dt = gmo_now_s() - t0;
     const double gbs = 24.0 * (double)n / dt * 1e-9;
     if (gbs > best) best = gbs;
   }

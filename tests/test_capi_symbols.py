@@ -199,3 +199,18 @@ def test_engine_options_from_the_environment(lib):
     assert out.stdout.decode().split()[-4:] == ["64", "2", "800", "0"]
     err = out.stderr.decode()
     assert "ignoring 'wave16_form=99'" in err and "ignoring 'nonsense=3'" in err
+
+
+def test_product_library_has_no_ablation_or_fault_injection_switches(lib):
+    """Result-invalidating switches live in separate builds (build/ablation, build/hooks) that tools and the negative
+    control load explicitly: the shipped library rejects their keys and does not know the fault-injection variable."""
+    assert lib.gm_set_option(b"ablate_cold_from", 1) != 0
+    assert lib.gm_set_option(b"ablate_cold_short", 1) != 0
+    for bit in (1, 2, 4, 8):
+        assert lib.gm_set_option(b"debug_flags", bit) != 0
+    assert lib.gm_set_option(b"debug_flags", 16) == 0 and lib.gm_set_option(b"debug_flags", 0) == 0  # (strategy choices stay)
+    assert lib.gm_graph_set_option(None, b"ablate_cold_from", 1) != 0
+    from graphmat_amd import _lib
+    blob = open(_lib.SO, "rb").read()
+    assert b"GRAPHMAT_DEBUG_DROP_WAIT" not in blob
+    lib.gm_reset_options()

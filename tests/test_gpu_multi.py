@@ -100,18 +100,25 @@ def test_missing_stream_wait_is_caught():
     before it copies the parts into x) a 3-rank PageRank must differ from the oracle.  A blocking transport would let
     this bug pass."""
     from graphmat_amd import build
-    build.build()
+    hooks_so = build.build_hooks()
     from oracle import binding
     binding.build()
+    # (the fault injection exists in the test-hooks build of the library only: build/hooks/libgraphmat_hip.so)
     env = dict(os.environ, GM_BACKEND="gloo", GM_SCALE="16", GM_EXCHANGE="native", GRAPHMAT_RCCL_LIBRARY=_shm_lib(), GM_NEGATIVE="1",
-               GRAPHMAT_DEBUG_DROP_WAIT="1")
+               GRAPHMAT_DEBUG_DROP_WAIT="1", GRAPHMAT_HIP_LIBRARY=hooks_so)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "multi_check.py")]
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env, cwd=ROOT)
     text = out.stdout.decode()
     assert out.returncode == 0 and "NEGATIVE_CAUGHT" in text, text[-3000:]
-    # ... and with the dependency in place the same run equals the oracle (the positive tests above at scale 13 / 14)
+    # ... with the dependency in place the same run equals the oracle (the positive tests above at scale 13 / 14) ...
     env.pop("GRAPHMAT_DEBUG_DROP_WAIT")
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env, cwd=ROOT)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "NEGATIVE_MISSED" in text, text[-3000:]
+    # ... and the PRODUCT library has no such switch: the variable changes nothing there
+    env.pop("GRAPHMAT_HIP_LIBRARY")
+    env["GRAPHMAT_DEBUG_DROP_WAIT"] = "1"
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env, cwd=ROOT)
     text = out.stdout.decode()
     assert out.returncode == 0 and "NEGATIVE_MISSED" in text, text[-3000:]

@@ -365,12 +365,12 @@ def test_row_stationary_sweep_bit_exact(env, scale, tiles, threads):
     rng = np.random.default_rng(1)
     seen_sets = [1]
     #        sweep_slices, sweep_form, keep_values, own_wave_row, acc_rows, long_slots
-    cases = [(0, 0, False, 4096, 10048, 128), (1, 0, False, 4096, 10048, 128), (1, 1, True, 4096, 10048, 128), (1, 2, False, 4096, 10048, 128),
-             (16, 0, False, 256, 10048, 128), (16, 4, True, 256, 10048, 128), (24, 5, False, 128, 3, 3), (128, 0, True, 512, 2, 128)]
+    cases = [(0, 0, False, 4096, 10048, 512), (1, 0, False, 0, 10048, 512), (1, 1, True, 4096, 10048, 512), (1, 2, False, 0, 10048, 512),
+             (16, 0, False, 256, 10048, 512), (16, 4, True, 256, 10048, 512), (24, 5, False, 128, 3, 3), (128, 0, True, 512, 2, 512)]
     try:
         for slices, form, keep, own, accl, longl in cases:
             api._lib.check(L.gm_reset_options())
-            for k_, v_ in ((b"sweep_slices", slices), (b"sweep_form", form), (b"own_wave_row", own), (b"sweep_acc_rows", accl), (b"sweep_long_slots", longl)):
+            for k_, v_ in ((b"sweep_slices", slices), (b"sweep_form", form), (b"sweep_long_row", own), (b"sweep_acc_rows", accl), (b"sweep_long_slots", longl)):
                 api._lib.check(L.gm_set_option(k_, v_))
             g = api.Graph(nv, s, d, v if keep else None, ref_threads=threads, keep_values=keep, col_tiles=tiles)
             assert g.col_tiles > 1
@@ -382,10 +382,10 @@ def test_row_stationary_sweep_bit_exact(env, scale, tiles, threads):
                 assert sw.nrows > 0 and sw.nslices % g.col_tiles == 0 and sw.val_bytes == (4 if keep else 0)
                 nmed, nlng = sw.nrows - sw.nrows_long, sw.nrows_long
                 assert sw.nsets == max(1, -(-(-(-nmed // 256)) // accl), -(-(-(-nlng // 256)) // longl))
-                if own < 4096 and scale >= 15:
+                if 0 < own < 4096 and scale >= 15:
                     assert sw.nrows_long > 0
                 seen_sets[0] = max(seen_sets[0], sw.nsets)
-                _check_sweep_structure(api, g, sw, keep, rng, own)
+                _check_sweep_structure(api, g, sw, keep, rng, own if own else sw.long_row)
             pr, deg, it = g.pagerank(6)
             assert (deg == odeg).all() and it == 6
             assert (f32bits(pr) == f32bits(opr)).all(), "sweep_slices %d sweep_form %d values %d own_wave_row %d" % (slices, form, keep, own)

@@ -9,6 +9,7 @@
 #include <string.h>
 #include <vector>
 #include <hip/hip_runtime.h>
+#define GM_SELL_PHASE_TIMES 1
 #include "GraphMatRuntime.h"
 
 #define OK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { printf("%s:%d %s: %s\n", __FILE__, __LINE__, #e, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -67,7 +68,7 @@ int main(int argc, char** argv) {
   gm_sweep_t S; GOK(gm_graph_sweep(g, &S));
   printf("RMAT-%d: %d tiles, %d slices, sweep: %d rows (%d long) in %d set(s), %lld + %lld edges, %lld entries (+%.1f %%), %lld groups (%.2f rows each + meta), largest long block %d\n",
          scale, gd.col_tiles, S.nslices, S.nrows, S.nrows_long, S.nsets, (long long)S.nedges, (long long)S.nedges_long, (long long)S.nentries,
-         S.nedges ? 100.0 * ((double)S.nentries / S.nedges - 1.0) : 0.0, (long long)S.ngroups, S.ngroups ? (double)S.nentries / 64 / S.ngroups - 1.0 : 0.0, S.max_long_block);
+         S.nedges ? 100.0 * ((double)S.nentries / S.nedges - 1.0) : 0.0, (long long)S.ngroups, S.ngroups ? (double)S.nentries / 64 / S.ngroups - 1.0 : 0.0, S.max_long_block); printf("medium / long border: %d edges\n", S.long_row);
   if (S.nrows <= 0) { printf("no sweep structure\n"); return 0; }
   float *x, *y, *yref;
   OK(hipMalloc(&x, (size_t)gd.ndevice * 4)); OK(hipMalloc(&y, (size_t)gd.ndevice * 4)); OK(hipMalloc(&yref, (size_t)gd.ndevice * 4));
@@ -114,6 +115,29 @@ int main(int argc, char** argv) {
   time_it([&]() { LAUNCH(2, stage); }, "  ... every gather served from LDS");
   time_it([&]() { LAUNCH(1, stage); }, "  ... no gathers at all");
   time_it([&]() { LAUNCH(5, stage); }, "  ... no gathers, no long rows");
+  {  // where a wave's time goes (100 MHz ticks summed over the slices of ONE launch)
+    static unsigned long long h[4096][8];
+    memset(h, 0, sizeof(h));
+    OK(hipMemcpyToSymbol(HIP_SYMBOL(GraphMat::dev::g_sell_phase_ticks), h, sizeof(h)));
+    LAUNCH(8, stage);
+    OK(hipDeviceSynchronize());
+    OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(GraphMat::dev::g_sell_phase_ticks), sizeof(h)));
+    const char* names[6] = {"wait at the slice's end", "hot set (load + barrier)", "long rows: staging", "long rows: fold", "groups", "prefetch issue"};
+    for (int cls = 0; cls < 2; cls++) {
+      double sum[6] = {0}, mx[6] = {0};
+      int n = 0;
+      for (int w = 0; w < 4096; w++) {
+        const bool folder = (w % 16) >= 16 - (((S.nrows_long + 255) / 256 + S.nsets - 1) / S.nsets + 63) / 64;
+        if (folder != (cls == 1)) continue;
+        n++;
+        for (int k = 0; k < 6; k++) { sum[k] += (double)h[w][k]; if ((double)h[w][k] > mx[k]) mx[k] = (double)h[w][k]; }
+      }
+      printf("%s waves: per-wave mean us (max) over one launch:", cls ? "folding (last of 16)" : "other");
+      double tot = 0;
+      for (int k = 0; k < 6; k++) { printf("  %s %.0f (%.0f)", names[k], sum[k] / n * 0.01, mx[k] * 0.01); tot += sum[k] / n * 0.01; }
+      printf("  | total %.0f us\n", tot);
+    }
+  }
   gm_graph_destroy(g);
   return 0;
 }
