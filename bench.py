@@ -790,6 +790,7 @@ def main():
         avg_ms = ms / launches * per_step
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
+        traffic_raw = None
         # HBM/fabric bytes per launch from the committed rocprofv3 PMC passes -- quoted only while they were taken on
         # exactly the kernels that just ran (fingerprint of the kernel sources); otherwise null
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -805,6 +806,13 @@ def main():
                              "multiply": ["k_spmv_rowblock", "k_spmv_rowwave", "k_spmv_wave", "k_spmv_wave16", "k_spmv_wave16p"]}.get(name, [name])
                     parts = [per.get(k + "_bytes_per_iteration") for k in names]
                     traffic = int(sum(v for v in parts if v is not None)) if any(v is not None for v in parts) else None
+                    traffic_raw = traffic
+                    # FETCH_SIZE counts a coalesced stream at half its bytes on this rocprofv3 / gfx950 (calibrated: tj["calibration"]):
+                    # the kernel's coalesced streams are known by construction, their uncounted half is added
+                    cal = tj.get("calibration", {}).get("FETCH_SIZE_reported_over_known_coalesced_stream")
+                    if traffic is not None and cal and swept:
+                        stream_bytes = 4 * (int(sweep.nentries) + int(sweep.nedges_long)) * (2 if int(sweep.val_bytes) else 1)
+                        traffic = int(traffic + (1.0 - cal) * stream_bytes)
                     traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernels (profiles/pmc_traffic.json); calibration of the counters "
                                     "on a pure coalesced stream and a pure random 4-byte gather: %s" % json.dumps(tj.get("calibration", "not recorded")))
                 else:
@@ -831,7 +839,7 @@ def main():
                       {"k_spmv_rowblock": kfrac(by_kernel[0], stats["rowblock_ms"]), "k_spmv_wave16+k_spmv_wave": kfrac(by_kernel[1] + by_kernel[2], stats["wave_ms"]),
                        "k_giant_terms+k_spmv_giant (auxiliary stream, overlapped)": kfrac(by_kernel[3], stats["giant_ms"])})
         roof = {"bound": "hbm", "kernel": kname + "<PageRank>", "achieved": round(ach, 1),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_raw_counters": traffic_raw, "traffic_source": traffic_note,
                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg_bytes,
                 "unit_note": ("one launch unit = all %d launches of these kernels in one iteration" % per_step) if per_step > 1 else "one launch per iteration",
                 "launches_per_iteration": per_step,

@@ -24,14 +24,34 @@ def per_iteration(path, counter):
     return out
 
 
+def calibration(tag):
+    """reported bytes / known bytes of tools/pmc_calibrate.hip's three kernels"""
+    known = {"k_cal_stream": (512 << 20) * 4, "k_cal_gather": (256 << 20) * 64, "k_cal_write": (256 << 20) * 4}
+    out = {}
+    for counter, kernels in (("FETCH_SIZE", ("k_cal_stream", "k_cal_gather")), ("WRITE_SIZE", ("k_cal_write",))):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_calibration_%s.md" % (tag, counter))
+        if not os.path.exists(path):
+            continue
+        for line in open(path):
+            m = re.match(r"\| `(k_cal_\w+)` \| %s \| (\d+) \| ([^|]+) \| [^|]+ \|" % counter, line)
+            if m and m.group(1) in kernels:
+                per = float(m.group(3)) / int(m.group(2)) * 1024
+                out["%s_reported_over_known_%s" % (counter, {"k_cal_stream": "coalesced_stream", "k_cal_gather": "random_4B_gather_at_64B_per_miss",
+                                                              "k_cal_write": "coalesced_write"}[m.group(1)])] = round(per / known[m.group(1)], 4)
+    return out
+
+
 def main():
     tag, scales = sys.argv[1], sys.argv[2:]
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     doc = json.load(open(path)) if os.path.exists(path) else {}
     doc["_note"] = ("HBM/fabric bytes per PageRank iteration and kernel (all its launches of the iteration) from rocprofv3 PMC passes of `python bench.py --scale S --steps 5 --warmup 1 "
-                    "--no-timing` (one counter set per run, kernel-trace only): (FETCH_SIZE + WRITE_SIZE) * 1024. No x2 correction "
-                    "is applied: FETCH_SIZE / TCC_MISS = 63.5-64 B per miss, i.e. these are 64-byte random fetches, not wide "
-                    "streaming reads (MI355X_MICROARCH.md HBM section). tools/final_profiles.sh + tools/pmc_to_json.py.")
+                    "--no-timing` (one counter set per run, kernel-trace only): RAW (FETCH_SIZE + WRITE_SIZE) * 1024 per kernel, plus the calibration of the two "
+                    "counters on known access patterns (tools/pmc_calibrate.hip, profiles/<tag>_pmc_calibration_*.md): on this gfx950 rocprofv3 FETCH_SIZE reports HALF "
+                    "the bytes of a coalesced stream (128-byte requests tallied at 64 B: MI355X_MICROARCH.md, HBM section) and 64 B per random 4-byte gather that misses; "
+                    "WRITE_SIZE reports a coalesced write exactly.  bench.py adds the uncounted half of each kernel's coalesced streams (their bytes are known by "
+                    "construction) to the raw figure. tools/final_profiles_r5.sh + tools/pmc_to_json.py.")
+    doc["calibration"] = calibration(tag)
     sys.path.insert(0, ROOT)
     import bench
     doc["kernels_fingerprint"] = bench.kernels_fingerprint()
@@ -44,6 +64,7 @@ def main():
         except Exception:
             doc["col_tiles"]["scale%s" % sc] = None
         doc["scale%s" % sc] = {k + "_bytes_per_iteration": int((f[k] + w.get(k, 0.0)) * 1024) for k in sorted(f)}
+        doc["scale%s" % sc].update({k + "_fetch_bytes_per_iteration": int(f[k] * 1024) for k in sorted(f)})
     json.dump(doc, open(path, "w"), indent=1)
     print(json.dumps(doc, indent=1))
 
