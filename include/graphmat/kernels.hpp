@@ -1452,14 +1452,14 @@ static __device__ unsigned long long g_sell_phase_ticks[4096][8];
 #else
 #define GM_SELL_TICK(k) do { } while (0)
 #endif
-template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL = 0>
+template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL = 0, int UBATCH = 6, int PIPE = 2>
 __global__ void __launch_bounds__(1024)
 k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long, const int32_t* __restrict__ slice_base, const uint32_t* __restrict__ scol,
             const uint32_t* __restrict__ sval, const uint32_t* __restrict__ wrow, const int32_t* __restrict__ row_of_slot, const uint32_t* __restrict__ lcol,
             const uint32_t* __restrict__ lval, const uint32_t* __restrict__ lps, const int32_t* __restrict__ lrow_of_slot, const T* __restrict__ x,
             U* __restrict__ y) {
   static_assert(sizeof(T) == 4 && sizeof(U) == 4, "4-byte messages and reductions");
-  constexpr int BLOCK = 1024, W = BLOCK / 64, UB = 8;
+  constexpr int BLOCK = 1024, W = BLOCK / 64, UB = UBATCH;
   constexpr int ACC = GM_SWEEP_ACC_ROWS, NLP = GM_SWEEP_LONG_SLOTS;
   constexpr int KMAX = GM_SWEEP_MAX_STAGE / BLOCK;  // entries of a staging round per thread
   __shared__ uint32_t s_pool[GM_SWEEP_POOL];  // [hot entries of the slice | stage of the long rows' products]
@@ -1590,56 +1590,127 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
     int slot = 0x7fff;
     U acc;
     bool has = false;
-    uint32_t c[UB], ev[UB];
+    if constexpr (PIPE == 2) {
+      // Two batches deep: while batch k is folded, the messages of batch k + 1 and the entries of batch k + 2 are in flight (one
+      // wait per iteration -- for the entries requested last, which the earlier gathers precede -- instead of entries, then
+      // messages).  Every load is unconditional (rows past the stream's end re-read its last row, their gathers the slice's
+      // first entry: cache hits), so the compiler counts outstanding loads exactly.
+      uint32_t cA[UB], eA[UB], mA[UB], cB[UB], eB[UB];
 #pragma unroll
-    for (int j = 0; j < UB; j++) { c[j] = pc[j]; ev[j] = pe[j]; }
-    auto entries = [&](uint32_t r0) {
+      for (int j = 0; j < UB; j++) { cA[j] = pc[j]; eA[j] = pe[j]; }
+      auto load_entries = [&](uint32_t r0, uint32_t (&cx)[UB], uint32_t (&ex)[UB]) {
 #pragma unroll
-      for (int j = 0; j < UB; j++) {
-        const uint32_t rr = r0 + j < rend ? r0 + j : rend - 1;
-        c[j] = __builtin_nontemporal_load(&scol[(size_t)rr * 64 + lane]);
-        if constexpr (HAS_VALS) ev[j] = __builtin_nontemporal_load(&sval[(size_t)rr * 64 + lane]); else ev[j] = 0u;
-      }
-    };
-    while (r < rend) {
-      uint32_t m[UB], cc[UB], e2[UB];
-      // which rows of the batch are meta rows (wave-uniform): they are not gathered
-      uint32_t metamask = 0, l = left;
+        for (int j = 0; j < UB; j++) {
+          const uint32_t rr = r0 + j < rend ? r0 + j : rend - 1;
+          cx[j] = __builtin_nontemporal_load(&scol[(size_t)rr * 64 + lane]);
+          if constexpr (HAS_VALS) ex[j] = __builtin_nontemporal_load(&sval[(size_t)rr * 64 + lane]); else ex[j] = 0u;
+        }
+      };
+      // meta rows of a batch (wave-uniform; advances `left`); rows past the end count as set bits of `skip` only
+      auto scan = [&](uint32_t r0, const uint32_t (&cx)[UB], uint32_t& skip) {
+        uint32_t mask = 0;
+        skip = 0;
 #pragma unroll
-      for (int j = 0; j < UB; j++) {
-        if (r + j < rend) {
-          if (l == 0) { metamask |= 1u << j; l = ((uint32_t)__builtin_amdgcn_readfirstlane((int)c[j]) >> 16) & 0x1fffu; }
-          else l--;
+        for (int j = 0; j < UB; j++) {
+          if (r0 + j < rend) {
+            if (left == 0) { mask |= 1u << j; left = ((uint32_t)__builtin_amdgcn_readfirstlane((int)cx[j]) >> 16) & 0x1fffu; }
+            else left--;
+          } else skip |= 1u << j;
+        }
+        skip |= mask;
+        return mask;
+      };
+      auto gathers = [&](const uint32_t (&cx)[UB], uint32_t skip, uint32_t (&mx)[UB]) {
+#pragma unroll
+        for (int j = 0; j < UB; j++) mx[j] = gather(((skip >> j) & 1u) ? base4 : (cx[j] & 0x7fffffffu));
+      };
+      if (r < rend) {
+        uint32_t skipA = 0, maskA = scan(r, cA, skipA);
+        gathers(cA, skipA, mA);
+        load_entries(r + UB, cB, eB);
+        while (true) {
+          const uint32_t rn = r + UB;
+          uint32_t mB[UB], cC[UB], eC[UB];
+          uint32_t skipB = 0;
+          const uint32_t maskB = scan(rn, cB, skipB);
+          gathers(cB, skipB, mB);
+          load_entries(rn + UB, cC, eC);
+#pragma unroll
+          for (int j = 0; j < UB; j++) {
+            if (r + j < rend) {
+              if ((maskA >> j) & 1u) {  // a new group: the previous group's running values go back to LDS, this one's come out
+                if (slot != 0x7fff) s_acc[slot] = raw_u(acc);
+                slot = (int)(cA[j] & 0x7fffu);
+                has = !(cA[j] & 0x8000u);
+                acc = as_u(slot != 0x7fff ? s_acc[slot] : 0u);
+              } else if ((int32_t)cA[j] >= 0) {
+                U res;
+                p.P::process_message(as_t(mA[j]), as_e(eA[j]), no_vp, res);
+                if (has) p.P::reduce_function(acc, res);
+                else acc = res;
+                has = true;
+              }
+            }
+          }
+          r = rn;
+          if (r >= rend) break;
+          maskA = maskB;
+#pragma unroll
+          for (int j = 0; j < UB; j++) { cA[j] = cB[j]; eA[j] = eB[j]; mA[j] = mB[j]; cB[j] = cC[j]; eB[j] = eC[j]; }
         }
       }
-#pragma unroll
-      for (int j = 0; j < UB; j++) {
-        cc[j] = c[j];
-        e2[j] = ev[j];
-        m[j] = 0u;
-        if (!((metamask >> j) & 1u)) m[j] = gather(c[j] & 0x7fffffffu);
-      }
-      const uint32_t r0 = r;
-      r += UB;
-      if (r < rend) entries(r);
-#pragma unroll
-      for (int j = 0; j < UB; j++) {
-        if (r0 + j < rend) {
-          if ((metamask >> j) & 1u) {  // a new group: the previous group's running values go back to LDS, this one's come out
-            if (slot != 0x7fff) s_acc[slot] = raw_u(acc);
-            slot = (int)(cc[j] & 0x7fffu);
-            has = !(cc[j] & 0x8000u);
-            acc = as_u(slot != 0x7fff ? s_acc[slot] : 0u);
-          } else if ((int32_t)cc[j] >= 0) {
-            U res;
-            p.P::process_message(as_t(m[j]), as_e(e2[j]), no_vp, res);
-            if (has) p.P::reduce_function(acc, res);  // SPMV.h:54-59: c = a; reduce(c, b)
-            else acc = res;                           // no additive identity: the first message assigns (spmspv.h:73-77)
-            has = true;
+    } else {
+    uint32_t c[UB], ev[UB];
+  #pragma unroll
+      for (int j = 0; j < UB; j++) { c[j] = pc[j]; ev[j] = pe[j]; }
+      auto entries = [&](uint32_t r0) {
+  #pragma unroll
+        for (int j = 0; j < UB; j++) {
+          const uint32_t rr = r0 + j < rend ? r0 + j : rend - 1;
+          c[j] = __builtin_nontemporal_load(&scol[(size_t)rr * 64 + lane]);
+          if constexpr (HAS_VALS) ev[j] = __builtin_nontemporal_load(&sval[(size_t)rr * 64 + lane]); else ev[j] = 0u;
+        }
+      };
+      while (r < rend) {
+        uint32_t m[UB], cc[UB], e2[UB];
+        // which rows of the batch are meta rows (wave-uniform): they are not gathered
+        uint32_t metamask = 0, l = left;
+  #pragma unroll
+        for (int j = 0; j < UB; j++) {
+          if (r + j < rend) {
+            if (l == 0) { metamask |= 1u << j; l = ((uint32_t)__builtin_amdgcn_readfirstlane((int)c[j]) >> 16) & 0x1fffu; }
+            else l--;
           }
         }
+  #pragma unroll
+        for (int j = 0; j < UB; j++) {
+          cc[j] = c[j];
+          e2[j] = ev[j];
+          m[j] = 0u;
+          if (!((metamask >> j) & 1u)) m[j] = gather(c[j] & 0x7fffffffu);
+        }
+        const uint32_t r0 = r;
+        r += UB;
+        if (r < rend) entries(r);
+  #pragma unroll
+        for (int j = 0; j < UB; j++) {
+          if (r0 + j < rend) {
+            if ((metamask >> j) & 1u) {  // a new group: the previous group's running values go back to LDS, this one's come out
+              if (slot != 0x7fff) s_acc[slot] = raw_u(acc);
+              slot = (int)(cc[j] & 0x7fffu);
+              has = !(cc[j] & 0x8000u);
+              acc = as_u(slot != 0x7fff ? s_acc[slot] : 0u);
+            } else if ((int32_t)cc[j] >= 0) {
+              U res;
+              p.P::process_message(as_t(m[j]), as_e(e2[j]), no_vp, res);
+              if (has) p.P::reduce_function(acc, res);  // SPMV.h:54-59: c = a; reduce(c, b)
+              else acc = res;                           // no additive identity: the first message assigns (spmspv.h:73-77)
+              has = true;
+            }
+          }
+        }
+        left = l;
       }
-      left = l;
     }
     if (slot != 0x7fff) s_acc[slot] = raw_u(acc);
     GM_SELL_TICK(4);  // groups

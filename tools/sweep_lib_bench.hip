@@ -94,7 +94,9 @@ int main(int argc, char** argv) {
     printf("%-58s best %.3f ms, mean %.3f ms  = %.2f ps per edge, %.1f G edges/s\n", name, best, sum / reps, best * 1e9 / nedges, nedges / best * 1e-6);
     fflush(stdout);
   };
-#define LAUNCH(ABL, STG) for (int set = 0; set < S.nsets; set++) hipLaunchKernelGGL((GraphMat::dev::k_spmv_sell<SumP, float, float, Vp, int, false, ABL>), dim3(256), dim3(1024), 0, 0, pa, set, STG, \
+#define LAUNCH(ABL, STG) LAUNCHP(ABL, STG, 6, 2)
+#define LAUNCHU(ABL, STG, UBAT) LAUNCHP(ABL, STG, UBAT, 1)
+#define LAUNCHP(ABL, STG, UBAT, PIPE) for (int set = 0; set < S.nsets; set++) hipLaunchKernelGGL((GraphMat::dev::k_spmv_sell<SumP, float, float, Vp, int, false, ABL, UBAT, PIPE>), dim3(256), dim3(1024), 0, 0, pa, set, STG, \
       S.nslices, S.nrows_long, S.slice_base, S.scol, (const uint32_t*)nullptr, S.wrow, S.row_of_slot, S.lcol, (const uint32_t*)nullptr, S.lps, S.lrow_of_slot, (const float*)x, y)
   time_it([&]() { LAUNCH(0, stage); }, "k_spmv_sell (the library's form)");
   {
@@ -109,6 +111,23 @@ int main(int argc, char** argv) {
     for (int i = 0; i < gd.ndevice; i++) { bad += memcmp(&a[i], &b[i], 4) != 0; set_ += b[i] != 0.f; }
     printf("   against the serial fold of the CSR rows: %lld of %lld rows differ (bit compare)\n", (long long)bad, (long long)set_);
   }
+  auto check = [&](const char* what) {
+    OK(hipDeviceSynchronize());
+    std::vector<float> a(gd.ndevice), b(gd.ndevice);
+    OK(hipMemcpy(a.data(), y, (size_t)gd.ndevice * 4, hipMemcpyDeviceToHost));
+    OK(hipMemcpy(b.data(), yref, (size_t)gd.ndevice * 4, hipMemcpyDeviceToHost));
+    int64_t bad = 0;
+    for (int i = 0; i < gd.ndevice; i++) bad += memcmp(&a[i], &b[i], 4) != 0;
+    printf("   %s: %lld rows differ from the serial fold\n", what, (long long)bad);
+  };
+  OK(hipMemset(y, 0, (size_t)gd.ndevice * 4));
+  time_it([&]() { LAUNCHP(0, stage, 8, 2); }, "  ... two batches deep, batches of 8 rows");
+  check("two batches deep, 8 rows");
+  time_it([&]() { LAUNCHP(0, stage, 4, 2); }, "  ... two batches deep, batches of 4 rows");
+  time_it([&]() { LAUNCHP(0, stage, 5, 2); }, "  ... two batches deep, batches of 5 rows");
+  time_it([&]() { LAUNCHP(0, stage, 7, 2); }, "  ... two batches deep, batches of 7 rows");
+  time_it([&]() { LAUNCHP(0, stage, 8, 1); }, "  ... one batch deep (round 5's first form), batches of 8 rows");
+  time_it([&]() { LAUNCHP(0, stage, 12, 1); }, "  ... one batch deep, batches of 12 rows");
   time_it([&]() { LAUNCH(0, GM_SWEEP_MAX_STAGE); }, "  ... with the largest stage (smallest hot set)");
   time_it([&]() { LAUNCH(4, 64); }, "  ... without the long rows' phase, largest hot set");
   time_it([&]() { LAUNCH(4, stage); }, "  ... without the long rows' phase, same hot set");
