@@ -45,7 +45,8 @@ class Sweep(C.Structure):
                 ("nedges", C.c_int64), ("nedges_long", C.c_int64), ("nentries", C.c_int64), ("ngroups", C.c_int64),
                 ("scol", C.c_void_p), ("sval", C.c_void_p), ("gbase", C.c_void_p), ("wrow", C.c_void_p), ("wfirst", C.c_void_p),
                 ("row_of_slot", C.c_void_p), ("lcol", C.c_void_p), ("lval", C.c_void_p), ("lps", C.c_void_p), ("lrow_of_slot", C.c_void_p),
-                ("slice_base", C.c_void_p), ("src_pos", C.c_void_p), ("lsrc_pos", C.c_void_p)]
+                ("slice_base", C.c_void_p), ("src_pos", C.c_void_p), ("lsrc_pos", C.c_void_p),
+                ("ngiant_edges", C.c_int64), ("gcol", C.c_void_p), ("gval", C.c_void_p), ("gdst", C.c_void_p), ("gslice", C.c_void_p), ("gsrc_pos", C.c_void_p)]
 
 
 class RunStats(C.Structure):

@@ -1094,6 +1094,44 @@ k_sweep_long_max(const uint32_t* __restrict__ lps, size_t nblk, unsigned int* __
   const size_t b = (size_t)blockIdx.x * kT + threadIdx.x;
   if (b < nblk) atomicMax(out, lps[(b + 1) * GM_SWEEP_LONG_SLOTS] - lps[b * GM_SWEEP_LONG_SLOTS]);
 }
+// The giant rows' edges for the sweep (gm_sweep_t.gcol / gdst): one wave per giant row writes, per edge, key = slice of its
+// column, value = CSR position, and the edge's place in the products stream (gterm_off + position in the row); the stable
+// sort by slice keeps (row, column) order inside a slice.
+__global__ void __launch_bounds__(kT)
+k_sweep_giant_keys(const int32_t* __restrict__ giant_row, int ngiant, const int64_t* __restrict__ gterm_off, const int64_t* __restrict__ rowptr,
+                   const int32_t* __restrict__ colidx, SweepSlices sl, int nslices, uint8_t* __restrict__ key, uint32_t* __restrict__ pos,
+                   uint32_t* __restrict__ dst) {
+  const int gi = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
+  if (gi >= ngiant) return;
+  const int lane = threadIdx.x & 63;
+  const int row = giant_row[gi];
+  const int64_t e0 = rowptr[row], e1 = rowptr[row + 1], o = gterm_off[gi];
+  for (int64_t e = e0 + lane; e < e1; e += 64) {
+    const int c = colidx[e];
+    int lo = 0, hi = nslices;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sl.b[mid] <= c) lo = mid; else hi = mid; }
+    key[o + (e - e0)] = (uint8_t)lo;
+    pos[o + (e - e0)] = (uint32_t)e;
+    dst[o + (e - e0)] = (uint32_t)(o + (e - e0));
+  }
+}
+// (gterm_off is padded per row to multiples of 64: slots between rows carry key 255 and sort to the end)
+__global__ void __launch_bounds__(kT)
+k_sweep_giant_fill(const uint32_t* __restrict__ pos_sorted, int64_t n, const int32_t* __restrict__ colidx, const uint32_t* __restrict__ vals,
+                   uint32_t* __restrict__ gcol, uint32_t* __restrict__ gval) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t p = pos_sorted[i];
+  gcol[i] = (uint32_t)colidx[p] << 2;
+  if (gval) gval[i] = vals[p];
+}
+__global__ void k_sweep_giant_bounds(const uint8_t* __restrict__ key_sorted, int64_t n, int nslices, uint32_t* __restrict__ out) {
+  const int t = threadIdx.x;
+  if (t > nslices) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int)key_sorted[mid] < t) lo = mid + 1; else hi = mid; }
+  out[t] = (uint32_t)lo;
+}
 // edge values rewritten in the CSR: the sweep's copies follow (gm_graph_sync_tile_vals)
 __global__ void __launch_bounds__(kT)
 k_sweep_sync_vals(const uint32_t* __restrict__ src_pos, size_t n, const uint32_t* __restrict__ vals, uint32_t* __restrict__ out) {
@@ -1102,7 +1140,7 @@ k_sweep_sync_vals(const uint32_t* __restrict__ src_pos, size_t n, const uint32_t
 }
 static void free_sweep(gm_graph* g) {
   gm_sweep_t& S = g->sweep;
-  const void* owned[] = {S.scol, S.sval, S.gbase, S.wrow, S.wfirst, S.row_of_slot, S.lcol, S.lval, S.lps, S.lrow_of_slot, S.src_pos, S.lsrc_pos};
+  const void* owned[] = {S.gcol, S.gval, S.gdst, S.gslice, S.gsrc_pos, S.scol, S.sval, S.gbase, S.wrow, S.wfirst, S.row_of_slot, S.lcol, S.lval, S.lps, S.lrow_of_slot, S.src_pos, S.lsrc_pos};
   for (const void* q : owned)
     if (q) (void)hipFree((void*)q);
   if (g->d_slice_base) (void)hipFree(g->d_slice_base);
@@ -1366,6 +1404,42 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
     GM_TRY_HIP(hipMemsetAsync(wrow.p, 0, nblk * 17 * 4, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
   }
+  // ---- the giant rows' edges by slice: the sweep gathers their messages with its hot sets and writes the products where the
+  // giant rows' fold passes expect them (gterm_off), so those passes need not gather at all
+  DevBuf gcol, gval, gdst, gslice, gpos;
+  int64_t ngiant_edges = 0;
+  if (whole->view.ngiant > 0 && whole->view.giant_edges > 0 && whole->view.giant_edges < ((int64_t)1 << 32)) {
+    const int64_t ge = whole->view.giant_edges;  // (slots, rows padded to multiples of 64)
+    DevBuf gk_in, gk_out, gp_in, gp_out, gd_in, gd_out;
+    if ((rc = gk_in.alloc((size_t)ge)) || (rc = gk_out.alloc((size_t)ge)) || (rc = gp_in.alloc((size_t)ge * 4)) || (rc = gp_out.alloc((size_t)ge * 4)) ||
+        (rc = gd_in.alloc((size_t)ge * 4)) || (rc = gd_out.alloc((size_t)ge * 4)) || (rc = gslice.alloc((GM_MAX_SLICES + 2) * 4)))
+      return rc;
+    GM_TRY_HIP(hipMemsetAsync(gk_in.p, 0xff, (size_t)ge, s));
+    GM_TRY_HIP(hipMemsetAsync(gp_in.p, 0, (size_t)ge * 4, s));
+    GM_TRY_HIP(hipMemsetAsync(gd_in.p, 0, (size_t)ge * 4, s));
+    hipLaunchKernelGGL(k_sweep_giant_keys, dim3((whole->view.ngiant + (kT / 64) - 1) / (kT / 64)), dim3(kT), 0, s, (const int32_t*)whole->giant_row, whole->view.ngiant,
+                       (const int64_t*)whole->gterm_off, rowptr, colidx, sl, TS, gk_in.as<uint8_t>(), gp_in.as<uint32_t>(), gd_in.as<uint32_t>());
+    // two stable sorts by the same keys: positions and destinations travel together
+    if ((rc = sweep_sort_pairs(gk_in.as<uint8_t>(), gk_out.as<uint8_t>(), gp_in.as<uint32_t>(), gp_out.as<uint32_t>(), (size_t)ge, 8, s))) return rc;
+    if ((rc = sweep_sort_pairs(gk_in.as<uint8_t>(), gk_out.as<uint8_t>(), gd_in.as<uint32_t>(), gd_out.as<uint32_t>(), (size_t)ge, 8, s))) return rc;
+    hipLaunchKernelGGL(k_sweep_giant_bounds, dim3(1), dim3(256), 0, s, (const uint8_t*)gk_out.as<uint8_t>(), ge, TS, gslice.as<uint32_t>());
+    uint32_t nreal = 0;
+    GM_TRY_HIP(hipMemcpyAsync(&nreal, gslice.as<uint32_t>() + TS, 4, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    ngiant_edges = (int64_t)nreal;
+    if ((rc = gcol.alloc(((size_t)nreal + 64) * 4))) return rc;
+    if (vals && (rc = gval.alloc(((size_t)nreal + 64) * 4))) return rc;
+    if (nreal > 0)
+      hipLaunchKernelGGL(k_sweep_giant_fill, dim3(grid_for((int64_t)nreal)), dim3(kT), 0, s, (const uint32_t*)gp_out.as<uint32_t>(), (int64_t)nreal, colidx, vals,
+                         gcol.as<uint32_t>(), vals ? gval.as<uint32_t>() : (uint32_t*)nullptr);
+    GM_TRY_HIP(hipGetLastError());
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    gdst.p = gd_out.release();
+    if (keep_pos) gpos.p = gp_out.release();
+  }
+  S.ngiant_edges = ngiant_edges;
+  S.gcol = (const uint32_t*)gcol.release(); S.gval = (const uint32_t*)gval.release(); S.gdst = (const uint32_t*)gdst.release();
+  S.gslice = (const uint32_t*)gslice.release(); S.gsrc_pos = (const uint32_t*)gpos.release();
   S.nrows = (int32_t)nswept; S.nrows_long = (int32_t)nlong; S.nsets = nsets; S.nslices = TS;
   S.acc_rows = GM_SWEEP_ACC_ROWS; S.long_slots = GM_SWEEP_LONG_SLOTS; S.max_long_block = (int32_t)max_block; S.val_bytes = vals ? 4 : 0;
   S.short_row = whole->view.short_row; S.long_row = (int32_t)long_limit;
@@ -2067,6 +2141,9 @@ int gm_graph_sync_tile_vals(gm_graph_t* g, gm_stream_t stream) {
     if (S.nrows > 0 && S.val_bytes == 4 && S.sval && S.src_pos && S.nentries > 0)
       hipLaunchKernelGGL(gm::k_sweep_sync_vals, dim3(gm::grid_for(S.nentries)), dim3(gm::kT), 0, s, S.src_pos, (size_t)S.nentries, (const uint32_t*)g->out.vals,
                          const_cast<uint32_t*>(S.sval));
+    if (S.nrows > 0 && S.val_bytes == 4 && S.gval && S.gsrc_pos && S.ngiant_edges > 0)
+      hipLaunchKernelGGL(gm::k_sweep_sync_vals, dim3(gm::grid_for(S.ngiant_edges)), dim3(gm::kT), 0, s, S.gsrc_pos, (size_t)S.ngiant_edges, (const uint32_t*)g->out.vals,
+                         const_cast<uint32_t*>(S.gval));
     if (S.nrows > 0 && S.val_bytes == 4 && S.lval && S.lsrc_pos && S.nedges_long > 0)
       hipLaunchKernelGGL(gm::k_sweep_sync_vals, dim3(gm::grid_for(S.nedges_long)), dim3(gm::kT), 0, s, S.lsrc_pos, (size_t)S.nedges_long, (const uint32_t*)g->out.vals,
                          const_cast<uint32_t*>(S.lval));

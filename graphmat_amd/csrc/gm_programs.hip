@@ -745,7 +745,7 @@ static const EngineKey kEngineKeys[] = {
   {"ablate_cold_short", 14, 0, 0, 0x7fffffff},
   {"two_stage_head_permille", 15, 900, 100, 990},
   {"giant_stream", 16, 1, 0, 2},
-  {"sweep_form", 17, 0, 0, 7},
+  {"sweep_form", 17, 0, 0, 15},
 };
 static_assert(offsetof(gm_engine_options_t, sweep_form) == 17 * sizeof(int32_t), "kEngineKeys follows the field order");
 static bool engine_value_ok(const EngineKey& k, int v) {

@@ -311,6 +311,7 @@ struct Launch {
   // Giant rows of float sums in two calls (swept tiled multiplies, giant_stream = 2): phase 1 launches only the products pass
   // (k_giant_terms) of a tile on `terms_stream` and records `terms_done`; phase 2 launches the replay (k_spmv_giant) behind
   // that event.  The products of all tiles then sit side by side in one scratch (terms_offset / terms_total bytes).
+  bool terms_ready = false;  // the giant rows' products are in the products stream already (the sweep gathered them): fold passes only
   int giant_phase = 0;
   hipStream_t terms_stream = nullptr;
   hipEvent_t terms_done = nullptr;
@@ -417,7 +418,13 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
         if constexpr (std::is_same<U, float>::value) {
           if (xbits == nullptr && want == nullptr && L.opt.giant_maps != 0) maps = (dev::gchunk_state*)A.gchunk_state;
         }
-        if (!split || L.giant_phase == 1) {
+        if (L.terms_ready) {
+          if (maps != nullptr) {  // the pieces' ulp-maps from the products the sweep wrote
+            hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP, true>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa, A, x, xbits, vp, terms, tpres,
+                               L.opt.debug_flags, maps);
+            (*launches)++;
+          }
+        } else if (!split || L.giant_phase == 1) {
           hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, split ? L.terms_stream : gs, pa,
                              A, x, xbits, vp, terms, tpres, L.opt.debug_flags, maps);
           (*launches)++;
@@ -439,9 +446,11 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
         void *p6 = nullptr, *p7 = nullptr;
         if (L.opt.ordered_giant_two_pass != 0 && gm_graph_workspace(g, 6, (size_t)A.giant_edges * sizeof(U) + 64, &p6) == GM_OK &&
             (xbits == nullptr || gm_graph_workspace(g, 14, (size_t)A.giant_edges / 8 + 64, &p7) == GM_OK)) {
-          hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa,
-                             A, x, xbits, vp, (U*)p6, (unsigned long long*)p7, L.opt.debug_flags, (dev::gchunk_state*)nullptr);
-          (*launches)++;
+          if (!L.terms_ready) {
+            hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa,
+                               A, x, xbits, vp, (U*)p6, (unsigned long long*)p7, L.opt.debug_flags, (dev::gchunk_state*)nullptr);
+            (*launches)++;
+          }
           hipLaunchKernelGGL((dev::k_giant_fold_ordered<P, U, V>), dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, vp, y,
                              ybits, accumulate, (const U*)p6, (const unsigned long long*)p7, want);
           two_pass = true;
@@ -1192,20 +1201,32 @@ class Run {
       const Launch L = launch_ctx();
       aux.keep = true;
       aux.pending = aux.giant_pending = aux.use_gs = false;
+      // Giant rows.  Their fold passes read a products stream (gm_csr_t.gterm_off); when the reduction has such a two-pass form
+      // (float sums: the exact replay; plain ordered folds) the SWEEP gathers for them -- slice by slice, with its LDS hot sets,
+      // a slice's giant edges dealt evenly over the workgroups -- and only the fold passes remain, on the auxiliary stream next to
+      // the short rows' pass BEHIND the sweep.  (Round 5, first form: k_giant_terms gathered the 36 M giant-row messages of
+      // RMAT-26 untiled -- 64 % L2 misses -- on the auxiliary stream next to the short rows' kernel, which it stretched from 1.27
+      // to 1.55 ms.)  sweep_form bit 3 keeps that first form; other reductions (commutative) gather in their own kernels as before.
+      U* gterms = nullptr;
+      if constexpr (dev::stageable<U>::value) {
+        const bool two_pass = (rk == REDUCE_F32_ADD && std::is_same<U, float>::value) || (rk == REDUCE_ORDERED && opt.ordered_giant_two_pass != 0);
+        void* p6 = nullptr;
+        if (two_pass && Aout.ngiant > 0 && sw.ngiant_edges > 0 && sw.gcol != nullptr && !(opt.sweep_form & 8) &&
+            gm_graph_workspace(g, 6, (size_t)Aout.giant_edges * sizeof(U) + 64, &p6) == GM_OK)
+          gterms = (U*)p6;
+      }
       GM_HIP_OK(hipEventRecord(aux.fork, s));
       GM_HIP_OK(hipStreamWaitEvent(aux.s, aux.fork, 0));
       aux.forked = true;
-      if (Aout.ngiant > 0) {
-        gm_csr_t Ag = Aout;
-        Ag.nblk = 0; Ag.nmid = 0; Ag.nmid_long = 0;
-        launch_spmv_vp<P, T, U, V, E>(use_vp, L, pa, Ag, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
-      }
+      gm_csr_t Ag = Aout;
+      Ag.nblk = 0; Ag.nmid = 0; Ag.nmid_long = 0;
+      if (Aout.ngiant > 0 && gterms == nullptr) launch_spmv_vp<P, T, U, V, E>(use_vp, L, pa, Ag, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
       gm_csr_t As = Aout;  // the short rows
       As.nmid = 0; As.nmid_long = 0; As.ngiant = 0; As.ngchunk = 0;
       Launch La = L;
       La.aux = nullptr;
       La.tiled_untiled_pass = true;
-      const int where = opt.sweep_form & 3;
+      const int where = gterms != nullptr ? 2 : (opt.sweep_form & 3);
       if (where == 1) { La.s = aux.s; La.timer = nullptr; }
       auto short_rows = [&]() {
         if (As.nblk <= 0) return;
@@ -1223,20 +1244,29 @@ class Run {
         if (opt.sweep_form & 4) stage = 1024;  // (tests: blocks staged in several rounds)
       }
       for (int set = 0; set < sw.nsets; set++) {
+        U* gt = set == 0 ? gterms : (U*)nullptr;  // (the first launch gathers for the giant rows)
         bool with_vals = false;
         if constexpr (sizeof(E) == 4 && std::is_trivially_copyable<E>::value) {
           if (Aout.vals != nullptr) {
             hipLaunchKernelGGL((dev::k_spmv_sell<P, T, U, V, E, true>), dim3(256), dim3(1024), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base, sw.scol,
-                               sw.sval, sw.wrow, sw.row_of_slot, sw.lcol, sw.lval, sw.lps, sw.lrow_of_slot, xq, y);
+                               sw.sval, sw.wrow, sw.row_of_slot, sw.lcol, sw.lval, sw.lps, sw.lrow_of_slot, sw.gcol, sw.gval, sw.gdst, sw.gslice, gt, xq, y);
             with_vals = true;
           }
         }
         if (!with_vals)
           hipLaunchKernelGGL((dev::k_spmv_sell<P, T, U, V, E, false>), dim3(256), dim3(1024), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base, sw.scol,
-                             (const uint32_t*)nullptr, sw.wrow, sw.row_of_slot, sw.lcol, (const uint32_t*)nullptr, sw.lps, sw.lrow_of_slot, xq, y);
+                             (const uint32_t*)nullptr, sw.wrow, sw.row_of_slot, sw.lcol, (const uint32_t*)nullptr, sw.lps, sw.lrow_of_slot, sw.gcol,
+                             (const uint32_t*)nullptr, sw.gdst, sw.gslice, gt, xq, y);
       }
       st.spmv_launches += sw.nsets;
       timer.mark(TAG_WAVE);
+      if (gterms != nullptr) {  // the giant rows' fold passes behind the sweep, on the auxiliary stream next to the short rows
+        GM_HIP_OK(hipEventRecord(aux.fork, s));
+        GM_HIP_OK(hipStreamWaitEvent(aux.s, aux.fork, 0));
+        Launch Lg = L;
+        Lg.terms_ready = true;
+        launch_spmv_vp<P, T, U, V, E>(use_vp, Lg, pa, Ag, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
+      }
       if (where == 2) short_rows();
       if (aux.pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
       if (aux.giant_pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.gjoin, 0));

@@ -1456,8 +1456,9 @@ template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL = 
 __global__ void __launch_bounds__(1024)
 k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long, const int32_t* __restrict__ slice_base, const uint32_t* __restrict__ scol,
             const uint32_t* __restrict__ sval, const uint32_t* __restrict__ wrow, const int32_t* __restrict__ row_of_slot, const uint32_t* __restrict__ lcol,
-            const uint32_t* __restrict__ lval, const uint32_t* __restrict__ lps, const int32_t* __restrict__ lrow_of_slot, const T* __restrict__ x,
-            U* __restrict__ y) {
+            const uint32_t* __restrict__ lval, const uint32_t* __restrict__ lps, const int32_t* __restrict__ lrow_of_slot,
+            const uint32_t* __restrict__ gcol, const uint32_t* __restrict__ gval, const uint32_t* __restrict__ gdst, const uint32_t* __restrict__ gslice,
+            U* __restrict__ gterms /* products stream of the giant rows, or null: they gather for themselves */, const T* __restrict__ x, U* __restrict__ y) {
   static_assert(sizeof(T) == 4 && sizeof(U) == 4, "4-byte messages and reductions");
   constexpr int BLOCK = 1024, W = BLOCK / 64, UB = UBATCH;
   constexpr int ACC = GM_SWEEP_ACC_ROWS, NLP = GM_SWEEP_LONG_SLOTS;
@@ -1482,8 +1483,9 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
   // slice: the wave's row range, its first batch of entries, the long rows' piece bounds and the first staging round's
   // entries -- after a workgroup barrier every wave would otherwise start with two or three exposed load latencies
   // (96 slices x ~3 us).  pc / pe: first batch, lc / le: staging round, (pr, prend): row range, (pl0, pl1, pps, ppe): long bounds.
-  uint32_t pc[UB], pe[UB], lc[KMAX], le[KMAX];
-  uint32_t pr = 0, prend = 0, pl0 = 0, pl1 = 0, pps = 0, ppe = 0;
+  constexpr int GK = 2;  // giant-row entries per thread requested ahead (a share of more than GK * 1024 takes the loop below)
+  uint32_t pc[UB], pe[UB], lc[KMAX], le[KMAX], gc[GK], gd[GK], ge[GK];
+  uint32_t pr = 0, prend = 0, pl0 = 0, pl1 = 0, pps = 0, ppe = 0, pga = 0, pgb = 0;
   auto prefetch = [&](int sl) {
     const size_t blk = vw * (size_t)nslices + (size_t)sl;
     const uint32_t* __restrict__ wr = wrow + blk * (W + 1);
@@ -1494,6 +1496,20 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
       const uint32_t rr = pr + j < prend ? pr + j : (prend > 0 ? prend - 1 : 0);
       pc[j] = __builtin_nontemporal_load(&scol[(size_t)rr * 64 + lane]);
       if constexpr (HAS_VALS) pe[j] = __builtin_nontemporal_load(&sval[(size_t)rr * 64 + lane]); else pe[j] = 0u;
+    }
+    if (gterms != nullptr) {  // this workgroup's share of the slice's giant-row edges: the first GK per thread
+      const uint32_t g0 = gslice[sl], gn = gslice[sl + 1] - g0;
+      pga = g0 + (uint32_t)((unsigned long long)gn * (unsigned)wg / 256ull);
+      pgb = g0 + (uint32_t)((unsigned long long)gn * (unsigned)(wg + 1) / 256ull);
+#pragma unroll
+      for (int j = 0; j < GK; j++) {
+        const uint32_t i = pga + (uint32_t)(j * BLOCK) + threadIdx.x;
+        if (i < pgb) {
+          gc[j] = __builtin_nontemporal_load(&gcol[i]);
+          gd[j] = __builtin_nontemporal_load(&gdst[i]);
+          if constexpr (HAS_VALS) ge[j] = __builtin_nontemporal_load(&gval[i]); else ge[j] = 0u;
+        }
+      }
     }
     if (nrows_long > 0 && !(ABL & 4)) {
       const size_t eb = blk * NLP;
@@ -1534,6 +1550,15 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
       const uint32_t mg = *(const uint32_t*)(xb + (h ? base4 : c4));
       return h ? mh : mg;
     };
+    // the giant rows' share of this slice: their messages are requested here, next to the staging round's, and their products
+    // go to the stream the giant rows' fold passes read (after the staging phase: by then they have arrived)
+    uint32_t gmsg[GK];
+    const uint32_t ga = pga, gb = pgb;
+    if (gterms != nullptr) {
+#pragma unroll
+      for (int j = 0; j < GK; j++)
+        if (ga + (uint32_t)(j * BLOCK) + threadIdx.x < gb) gmsg[j] = gather(gc[j]);
+    }
     if (nrows_long > 0 && !(ABL & 4)) {
       const uint32_t l0 = pl0, l1 = pl1, ps = pps, pe_ = ppe;
       for (uint32_t c0 = l0; c0 < l1; c0 += (uint32_t)stage_words) {
@@ -1578,6 +1603,24 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
           }
           for (; k < ke; k++) p.P::reduce_function(lacc, as_u(s_stage[k - c0]));
         }
+      }
+    }
+    if (gterms != nullptr) {
+#pragma unroll
+      for (int j = 0; j < GK; j++) {
+        if (ga + (uint32_t)(j * BLOCK) + threadIdx.x < gb) {
+          U res;
+          p.P::process_message(as_t(gmsg[j]), as_e(ge[j]), no_vp, res);
+          gterms[gd[j]] = res;
+        }
+      }
+      for (uint32_t i = ga + (uint32_t)(GK * BLOCK) + threadIdx.x; i < gb; i += BLOCK) {  // (a slice heavy in giant-row edges)
+        const uint32_t c = __builtin_nontemporal_load(&gcol[i]), d = __builtin_nontemporal_load(&gdst[i]);
+        uint32_t e = 0u;
+        if constexpr (HAS_VALS) e = __builtin_nontemporal_load(&gval[i]);
+        U res;
+        p.P::process_message(as_t(gather(c)), as_e(e), no_vp, res);
+        gterms[d] = res;
       }
     }
     // The wave's part of the block: rows [r, rend) of 64 entries each.  A group = one META row (bit 31 set in every lane;
@@ -1919,7 +1962,9 @@ struct gchunk_state {
 // over many workgroups (one per GM_GIANT_CHUNK edges) because a single CU can only issue
 // about one gather per 2.7 cycles; the products go to a scratch stream in edge order
 // (plus presence words when x is sparse) that the ordered fold of pass 2 merely streams.
-template <class P, class T, class U, class V, class E, bool USE_VP>
+// (FROM_TERMS: the products are in `terms` already -- the sweep, k_spmv_sell, gathered them slice by slice with its hot sets --
+// and only the pieces' ulp-maps are composed here)
+template <class P, class T, class U, class V, class E, bool USE_VP, bool FROM_TERMS = false>
 __global__ void __launch_bounds__(kBlock)
 k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
               const V* __restrict__ vp, U* __restrict__ terms, unsigned long long* __restrict__ tpres, int dbg,
@@ -1938,9 +1983,10 @@ k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t
 #pragma unroll
   for (int j = 0; j < PER; j++) {
     int k = threadIdx.x + j * kBlock;
-    c[j] = (k < n) ? stream_load(&A.colidx[eb + k]) : -1;
+    if constexpr (FROM_TERMS) c[j] = (k < n) ? 0 : -1;
+    else c[j] = (k < n) ? stream_load(&A.colidx[eb + k]) : -1;
   }
-  if (xbits != nullptr) {
+  if (!FROM_TERMS && xbits != nullptr) {
 #pragma unroll
     for (int j = 0; j < PER; j++)
       if (c[j] >= 0 && !bit_get(xbits, c[j])) c[j] = -1;
@@ -1948,7 +1994,7 @@ k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t
   T m[PER];
 #pragma unroll
   for (int j = 0; j < PER; j++)
-    if (c[j] >= 0) { if ((dbg & DBG_SKIP_GATHER) || GM_ABL_COLD(c[j], A)) memset(&m[j], 0, sizeof(T)); else m[j] = x[c[j]]; }
+    if (!FROM_TERMS && c[j] >= 0) { if ((dbg & DBG_SKIP_GATHER) || GM_ABL_COLD(c[j], A)) memset(&m[j], 0, sizeof(T)); else m[j] = x[c[j]]; }
   // the exact replay spread over the chip (see gchunk_state): with a hint of the binade S will be in, the piece's
   // products are also composed into one ulp-map here, where they are in registers anyway
   constexpr bool kMaps = std::is_same<U, float>::value;
@@ -1962,8 +2008,12 @@ k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t
     int k = threadIdx.x + j * kBlock;
     if (c[j] >= 0) {
       U t;
-      p.P::process_message(m[j], edge_at<E>(A.vals, eb + k), vprow, t);
-      terms[out0 + k] = t;
+      if constexpr (FROM_TERMS) {
+        t = terms[out0 + k];
+      } else {
+        p.P::process_message(m[j], edge_at<E>(A.vals, eb + k), vprow, t);
+        terms[out0 + k] = t;
+      }
       if constexpr (kMaps) { if (ehint > 0) s_prod[k] = t; }
     }
     if (tpres != nullptr) {

@@ -306,6 +306,17 @@ typedef struct {
   const int32_t* slice_base; /* [nslices + 1] first device id of every slice */
   const uint32_t* src_pos;
   const uint32_t* lsrc_pos;
+  /* GIANT rows (the whole-graph CSR's giant_row list): they keep their own fold passes (the exact replay / the ordered fold of
+     their products stream, gm_csr_t.gterm_off), but the sweep can do the gathers for them, slice by slice with its hot sets:
+     gcol[i] (column << 2) / gval[i] = the giant rows' edges sorted by slice (inside a slice: row, then ascending native column),
+     gdst[i] = the edge's place in the products stream, gslice[s] = first entry of slice s (gslice[nslices] = ngiant_edges);
+     a slice's entries are dealt evenly over the 256 workgroups.  NULL / 0: the giant rows gather for themselves. */
+  int64_t ngiant_edges;
+  const uint32_t* gcol;
+  const uint32_t* gval;
+  const uint32_t* gdst;
+  const uint32_t* gslice;
+  const uint32_t* gsrc_pos;
 } gm_sweep_t;
 #define GM_MAX_SLICES 128
 #define GM_SWEEP_ACC_ROWS 10048
@@ -538,7 +549,8 @@ typedef struct {
                                      profiles/r04_streams_and_scalar_path.md.) */
   int32_t sweep_form;             /* the swept multiply (engine.hpp: multiply_out_swept): bits 0-1 = where the short rows' pass runs: 0 on the main stream
                                      in front of the sweep (default), 1 on the auxiliary stream behind the giant rows' passes (next to the sweep),
-                                     2 on the main stream behind the sweep; bit 2 = the long rows staged in rounds of 1024 entries (tests) */
+                                     2 on the main stream behind the sweep; bit 2 = the long rows staged in rounds of 1024 entries (tests); bit 3 = the
+                                     giant rows gather for themselves on the auxiliary stream (k_giant_terms) instead of the sweep gathering for them */
   int32_t reserved_[14];
 } gm_engine_options_t;
 /* the options a run on `g` uses (g may be NULL: the process defaults) */

@@ -270,6 +270,9 @@ def _sweep_arrays(api, sw):
     get("wfirst", nvw * T * 17, np.uint32); get("wrow", nvw * T * 17, np.uint32); get("row_of_slot", nvw * sw.acc_rows, np.int32)
     get("lcol", sw.nedges_long, np.uint32); get("lps", nvw * T * sw.long_slots + 1, np.uint32); get("lrow_of_slot", nvw * sw.long_slots, np.int32)
     get("slice_base", T + 1, np.int32)
+    get("gcol", sw.ngiant_edges, np.uint32); get("gdst", sw.ngiant_edges, np.uint32); get("gslice", T + 1, np.uint32)
+    if sw.val_bytes:
+        get("gval", sw.ngiant_edges, np.uint32)
     if sw.val_bytes:
         get("sval", sw.nentries, np.uint32); get("lval", sw.nedges_long, np.uint32)
         get("src_pos", sw.nentries, np.uint32); get("lsrc_pos", sw.nedges_long, np.uint32)
@@ -333,6 +336,26 @@ def _check_sweep_structure(api, g, sw, keep_values, rng, own=4096):
                 assert (A["src_pos"][gb[gI]: gb[gI + 1]].reshape(width + 1, 64)[1: n + 1, lane] == pos).all()
             lens.append(n)
         assert lens[0] == width and all(x >= y for x, y in zip(lens[:-1], lens[1:]))  # longest first, padded to the longest
+    # the giant rows' edges by slice: every edge once, at its place in the products stream (gterm_off + position in the row)
+    if c.ngiant:
+        gto = np.zeros(c.ngiant + 1, np.int64)
+        api.copy_from_device(gto, c.gterm_off)
+        assert sw.ngiant_edges == int(ln[giant[: c.ngiant]].sum())
+        gs = A["gslice"].astype(np.int64)
+        assert gs[0] == 0 and gs[-1] == sw.ngiant_edges and (np.diff(gs) >= 0).all()
+        want_dst, want_col, want_val = [], [], []
+        for gi in range(c.ngiant):
+            row = int(giant[gi])
+            want_dst.append(gto[gi] + np.arange(ln[row])); want_col.append(ci[rp[row]: rp[row + 1]])
+            if keep_values:
+                want_val.append(vv[rp[row]: rp[row + 1]])
+        want_dst, want_col = np.concatenate(want_dst), np.concatenate(want_col)
+        sl_of = np.searchsorted(cuts, want_col, side="right") - 1
+        order = np.argsort(sl_of, kind="stable")  # by slice; inside a slice: row, then CSR position
+        assert (A["gdst"] == want_dst[order]).all() and ((A["gcol"] >> 2) == want_col[order]).all()
+        assert (np.diff(gs) == np.bincount(sl_of, minlength=T)).all()
+        if keep_values:
+            assert (A["gval"] == np.concatenate(want_val)[order].view(np.uint32)).all()
     lps = A["lps"].astype(np.int64)
     assert lps[0] == 0 and lps[-1] == sw.nedges_long and (np.diff(lps) >= 0).all()
     if sw.nrows_long:
@@ -365,7 +388,7 @@ def test_row_stationary_sweep_bit_exact(env, scale, tiles, threads):
     rng = np.random.default_rng(1)
     seen_sets = [1]
     #        sweep_slices, sweep_form, keep_values, own_wave_row, acc_rows, long_slots
-    cases = [(0, 0, False, 4096, 10048, 512), (1, 0, False, 0, 10048, 512), (1, 1, True, 4096, 10048, 512), (1, 2, False, 0, 10048, 512),
+    cases = [(0, 0, False, 4096, 10048, 512), (1, 0, False, 0, 10048, 512), (1, 1, True, 4096, 10048, 512), (1, 2, False, 0, 10048, 512), (1, 8, False, 0, 10048, 512), (1, 9, True, 4096, 10048, 512),
              (16, 0, False, 256, 10048, 512), (16, 4, True, 256, 10048, 512), (24, 5, False, 128, 3, 3), (128, 0, True, 512, 2, 512)]
     try:
         for slices, form, keep, own, accl, longl in cases:

@@ -78,6 +78,7 @@ int main(int argc, char** argv) {
   GraphMat::dev::ProgArg<SumP> pa = GraphMat::dev::make_prog_arg(&prog);
   int stage = 64;
   if (S.nrows_long > 0) { stage = (S.max_long_block + 63) / 64 * 64; if (stage > GM_SWEEP_MAX_STAGE) stage = GM_SWEEP_MAX_STAGE; if (stage < 1024) stage = 1024; }
+  float* gterms = nullptr;  // (set below for the form that also gathers for the giant rows)
   hipEvent_t e0, e1; OK(hipEventCreate(&e0)); OK(hipEventCreate(&e1));
   const int64_t nedges = S.nedges + S.nedges_long;
   auto time_it = [&](auto launch, const char* name) {
@@ -97,7 +98,8 @@ int main(int argc, char** argv) {
 #define LAUNCH(ABL, STG) LAUNCHP(ABL, STG, 6, 2)
 #define LAUNCHU(ABL, STG, UBAT) LAUNCHP(ABL, STG, UBAT, 1)
 #define LAUNCHP(ABL, STG, UBAT, PIPE) for (int set = 0; set < S.nsets; set++) hipLaunchKernelGGL((GraphMat::dev::k_spmv_sell<SumP, float, float, Vp, int, false, ABL, UBAT, PIPE>), dim3(256), dim3(1024), 0, 0, pa, set, STG, \
-      S.nslices, S.nrows_long, S.slice_base, S.scol, (const uint32_t*)nullptr, S.wrow, S.row_of_slot, S.lcol, (const uint32_t*)nullptr, S.lps, S.lrow_of_slot, (const float*)x, y)
+      S.nslices, S.nrows_long, S.slice_base, S.scol, (const uint32_t*)nullptr, S.wrow, S.row_of_slot, S.lcol, (const uint32_t*)nullptr, S.lps, S.lrow_of_slot, \
+      S.gcol, (const uint32_t*)nullptr, S.gdst, S.gslice, gterms, (const float*)x, y)
   time_it([&]() { LAUNCH(0, stage); }, "k_spmv_sell (the library's form)");
   {
     const size_t nm = (size_t)S.nsets * 256 * S.acc_rows, nl = (size_t)S.nsets * 256 * S.long_slots;
@@ -128,6 +130,12 @@ int main(int argc, char** argv) {
   time_it([&]() { LAUNCHP(0, stage, 7, 2); }, "  ... two batches deep, batches of 7 rows");
   time_it([&]() { LAUNCHP(0, stage, 8, 1); }, "  ... one batch deep (round 5's first form), batches of 8 rows");
   time_it([&]() { LAUNCHP(0, stage, 12, 1); }, "  ... one batch deep, batches of 12 rows");
+  if (S.ngiant_edges > 0) {
+    OK(hipMalloc(&gterms, (size_t)A.giant_edges * 4 + 256));
+    time_it([&]() { LAUNCH(0, stage); }, "  ... gathering for the giant rows as well");
+    OK(hipFree(gterms));
+    gterms = nullptr;
+  }
   time_it([&]() { LAUNCH(0, GM_SWEEP_MAX_STAGE); }, "  ... with the largest stage (smallest hot set)");
   time_it([&]() { LAUNCH(4, 64); }, "  ... without the long rows' phase, largest hot set");
   time_it([&]() { LAUNCH(4, stage); }, "  ... without the long rows' phase, same hot set");
