@@ -827,7 +827,8 @@ def main():
         if swept:
             kname = "k_spmv_sell (row-stationary sweep over %d slices, %d launch(es) per iteration)" % (int(sweep.nslices), int(sweep.nsets))
         # every multiply kernel of the iteration by itself: edges x 4 B / its average time / the HBM peak.  (The giant rows'
-        # passes run on the auxiliary stream next to the row-block kernel: their time overlaps it.)
+        # fold passes run on the auxiliary stream next to the row-block kernel: their time overlaps it; the sweep's time includes
+        # the gathers it does for the giant rows.)
         steps_ = max(args.steps, 1)
         def kfrac(edges, ms_total):
             t = ms_total / steps_
@@ -835,7 +836,7 @@ def main():
                     "frac": round(4 * edges / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if t > 0 else None}
         per_kernel = ({"k_spmv_rowblock (rows of up to 64 edges)": kfrac(by_kernel[0], stats["rowblock_ms"]),
                        "k_spmv_sell (rows of 65 .. giant-limit edges)": kfrac(by_kernel[1], stats["wave_ms"]),
-                       "k_giant_terms+k_spmv_giant (auxiliary stream, overlapping the row-block kernel)": kfrac(by_kernel[3], stats["giant_ms"])} if swept else
+                       "k_giant_terms (maps only) + k_spmv_giant: the giant rows' fold passes (auxiliary stream, next to the row-block kernel; their gathers are done by the sweep)": kfrac(by_kernel[3], stats["giant_ms"])} if swept else
                       {"k_spmv_rowblock": kfrac(by_kernel[0], stats["rowblock_ms"]), "k_spmv_wave16+k_spmv_wave": kfrac(by_kernel[1] + by_kernel[2], stats["wave_ms"]),
                        "k_giant_terms+k_spmv_giant (auxiliary stream, overlapped)": kfrac(by_kernel[3], stats["giant_ms"])})
         roof = {"bound": "hbm", "kernel": kname + "<PageRank>", "achieved": round(ach, 1),

@@ -33,7 +33,7 @@ int g_long_mid = 0;  // > 0: experiment -- wave rows of more than this many edge
 int g_sweep_slices = 1;  // 1: cut the device order into ntiles * k <= 64 slices and build the row-stationary sweep of the medium rows (gm_graph_sweep)
 int g_sort_tile_lists = 1;  // column tiles: the wave-row lists by descending piece length (sort_rows_by_length)
 int g_sweep_border_factor = 4;  // the medium / long border is lowered while it exceeds this many times a wave's share of a block per slice
-int g_sweep_fold_share = 70;  // share (percent of an equal share) of a block's groups that the waves folding the long rows get
+int g_sweep_fold_share = 50;  // share (percent of an equal share) of a block's groups that the waves folding the long rows get
 int g_sweep_long_row = 0;  // the sweep's medium / long border (edges per row): 0 = chosen per graph (build_sweep)
 int g_sweep_acc_limit = GM_SWEEP_ACC_ROWS, g_sweep_long_limit = GM_SWEEP_LONG_SLOTS;  // rows per workgroup and launch of the sweep (tests force several launches with small values)
 int g_own_wave_row = 4096;  // column tiles: rows of more than this many edges (whole graph) keep the wave / giant kernels in every tile (0: classes per tile piece)

@@ -834,7 +834,7 @@ int gm_reset_options(void) {
   gm::g_sweep_acc_limit = GM_SWEEP_ACC_ROWS;
   gm::g_sweep_long_limit = GM_SWEEP_LONG_SLOTS;
   gm::g_sweep_long_row = 0;
-  gm::g_sweep_fold_share = 70;
+  gm::g_sweep_fold_share = 50;
   gm::g_sweep_border_factor = 4;
   gm::g_col_tiles = 0;
   return GM_OK;

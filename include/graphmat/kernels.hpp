@@ -1452,7 +1452,7 @@ static __device__ unsigned long long g_sell_phase_ticks[4096][8];
 #else
 #define GM_SELL_TICK(k) do { } while (0)
 #endif
-template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL = 0, int UBATCH = 6, int PIPE = 2>
+template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL = 0, int UBATCH = 7, int PIPE = 2>
 __global__ void __launch_bounds__(1024)
 k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long, const int32_t* __restrict__ slice_base, const uint32_t* __restrict__ scol,
             const uint32_t* __restrict__ sval, const uint32_t* __restrict__ wrow, const int32_t* __restrict__ row_of_slot, const uint32_t* __restrict__ lcol,
@@ -1538,6 +1538,8 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
     const uint32_t base4 = (uint32_t)base << 2, nhot4 = (uint32_t)nhot << 2;
     __syncthreads();  // the previous slice's folds are done: its hot set and stage may go, the running values are in s_acc
     GM_SELL_TICK(0);  // waiting for the other waves at the end of a slice
+    // (requesting the hot entries before the barrier as well -- 12 of them per thread in registers -- was measured: 2.19 against
+    // 2.09 ms, the kernel then needs all 128 VGPRs)
     for (int i = threadIdx.x; i < nhot; i += BLOCK) s_pool[i] = ((const uint32_t*)x)[base + i];
     __syncthreads();
     GM_SELL_TICK(1);  // hot set

@@ -95,7 +95,7 @@ int main(int argc, char** argv) {
     printf("%-58s best %.3f ms, mean %.3f ms  = %.2f ps per edge, %.1f G edges/s\n", name, best, sum / reps, best * 1e9 / nedges, nedges / best * 1e-6);
     fflush(stdout);
   };
-#define LAUNCH(ABL, STG) LAUNCHP(ABL, STG, 6, 2)
+#define LAUNCH(ABL, STG) LAUNCHP(ABL, STG, 7, 2)
 #define LAUNCHU(ABL, STG, UBAT) LAUNCHP(ABL, STG, UBAT, 1)
 #define LAUNCHP(ABL, STG, UBAT, PIPE) for (int set = 0; set < S.nsets; set++) hipLaunchKernelGGL((GraphMat::dev::k_spmv_sell<SumP, float, float, Vp, int, false, ABL, UBAT, PIPE>), dim3(256), dim3(1024), 0, 0, pa, set, STG, \
       S.nslices, S.nrows_long, S.slice_base, S.scol, (const uint32_t*)nullptr, S.wrow, S.row_of_slot, S.lcol, (const uint32_t*)nullptr, S.lps, S.lrow_of_slot, \
@@ -127,7 +127,7 @@ int main(int argc, char** argv) {
   check("two batches deep, 8 rows");
   time_it([&]() { LAUNCHP(0, stage, 4, 2); }, "  ... two batches deep, batches of 4 rows");
   time_it([&]() { LAUNCHP(0, stage, 5, 2); }, "  ... two batches deep, batches of 5 rows");
-  time_it([&]() { LAUNCHP(0, stage, 7, 2); }, "  ... two batches deep, batches of 7 rows");
+  time_it([&]() { LAUNCHP(0, stage, 6, 2); }, "  ... two batches deep, batches of 6 rows");
   time_it([&]() { LAUNCHP(0, stage, 8, 1); }, "  ... one batch deep (round 5's first form), batches of 8 rows");
   time_it([&]() { LAUNCHP(0, stage, 12, 1); }, "  ... one batch deep, batches of 12 rows");
   if (S.ngiant_edges > 0) {
