@@ -1539,7 +1539,8 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
     __syncthreads();  // the previous slice's folds are done: its hot set and stage may go, the running values are in s_acc
     GM_SELL_TICK(0);  // waiting for the other waves at the end of a slice
     // (requesting the hot entries before the barrier as well -- 12 of them per thread in registers -- was measured: 2.19 against
-    // 2.09 ms, the kernel then needs all 128 VGPRs)
+    // 2.09 ms, the kernel then needs all 128 VGPRs; the cold parts of the first staging round's and the giant rows' gathers
+    // requested before the barriers: 2.15 against 2.10, with the giant rows 2.32 against 2.23)
     for (int i = threadIdx.x; i < nhot; i += BLOCK) s_pool[i] = ((const uint32_t*)x)[base + i];
     __syncthreads();
     GM_SELL_TICK(1);  // hot set
