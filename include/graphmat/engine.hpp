@@ -1209,7 +1209,11 @@ class Run {
       // to 1.55 ms.)  sweep_form bit 3 keeps that first form; other reductions (commutative) gather in their own kernels as before.
       U* gterms = nullptr;
       if constexpr (dev::stageable<U>::value) {
-        const bool two_pass = (rk == REDUCE_F32_ADD && std::is_same<U, float>::value) || (rk == REDUCE_ORDERED && opt.ordered_giant_two_pass != 0);
+        // (float sums only.  A plain ordered fold of a giant row is a chain of dependent reduce_function calls -- 4-5 ms for RMAT-26's
+        // hub row -- that has to start as early as possible: such programs keep the first form, k_giant_terms and the fold on the
+        // auxiliary stream from the moment x is complete, next to the short rows AND the sweep; unchanged PageRank.cpp, RMAT-26:
+        // 459 ms with its chain behind the sweep, 444 with it beside everything)
+        const bool two_pass = rk == REDUCE_F32_ADD && std::is_same<U, float>::value;
         void* p6 = nullptr;
         if (two_pass && Aout.ngiant > 0 && sw.ngiant_edges > 0 && sw.gcol != nullptr && !(opt.sweep_form & 8) &&
             gm_graph_workspace(g, 6, (size_t)Aout.giant_edges * sizeof(U) + 64, &p6) == GM_OK)

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #define GM_SELL_PHASE_TIMES 1
 #include "GraphMatRuntime.h"
+#include <rocprim/rocprim.hpp>
 
 #define OK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { printf("%s:%d %s: %s\n", __FILE__, __LINE__, #e, hipGetErrorString(e_)); exit(1); } } while (0)
 #define GOK(e) do { int r_ = (e); if (r_ != 0) { printf("%s:%d %s: %s\n", __FILE__, __LINE__, #e, gm_last_error()); exit(1); } } while (0)
@@ -35,6 +36,67 @@ __global__ void k_ref(const int32_t* __restrict__ rows, int n, const int64_t* __
   if (i >= n) return;
   const int r = rows[i];
   if (r < 0) return;
+  const int64_t e0 = rowptr[r], e1 = rowptr[r + 1];
+  float acc = x[col[e0]];
+  for (int64_t k = e0 + 1; k < e1; k++) acc += x[col[k]];
+  y[r] = acc;
+}
+
+// ---- feasibility of running the short rows NEXT TO the sweep (round 5): a sliced-ELLPACK form of the rows of 1..64 edges that
+// needs no LDS and few registers (lane = row, whole rows, groups of 64 rows of nearly equal length), built here from the library's CSR
+__global__ void k_short_lens(const int64_t* __restrict__ rowptr, int nrows, int short_row, uint32_t* __restrict__ key, int32_t* __restrict__ id) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const int64_t l = rowptr[r + 1] - rowptr[r];
+  key[r] = (l >= 1 && l <= short_row) ? (uint32_t)(short_row - l) : 0xffffffffu;  // ascending key = descending length; others last
+  id[r] = r;
+}
+__global__ void k_short_gsize(const int32_t* __restrict__ rows, uint32_t ngroups, const int64_t* __restrict__ rowptr, uint32_t* __restrict__ gsize) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ngroups) return;
+  const int r = rows[(size_t)g * 64];
+  gsize[g] = (uint32_t)(rowptr[r + 1] - rowptr[r]) * 64u;
+}
+__global__ void k_short_fill(const int32_t* __restrict__ rows, int nshort, uint32_t ngroups, const uint32_t* __restrict__ gbase, const int64_t* __restrict__ rowptr,
+                             const int32_t* __restrict__ col, uint32_t* __restrict__ scol) {
+  const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (g >= ngroups) return;
+  const size_t q = (size_t)g * 64 + lane;
+  int64_t e0 = 0, e1 = 0;
+  if (q < (size_t)nshort) { const int r = rows[q]; e0 = rowptr[r]; e1 = rowptr[r + 1]; }
+  const uint32_t b = gbase[g], w = (gbase[g + 1] - b) >> 6;
+  for (uint32_t k = 0; k < w; k++) scol[(size_t)b + (size_t)k * 64 + lane] = (int64_t)k < e1 - e0 ? ((uint32_t)col[e0 + k] << 2) : 0x80000000u;
+}
+template <int UBS>
+__global__ void __launch_bounds__(256)
+k_sell_short(const uint32_t* __restrict__ scol, const uint32_t* __restrict__ gbase, uint32_t ngroups, const int32_t* __restrict__ rows, int nshort,
+             const float* __restrict__ x, float* __restrict__ y) {
+  const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (g >= ngroups) return;
+  const uint32_t b = gbase[g], w = (gbase[g + 1] - b) >> 6;
+  const char* __restrict__ xb = (const char*)x;
+  float acc = 0.f;
+  bool has = false;
+  for (uint32_t k = 0; k < w; k += UBS) {
+    uint32_t c[UBS];
+#pragma unroll
+    for (int j = 0; j < UBS; j++) c[j] = __builtin_nontemporal_load(&scol[(size_t)b + (size_t)(k + j < w ? k + j : w - 1) * 64 + lane]);
+    float m[UBS];
+#pragma unroll
+    for (int j = 0; j < UBS; j++) m[j] = *(const float*)(xb + (c[j] & 0x7fffffffu));
+#pragma unroll
+    for (int j = 0; j < UBS; j++)
+      if (k + j < w && (int32_t)c[j] >= 0) { acc = has ? acc + m[j] : m[j]; has = true; }
+  }
+  const size_t q = (size_t)g * 64 + lane;
+  if (q < (size_t)nshort && has) y[rows[q]] = acc;
+}
+__global__ void k_ref_rows(const int32_t* __restrict__ rows, int n, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ x, float* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int r = rows[i];
   const int64_t e0 = rowptr[r], e1 = rowptr[r + 1];
   float acc = x[col[e0]];
   for (int64_t k = e0 + 1; k < e1; k++) acc += x[col[k]];
@@ -142,6 +204,85 @@ int main(int argc, char** argv) {
   time_it([&]() { LAUNCH(2, stage); }, "  ... every gather served from LDS");
   time_it([&]() { LAUNCH(1, stage); }, "  ... no gathers at all");
   time_it([&]() { LAUNCH(5, stage); }, "  ... no gathers, no long rows");
+  {  // ---- the short rows next to the sweep
+    const int nr = A.nrows;
+    uint32_t *key, *key2; int32_t *id, *rows;
+    OK(hipMalloc(&key, (size_t)nr * 4)); OK(hipMalloc(&key2, (size_t)nr * 4)); OK(hipMalloc(&id, (size_t)nr * 4)); OK(hipMalloc(&rows, (size_t)nr * 4));
+    k_short_lens<<<(nr + 255) / 256, 256>>>(A.rowptr, nr, A.short_row, key, id);
+    {
+      size_t tb = 0;
+      OK(rocprim::radix_sort_pairs(nullptr, tb, key, key2, id, rows, (size_t)nr, 0, 32, (hipStream_t)0));
+      void* tmp; OK(hipMalloc(&tmp, tb + 256));
+      OK(rocprim::radix_sort_pairs(tmp, tb, key, key2, id, rows, (size_t)nr, 0, 32, (hipStream_t)0));
+      OK(hipDeviceSynchronize()); OK(hipFree(tmp));
+    }
+    std::vector<uint32_t> hk(nr);
+    OK(hipMemcpy(hk.data(), key2, (size_t)nr * 4, hipMemcpyDeviceToHost));
+    int nshort = 0;
+    while (nshort < nr && hk[nshort] != 0xffffffffu) nshort++;
+    const uint32_t ngroups = (uint32_t)((nshort + 63) / 64);
+    uint32_t *gsize, *gbase;
+    OK(hipMalloc(&gsize, ((size_t)ngroups + 1) * 4)); OK(hipMalloc(&gbase, ((size_t)ngroups + 1) * 4));
+    OK(hipMemset(gsize, 0, ((size_t)ngroups + 1) * 4));
+    k_short_gsize<<<(ngroups + 255) / 256, 256>>>(rows, ngroups, A.rowptr, gsize);
+    {
+      size_t tb = 0;
+      OK(rocprim::exclusive_scan(nullptr, tb, gsize, gbase, 0u, (size_t)ngroups + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
+      void* tmp; OK(hipMalloc(&tmp, tb + 256));
+      OK(rocprim::exclusive_scan(tmp, tb, gsize, gbase, 0u, (size_t)ngroups + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
+      OK(hipDeviceSynchronize()); OK(hipFree(tmp));
+    }
+    uint32_t total = 0; OK(hipMemcpy(&total, gbase + ngroups, 4, hipMemcpyDeviceToHost));
+    uint32_t* scs; OK(hipMalloc(&scs, ((size_t)total + 64) * 4));
+    k_short_fill<<<(ngroups + 3) / 4, 256>>>(rows, nshort, ngroups, gbase, A.rowptr, A.colidx, scs);
+    k_ref_rows<<<(nshort + 255) / 256, 256>>>(rows, nshort, A.rowptr, A.colidx, x, yref);
+    OK(hipDeviceSynchronize());
+    printf("short rows 1..%d: %d rows, %u entries in %u groups\n", A.short_row, nshort, total, ngroups);
+    const int64_t keep_nedges = nedges;
+    hipStream_t s1, s2; OK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); OK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    hipEvent_t ea, eb, ec; OK(hipEventCreate(&ea)); OK(hipEventCreate(&eb)); OK(hipEventCreate(&ec));
+    auto wall = [&](auto both, const char* name) {
+      float best = 1e9f;
+      for (int r = 0; r < reps + 1; r++) {
+        OK(hipDeviceSynchronize());
+        OK(hipEventRecord(ea, s1));
+        OK(hipStreamWaitEvent(s2, ea, 0));
+        both();
+        OK(hipEventRecord(eb, s2));
+        OK(hipStreamWaitEvent(s1, eb, 0));
+        OK(hipEventRecord(ec, s1));
+        OK(hipEventSynchronize(ec));
+        float ms; OK(hipEventElapsedTime(&ms, ea, ec));
+        if (r) best = ms < best ? ms : best;
+      }
+      OK(hipGetLastError());
+      printf("%-70s best %.3f ms\n", name, best);
+      fflush(stdout);
+    };
+#define SWEEP_ON(ABL, STREAM) for (int set = 0; set < S.nsets; set++) hipLaunchKernelGGL((GraphMat::dev::k_spmv_sell<SumP, float, float, Vp, int, false, ABL, 7, 2>), dim3(256), dim3(1024), 0, STREAM, pa, set, stage, \
+      S.nslices, S.nrows_long, S.slice_base, S.scol, (const uint32_t*)nullptr, S.wrow, S.row_of_slot, S.lcol, (const uint32_t*)nullptr, S.lps, S.lrow_of_slot, \
+      S.gcol, (const uint32_t*)nullptr, S.gdst, S.gslice, (float*)nullptr, (const float*)x, y)
+    wall([&]() { SWEEP_ON(0, s1); }, "sweep alone (121 VGPRs)");
+    wall([&]() { SWEEP_ON(4, s1); }, "sweep without its long rows alone (fewer VGPRs)");
+    wall([&]() { k_sell_short<2><<<(ngroups + 3) / 4, 256, 0, s2>>>(scs, gbase, ngroups, rows, nshort, x, y); }, "short rows (sliced-ELLPACK form, batch 2) alone");
+    wall([&]() { k_sell_short<4><<<(ngroups + 3) / 4, 256, 0, s2>>>(scs, gbase, ngroups, rows, nshort, x, y); }, "short rows (batch 4) alone");
+    wall([&]() { SWEEP_ON(0, s1); k_sell_short<2><<<(ngroups + 3) / 4, 256, 0, s2>>>(scs, gbase, ngroups, rows, nshort, x, y); }, "sweep + short rows on two streams");
+    wall([&]() { k_sell_short<2><<<(ngroups + 3) / 4, 256, 0, s2>>>(scs, gbase, ngroups, rows, nshort, x, y); SWEEP_ON(0, s1); }, "short rows + sweep on two streams (short launched first)");
+    wall([&]() { SWEEP_ON(4, s1); k_sell_short<2><<<(ngroups + 3) / 4, 256, 0, s2>>>(scs, gbase, ngroups, rows, nshort, x, y); }, "sweep without long rows + short rows on two streams");
+    wall([&]() { SWEEP_ON(4, s1); k_sell_short<4><<<(ngroups + 3) / 4, 256, 0, s2>>>(scs, gbase, ngroups, rows, nshort, x, y); }, "sweep without long rows + short rows (batch 4) on two streams");
+    {
+      OK(hipDeviceSynchronize());
+      std::vector<float> a(gd.ndevice), b(gd.ndevice);
+      std::vector<int32_t> hr(nshort);
+      OK(hipMemcpy(a.data(), y, (size_t)gd.ndevice * 4, hipMemcpyDeviceToHost));
+      OK(hipMemcpy(b.data(), yref, (size_t)gd.ndevice * 4, hipMemcpyDeviceToHost));
+      OK(hipMemcpy(hr.data(), rows, (size_t)nshort * 4, hipMemcpyDeviceToHost));
+      int64_t bad = 0;
+      for (int i = 0; i < nshort; i++) bad += memcmp(&a[hr[i]], &b[hr[i]], 4) != 0;
+      printf("   short rows against the serial fold: %lld of %d differ\n", (long long)bad, nshort);
+    }
+    (void)keep_nedges;
+  }
   {  // where a wave's time goes (100 MHz ticks summed over the slices of ONE launch)
     static unsigned long long h[4096][8];
     memset(h, 0, sizeof(h));
