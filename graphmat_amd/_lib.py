@@ -133,7 +133,6 @@ SIGNATURES = {
     "gm_graph_note_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
     "gm_graph_workspace_info": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "gm_graph_run_resources": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
-    "gm_graph_giant_stream": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "gm_graph_record_stats": (C.c_int, [_P, C.POINTER(RunStats)]),
     "gm_reduce_sum_f64": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_double), _P]),
     "gm_reduce_sum_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_double), _P]),

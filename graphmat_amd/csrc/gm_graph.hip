@@ -1930,17 +1930,6 @@ int gm_graph_run_resources(gm_graph_t* g, void** aux_stream, void** fork_event, 
   return GM_OK;
 }
 
-int gm_graph_giant_stream(gm_graph_t* g, void** stream, void** join_event) {
-  if (!g || !stream || !join_event) { gm::set_error("gm_graph_giant_stream: null argument"); return GM_ERR_INVALID; }
-  if (!g->giant_stream) {
-    GM_TRY_HIP(hipStreamCreateWithFlags(&g->giant_stream, hipStreamNonBlocking));
-    GM_TRY_HIP(hipEventCreateWithFlags(&g->giant_join, hipEventDisableTiming));
-  }
-  *stream = (void*)g->giant_stream;
-  *join_event = (void*)g->giant_join;
-  return GM_OK;
-}
-
 int gm_graph_destroy(gm_graph_t* g) {
   if (!g) return GM_OK;
   gm::free_csr(&g->out);
@@ -1958,11 +1947,6 @@ int gm_graph_destroy(gm_graph_t* g) {
     (void)hipEventDestroy(g->aux_fork);
     (void)hipEventDestroy(g->aux_join);
     (void)hipHostFree(g->pinned_flag);
-  }
-  if (g->giant_stream) {
-    (void)hipStreamSynchronize(g->giant_stream);
-    (void)hipStreamDestroy(g->giant_stream);
-    (void)hipEventDestroy(g->giant_join);
   }
   delete g;
   return GM_OK;

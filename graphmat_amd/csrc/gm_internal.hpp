@@ -76,8 +76,6 @@ struct gm_graph {
   // stream / pinned-memory creation lands inside a timed run_graph_program call
   hipStream_t aux_stream;
   hipEvent_t aux_fork, aux_join;
-  hipStream_t giant_stream;  // gm_graph_giant_stream (created on first use)
-  hipEvent_t giant_join;
   void* pinned_flag;
   // small per-graph memo for the header layer (gm_graph_note_*): e.g. the row split the shards agreed on
   int64_t note_val[GM_NOTE_SLOTS];

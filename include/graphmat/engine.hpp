@@ -159,24 +159,6 @@ struct AuxStream {
   // defer: the giant-row passes launched next are not waited for by their launch_spmv call; whoever needs their
   // rows calls wait_join (the two-stage schedule starts them before the tail stage and joins before the head apply)
   bool defer = false;
-  // gs / gjoin: a stream of their own for the giant rows' passes of a tiled multiply whose medium rows are swept (engine
-  // option giant_stream; use_gs is set by the column-tile loop): their chain of small latency-bound launches then runs NEXT
-  // TO this stream's short-row and one-wave-per-row kernels; giant_pending: something was launched there since the fork
-  hipStream_t gs = nullptr;
-  hipEvent_t gjoin = nullptr;
-  bool use_gs = false, giant_pending = false;
-  // A row of more than own_wave_row edges is a giant row in one tile and a one-wave-per-row row in another (the classes
-  // follow the PIECE's length), so with the giant passes on `gs` and the one-wave-per-row kernels on `s` tile t + 1 of
-  // either stream waits for tile t of the other: tile_ev[2 t] = giant passes of tile t done, [2 t + 1] = the others
-  std::vector<hipEvent_t> tile_ev;
-  hipEvent_t tile_event(int i) {
-    while ((int)tile_ev.size() <= i) {
-      hipEvent_t e = nullptr;
-      (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-      tile_ev.push_back(e);
-    }
-    return tile_ev[i];
-  }
   void wait_join(hipStream_t main) {
     if (s) (void)hipStreamWaitEvent(main, join, 0);
   }
@@ -187,9 +169,6 @@ struct AuxStream {
   }
   void finish() {
     if (s) (void)hipStreamSynchronize(s);
-    if (gs) (void)hipStreamSynchronize(gs);
-    for (hipEvent_t e : tile_ev) (void)hipEventDestroy(e);
-    tile_ev.clear();
   }
 };
 
@@ -308,14 +287,7 @@ struct Launch {
   PhaseTimer* timer;
   AuxStream* aux;
   bool tiled_untiled_pass = false;  // this launch is the untiled pass of a tiled multiply (set when aux is detached from it)
-  // Giant rows of float sums in two calls (swept tiled multiplies, giant_stream = 2): phase 1 launches only the products pass
-  // (k_giant_terms) of a tile on `terms_stream` and records `terms_done`; phase 2 launches the replay (k_spmv_giant) behind
-  // that event.  The products of all tiles then sit side by side in one scratch (terms_offset / terms_total bytes).
   bool terms_ready = false;  // the giant rows' products are in the products stream already (the sweep gathered them): fold passes only
-  int giant_phase = 0;
-  hipStream_t terms_stream = nullptr;
-  hipEvent_t terms_done = nullptr;
-  size_t terms_offset = 0, terms_total = 0;
 };
 
 // one multiply+reduce pass over one direction of the adjacency, strategy RK
@@ -388,10 +360,7 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
   };
   if (A.ngiant > 0) {
     hipStream_t gs = s;
-    const bool own_stream = overlap && keep && aux->use_gs && aux->gs != nullptr;  // (forked by the caller together with the auxiliary stream)
-    if (own_stream) {
-      gs = aux->gs;
-    } else if (overlap) {
+    if (overlap) {
       fork_aux();
       gs = aux->s;
       if (timer) timer->aux_mark(gs);
@@ -403,12 +372,11 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
       U* terms = nullptr;
       unsigned long long* tpres = nullptr;
       dev::gchunk_state* maps = nullptr;
-      const bool split = L.giant_phase != 0 && RK == REDUCE_F32_ADD && xbits == nullptr && own_stream;
       if constexpr (RK == REDUCE_F32_ADD) {
         // pass 1: products of all giant-row edges, spread over the whole chip
         void *p6 = nullptr, *p7 = nullptr;
-        gm_graph_workspace(g, 6, split ? L.terms_total : (size_t)A.giant_edges * sizeof(U) + 64, &p6);
-        terms = (U*)((char*)p6 + (split ? L.terms_offset : (size_t)0));
+        gm_graph_workspace(g, 6, (size_t)A.giant_edges * sizeof(U) + 64, &p6);
+        terms = (U*)p6;
         if (xbits != nullptr) {
           gm_graph_workspace(g, 14, (size_t)A.giant_edges / 8 + 64, &p7);  // (slot 7 holds the active-set list of sharded ACTIVE_ONLY runs)
           tpres = (unsigned long long*)p7;
@@ -424,19 +392,15 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
                                L.opt.debug_flags, maps);
             (*launches)++;
           }
-        } else if (!split || L.giant_phase == 1) {
-          hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, split ? L.terms_stream : gs, pa,
-                             A, x, xbits, vp, terms, tpres, L.opt.debug_flags, maps);
+        } else {
+          hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa, A, x, xbits, vp, terms, tpres,
+                             L.opt.debug_flags, maps);
           (*launches)++;
-          if (split) GM_HIP_OK(hipEventRecord(L.terms_done, L.terms_stream));
         }
       }
-      if (!split || L.giant_phase == 2) {
-        if (split) GM_HIP_OK(hipStreamWaitEvent(gs, L.terms_done, 0));
-        hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa,
-                           A, x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, (const U*)terms,
-                           (const unsigned long long*)tpres, want, maps);
-      }
+      hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa,
+                         A, x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, (const U*)terms,
+                         (const unsigned long long*)tpres, want, maps);
     } else {
       // plain ordered fold (any reduce_function): products spread over the chip by k_giant_terms, then one wave per row
       // folds the dense products stream in stored order (kernels.hpp: k_giant_fold_ordered).  Larger reduction types keep
@@ -462,10 +426,7 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
                            xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want);
     }
     (*launches)++;
-    if (own_stream) {
-      GM_HIP_OK(hipEventRecord(aux->gjoin, gs));
-      aux->giant_pending = true;
-    } else if (overlap) {
+    if (overlap) {
       if (timer) timer->aux_mark(gs);
       GM_HIP_OK(hipEventRecord(aux->join, gs));
     } else if (timer) {
@@ -1200,7 +1161,7 @@ class Run {
     if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
       const Launch L = launch_ctx();
       aux.keep = true;
-      aux.pending = aux.giant_pending = aux.use_gs = false;
+      aux.pending = false;
       // Giant rows.  Their fold passes read a products stream (gm_csr_t.gterm_off); when the reduction has such a two-pass form
       // (float sums: the exact replay; plain ordered folds) the SWEEP gathers for them -- slice by slice, with its LDS hot sets,
       // a slice's giant edges dealt evenly over the workgroups -- and only the fold passes remain, on the auxiliary stream next to
@@ -1273,8 +1234,7 @@ class Run {
       }
       if (where == 2) short_rows();
       if (aux.pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
-      if (aux.giant_pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.gjoin, 0));
-      aux.keep = aux.forked = aux.pending = aux.giant_pending = aux.use_gs = false;
+      aux.keep = aux.forked = aux.pending = false;
       timer.mark(TAG_GIANT);  // (the multiply ends when the auxiliary stream has joined: the wait is charged to the giant rows' passes)
       check_probed(pa, Aout, Aout.rowbits, nullptr, acc, ybits, true);
     } else {
@@ -1306,9 +1266,6 @@ class Run {
       GM_HIP_OK(hipEventRecord(aux.fork, s));  // x is complete here: the auxiliary stream may start on tile 0 during the untiled pass
       GM_HIP_OK(hipStreamWaitEvent(aux.s, aux.fork, 0));
       aux.forked = true;
-      if (aux.gs) GM_HIP_OK(hipStreamWaitEvent(aux.gs, aux.fork, 0));
-      aux.giant_pending = false;
-      aux.use_gs = false;
     }
     gm_csr_t As = Aout;  // the rows that are not tiled: row-blocks and the shorter wave rows
     As.mid_row = Aout.umid_row; As.nmid = Aout.numid; As.nmid_long = Aout.numid_long; As.ngiant = 0; As.ngchunk = 0;
@@ -1327,8 +1284,7 @@ class Run {
     aux.long_rows = false;
     if (aux.keep) {
       if (aux.pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
-      if (aux.giant_pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.gjoin, 0));
-      aux.keep = aux.forked = aux.pending = aux.giant_pending = aux.use_gs = false;
+      aux.keep = aux.forked = aux.pending = false;
     }
     // (a probed strategy is cross-checked against the ordered fold of the WHOLE rows; a mismatch redoes this iteration
     // untiled with the ordered fold, which then also governs the tiled iterations that follow)

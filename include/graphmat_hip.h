@@ -540,13 +540,8 @@ typedef struct {
                                      is multiplied.  Default 900: the tail then holds (almost) only short rows, so the 16-rows-per-wave kernel is
                                      not cut into two launches (shard of 8 of RMAT-26, compute only: 1.103 ms against 1.196 with 650 and 1.100 for
                                      the plain loop; profiles/r04_shard_emulation_rmat26.txt) */
-  int32_t giant_stream;           /* tiled multiplies with the row-stationary sweep (gm_graph_sweep): 1 = the giant rows' passes (products, then
-                                     the exact replay: a chain of small latency-bound launches) run on a stream of their own
-                                     (gm_graph_giant_stream) next to the auxiliary stream's short-row and one-wave-per-row kernels (default); 2 =
-                                     moreover the products passes (k_giant_terms) of ALL tiles run first, on the auxiliary stream (measured: the
-                                     replay chain ends 0.18 ms earlier and the short-row pass takes 0.17 ms longer: RMAT-26 5.10-5.12 against
-                                     5.09-5.16 ms); 0 = everything shares the auxiliary stream.  (Without the sweep a third stream was measured and loses:
-                                     profiles/r04_streams_and_scalar_path.md.) */
+  int32_t giant_stream;           /* without effect since round 5 (a third stream for the giant rows' passes of round 4's tiled sweep); kept so that
+                                     the fields keep their places */
   int32_t sweep_form;             /* the swept multiply (engine.hpp: multiply_out_swept): bits 0-1 = where the short rows' pass runs: 0 on the main stream
                                      in front of the sweep (default), 1 on the auxiliary stream behind the giant rows' passes (next to the sweep),
                                      2 on the main stream behind the sweep; bit 2 = the long rows staged in rounds of 1024 entries (tests); bit 3 = the
@@ -592,9 +587,6 @@ int gm_graph_adopt_workspace(gm_graph_t* g, int slot, void* d_ptr, size_t bytes)
  * convergence flag and frontier statistics are copied there every iteration).  Returned as
  * void* so this header stays free of HIP types. */
 int gm_graph_run_resources(gm_graph_t* g, void** aux_stream, void** fork_event, void** join_event, void** pinned);
-/* A second non-blocking stream and its join event for the giant rows' passes of a tiled multiply (engine option
- * giant_stream); created on first use, destroyed with the graph. */
-int gm_graph_giant_stream(gm_graph_t* g, void** stream, void** join_event);
 /* counters of the giant-row kernel since the last call (then reset): 16-edge groups
  * out[0] taken by the exact parallel fp32 replay, out[1] folded serially */
 int gm_debug_counters(int64_t out[4]);

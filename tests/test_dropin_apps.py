@@ -360,6 +360,18 @@ def test_edge_updates_and_shared_properties_on_tiled_graphs():
 
 
 @pytest.mark.gpu
+def test_edge_values_through_the_sweep():
+    """apps/swept_edge_values.cpp: a weighted float SpMV (process_message = message * edge value) on a graph with medium, long and
+    giant rows whose device order is sliced: the rows above 64 edges go through the row-stationary sweep WITH edge values
+    (k_spmv_sell, gm_sweep_t.sval / lval / gval), also after applyToAllEdges rewrote the values (device functor and host
+    function pointer: gm_graph_sync_tile_vals brings the sweep's copies over) and on a graph relayouted by shareVertexProperty;
+    every vertex against a host evaluation."""
+    text = _run(_need(os.path.join(OWN_APPS, "swept_edge_values")))
+    assert "SWEPTEDGES PASS" in text, text[-2000:]
+    assert re.search(r"sweep: [1-9][0-9]* rows \([1-9][0-9]* long\), value bytes 4, [1-9][0-9]* giant-row edges gathered by the sweep", text), text[-2000:]
+
+
+@pytest.mark.gpu
 def test_reference_pagerank_timing_build_prints_the_per_iteration_lines(golden_dir, ref):
     """The reference's tracing flavour (-D__TIMING) of the UNCHANGED src/PageRank.cpp: per iteration the phase lines and
     "Iteration %d :: %f msec :: updated %d vertices :: changed %d vertices" (include/GraphMatRuntime.h:150-248 of the
