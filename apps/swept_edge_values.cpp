@@ -45,9 +45,9 @@ static edges_t make_edges(int lo, int hi, int nhub, unsigned seed) {
   unsigned st = seed;
   auto next = [&]() { st = st * 1664525u + 1013904223u; return st >> 8; };
   const int span = hi - lo + 1;
-  // (hub 0: 6000 in-edges -- a giant row at this size; hubs 1..3: 1500..2100 -- long rows of the sweep; the others 150..: medium rows)
+  // (hub 0: 6000 in-edges -- a giant row at this size; hubs 1..3: 1500..2100 -- long rows of the sweep; the others 100..230: medium rows)
   for (int h = 0; h < nhub; h++)
-    for (int k = 0; k < (h == 0 ? 6000 : h <= 3 ? 1200 + 300 * h : 150 + 40 * h); k++) ed.push_back(GraphMat::edge_t<int>(lo + (int)(next() % span), lo + h, 1 + (int)(next() % 4)));
+    for (int k = 0; k < (h == 0 ? 6000 : h <= 3 ? 1200 + 300 * h : 70 + 7 * h); k++) ed.push_back(GraphMat::edge_t<int>(lo + (int)(next() % span), lo + h, 1 + (int)(next() % 4)));
   for (int i = 0; i < span; i++) ed.push_back(GraphMat::edge_t<int>(lo + i, lo + (i + 1) % span, 2));  // every vertex of the range has an edge
   for (int i = 0; i < 4 * span; i++) ed.push_back(GraphMat::edge_t<int>(lo + (int)(next() % span), lo + (int)(next() % span), 1 + (int)(next() % 4)));
   return ed;
@@ -96,7 +96,7 @@ int main(int argc, char** argv) {
     printf("graph 1: %d column tiles, %d slices, sweep: %d rows (%d long), value bytes %d, %lld giant-row edges gathered by the sweep, %d giant rows\n", nt, sw.nslices, sw.nrows,
            sw.nrows_long, sw.val_bytes, (long long)sw.ngiant_edges, ca.ngiant);
     CHECK(nt > 1);
-    CHECK(sw.nrows > 0 && sw.nrows_long > 0 && sw.val_bytes == 4 && ca.ngiant > 0 && sw.ngiant_edges > 0);
+    CHECK(sw.nrows > sw.nrows_long && sw.nrows_long > 0 && sw.val_bytes == 4 && ca.ngiant > 0 && sw.ngiant_edges > 0);
     CHECK(spmv_matches(G, ed, n, x, [](const GraphMat::edge_t<int>& e) { return (float)e.val; }));
     // device functor form: the whole-CSR values are rewritten in place, the tile copies must follow
     for (int v = 1; v <= n; v++) G.setVertexproperty(v, x[v]);

@@ -1398,7 +1398,13 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
     GM_TRY_HIP(hipStreamSynchronize(s));
   } else {
     // no medium row: empty blocks for every wave
+    // (the kernel requests a wave's first batch of entries -- and their values -- before it knows that the stream is empty: both arrays exist)
     if ((rc = gbase.alloc(64)) || (rc = wrow.alloc(nblk * 17 * 4)) || (rc = wfirst.alloc(nblk * 17 * 4)) || (rc = scol.alloc(64 * 64 * 4))) return rc;
+    GM_TRY_HIP(hipMemsetAsync(scol.p, 0xff, 64 * 64 * 4, s));
+    if (vals) {
+      if ((rc = sval.alloc(64 * 64 * 4))) return rc;
+      GM_TRY_HIP(hipMemsetAsync(sval.p, 0, 64 * 64 * 4, s));
+    }
     GM_TRY_HIP(hipMemsetAsync(gbase.p, 0, 64, s));
     GM_TRY_HIP(hipMemsetAsync(wfirst.p, 0, nblk * 17 * 4, s));
     GM_TRY_HIP(hipMemsetAsync(wrow.p, 0, nblk * 17 * 4, s));
