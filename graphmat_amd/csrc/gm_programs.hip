@@ -752,8 +752,8 @@ static bool engine_value_ok(const EngineKey& k, int v) {
   if (v < k.lo || v > k.hi) return false;
 #ifndef GRAPHMAT_ABLATION
   // result-invalidating switches exist in -DGRAPHMAT_ABLATION builds only (build/ablation/libgraphmat_hip.so, tools/): the
-  // product library rejects them -- the in-kernel ablation bits of debug_flags (1, 2, 4, 8) and the cold-column ablation
-  if (!strcmp(k.name, "debug_flags") && (v & 15) != 0) return false;
+  // product library rejects them -- the in-kernel ablation bits of debug_flags (1, 2, 4, 8, 16384) and the cold-column ablation
+  if (!strcmp(k.name, "debug_flags") && (v & (15 | 16384)) != 0) return false;
   if (!strncmp(k.name, "ablate_", 7)) return false;
 #endif
   if (!strcmp(k.name, "wave16_form")) return (v & 15) <= 5;

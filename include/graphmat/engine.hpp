@@ -388,18 +388,18 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
         }
         if (L.terms_ready) {
           if (maps != nullptr) {  // the pieces' ulp-maps from the products the sweep wrote
-            hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP, true>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa, A, x, xbits, vp, terms, tpres,
-                               L.opt.debug_flags, maps);
+            hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP, true>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa, A, x, xbits, vp, terms, tpres
+                               GM_DBG_ARG(L.opt.debug_flags), maps);
             (*launches)++;
           }
         } else {
-          hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa, A, x, xbits, vp, terms, tpres,
-                             L.opt.debug_flags, maps);
+          hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa, A, x, xbits, vp, terms, tpres
+                             GM_DBG_ARG(L.opt.debug_flags), maps);
           (*launches)++;
         }
       }
       hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa,
-                         A, x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, (const U*)terms,
+                         A, x, xbits, vp, y, ybits, accumulate GM_DBG_ARG(L.opt.debug_flags), (const U*)terms,
                          (const unsigned long long*)tpres, want, maps);
     } else {
       // plain ordered fold (any reduce_function): products spread over the chip by k_giant_terms, then one wave per row
@@ -412,7 +412,7 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
             (xbits == nullptr || gm_graph_workspace(g, 14, (size_t)A.giant_edges / 8 + 64, &p7) == GM_OK)) {
           if (!L.terms_ready) {
             hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa,
-                               A, x, xbits, vp, (U*)p6, (unsigned long long*)p7, L.opt.debug_flags, (dev::gchunk_state*)nullptr);
+                               A, x, xbits, vp, (U*)p6, (unsigned long long*)p7 GM_DBG_ARG(L.opt.debug_flags), (dev::gchunk_state*)nullptr);
             (*launches)++;
           }
           hipLaunchKernelGGL((dev::k_giant_fold_ordered<P, U, V>), dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, vp, y,
@@ -423,7 +423,7 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
       if (!two_pass)
         hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, REDUCE_ORDERED>),
                            dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, A.giant_row, A.ngiant, x,
-                           xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want);
+                           xbits, vp, y, ybits, accumulate GM_DBG_ARG(L.opt.debug_flags), want);
     }
     (*launches)++;
     if (overlap) {
@@ -437,7 +437,7 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
     // a=b: one lane per row over the whole row range (short rows pick themselves by their length)
     if constexpr (RK == REDUCE_LAST) {
       hipLaunchKernelGGL((dev::k_spmv_short_last<P, T, U, V, E, USE_VP>), dim3(grid_for(A.nrows)), dim3(dev::kBlock), 0, s,
-                         pa, A, x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want, xsum);
+                         pa, A, x, xbits, vp, y, ybits, accumulate GM_DBG_ARG(L.opt.debug_flags), want, xsum);
       (*launches)++;
       if (timer) timer->mark(TAG_ROWBLOCK);
     }
@@ -467,10 +467,10 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
     if (done) {
     } else if (xbits == nullptr)
       hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP, true, RK>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A,
-                         x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want);
+                         x, xbits, vp, y, ybits, accumulate GM_DBG_ARG(L.opt.debug_flags), want);
     else
       hipLaunchKernelGGL((dev::k_spmv_rowblock<P, T, U, V, E, USE_VP, false, RK>), dim3(A.nblk), dim3(dev::kBlock), 0, s, pa, A,
-                         x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want);
+                         x, xbits, vp, y, ybits, accumulate GM_DBG_ARG(L.opt.debug_flags), want);
     (*launches)++;
     if (timer) timer->mark(TAG_ROWBLOCK);
   }
@@ -483,15 +483,15 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
       if constexpr (RK == REDUCE_LAST) {
         if (L.opt.last_rows_lanes == 16) {
           hipLaunchKernelGGL((dev::k_spmv_wave_grouped<P, T, U, V, E, USE_VP, RK, 16>), dim3((groups + WPB - 1) / WPB),
-                             dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
-                             L.opt.debug_flags, want, xsum);
+                             dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate
+                             GM_DBG_ARG(L.opt.debug_flags), want, xsum);
           done = true;
         }
       }
       if (!done)
         hipLaunchKernelGGL((dev::k_spmv_wave_grouped<P, T, U, V, E, USE_VP, RK>), dim3((groups + WPB - 1) / WPB),
-                           dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
-                           L.opt.debug_flags, want, xsum);
+                           dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate
+                           GM_DBG_ARG(L.opt.debug_flags), want, xsum);
     } else if (wave16_ok<U, USE_VP, RK>() && !(L.opt.debug_flags & dev::DBG_NO_WAVE16)) {
       if constexpr (wave16_ok<U, USE_VP, RK>()) {
         // ordered folds: the long rows at the head of the list get a wave each, the rest are folded 16 to a wave
@@ -510,7 +510,7 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
             if (timer) timer->aux_mark(ls);
           }
           hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, RK>), dim3((nlong + WPB - 1) / WPB), dim3(dev::kBlock), 0, ls,
-                             pa, A, A.mid_row, nlong, x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want);
+                             pa, A, A.mid_row, nlong, x, xbits, vp, y, ybits, accumulate GM_DBG_ARG(L.opt.debug_flags), want);
           if (long_on_aux) {
             if (timer) timer->aux_mark(ls);
             GM_HIP_OK(hipEventRecord(aux->join, ls));  // (re-recorded behind the giant passes' record: the wait below sees this one)
@@ -528,20 +528,20 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
             const int need = (groups + BLOCK / 64 - 1) / (BLOCK / 64);
             if (grid > need) grid = need;
             hipLaunchKernelGGL((dev::k_spmv_wave16p<P, T, U, V, E, BLOCK, HOT>), dim3(grid), dim3(BLOCK), 0, s, pa, A, A.mid_row + nlong, rest,
-                               x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want);
+                               x, xbits, vp, y, ybits, accumulate GM_DBG_ARG(L.opt.debug_flags), want);
             done = true;
           }
         }
         if (!done && rest > 0) {
           constexpr int W16 = dev::kWave16Block / 64;
           hipLaunchKernelGGL((dev::k_spmv_wave16<P, T, U, V, E>), dim3((groups + W16 - 1) / W16), dim3(dev::kWave16Block), 0, s, pa, A,
-                             A.mid_row + nlong, rest, x, xbits, vp, y, ybits, accumulate, L.opt.debug_flags, want);
+                             A.mid_row + nlong, rest, x, xbits, vp, y, ybits, accumulate GM_DBG_ARG(L.opt.debug_flags), want);
         }
       }
     } else
       hipLaunchKernelGGL((dev::k_spmv_wave<P, T, U, V, E, USE_VP, RK>), dim3((A.nmid + WPB - 1) / WPB),
-                         dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate,
-                         L.opt.debug_flags, want);
+                         dim3(dev::kBlock), 0, s, pa, A, A.mid_row, A.nmid, x, xbits, vp, y, ybits, accumulate
+                         GM_DBG_ARG(L.opt.debug_flags), want);
     (*launches)++;
     if (timer && !long_on_aux) timer->mark(TAG_WAVE);
   }

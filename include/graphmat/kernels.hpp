@@ -441,16 +441,24 @@ __device__ __forceinline__ E edge_at(const void* __restrict__ vals, int64_t k) {
 // earlier pass (their presence is read from ybits); ACC_STATIC_BITS = do not write presence
 // bits (every x entry is present, so y's presence equals the graph's static row bits)
 enum { ACC_READ_PREV = 1, ACC_STATIC_BITS = 2 };
-// The first four are tested INSIDE the multiply kernels (skip the fold, skip the gathers ...): they exist for ablation
+// The first four and the last are tested INSIDE the multiply kernels (skip the fold, skip the gathers ...): they exist for ablation
 // builds only (-DGRAPHMAT_ABLATION, graphmat_amd/build.py with GRAPHMAT_ABLATION=1).  In a production build they are 0,
 // so every `dbg & DBG_*` in a kernel is a compile-time false and the tests are not in the code.  The others pick
 // between exact strategies on the host side of a launch and are always available.
 #ifdef GRAPHMAT_ABLATION
 #define GM_ABL(bit) (bit)
+#define GM_DBG_PARAM , const int dbg
+#define GM_DBG_ARG(flags) , (int)(flags)
+#define GM_DBG_PASS , dbg
 #else
 #define GM_ABL(bit) 0
+// a production build's kernels have no such parameter at all: `dbg` inside them names this constant
+#define GM_DBG_PARAM
+#define GM_DBG_ARG(flags)
+#define GM_DBG_PASS
+static constexpr int dbg = 0;
 #endif
-enum { DBG_SKIP_FOLD = GM_ABL(1), DBG_SKIP_GATHER = GM_ABL(2), DBG_FIRST_CHUNK_ONLY = GM_ABL(4), DBG_NO_REPLAY = GM_ABL(8), DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64, DBG_NO_PIPELINE = 128, DBG_NO_LAZY_SEND = 256, DBG_NO_WAVE16 = 512, DBG_NO_TILES = 1024, DBG_NO_SPARSE_XCHG = 2048, DBG_LATE_GIANTS = 4096, DBG_LONG_ON_MAIN = 8192, DBG_PLAIN_WAVE16 = 16384 };
+enum { DBG_SKIP_FOLD = GM_ABL(1), DBG_SKIP_GATHER = GM_ABL(2), DBG_FIRST_CHUNK_ONLY = GM_ABL(4), DBG_NO_REPLAY = GM_ABL(8), DBG_NO_OVERLAP = 16, DBG_NO_PUSH = 32, DBG_NO_GROUPED = 64, DBG_NO_PIPELINE = 128, DBG_NO_LAZY_SEND = 256, DBG_NO_WAVE16 = 512, DBG_NO_TILES = 1024, DBG_NO_SPARSE_XCHG = 2048, DBG_LATE_GIANTS = 4096, DBG_LONG_ON_MAIN = 8192, DBG_PLAIN_WAVE16 = GM_ABL(16384) };
 
 // presence bits of a wave's 64 consecutive rows: one atomicOr per 32-row word (not per row:
 // same-word atomics from 32 lanes serialise in the L2); nothing when the bits are static
@@ -478,7 +486,7 @@ __device__ __forceinline__ void publish_row_bits(bool wrote, int row, uint32_t* 
 template <class P, class T, class U, class V, class E, bool USE_VP>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_short_last(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
-                  const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg,
+                  const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate GM_DBG_PARAM,
                   const uint32_t* __restrict__ want,
                   const uint32_t* __restrict__ xsum /* 1 bit per 64 x entries "any present", or null (k_bits_summary) */) {
   const P& p = *reinterpret_cast<const P*>(pa.b);
@@ -528,7 +536,7 @@ k_spmv_short_last(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint
 template <class P, class T, class U, class V, class E, bool USE_VP, bool DENSE, int RK>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_rowblock(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
-                const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg,
+                const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate GM_DBG_PARAM,
                 const uint32_t* __restrict__ want) {
   // a=b needs one message per row (the last present one): gather it in phase 2 instead of all of them
   constexpr bool STAGE = stageable<T>::value && RK != REDUCE_LAST;
@@ -769,7 +777,7 @@ template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
 __device__ __forceinline__ void wave_row(const P& p, const gm_csr_t& A, const int row, const int64_t e0, const int64_t e1,
                                          const int lane, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
                                          const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits,
-                                         const int accumulate, const int dbg, U* out_acc = nullptr, bool* out_has = nullptr,
+                                         const int accumulate GM_DBG_PARAM, U* out_acc = nullptr, bool* out_has = nullptr,
                                          const uint32_t* __restrict__ xsum = nullptr) {
   // (out_acc / out_has, ordered kind only: hand the result back instead of storing it -- k_check_rows)
   // (xsum, REDUCE_LAST only: 1 bit per 64 x entries "any present" (k_bits_summary), tested before the presence bit)
@@ -926,7 +934,7 @@ k_check_rows(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nl
   if (e1 == e0) return;
   U acc;
   bool has = false;
-  wave_row<P, T, U, V, E, USE_VP, REDUCE_ORDERED>(p, A, row, e0, e1, threadIdx.x & 63, x, xbits, vp, (U*)nullptr, (uint32_t*)nullptr, 0, 0,
+  wave_row<P, T, U, V, E, USE_VP, REDUCE_ORDERED>(p, A, row, e0, e1, threadIdx.x & 63, x, xbits, vp, (U*)nullptr, (uint32_t*)nullptr, 0 GM_DBG_ARG(0),
                                                   &acc, &has);
   if ((threadIdx.x & 63) == 0) {
     const bool present = bit_get(ybits, row);
@@ -945,14 +953,14 @@ template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_wave(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nlist, const T* __restrict__ x,
             const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
-            uint32_t* __restrict__ ybits, int accumulate, int dbg, const uint32_t* __restrict__ want) {
+            uint32_t* __restrict__ ybits, int accumulate GM_DBG_PARAM, const uint32_t* __restrict__ want) {
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (w >= nlist) return;
   const int row = rows[w];
   if (!row_wanted(p, vp, want, row)) return;
   wave_row<P, T, U, V, E, USE_VP, RK>(p, A, row, A.rowptr[row], A.rowptr[row + 1], threadIdx.x & 63, x, xbits, vp, y, ybits,
-                                      accumulate, dbg);
+                                      accumulate GM_DBG_PASS);
 }
 
 // Ordered folds of wave rows without paying 64 serial broadcasts per 64 edges: a wave takes kWaveRows
@@ -972,7 +980,7 @@ template <class P, class T, class U, class V, class E, int KSTRIDE>
 __device__ __forceinline__ void wave16_group(const P& p, const gm_csr_t& A, const int32_t* __restrict__ rows, const int nlist,
                                              const int first, const int lane, const T* __restrict__ x,
                                              const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
-                                             uint32_t* __restrict__ ybits, const int accumulate, const int dbg,
+                                             uint32_t* __restrict__ ybits, const int accumulate GM_DBG_PARAM,
                                              const uint32_t* __restrict__ want, const HotSet<T>& hot, U (*s_t)[KSTRIDE],
                                              unsigned long long* s_mask) {
   constexpr int G = kWaveRows;
@@ -1117,7 +1125,7 @@ __device__ __forceinline__ W16Meta<U> w16_meta(const gm_csr_t& A, int row, const
 }
 template <class P, class T, class U, class V, class E, int KSTRIDE>
 __device__ __forceinline__ void wave16_dense(const P& p, const gm_csr_t& A, const W16Meta<U>& mt, const int lane, const T* __restrict__ x,
-                                             U* __restrict__ y, uint32_t* __restrict__ ybits, const int accumulate, const int dbg,
+                                             U* __restrict__ y, uint32_t* __restrict__ ybits, const int accumulate GM_DBG_PARAM,
                                              const HotSet<T>& hot, U (*s_t)[KSTRIDE]) {
   constexpr int G = kWaveRows;
   int longest = mt.len;
@@ -1231,7 +1239,7 @@ template <class P, class T, class U, class V, class E>
 __global__ void __launch_bounds__(kWave16Block)
 k_spmv_wave16(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nlist, const T* __restrict__ x,
               const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
-              uint32_t* __restrict__ ybits, int accumulate, int dbg, const uint32_t* __restrict__ want) {
+              uint32_t* __restrict__ ybits, int accumulate GM_DBG_PARAM, const uint32_t* __restrict__ want) {
   static_assert(sizeof(U) == 4 || sizeof(U) == 8, "LDS tile of 4- or 8-byte products");
   constexpr int G = kWaveRows;
   constexpr int kStride = 64 + 16 / (int)sizeof(U);  // padded row of the tile (keeps 16-byte alignment, staggers banks)
@@ -1249,7 +1257,7 @@ k_spmv_wave16(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int n
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int first = (blockIdx.x * (kWave16Block / 64) + wv) * G;
   if (first >= nlist) return;
-  wave16_group<P, T, U, V, E, kStride>(p, A, rows, nlist, first, lane, x, xbits, vp, y, ybits, accumulate, dbg, want, hot, s_t[wv], s_mask[wv]);
+  wave16_group<P, T, U, V, E, kStride>(p, A, rows, nlist, first, lane, x, xbits, vp, y, ybits, accumulate GM_DBG_PASS, want, hot, s_t[wv], s_mask[wv]);
 }
 
 // Persistent form with a LARGE hot set: the grid is a few workgroups per CU (not one per 64 rows), each
@@ -1261,7 +1269,7 @@ template <class P, class T, class U, class V, class E, int BLOCK, int HOT>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv_wave16p(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nlist, const T* __restrict__ x,
                const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
-               uint32_t* __restrict__ ybits, int accumulate, int dbg, const uint32_t* __restrict__ want) {
+               uint32_t* __restrict__ ybits, int accumulate GM_DBG_PARAM, const uint32_t* __restrict__ want) {
   static_assert(sizeof(U) == 4 || sizeof(U) == 8, "LDS tile of 4- or 8-byte products");
   static_assert(sizeof(T) == 4, "4-byte messages");
   constexpr int G = kWaveRows;
@@ -1302,7 +1310,7 @@ k_spmv_wave16p(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int 
       const int gn = g + nwaves;
       const int row_nn = w16_row(rows, nlist, gn + nwaves < ngroups ? (gn + nwaves) * G : -1, lane);
       const W16Meta<U> nxt = w16_meta<U>(A, row_n, y, ybits, accumulate);
-      wave16_dense<P, T, U, V, E, kStride>(p, A, cur, lane, x, y, ybits, accumulate, dbg, hot, s_t[wv]);
+      wave16_dense<P, T, U, V, E, kStride>(p, A, cur, lane, x, y, ybits, accumulate GM_DBG_PASS, hot, s_t[wv]);
       cur = nxt;
       row_n = row_nn;
       g = gn;
@@ -1310,7 +1318,7 @@ k_spmv_wave16p(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int 
     return;
   }
   for (int g = wv * gridDim.x + blockIdx.x; g < ngroups; g += nwaves)
-    wave16_group<P, T, U, V, E, kStride>(p, A, rows, nlist, g * G, lane, x, xbits, vp, y, ybits, accumulate, dbg, want, hot, s_t[wv], s_mask[wv]);
+    wave16_group<P, T, U, V, E, kStride>(p, A, rows, nlist, g * G, lane, x, xbits, vp, y, ybits, accumulate GM_DBG_PASS, want, hot, s_t[wv], s_mask[wv]);
 }
 
 // Row-blocks by WAVES of persistent workgroups that share a large LDS hot set.  k_spmv_rowblock is bound by the
@@ -1452,7 +1460,7 @@ static __device__ unsigned long long g_sell_phase_ticks[4096][8];
 #else
 #define GM_SELL_TICK(k) do { } while (0)
 #endif
-template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL = 0, int UBATCH = 7, int PIPE = 2>
+template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL = 0, int UBATCH = 7, int PIPE = 2, int POOLW = GM_SWEEP_POOL>
 __global__ void __launch_bounds__(1024)
 k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long, const int32_t* __restrict__ slice_base, const uint32_t* __restrict__ scol,
             const uint32_t* __restrict__ sval, const uint32_t* __restrict__ wrow, const int32_t* __restrict__ row_of_slot, const uint32_t* __restrict__ lcol,
@@ -1463,11 +1471,11 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
   constexpr int BLOCK = 1024, W = BLOCK / 64, UB = UBATCH;
   constexpr int ACC = GM_SWEEP_ACC_ROWS, NLP = GM_SWEEP_LONG_SLOTS;
   constexpr int KMAX = GM_SWEEP_MAX_STAGE / BLOCK;  // entries of a staging round per thread
-  __shared__ uint32_t s_pool[GM_SWEEP_POOL];  // [hot entries of the slice | stage of the long rows' products]
+  __shared__ uint32_t s_pool[POOLW];  // [hot entries of the slice | stage of the long rows' products]
   __shared__ uint32_t s_acc[ACC];
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int wg = blockIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int HOT = GM_SWEEP_POOL - stage_words;
+  const int HOT = POOLW - stage_words;
   uint32_t* const s_stage = s_pool + HOT;
   const char* __restrict__ xb = (const char*)x;
   V no_vp;
@@ -1863,7 +1871,7 @@ template <class P, class T, class U, class V, class E, bool USE_VP, int RK, int 
 __global__ void __launch_bounds__(kBlock)
 k_spmv_wave_grouped(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows, int nlist, const T* __restrict__ x,
                     const uint32_t* __restrict__ xbits, const V* __restrict__ vp, U* __restrict__ y,
-                    uint32_t* __restrict__ ybits, int accumulate, int dbg, const uint32_t* __restrict__ want,
+                    uint32_t* __restrict__ ybits, int accumulate GM_DBG_PARAM, const uint32_t* __restrict__ want,
                     const uint32_t* __restrict__ xsum = nullptr) {
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int lane = threadIdx.x & 63;
@@ -1887,7 +1895,7 @@ k_spmv_wave_grouped(ProgArg<P> pa, gm_csr_t A, const int32_t* __restrict__ rows,
     todo &= todo - 1;
     const int rr = __builtin_amdgcn_readlane(row, r);
     const int64_t a = wave_bcast(e0, r), b = wave_bcast(e1, r);
-    wave_row<P, T, U, V, E, USE_VP, RK>(p, A, rr, a, b, lane, x, xbits, vp, y, ybits, accumulate, dbg, nullptr, nullptr, xsum);
+    wave_row<P, T, U, V, E, USE_VP, RK>(p, A, rr, a, b, lane, x, xbits, vp, y, ybits, accumulate GM_DBG_PASS, nullptr, nullptr, xsum);
   }
 }
 
@@ -1970,7 +1978,7 @@ struct gchunk_state {
 template <class P, class T, class U, class V, class E, bool USE_VP, bool FROM_TERMS = false>
 __global__ void __launch_bounds__(kBlock)
 k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
-              const V* __restrict__ vp, U* __restrict__ terms, unsigned long long* __restrict__ tpres, int dbg,
+              const V* __restrict__ vp, U* __restrict__ terms, unsigned long long* __restrict__ tpres GM_DBG_PARAM,
               gchunk_state* __restrict__ state /* per piece: exponent hint in, composed ulp-map out (float sums over a dense x), or null */) {
   constexpr int PER = GM_GIANT_CHUNK / kBlock;
   const P& p = *reinterpret_cast<const P*>(pa.b);
@@ -2186,7 +2194,7 @@ __device__ __forceinline__ int lower_piece(const int32_t* __restrict__ gchunk_ro
 template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
 __global__ void __launch_bounds__(kGiant)
 k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
-               const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, int dbg,
+               const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate GM_DBG_PARAM,
                const U* __restrict__ terms, const unsigned long long* __restrict__ tpres, const uint32_t* __restrict__ want,
                gchunk_state* __restrict__ maps = nullptr /* per-piece maps (k_giant_terms) in, binade hints out; or null */) {
   constexpr bool SMALL_U = sizeof(U) <= 8;

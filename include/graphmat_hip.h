@@ -513,8 +513,8 @@ int gm_set_option(const char* key, int value);
 typedef struct {
   int32_t debug_flags;            /* dev::DBG_* of kernels.hpp: 16 no auxiliary stream, 32 no top-down steps, 64 no grouped wave rows, 128 no two-stage
                                      sharded schedule, 256 no on-demand messages, 512 no 16-rows-per-wave kernel, 1024 no column tiles, 2048 dense
-                                     exchanges only, 4096 giant rows start with the head stage, 8192 long wave rows on the main stream; 1-8 are
-                                     in-kernel ablations that exist in -DGRAPHMAT_ABLATION builds only.  Default 0 */
+                                     exchanges only, 4096 giant rows start with the head stage, 8192 long wave rows on the main stream; 1-8 and
+                                     16384 are in-kernel ablations: -DGRAPHMAT_ABLATION builds only (a product kernel has no such argument).  Default 0 */
   int32_t wave16_form;            /* 16-rows-per-wave kernel: 0 = one workgroup per 64 rows with an 8192-entry LDS hot set; 2 = persistent 1024-thread
                                      workgroups with a 22528-entry hot set where that pays (large unsharded graphs); +16 = on graphs of any size.  Default 2 */
   int32_t rowwave_form;           /* row-blocks: 0 = one workgroup per block (k_spmv_rowblock); 4 = waves of persistent 1024-thread workgroups sharing a

@@ -206,7 +206,7 @@ def test_product_library_has_no_ablation_or_fault_injection_switches(lib):
     control load explicitly: the shipped library rejects their keys and does not know the fault-injection variable."""
     assert lib.gm_set_option(b"ablate_cold_from", 1) != 0
     assert lib.gm_set_option(b"ablate_cold_short", 1) != 0
-    for bit in (1, 2, 4, 8):
+    for bit in (1, 2, 4, 8, 16384):
         assert lib.gm_set_option(b"debug_flags", bit) != 0
     assert lib.gm_set_option(b"debug_flags", 16) == 0 and lib.gm_set_option(b"debug_flags", 0) == 0  # (strategy choices stay)
     assert lib.gm_graph_set_option(None, b"ablate_cold_from", 1) != 0

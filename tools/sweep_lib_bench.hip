@@ -270,6 +270,21 @@ int main(int argc, char** argv) {
     wall([&]() { k_sell_short<2><<<(ngroups + 3) / 4, 256, 0, s2>>>(scs, gbase, ngroups, rows, nshort, x, y); SWEEP_ON(0, s1); }, "short rows + sweep on two streams (short launched first)");
     wall([&]() { SWEEP_ON(4, s1); k_sell_short<2><<<(ngroups + 3) / 4, 256, 0, s2>>>(scs, gbase, ngroups, rows, nshort, x, y); }, "sweep without long rows + short rows on two streams");
     wall([&]() { SWEEP_ON(4, s1); k_sell_short<4><<<(ngroups + 3) / 4, 256, 0, s2>>>(scs, gbase, ngroups, rows, nshort, x, y); }, "sweep without long rows + short rows (batch 4) on two streams");
+    // the library's own short-row kernel (k_spmv_rowblock: 17 KB of LDS per workgroup) next to a sweep that leaves it LDS and registers
+    {
+      gm_csr_t As = A;
+      As.nmid = 0; As.nmid_long = 0; As.ngiant = 0; As.ngchunk = 0;
+      Vp* novp = nullptr;
+#define SWEEP_SMALL(STREAM) for (int set = 0; set < S.nsets; set++) hipLaunchKernelGGL((GraphMat::dev::k_spmv_sell<SumP, float, float, Vp, int, false, 4, 7, 2, GM_SWEEP_POOL - 9216>), dim3(256), dim3(1024), 0, STREAM, pa, set, stage, \
+      S.nslices, S.nrows_long, S.slice_base, S.scol, (const uint32_t*)nullptr, S.wrow, S.row_of_slot, S.lcol, (const uint32_t*)nullptr, S.lps, S.lrow_of_slot, \
+      S.gcol, (const uint32_t*)nullptr, S.gdst, S.gslice, (float*)nullptr, (const float*)x, y)
+#define ROWBLOCK(STREAM) hipLaunchKernelGGL((GraphMat::dev::k_spmv_rowblock<SumP, float, float, Vp, int, false, true, GraphMat::REDUCE_F32_ADD>), dim3(As.nblk), dim3(GraphMat::dev::kBlock), 0, STREAM, pa, As, \
+      (const float*)x, (const uint32_t*)nullptr, (const Vp*)novp, y, (uint32_t*)nullptr, (int)GraphMat::dev::ACC_STATIC_BITS GM_DBG_ARG(0), (const uint32_t*)nullptr)
+      wall([&]() { ROWBLOCK(s2); }, "k_spmv_rowblock alone");
+      wall([&]() { SWEEP_SMALL(s1); }, "sweep without long rows, pool cut by 9216 words (36 KB of LDS free), alone");
+      wall([&]() { SWEEP_SMALL(s1); ROWBLOCK(s2); }, "that sweep + k_spmv_rowblock on two streams");
+      wall([&]() { ROWBLOCK(s2); SWEEP_SMALL(s1); }, "k_spmv_rowblock + that sweep on two streams (row-blocks launched first)");
+    }
     {
       OK(hipDeviceSynchronize());
       std::vector<float> a(gd.ndevice), b(gd.ndevice);
