@@ -733,7 +733,7 @@ static const EngineKey kEngineKeys[] = {
   {"rowwave_form", 2, 4, 0, 31},
   {"persist_per_cu", 3, 0, 0, 8},
   {"giant_maps", 4, 1, 0, 1},
-  {"ordered_giant_two_pass", 5, 1, 0, 1},
+  {"ordered_giant_two_pass", 5, 2, 0, 2},
   {"fuse_apply_send", 6, 1, 0, 1},
   {"untiled_pass_plain", 7, 1, 0, 1},
   {"last_rows_lanes", 8, 8, 8, 16},

@@ -182,12 +182,11 @@ struct AuxStream {
 // The probe is OPT-IN (GRAPHMAT_TRUST_PROBE=1): a finite set of operands plus a sampled device cross-check is
 // evidence, not a proof, and this library's contract is the reference's bits (SPMV.h:54-59: `c = a; reduce(c, b)`
 // in stored order).  Without the opt-in a program that declares no trait gets the ordered fold -- always exact.
+// (probe_reduce_guess: the questions and what the answers look like, nothing decided.  Besides the opt-in above, the engine
+// uses a "float addition" answer of a program that declares nothing to SPECULATE on its giant rows -- the replay of the sum is
+// then proven chunk by chunk with the program's own function, kernels.hpp: k_giant_verify_chunks -- which needs no trust.)
 template <class P, class U>
-int probe_reduce_kind(const P* gp) {
-  const char* on = getenv("GRAPHMAT_TRUST_PROBE");
-  if (!(on && on[0] == '1')) return REDUCE_ORDERED;
-  const char* off = getenv("GRAPHMAT_NO_PROBE");
-  if (off && off[0] == '1') return REDUCE_ORDERED;
+int probe_reduce_guess(const P* gp) {
   // arithmetic reduction types only: the function is called on the host with synthetic operands, which is
   // harmless for numbers and not for pointers or structures with invariants
   if constexpr (!std::is_arithmetic<U>::value || std::is_same<U, bool>::value || sizeof(U) > 8) {
@@ -265,6 +264,14 @@ int probe_reduce_kind(const P* gp) {
   }
 }
 template <class P, class U>
+int probe_reduce_kind(const P* gp) {
+  const char* on = getenv("GRAPHMAT_TRUST_PROBE");
+  if (!(on && on[0] == '1')) return REDUCE_ORDERED;
+  const char* off = getenv("GRAPHMAT_NO_PROBE");
+  if (off && off[0] == '1') return REDUCE_ORDERED;
+  return probe_reduce_guess<P, U>(gp);
+}
+template <class P, class U>
 int reduce_kind_of(const P* gp) {
   if constexpr ((int)program_traits<P>::reduce != (int)REDUCE_AUTO) return (int)program_traits<P>::reduce;
   else return probe_reduce_kind<P, U>(gp);
@@ -288,6 +295,8 @@ struct Launch {
   AuxStream* aux;
   bool tiled_untiled_pass = false;  // this launch is the untiled pass of a tiled multiply (set when aux is detached from it)
   bool terms_ready = false;  // the giant rows' products are in the products stream already (the sweep gathered them): fold passes only
+  bool guess_f32_add = false;  // the program declares no reduction, but its reduce_function answers like a float addition (probe_reduce_guess):
+                               // giant rows are replayed as float sums and every chunk is PROVEN with the program's own function (k_giant_verify_chunks)
 };
 
 // one multiply+reduce pass over one direction of the adjacency, strategy RK
@@ -406,8 +415,41 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
       // folds the dense products stream in stored order (kernels.hpp: k_giant_fold_ordered).  Larger reduction types keep
       // the one-wave-per-row kernel that gathers by itself.
       bool two_pass = false;
+      if constexpr (std::is_same<U, float>::value) {
+        // speculate-and-prove (kernels.hpp: k_giant_verify_chunks): a dense x, every row wanted, the ordered fold of the whole rows
+        void *p6 = nullptr, *p15 = nullptr;
+        const size_t bounds_bytes = ((size_t)A.ngchunk + 2) * 8;
+        if (L.guess_f32_add && L.opt.ordered_giant_two_pass >= 2 && xbits == nullptr && want == nullptr && A.gchunk_row != nullptr &&
+            gm_graph_workspace(g, 6, (size_t)A.giant_edges * sizeof(U) + 64, &p6) == GM_OK &&
+            gm_graph_workspace(g, 15, bounds_bytes + (size_t)A.ngiant * 4 + 64, &p15) == GM_OK) {
+          U* terms = (U*)p6;
+          unsigned long long* bounds = (unsigned long long*)p15;
+          int32_t* redo = (int32_t*)((char*)p15 + bounds_bytes);
+          dev::gchunk_state* maps = L.opt.giant_maps != 0 ? (dev::gchunk_state*)A.gchunk_state : nullptr;
+          GM_HIP_OK(hipMemsetAsync(redo, 0, (size_t)A.ngiant * 4, gs));
+          if (!L.terms_ready) {
+            hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa, A, x, xbits, vp, terms,
+                               (unsigned long long*)nullptr GM_DBG_ARG(L.opt.debug_flags), maps);
+            (*launches)++;
+          } else if (maps != nullptr) {
+            hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP, true>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa, A, x, xbits, vp, terms,
+                               (unsigned long long*)nullptr GM_DBG_ARG(L.opt.debug_flags), maps);
+            (*launches)++;
+          }
+          hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, REDUCE_F32_ADD>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa, A, x, xbits, vp, y,
+                             ybits, accumulate GM_DBG_ARG(L.opt.debug_flags), (const U*)terms, (const unsigned long long*)nullptr, want, maps, bounds);
+          hipLaunchKernelGGL((dev::k_giant_verify_chunks<P, U>), dim3((A.ngchunk + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, (const U*)terms,
+                             (const unsigned long long*)bounds, (const U*)y, redo);
+          hipLaunchKernelGGL((dev::k_giant_fold_ordered<P, U, V>), dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, vp, y, ybits,
+                             accumulate, (const U*)terms, (const unsigned long long*)nullptr, want, (const int32_t*)redo);
+          (*launches) += 2;
+          two_pass = true;
+        }
+      }
       if constexpr (dev::stageable<U>::value && std::is_trivially_copyable<U>::value) {
         void *p6 = nullptr, *p7 = nullptr;
+        if (two_pass) {
+        } else
         if (L.opt.ordered_giant_two_pass != 0 && gm_graph_workspace(g, 6, (size_t)A.giant_edges * sizeof(U) + 64, &p6) == GM_OK &&
             (xbits == nullptr || gm_graph_workspace(g, 14, (size_t)A.giant_edges / 8 + 64, &p7) == GM_OK)) {
           if (!L.terms_ready) {
@@ -642,6 +684,7 @@ class Run {
   bool multi = false;
   int rk = REDUCE_ORDERED;
   bool rk_unverified = false;  // a probed strategy still to be cross-checked on the device (k_check_rows)
+  bool guess_f32_add = false;  // rk is the ordered fold and reduce_function answers like a float addition: speculation for the giant rows only, proven chunk by chunk
   bool can_push = false, xsparse_ok = false, lazy_send = false;
   const int32_t *dev_of_native = nullptr, *native_of_dev = nullptr;
   xentry_t* d_gather = nullptr;
@@ -672,7 +715,11 @@ class Run {
   struct timeval tr_iter, tr_last;
   long long tr_updated = -1;
 
-  Launch launch_ctx() { return Launch{g, s, opt, &st.spmv_launches, &timer, &aux}; }
+  Launch launch_ctx() {
+    Launch L{g, s, opt, &st.spmv_launches, &timer, &aux};
+    L.guess_f32_add = guess_f32_add;
+    return L;
+  }
   static void die(const char* what) {
     printf("GraphMat(HIP): %s\n", what);
     exit(1);
@@ -752,6 +799,10 @@ class Run {
     // a strategy the program did not declare but the probe inferred is cross-checked on the device against the
     // ordered fold the first time a pull multiply runs (k_check_rows); a disagreement falls back to the ordered fold
     rk_unverified = (int)program_traits<P>::reduce == (int)REDUCE_AUTO && rk != REDUCE_ORDERED && !getenv("GRAPHMAT_NO_PROBE_CHECK");
+    if constexpr (std::is_same<U, float>::value && (int)program_traits<P>::reduce == (int)REDUCE_AUTO) {
+      const char* off = getenv("GRAPHMAT_NO_PROBE");
+      guess_f32_add = rk == REDUCE_ORDERED && !(off && off[0] == '1') && probe_reduce_guess<P, U>(gp) == REDUCE_F32_ADD;
+    }
     tick("reduce_function probed", rk);
     if (verbose) printf("GraphMat(HIP): reduce strategy %d (0 ordered, 1 commutative, 2 last, 3 float add)\n", rk);
     // Top-down steps for small active sets (kernels.hpp: k_push_*): REDUCE_LAST programs over OUT_EDGES, running until

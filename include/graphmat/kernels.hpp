@@ -2084,24 +2084,12 @@ k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t
 // dense, coalesced stream that is loaded one chunk ahead, staged in the wave's LDS strip, and lane 0 folds the chunk out
 // of LDS -- the LDS reads pipeline under the dependent reduce calls, so an edge costs one reduce_function issue
 // (~4-5 cycles) instead of a v_readlane plus the call in wave_row.
-template <class P, class U, class V>
-__global__ void __launch_bounds__(kBlock)
-k_giant_fold_ordered(ProgArg<P> pa, gm_csr_t A, const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate,
-                     const U* __restrict__ terms, const unsigned long long* __restrict__ tpres, const uint32_t* __restrict__ want) {
-  static_assert(stageable<U>::value, "products of at most 8 bytes");
+// the ordered fold of `deg` products that lie at terms[t0 ...] (t0 a multiple of 64 when presence words come with them) by one
+// wave: lane 0 carries acc / has in and out, st is the wave's LDS strip of 512 products
+template <class P, class U>
+__device__ __forceinline__ void fold_products_ordered(const P& p, const U* __restrict__ terms, const unsigned long long* __restrict__ tpres,
+                                                      const int64_t t0, const int64_t deg, const int lane, U* __restrict__ st, U& acc, bool& has) {
   constexpr int PER = 8, CH = PER * 64;
-  __shared__ __attribute__((aligned(16))) U s_t[kBlock / 64][CH];
-  const P& p = *reinterpret_cast<const P*>(pa.b);
-  const int w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (w >= A.ngiant) return;
-  const int row = A.giant_row[w];
-  if (!row_wanted(p, vp, want, row)) return;
-  const int64_t deg = A.rowptr[row + 1] - A.rowptr[row];
-  const int64_t t0 = A.gterm_off[w];  // multiple of 64
-  U* st = s_t[threadIdx.x >> 6];
-  bool has = false;
-  U acc;
-  if (lane == 0 && (accumulate & ACC_READ_PREV) && bit_get(ybits, row)) { acc = y[row]; has = true; }
   U cur[PER], nxt[PER];
   unsigned long long pm[PER], pmn[PER];
   auto load = [&](int64_t base, U (&r)[PER], unsigned long long (&m)[PER]) {
@@ -2169,6 +2157,26 @@ k_giant_fold_ordered(ProgArg<P> pa, gm_csr_t A, const V* __restrict__ vp, U* __r
 #pragma unroll
     for (int j = 0; j < PER; j++) { cur[j] = nxt[j]; pm[j] = pmn[j]; }
   }
+}
+
+template <class P, class U, class V>
+__global__ void __launch_bounds__(kBlock)
+k_giant_fold_ordered(ProgArg<P> pa, gm_csr_t A, const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate,
+                     const U* __restrict__ terms, const unsigned long long* __restrict__ tpres, const uint32_t* __restrict__ want,
+                     const int32_t* __restrict__ only = nullptr /* per giant row: fold it (non-zero) or leave what is in y; null = every row */) {
+  static_assert(stageable<U>::value, "products of at most 8 bytes");
+  __shared__ __attribute__((aligned(16))) U s_t[kBlock / 64][512];
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= A.ngiant) return;
+  if (only != nullptr && only[w] == 0) return;
+  const int row = A.giant_row[w];
+  if (!row_wanted(p, vp, want, row)) return;
+  const int64_t deg = A.rowptr[row + 1] - A.rowptr[row];
+  bool has = false;
+  U acc;
+  if (lane == 0 && (accumulate & ACC_READ_PREV) && bit_get(ybits, row)) { acc = y[row]; has = true; }
+  fold_products_ordered<P, U>(p, terms, tpres, A.gterm_off[w], deg, lane, s_t[threadIdx.x >> 6], acc, has);
   if (lane == 0 && has) {
     y[row] = acc;
     if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
@@ -2196,7 +2204,9 @@ __global__ void __launch_bounds__(kGiant)
 k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
                const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate GM_DBG_PARAM,
                const U* __restrict__ terms, const unsigned long long* __restrict__ tpres, const uint32_t* __restrict__ want,
-               gchunk_state* __restrict__ maps = nullptr /* per-piece maps (k_giant_terms) in, binade hints out; or null */) {
+               gchunk_state* __restrict__ maps = nullptr /* per-piece maps (k_giant_terms) in, binade hints out; or null */,
+               unsigned long long* __restrict__ bounds = nullptr /* REDUCE_F32_ADD, out: per piece that starts an 8192-product chunk, the running sum
+                                                                    when the chunk starts (bits | has << 32): k_giant_verify_chunks */) {
   constexpr bool SMALL_U = sizeof(U) <= 8;
   constexpr int CH = kLongChunk, PER = kLongPer;
   // ordered kinds stage the per-edge products (U) of a chunk in LDS for the serial fold
@@ -2309,8 +2319,8 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
     const int npieces = (int)((deg + GM_GIANT_CHUNK - 1) / GM_GIANT_CHUNK);
     const bool mapped = maps != nullptr && nchunks <= kMapsLds && !(dbg & DBG_NO_REPLAY);
     int piece0 = 0;
+    if (mapped || bounds != nullptr) piece0 = lower_piece(A.gchunk_row, A.ngchunk, (int)blockIdx.x);
     if (mapped) {
-      piece0 = lower_piece(A.gchunk_row, A.ngchunk, (int)blockIdx.x);
       for (int c = tid; c < nchunks; c += kGiant) {
         const gchunk_state a = maps[piece0 + 2 * c];
         chunk_rec r = {a.e_map, a.de, a.dod};
@@ -2356,6 +2366,7 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
               const uint32_t Sint = (sbm & 0x7fffffu) | 0x800000u;
               const uint32_t Safter = Sint + ((Sint & 1u) ? rec.dod : rec.de);
               if (!(rec.e > 0 && !(sbm >> 31) && (int)((sbm >> 23) & 0xff) == rec.e && Safter < 0x1000000u)) break;
+              if (bounds != nullptr) bounds[piece0 + 2 * c] = (unsigned long long)sbm | (1ull << 32);
               sbm = (sbm & 0xff800000u) | (Safter & 0x7fffffu);  // (same binade: the hint stays what it is)
               c++;
               skipped++;
@@ -2367,6 +2378,7 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
           }
           s_skip = skipped;
           if (c < nchunks) {
+            if (bounds != nullptr) bounds[piece0 + 2 * c] = (unsigned long long)sbm | ((unsigned long long)(h ? 1 : 0) << 32);
             pend_c = c;
             pend_e = (h && !(sbm >> 31)) ? (int)((sbm >> 23) & 0xff) : 0;
           }
@@ -2375,6 +2387,8 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
         base += (int64_t)s_skip * CH;
         if (base >= e1) break;
         load_chunk(base - e0, pre);
+      } else if (bounds != nullptr && tid == 0) {
+        bounds[piece0 + 2 * (int)((base - e0) / CH)] = (unsigned long long)s_Sbits | ((unsigned long long)(s_has[0] != 0 ? 1 : 0) << 32);
       }
       const int n = (int)((e1 - base) < CH ? (e1 - base) : CH);
       const int ngroups = (n + PER - 1) / PER;
@@ -2515,6 +2529,55 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
       y[row] = r;
       if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Giant rows of a program that DECLARES nothing (REDUCE_ORDERED: the reference's `c = a; reduce(c, b)` in stored order,
+// SPMV.h:54-59) whose reduce_function nevertheless answers like a float addition when the host asks it (engine.hpp:
+// probe_reduce_guess).  The serial chain of such a row is the longest thing in the iteration (RMAT-26's hub: 854 K
+// dependent calls), and an answer to a finite set of questions is no proof, so the guess is only used to SPECULATE:
+// k_spmv_giant<REDUCE_F32_ADD> replays the row as float additions and leaves the running sum at every 8192-product chunk
+// boundary; here one wave per chunk -- all chunks of all rows at once -- folds its chunk strictly in order with the PROGRAM'S
+// OWN reduce_function, starting from the value the replay had at the chunk's start, and compares the bits with what the
+// replay had at its end (the next boundary, or the row's result).  When every chunk of a row agrees, the row's result IS
+// the ordered fold's, by induction over its chunks, whatever the function is; a row with a disagreeing chunk is flagged and
+// folded again by k_giant_fold_ordered.  The serial part of a row shrinks from its length to one chunk.
+template <class P, class U>
+__global__ void __launch_bounds__(kBlock)
+k_giant_verify_chunks(ProgArg<P> pa, gm_csr_t A, const U* __restrict__ terms, const unsigned long long* __restrict__ bounds, const U* __restrict__ y,
+                      int32_t* __restrict__ redo /* per giant row, zeroed before: set when a chunk of the row disagrees */) {
+  static_assert(sizeof(U) == 4, "float sums");
+  __shared__ __attribute__((aligned(16))) U s_t[kBlock / 64][512];
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (q >= A.ngchunk) return;
+  const int gi = A.gchunk_row[q];
+  const int piece0 = lower_piece(A.gchunk_row, A.ngchunk, gi);
+  if ((q - piece0) & 1) return;  // (a chunk of the replay = two pieces)
+  const int row = A.giant_row[gi];
+  const int64_t deg = A.rowptr[row + 1] - A.rowptr[row];
+  const int64_t rel = (int64_t)(q - piece0) * GM_GIANT_CHUNK;
+  const int64_t n = deg - rel < (int64_t)kLongChunk ? deg - rel : (int64_t)kLongChunk;
+  const unsigned long long b0 = bounds[q];
+  const uint32_t bits0 = (uint32_t)b0;
+  U acc;
+  memcpy(&acc, &bits0, 4);
+  bool has = ((b0 >> 32) & 1ull) != 0;
+  fold_products_ordered<P, U>(p, terms, nullptr, A.gterm_off[gi] + rel, n, lane, s_t[threadIdx.x >> 6], acc, has);
+  if (lane == 0) {
+    uint32_t got, want_bits;
+    memcpy(&got, &acc, 4);
+    bool ok = has;
+    if (rel + (int64_t)kLongChunk < deg) {
+      const unsigned long long b1 = bounds[q + 2];
+      want_bits = (uint32_t)b1;
+      ok = ok && ((b1 >> 32) & 1ull) != 0;
+    } else {
+      const U fin = y[row];
+      memcpy(&want_bits, &fin, 4);
+    }
+    if (!ok || got != want_bits) redo[gi] = 1;
   }
 }
 

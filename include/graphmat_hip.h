@@ -523,7 +523,9 @@ typedef struct {
   int32_t giant_maps;             /* giant rows of float sums: 1 = the exact replay spread over many workgroups (per-piece ulp-maps), 0 = one workgroup
                                      walks the row.  Default 1 */
   int32_t ordered_giant_two_pass; /* giant rows of plain ordered folds: 1 = products by k_giant_terms, then k_giant_fold_ordered; 0 = one wave per row
-                                     gathering by itself.  Default 1 */
+                                     gathering by itself; 2 = as 1, and when the undeclared reduce_function answers like a float addition (dense x):
+                                     the exact replay of the float sum, every 8192-product chunk of it proven with the program's own function
+                                     (k_giant_verify_chunks), rows with a disagreeing chunk folded again in order.  Default 2 */
   int32_t fuse_apply_send;        /* 1 = apply of iteration i and send of iteration i+1 in one pass (fixed-count ALL_VERTICES programs that leave
                                      do_every_iteration to the base class).  Default 1 */
   int32_t untiled_pass_plain;     /* tiled graphs: the untiled short-row pass through the plain row-block kernel (1) or the persistent one (0).  Default 1 */

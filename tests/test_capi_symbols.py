@@ -174,7 +174,7 @@ def test_engine_options_defaults_overrides_and_reset(lib):
     from graphmat_amd import _lib
     o = _lib.EngineOptions()
     assert lib.gm_graph_engine_options(None, C.byref(o)) == 0
-    assert (o.debug_flags, o.wave16_form, o.rowwave_form, o.giant_maps, o.ordered_giant_two_pass, o.fuse_apply_send) == (0, 2, 4, 1, 1, 1)
+    assert (o.debug_flags, o.wave16_form, o.rowwave_form, o.giant_maps, o.ordered_giant_two_pass, o.fuse_apply_send) == (0, 2, 4, 1, 2, 1)
     assert (o.untiled_pass_plain, o.last_rows_lanes, o.push_edge_permille, o.bits_step_edges, o.sparse_step_edges) == (1, 8, 50, 2 << 20, 1 << 20)
     assert lib.gm_set_option(b"debug_flags", 128) == 0 and lib.gm_set_option(b"wave16_form", 16 + 2) == 0
     assert lib.gm_set_option(b"wave16_form", 7) != 0 and lib.gm_set_option(b"last_rows_lanes", 12) != 0  # out of range: refused

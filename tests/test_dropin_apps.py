@@ -395,3 +395,14 @@ def test_reference_pagerank_timing_build_prints_the_per_iteration_lines(golden_d
         assert text.count(name + " = ") == n_deg + n_pr, name
     rows = re.findall(r"^(\d+) : (\d+) ([0-9.]+)$", text, flags=re.M)
     assert [r[2] for r in rows] == g1["pagerank_6dp"]
+
+
+@pytest.mark.gpu
+def test_undeclared_float_sums_speculated_and_proven():
+    """apps/speculated_float_sum.cpp: giant rows of programs that declare nothing.  A reduce_function that answers like a float addition
+    gets the exact parallel replay of the sum, every 8192-product chunk of which is proven with the program's own function
+    (kernels.hpp: k_giant_verify_chunks); one that answers like an addition but is none on the data at hand must be caught by that proof
+    and folded in order; results compared bit for bit with a host fold in the reference's order (SPMV.h:54-59)."""
+    text = _run(_need(os.path.join(OWN_APPS, "speculated_float_sum")))
+    assert "SPECULATED PASS" in text, text[-2000:]
+
