@@ -8,7 +8,10 @@
 //   (1) PlainSum: a += b                                   -- the speculation holds
 //   (2) TrickySum: a += b, except that b == 1/64 adds 1 more -- answers every question like an addition, is none on this data:
 //       the proof must fail for the rows that receive such a message and their results must still be the ordered fold's
-//   (3) SmallerOf: the smaller of a and b                   -- not an addition: the plain ordered passes
+//   (3) the smaller of a and b -- no addition; ANY function is speculated to be associative on the operands at hand (chunk totals
+//       combined in order give candidates for the running values, every chunk is folded again from its candidate and compared:
+//       k_giant_verify_chunks_any); holds for a minimum
+//   (4) a = a / 2 + b -- neither: every proof fails, the rows are folded in order
 // Prints "SPECULATED PASS" and exits 0.
 #include <algorithm>
 #include <cstdio>
@@ -35,7 +38,8 @@ class Fold : public GraphMat::GraphProgram<float, float, float> {
   void reduce_function(float& a, const float& b) const {
     if (KIND == 0) a += b;
     else if (KIND == 1) { if (b == 0.015625f) a = a + b + 1.0f; else a += b; }
-    else a = b < a ? b : a;
+    else if (KIND == 2) a = b < a ? b : a;
+    else a = a * 0.5f + b;
   }
   void apply(const float& y, float& v) { v = y; }
 };
@@ -133,8 +137,12 @@ int main(int argc, char** argv) {
   CHECK(run_case<0>(G, ed, n, xt, "a += b on the same messages") == 0);
   CHECK(rows_folded_again(G) == 0);
   CHECK(run_case<2>(G, ed, n, x, "the smaller of a and b") == 0);
+  CHECK(rows_folded_again(G) == 0);  // associative on any data: the chunk totals combine to the ordered fold's running values
+  CHECK(run_case<3>(G, ed, n, x, "half of a, plus b") == 0);
+  CHECK(rows_folded_again(G) > 0);   // neither an addition nor associative: every proof fails, the rows are folded in order
   // a second iteration on the results of the first (the replay's binade hints come from the pass before)
   CHECK(run_case<0>(G, ed, n, x, "a += b again") == 0);
+  CHECK(rows_folded_again(G) == 0);  // (a failed proof stops the speculation for the rest of THAT run only)
   printf(failures == 0 ? "SPECULATED PASS\n" : "SPECULATED FAIL (%d)\n", failures);
   MPI_Finalize();
   return failures == 0 ? 0 : 1;

@@ -295,6 +295,7 @@ struct Launch {
   AuxStream* aux;
   bool tiled_untiled_pass = false;  // this launch is the untiled pass of a tiled multiply (set when aux is detached from it)
   bool terms_ready = false;  // the giant rows' products are in the products stream already (the sweep gathered them): fold passes only
+  int32_t* spec_off = nullptr;  // device flag of this run: a speculation on the giant rows failed its proof, later passes fold in order right away
   bool guess_f32_add = false;  // the program declares no reduction, but its reduce_function answers like a float addition (probe_reduce_guess):
                                // giant rows are replayed as float sums and every chunk is PROVEN with the program's own function (k_giant_verify_chunks)
 };
@@ -415,16 +416,20 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
       // folds the dense products stream in stored order (kernels.hpp: k_giant_fold_ordered).  Larger reduction types keep
       // the one-wave-per-row kernel that gathers by itself.
       bool two_pass = false;
+      // speculate-and-prove (kernels.hpp: k_giant_verify_chunks / k_giant_verify_chunks_any): the whole rows, nothing in y to start from
+      const bool may_speculate = L.opt.ordered_giant_two_pass >= 2 && L.spec_off != nullptr && !(accumulate & dev::ACC_READ_PREV) && A.gchunk_row != nullptr;
+      // workspace slot 15: [chunk boundaries, 8 bytes each][redo flag per giant row] (apps/speculated_float_sum.cpp reads these two), then the other arrays
+      const size_t o_redo = ((size_t)A.ngchunk + 2) * 8, o_bhas = o_redo + (((size_t)A.ngiant * 4 + 7) & ~(size_t)7), o_tval = o_bhas + (((size_t)A.ngchunk * 4 + 7) & ~(size_t)7),
+                   o_thas = o_tval + (size_t)A.ngchunk * 8, o_fin = o_thas + (((size_t)A.ngchunk * 4 + 7) & ~(size_t)7), o_finhas = o_fin + (size_t)A.ngiant * 8,
+                   o_end = o_finhas + (size_t)A.ngiant * 4 + 64;
       if constexpr (std::is_same<U, float>::value) {
-        // speculate-and-prove (kernels.hpp: k_giant_verify_chunks): a dense x, every row wanted, the ordered fold of the whole rows
+        // a float sum by its answers, a dense x, every row wanted: the exact replay, proven chunk by chunk
         void *p6 = nullptr, *p15 = nullptr;
-        const size_t bounds_bytes = ((size_t)A.ngchunk + 2) * 8;
-        if (L.guess_f32_add && L.opt.ordered_giant_two_pass >= 2 && xbits == nullptr && want == nullptr && A.gchunk_row != nullptr &&
-            gm_graph_workspace(g, 6, (size_t)A.giant_edges * sizeof(U) + 64, &p6) == GM_OK &&
-            gm_graph_workspace(g, 15, bounds_bytes + (size_t)A.ngiant * 4 + 64, &p15) == GM_OK) {
+        if (may_speculate && L.guess_f32_add && xbits == nullptr && want == nullptr &&
+            gm_graph_workspace(g, 6, (size_t)A.giant_edges * sizeof(U) + 64, &p6) == GM_OK && gm_graph_workspace(g, 15, o_end, &p15) == GM_OK) {
           U* terms = (U*)p6;
           unsigned long long* bounds = (unsigned long long*)p15;
-          int32_t* redo = (int32_t*)((char*)p15 + bounds_bytes);
+          int32_t* redo = (int32_t*)((char*)p15 + o_redo);
           dev::gchunk_state* maps = L.opt.giant_maps != 0 ? (dev::gchunk_state*)A.gchunk_state : nullptr;
           GM_HIP_OK(hipMemsetAsync(redo, 0, (size_t)A.ngiant * 4, gs));
           if (!L.terms_ready) {
@@ -437,12 +442,42 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
             (*launches)++;
           }
           hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, REDUCE_F32_ADD>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa, A, x, xbits, vp, y,
-                             ybits, accumulate GM_DBG_ARG(L.opt.debug_flags), (const U*)terms, (const unsigned long long*)nullptr, want, maps, bounds);
+                             ybits, accumulate GM_DBG_ARG(L.opt.debug_flags), (const U*)terms, (const unsigned long long*)nullptr, want, maps, bounds,
+                             (const int32_t*)L.spec_off);
           hipLaunchKernelGGL((dev::k_giant_verify_chunks<P, U>), dim3((A.ngchunk + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, (const U*)terms,
-                             (const unsigned long long*)bounds, (const U*)y, redo);
+                             (const unsigned long long*)bounds, (const U*)y, redo, L.spec_off);
           hipLaunchKernelGGL((dev::k_giant_fold_ordered<P, U, V>), dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, vp, y, ybits,
-                             accumulate, (const U*)terms, (const unsigned long long*)nullptr, want, (const int32_t*)redo);
+                             accumulate, (const U*)terms, (const unsigned long long*)nullptr, want, (const int32_t*)redo, (const int32_t*)L.spec_off);
           (*launches) += 2;
+          two_pass = true;
+        }
+      }
+      if constexpr (dev::stageable<U>::value && std::is_trivially_copyable<U>::value && (sizeof(U) == 4 || sizeof(U) == 8)) {
+        // any function: associativity on the operands at hand, speculated and proven chunk by chunk
+        void *p6 = nullptr, *p7 = nullptr, *p15 = nullptr;
+        if (!two_pass && may_speculate && gm_graph_workspace(g, 6, (size_t)A.giant_edges * sizeof(U) + 64, &p6) == GM_OK &&
+            (xbits == nullptr || gm_graph_workspace(g, 14, (size_t)A.giant_edges / 8 + 64, &p7) == GM_OK) && gm_graph_workspace(g, 15, o_end, &p15) == GM_OK) {
+          const U* terms = (const U*)p6;
+          const unsigned long long* tpres = (const unsigned long long*)p7;
+          char* w = (char*)p15;
+          U *bval = (U*)w, *tval = (U*)(w + o_tval), *fin = (U*)(w + o_fin);
+          int32_t *redo = (int32_t*)(w + o_redo), *bhas = (int32_t*)(w + o_bhas), *thas = (int32_t*)(w + o_thas), *finhas = (int32_t*)(w + o_finhas);
+          const unsigned cgrid = (unsigned)((A.ngchunk + WPB - 1) / WPB), rgrid = (unsigned)((A.ngiant + WPB - 1) / WPB);
+          GM_HIP_OK(hipMemsetAsync(redo, 0, (size_t)A.ngiant * 4, gs));
+          if (!L.terms_ready) {
+            hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa, A, x, xbits, vp, (U*)p6,
+                               (unsigned long long*)p7 GM_DBG_ARG(L.opt.debug_flags), (dev::gchunk_state*)nullptr);
+            (*launches)++;
+          }
+          hipLaunchKernelGGL((dev::k_giant_chunk_totals<P, U, V>), dim3(cgrid), dim3(dev::kBlock), 0, gs, pa, A, vp, want, terms, tpres, tval, thas,
+                             (const int32_t*)L.spec_off);
+          hipLaunchKernelGGL((dev::k_giant_chunk_scan<P, U, V>), dim3(rgrid), dim3(dev::kBlock), 0, gs, pa, A, vp, want, y, ybits, accumulate, (const U*)tval,
+                             (const int32_t*)thas, bval, bhas, fin, finhas, (const int32_t*)L.spec_off);
+          hipLaunchKernelGGL((dev::k_giant_verify_chunks_any<P, U, V>), dim3(cgrid), dim3(dev::kBlock), 0, gs, pa, A, vp, want, terms, tpres, (const U*)bval,
+                             (const int32_t*)bhas, (const U*)fin, (const int32_t*)finhas, redo, L.spec_off);
+          hipLaunchKernelGGL((dev::k_giant_fold_ordered<P, U, V>), dim3(rgrid), dim3(dev::kBlock), 0, gs, pa, A, vp, y, ybits, accumulate, terms, tpres, want,
+                             (const int32_t*)redo, (const int32_t*)L.spec_off);
+          (*launches) += 3;
           two_pass = true;
         }
       }
@@ -718,6 +753,7 @@ class Run {
   Launch launch_ctx() {
     Launch L{g, s, opt, &st.spmv_launches, &timer, &aux};
     L.guess_f32_add = guess_f32_add;
+    L.spec_off = flag_v ? (int32_t*)flag_v + 720 : nullptr;
     return L;
   }
   static void die(const char* what) {
@@ -831,6 +867,7 @@ class Run {
     // (the changed flag sits directly in front of the striped statistics, so that one memset clears and one copy fetches
     // "flag + statistics": every call the host makes between two short levels of a traversal shows up as idle time on the GPU)
     d_changed = (int*)flag_v + 127;
+    GM_HIP_OK(hipMemsetAsync((int*)flag_v + 720, 0, 4, s));  // Launch::spec_off
     d_count = (unsigned int*)flag_v + 2;   // entries of d_list (the active set, when it is small)
     d_tcount = (unsigned int*)flag_v + 3;  // entries of d_touched (destinations bid for in a top-down step)
     d_stats = (unsigned long long*)flag_v + 2;    // byte offset 16

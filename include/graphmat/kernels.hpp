@@ -2163,13 +2163,14 @@ template <class P, class U, class V>
 __global__ void __launch_bounds__(kBlock)
 k_giant_fold_ordered(ProgArg<P> pa, gm_csr_t A, const V* __restrict__ vp, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate,
                      const U* __restrict__ terms, const unsigned long long* __restrict__ tpres, const uint32_t* __restrict__ want,
-                     const int32_t* __restrict__ only = nullptr /* per giant row: fold it (non-zero) or leave what is in y; null = every row */) {
+                     const int32_t* __restrict__ only = nullptr /* per giant row: fold it (non-zero) or leave what is in y; null = every row */,
+                     const int32_t* __restrict__ spec_off = nullptr /* non-zero: no speculation ran this pass, every row is folded here */) {
   static_assert(stageable<U>::value, "products of at most 8 bytes");
   __shared__ __attribute__((aligned(16))) U s_t[kBlock / 64][512];
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (w >= A.ngiant) return;
-  if (only != nullptr && only[w] == 0) return;
+  if (only != nullptr && only[w] == 0 && !(spec_off != nullptr && spec_off[0] != 0)) return;
   const int row = A.giant_row[w];
   if (!row_wanted(p, vp, want, row)) return;
   const int64_t deg = A.rowptr[row + 1] - A.rowptr[row];
@@ -2206,7 +2207,8 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
                const U* __restrict__ terms, const unsigned long long* __restrict__ tpres, const uint32_t* __restrict__ want,
                gchunk_state* __restrict__ maps = nullptr /* per-piece maps (k_giant_terms) in, binade hints out; or null */,
                unsigned long long* __restrict__ bounds = nullptr /* REDUCE_F32_ADD, out: per piece that starts an 8192-product chunk, the running sum
-                                                                    when the chunk starts (bits | has << 32): k_giant_verify_chunks */) {
+                                                                    when the chunk starts (bits | has << 32): k_giant_verify_chunks */,
+               const int32_t* __restrict__ spec_off = nullptr /* non-zero: an earlier pass of this run saw the speculation fail; do nothing */) {
   constexpr bool SMALL_U = sizeof(U) <= 8;
   constexpr int CH = kLongChunk, PER = kLongPer;
   // ordered kinds stage the per-edge products (U) of a chunk in LDS for the serial fold
@@ -2218,6 +2220,7 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
   __shared__ uint32_t s_Sbits;
 
   const P& p = *reinterpret_cast<const P*>(pa.b);
+  if (spec_off != nullptr && spec_off[0] != 0) return;
   const int row = A.giant_row[blockIdx.x];
   if (!row_wanted(p, vp, want, row)) return;
   const int64_t e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
@@ -2546,12 +2549,13 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
 template <class P, class U>
 __global__ void __launch_bounds__(kBlock)
 k_giant_verify_chunks(ProgArg<P> pa, gm_csr_t A, const U* __restrict__ terms, const unsigned long long* __restrict__ bounds, const U* __restrict__ y,
-                      int32_t* __restrict__ redo /* per giant row, zeroed before: set when a chunk of the row disagrees */) {
+                      int32_t* __restrict__ redo /* per giant row, zeroed before: set when a chunk of the row disagrees */,
+                      int32_t* __restrict__ spec_off /* set as well then: the following passes of this run do not speculate */) {
   static_assert(sizeof(U) == 4, "float sums");
   __shared__ __attribute__((aligned(16))) U s_t[kBlock / 64][512];
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (q >= A.ngchunk) return;
+  if (q >= A.ngchunk || spec_off[0] != 0) return;
   const int gi = A.gchunk_row[q];
   const int piece0 = lower_piece(A.gchunk_row, A.ngchunk, gi);
   if ((q - piece0) & 1) return;  // (a chunk of the replay = two pieces)
@@ -2577,7 +2581,123 @@ k_giant_verify_chunks(ProgArg<P> pa, gm_csr_t A, const U* __restrict__ terms, co
       const U fin = y[row];
       memcpy(&want_bits, &fin, 4);
     }
-    if (!ok || got != want_bits) redo[gi] = 1;
+    if (!ok || got != want_bits) { redo[gi] = 1; spec_off[0] = 1; }
+  }
+}
+
+// The same idea for ANY reduce_function of a program that declares nothing, without asking it anything: speculate that the function is
+// ASSOCIATIVE on the operands at hand (min, max, integer sums, a = b ... are; a float sum is not, its rows end up folded again).
+// k_giant_chunk_totals folds every 8192-product chunk by itself (all chunks of all rows at once, present messages only, in order);
+// k_giant_chunk_scan combines a row's chunk totals in order -- a few dozen calls -- which gives a candidate for the running value at
+// every chunk boundary and for the row's result; k_giant_verify_chunks_any then folds every chunk once more, in order, STARTING from the
+// candidate at its start, and compares with the candidate at its end.  Agreement of all chunks of a row proves, by induction, that
+// the candidates are the running values of the one ordered fold (SPMV.h:54-59) -- for this function on these operands, associative
+// in general or not.  The serial part of a row: two chunks and the scan instead of its length.
+template <class P, class U, class V>
+__global__ void __launch_bounds__(kBlock)
+k_giant_chunk_totals(ProgArg<P> pa, gm_csr_t A, const V* __restrict__ vp, const uint32_t* __restrict__ want, const U* __restrict__ terms,
+                     const unsigned long long* __restrict__ tpres, U* __restrict__ tval, int32_t* __restrict__ thas, const int32_t* __restrict__ spec_off) {
+  static_assert(stageable<U>::value, "products of at most 8 bytes");
+  __shared__ __attribute__((aligned(16))) U s_t[kBlock / 64][512];
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (q >= A.ngchunk || spec_off[0] != 0) return;
+  const int gi = A.gchunk_row[q];
+  const int piece0 = lower_piece(A.gchunk_row, A.ngchunk, gi);
+  if ((q - piece0) & 1) return;
+  const int row = A.giant_row[gi];
+  if (!row_wanted(p, vp, want, row)) return;
+  const int64_t deg = A.rowptr[row + 1] - A.rowptr[row];
+  const int64_t rel = (int64_t)(q - piece0) * GM_GIANT_CHUNK;
+  const int64_t n = deg - rel < (int64_t)kLongChunk ? deg - rel : (int64_t)kLongChunk;
+  U acc;
+  bool has = false;
+  fold_products_ordered<P, U>(p, terms, tpres, A.gterm_off[gi] + rel, n, lane, s_t[threadIdx.x >> 6], acc, has);
+  if (lane == 0) {
+    thas[q] = has ? 1 : 0;
+    if (has) tval[q] = acc;
+  }
+}
+
+// one wave per giant row: the chunk totals combined in order; bval / bhas[first piece of chunk c] = the candidate running value when
+// chunk c starts, fin / finhas[row] = the candidate result, which is also stored as the row's result
+template <class P, class U, class V>
+__global__ void __launch_bounds__(kBlock)
+k_giant_chunk_scan(ProgArg<P> pa, gm_csr_t A, const V* __restrict__ vp, const uint32_t* __restrict__ want, U* __restrict__ y, uint32_t* __restrict__ ybits,
+                   int accumulate, const U* __restrict__ tval, const int32_t* __restrict__ thas, U* __restrict__ bval, int32_t* __restrict__ bhas,
+                   U* __restrict__ fin, int32_t* __restrict__ finhas, const int32_t* __restrict__ spec_off) {
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int gi = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (gi >= A.ngiant || spec_off[0] != 0) return;
+  const int row = A.giant_row[gi];
+  if (!row_wanted(p, vp, want, row)) return;
+  const int64_t deg = A.rowptr[row + 1] - A.rowptr[row];
+  const int nchunks = (int)((deg + kLongChunk - 1) / kLongChunk);
+  const int piece0 = lower_piece(A.gchunk_row, A.ngchunk, gi);
+  U B;
+  bool h = false;  // (wave-uniform)
+  for (int c0 = 0; c0 < nchunks; c0 += 64) {
+    const int c = c0 + lane;
+    U tv;
+    int th = 0;
+    if (c < nchunks) {
+      th = thas[piece0 + 2 * c];
+      if (th) tv = tval[piece0 + 2 * c];
+    }
+    const int m = nchunks - c0 < 64 ? nchunks - c0 : 64;
+    for (int i = 0; i < m; i++) {
+      if (lane == 0) {
+        bhas[piece0 + 2 * (c0 + i)] = h ? 1 : 0;
+        if (h) bval[piece0 + 2 * (c0 + i)] = B;
+      }
+      if (__builtin_amdgcn_readlane(th, i)) {
+        U t = wave_bcast(tv, i);
+        if (h) p.P::reduce_function(B, t); else { B = t; h = true; }
+      }
+    }
+  }
+  if (lane == 0) {
+    finhas[gi] = h ? 1 : 0;
+    if (h) {
+      fin[gi] = B;
+      y[row] = B;
+      if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
+    }
+  }
+}
+
+template <class P, class U, class V>
+__global__ void __launch_bounds__(kBlock)
+k_giant_verify_chunks_any(ProgArg<P> pa, gm_csr_t A, const V* __restrict__ vp, const uint32_t* __restrict__ want, const U* __restrict__ terms,
+                          const unsigned long long* __restrict__ tpres, const U* __restrict__ bval, const int32_t* __restrict__ bhas,
+                          const U* __restrict__ fin, const int32_t* __restrict__ finhas, int32_t* __restrict__ redo, int32_t* __restrict__ spec_off) {
+  static_assert(stageable<U>::value, "products of at most 8 bytes");
+  __shared__ __attribute__((aligned(16))) U s_t[kBlock / 64][512];
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (q >= A.ngchunk || spec_off[0] != 0) return;
+  const int gi = A.gchunk_row[q];
+  const int piece0 = lower_piece(A.gchunk_row, A.ngchunk, gi);
+  if ((q - piece0) & 1) return;
+  const int row = A.giant_row[gi];
+  if (!row_wanted(p, vp, want, row)) return;
+  const int64_t deg = A.rowptr[row + 1] - A.rowptr[row];
+  const int64_t rel = (int64_t)(q - piece0) * GM_GIANT_CHUNK;
+  const int64_t n = deg - rel < (int64_t)kLongChunk ? deg - rel : (int64_t)kLongChunk;
+  bool has = bhas[q] != 0;
+  U acc;
+  if (has) acc = bval[q];
+  fold_products_ordered<P, U>(p, terms, tpres, A.gterm_off[gi] + rel, n, lane, s_t[threadIdx.x >> 6], acc, has);
+  if (lane == 0) {
+    const bool last = rel + (int64_t)kLongChunk >= deg;
+    const bool ehas = (last ? finhas[gi] : bhas[q + 2]) != 0;
+    bool ok = has == ehas;
+    if (ok && has) {
+      const U e = last ? fin[gi] : bval[q + 2];
+      const unsigned char *a_ = reinterpret_cast<const unsigned char*>(&acc), *b_ = reinterpret_cast<const unsigned char*>(&e);
+      for (size_t i = 0; i < sizeof(U); i++) ok = ok && a_[i] == b_[i];
+    }
+    if (!ok) { redo[gi] = 1; spec_off[0] = 1; }
   }
 }
 
