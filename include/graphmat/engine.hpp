@@ -835,7 +835,8 @@ class Run {
     // a strategy the program did not declare but the probe inferred is cross-checked on the device against the
     // ordered fold the first time a pull multiply runs (k_check_rows); a disagreement falls back to the ordered fold
     rk_unverified = (int)program_traits<P>::reduce == (int)REDUCE_AUTO && rk != REDUCE_ORDERED && !getenv("GRAPHMAT_NO_PROBE_CHECK");
-    if constexpr (std::is_same<U, float>::value && (int)program_traits<P>::reduce == (int)REDUCE_AUTO) {
+    if constexpr (std::is_same<U, float>::value && ((int)program_traits<P>::reduce == (int)REDUCE_AUTO || (int)program_traits<P>::reduce == (int)REDUCE_ORDERED)) {
+      // (also for a program that DECLARES the ordered fold: the guess decides nothing about its bits, only which speculation its giant rows try)
       const char* off = getenv("GRAPHMAT_NO_PROBE");
       guess_f32_add = rk == REDUCE_ORDERED && !(off && off[0] == '1') && probe_reduce_guess<P, U>(gp) == REDUCE_F32_ADD;
     }

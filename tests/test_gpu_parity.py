@@ -108,6 +108,46 @@ def test_csr_build_order(env, threads, layout):
         assert (np.diff(deg[nod]) <= 0).all()
 
 
+def _giant_rows_folded_again(api, g):
+    """White box: the engine keeps, in workspace slot 15 of the graph, [ngchunk + 2] chunk boundaries of 8 bytes and then one flag per giant row that
+    k_giant_verify_chunks* sets when a chunk of the row fails its proof (engine.hpp: multiply_out).  (rows folded again, giant rows), or None."""
+    import ctypes as C
+    ca = g.csr(api.GM_DIR_OUT)
+    ptr, size, ext = C.c_void_p(), C.c_size_t(), C.c_int()
+    if api._lib.lib().gm_graph_workspace_info(g.h, 15, C.byref(ptr), C.byref(size), C.byref(ext)) != 0 or not ptr.value:
+        return None
+    if size.value < (ca.ngchunk + 2) * 8 + ca.ngiant * 4:
+        return None
+    redo = np.zeros(ca.ngiant, dtype=np.int32)
+    api.copy_from_device(redo, ptr.value + (ca.ngchunk + 2) * 8)
+    return int((redo != 0).sum()), int(ca.ngiant)
+
+
+def test_ordered_float_sum_giant_rows_speculated_and_proven(env):
+    """PageRank with the ORDERED fold forced (the program then declares REDUCE_ORDERED: `c = a; reduce(c, b)` in stored order, SPMV.h:54-59) on a
+    graph whose hub rows span several 8192-product chunks: the giant rows are replayed as float sums and every chunk is proven with the
+    program's own reduce_function (kernels.hpp: k_giant_verify_chunks) -- no row has to be folded again, and the bits are the oracle's."""
+    api, ob = env
+    nv, s, d, v = gen.rmat_edges(18, 16, seed=5)
+    og = ob.OracleGraph(nv, s, d, v, 1)
+    g = api.Graph(nv, s, d, v, ref_threads=1, layout=1)
+    ca = g.csr(api.GM_DIR_OUT)
+    assert ca.ngiant > 0 and ca.ngchunk > 2 * ca.ngiant, (ca.ngiant, ca.ngchunk)  # (pieces of 4096: rows of several chunks among them)
+    api._lib.lib().gm_set_option(b"force_ordered", 1)
+    try:
+        pr, deg, it = g.pagerank(6)
+        opr, oit, _ = og.pagerank(6)
+        assert (f32bits(pr) == f32bits(opr)).all()
+        again = _giant_rows_folded_again(api, g)
+        assert again is not None and again[0] == 0 and again[1] == ca.ngiant, again
+        # the same run without the speculation (one chain per giant row): the same bits
+        api._lib.lib().gm_set_option(b"ordered_giant_two_pass", 1)
+        pr1, _, _ = g.pagerank(6)
+        assert (f32bits(pr1) == f32bits(opr)).all()
+    finally:
+        api._lib.lib().gm_reset_options()
+
+
 # ---------------- programs on synthetic graphs -----------------------------------------------------
 @pytest.mark.parametrize("scale,threads,layout", [(10, 1, 1), (12, 4, 0), (14, 1, 1), (16, 2, 1), (16, 1, 0)])
 def test_pagerank_bit_exact_rmat(env, scale, threads, layout):
