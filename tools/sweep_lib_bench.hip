@@ -26,6 +26,16 @@ struct SumP : GraphMat::GraphProgram<float, float, Vp, int> {
   HD void apply(const float& y, Vp& v) { v.a = y; }
 };
 
+__global__ void k_keep_rows(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t ne, int k, int32_t* __restrict__ s2, int32_t* __restrict__ d2,
+                            unsigned long long* __restrict__ cnt) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += (int64_t)gridDim.x * blockDim.x) {
+    if ((((uint32_t)dst[i] * 2654435761u) >> 12) % (uint32_t)k == 0u) {  // (a hash: the low bits of an RMAT id are not independent of its degree)
+      const unsigned long long p = atomicAdd(cnt, 1ull);
+      s2[p] = src[i];
+      d2[p] = dst[i];
+    }
+  }
+}
 __global__ void k_fill_x(float* __restrict__ x, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { uint32_t h = (uint32_t)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; x[i] = (float)(h >> 8) * (1.0f / 16777216.0f) + 1e-3f; }
@@ -106,18 +116,31 @@ __global__ void k_ref_rows(const int32_t* __restrict__ rows, int n, const int64_
 int main(int argc, char** argv) {
   const int scale = argc > 1 ? atoi(argv[1]) : 26;
   const int reps = argc > 2 ? atoi(argv[2]) : 5;
+  int rows_of = 1;  // rows_of=K: only the in-edges of every K-th vertex are kept -- the rows a shard of K would own, against the WHOLE message vector
   for (int a = 3; a < argc; a++) {
     char* eq = strchr(argv[a], '=');
     if (!eq) continue;
     *eq = 0;
+    if (!strcmp(argv[a], "rows_of")) { rows_of = atoi(eq + 1); continue; }
     if (gm_set_option(argv[a], atoi(eq + 1)) != 0) { printf("option %s: %s\n", argv[a], gm_last_error()); return 1; }
   }
   const int nv = 1 << scale;
-  const int64_t ne = 16ll * nv;
+  int64_t ne = 16ll * nv;
   int32_t *src, *dst;
   OK(hipMalloc(&src, ne * 4)); OK(hipMalloc(&dst, ne * 4));
   GOK(gm_rmat_generate(scale, 1, 0, ne, src, dst, nullptr, 0, nullptr));
   OK(hipDeviceSynchronize());
+  if (rows_of > 1) {
+    int32_t *s2, *d2; unsigned long long* cnt;
+    OK(hipMalloc(&s2, ne * 4)); OK(hipMalloc(&d2, ne * 4)); OK(hipMalloc(&cnt, 8)); OK(hipMemset(cnt, 0, 8));
+    k_keep_rows<<<65536, 256>>>(src, dst, ne, rows_of, s2, d2, cnt);
+    unsigned long long kept = 0;
+    OK(hipMemcpy(&kept, cnt, 8, hipMemcpyDeviceToHost));
+    OK(hipFree(src)); OK(hipFree(dst)); OK(hipFree(cnt));
+    src = s2; dst = d2;
+    printf("rows_of=%d: %llu of %lld edges kept (the in-edges of one vertex in %d, by a hash of its id)\n", rows_of, kept, (long long)ne, rows_of);
+    ne = (int64_t)kept;
+  }
   gm_graph_desc_t d;
   memset(&d, 0, sizeof(d));
   d.nvertices = nv; d.nparts = 16; d.row_lo = 0; d.row_hi = nv; d.directions = GM_DIR_OUT | GM_DIR_IN; d.val_bytes = 0; d.ids_on_device = 1;
