@@ -17,7 +17,7 @@
 //     run whose head lane reads the running value from LDS, adds the run's messages one after the other and writes it back.
 // Every result is compared bit for bit with a serial fold of the rows' edges in ascending native column order.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Iinclude tools/blocked_bench.hip -Lgraphmat_amd -lgraphmat_hip -o build/blocked_bench
-//   LD_LIBRARY_PATH=graphmat_amd build/blocked_bench [scale 26] [graph 0 = RMAT, 1 = uniform] [slices 128] [reps 5] [row_hi 64]
+//   LD_LIBRARY_PATH=graphmat_amd build/blocked_bench [scale 26] [graph 0 = RMAT, 1 = uniform] [slices 128] [reps 5] [row_hi 64] [forms 3]
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -274,12 +274,326 @@ static void build_and_run(const int32_t* src, const int32_t* dst, int64_t ne, in
   OK(hipFree(st.ecol)); OK(hipFree(st.erow)); OK(hipFree(st.boff));
 }
 
+// ---- the workgroup-stationary form, workgroups kept in step ----------------------------------------------------------------
+// A workgroup owns kRBW rows per pass (their running values fill its LDS); the grid's workgroups take the blocks of a pass side by
+// side and walk the slices TOGETHER: a workgroup that has finished slice s tells its XCD's counter so, and nobody starts slice
+// s + 1 before every workgroup of the XCD has finished slice s + 1 - window -- the L2 then holds `window` + 1 slices of x, whatever the
+// workgroups' pace.  The wait is bounded: a workgroup that never arrives costs locality, not progress.
+constexpr int kRBW = 32768, kRBWBits = 15;
+__global__ void k_entries_wg(const unsigned long long* __restrict__ key, int64_t n, int cbits, int S, const uint32_t* __restrict__ rowmin,
+                             uint32_t* __restrict__ ecol, uint16_t* __restrict__ erow, uint32_t* __restrict__ toff) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long k = key[i];
+    const uint32_t c = (uint32_t)(k & ((1ull << cbits) - 1));
+    const uint32_t local = (uint32_t)(k >> cbits) & (kRBW - 1);
+    const uint32_t slice = (uint32_t)(k >> (cbits + kRBWBits)) & 511u;
+    const uint32_t blk = (uint32_t)(k >> (cbits + kRBWBits + 9));
+    const uint32_t r = (blk << kRBWBits) | local;
+    const bool first = c == rowmin[r] && (i == 0 || key[i - 1] != k);
+    ecol[i] = c;
+    erow[i] = (uint16_t)(local | (first ? 0x8000u : 0u));
+    if (i == 0 || (key[i - 1] >> (cbits + kRBWBits)) != (k >> (cbits + kRBWBits))) toff[(size_t)blk * S + slice] = (uint32_t)i;
+  }
+}
+// where the 16 waves of a workgroup start inside a (block, slice) segment: equal shares, moved forward to the next row border
+__global__ void k_wave_offsets(const uint32_t* __restrict__ toff, const uint16_t* __restrict__ erow, size_t nseg, uint32_t* __restrict__ woff) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= nseg * 17) return;
+  const size_t seg = t / 17;
+  const int w = (int)(t % 17);
+  const uint32_t a = toff[seg], e = toff[seg + 1];
+  uint32_t p = a + (uint32_t)(((unsigned long long)(e - a) * (unsigned)w) / 16u);
+  if (w == 16) p = e;
+  while (p > a && p < e && (erow[p] & 0x7fffu) == (erow[p - 1] & 0x7fffu)) p++;
+  woff[t] = p;
+}
+
+template <int U, int NT>
+__global__ void __launch_bounds__(1024) k_blocked_wg(const uint32_t* __restrict__ ecol, const uint16_t* __restrict__ erow, const uint32_t* __restrict__ woff, int S, int nblk,
+                                                     const float* __restrict__ x, float* __restrict__ y, int nrows, unsigned int* __restrict__ cnt, int window,
+                                                     unsigned int epoch) {
+  extern __shared__ float acc[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int xcd = blockIdx.x & 7;
+  const unsigned int nwg = gridDim.x >> 3;
+  const int npass = (nblk + gridDim.x - 1) / gridDim.x;
+  const int nsteps = npass * S;
+  unsigned int* mycnt = cnt + (size_t)xcd * nsteps;
+  for (int pass = 0; pass < npass; pass++) {
+    const int blk = pass * gridDim.x + blockIdx.x;
+    const bool has = blk < nblk;
+    uint32_t ws = 0, we = 0;
+    if (has) { const uint32_t* wo = woff + ((size_t)blk * S) * 17 + wave; ws = wo[0]; we = wo[1]; }
+    for (int s = 0; s < S; s++) {
+      uint32_t nws = 0, nwe = 0;
+      if (has && s + 1 < S) { const uint32_t* wo = woff + ((size_t)blk * S + s + 1) * 17 + wave; nws = wo[0]; nwe = wo[1]; }  // (the next slice's range: requested now)
+      for (uint32_t p0 = ws; p0 < we; p0 += 64 * U) {
+        uint32_t c[U], r[U];
+        float m[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const uint32_t p = p0 + u * 64 + lane;
+          if (NT) { c[u] = __builtin_nontemporal_load(ecol + p); r[u] = __builtin_nontemporal_load(erow + p); }
+          else { c[u] = ecol[p]; r[u] = erow[p]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) m[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const uint32_t p = p0 + u * 64 + lane;
+          const bool valid = p < we;
+          const uint32_t id = valid ? (r[u] & 0x7fffu) : (0x10000u + lane);
+          const uint32_t prev = __shfl_up(id, 1);
+          const bool head = valid && (lane == 0 || id != prev);
+          const unsigned long long H = __ballot(head) | (__ballot(!valid));
+          const unsigned long long above = lane == 63 ? 0ull : (H >> (lane + 1));
+          const int runlen = above ? (__builtin_ctzll(above) + 1) : (64 - lane);
+          float v = 0.f;
+          if (head) v = (r[u] & 0x8000u) ? m[u] : acc[id] + m[u];
+          for (int k = 1; __ballot(head && k < runlen); k++) {
+            const float t = __shfl(m[u], (lane + k) & 63);
+            if (head && k < runlen) v += t;
+          }
+          if (head) acc[id] = v;
+        }
+      }
+      __syncthreads();
+      const int step = pass * S + s;
+      if (window >= 0) {
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&mycnt[step], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int need = step + 1 - window;
+        if (need >= 0) {
+          const unsigned int target = nwg * (epoch + 1);
+          for (int tries = 0; tries < 20000; tries++)
+            if (__hip_atomic_load(&mycnt[need], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+        }
+      }
+      ws = nws; we = nwe;
+    }
+    if (has) {
+      const int r0 = blk * kRBW;
+      for (int i = threadIdx.x; i < kRBW; i += 1024) if (r0 + i < nrows) y[r0 + i] = acc[i];
+    }
+    __syncthreads();
+  }
+}
+
+// ... and without a workgroup barrier: wave w of the workgroup owns the block's rows [w * 2048, (w + 1) * 2048) in EVERY slice (its part of a
+// segment is found by row, not by share), so no two waves ever touch the same running value; the entries of the wave's next batch -- in this
+// slice or the next -- are requested before the current batch is folded; wave 0 reports the slice done, every wave paces itself.
+__global__ void k_wave_offsets_by_row(const uint32_t* __restrict__ toff, const uint16_t* __restrict__ erow, size_t nseg, uint32_t* __restrict__ woff) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= nseg * 17) return;
+  const size_t seg = t / 17;
+  const uint32_t w = (uint32_t)(t % 17);
+  const uint32_t a = toff[seg], e = toff[seg + 1];
+  uint32_t lo = a, hi = e;  // first entry whose local row is >= w * 2048
+  while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if ((uint32_t)(erow[mid] & 0x7fffu) >= w * 2048u) hi = mid; else lo = mid + 1; }
+  woff[t] = lo;
+}
+
+template <int U, bool BARRIER>
+__global__ void __launch_bounds__(1024) k_blocked_wg2(const uint32_t* __restrict__ ecol, const uint16_t* __restrict__ erow, const uint32_t* __restrict__ woff, int S, int nblk,
+                                                      const float* __restrict__ x, float* __restrict__ y, int nrows, unsigned int* __restrict__ cnt, int window,
+                                                      unsigned int epoch) {
+  extern __shared__ float acc[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int xcd = blockIdx.x & 7;
+  const unsigned int nwg = gridDim.x >> 3;
+  const int npass = (nblk + gridDim.x - 1) / gridDim.x;
+  const int nsteps = npass * S;
+  unsigned int* mycnt = cnt + (size_t)xcd * nsteps;
+  for (int pass = 0; pass < npass; pass++) {
+    const int blk = pass * gridDim.x + blockIdx.x;
+    const bool has = blk < nblk;
+    uint32_t ws = 0, we = 0;
+    if (has) { const uint32_t* wo = woff + ((size_t)blk * S) * 17 + wave; ws = wo[0]; we = wo[1]; }
+    uint32_t c[U], r[U];
+    uint32_t pre = ws;
+#pragma unroll
+    for (int u = 0; u < U; u++) { c[u] = ecol[pre + u * 64 + lane]; r[u] = erow[pre + u * 64 + lane]; }
+    for (int s = 0; s < S; s++) {
+      uint32_t nws = 0, nwe = 0;
+      if (has && s + 1 < S) { const uint32_t* wo = woff + ((size_t)blk * S + s + 1) * 17 + wave; nws = wo[0]; nwe = wo[1]; }
+      if (pre != ws && ws < we) {
+        pre = ws;
+#pragma unroll
+        for (int u = 0; u < U; u++) { c[u] = ecol[pre + u * 64 + lane]; r[u] = erow[pre + u * 64 + lane]; }
+      }
+      for (uint32_t p0 = ws; p0 < we;) {
+        float m[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) m[u] = x[c[u]];
+        const uint32_t np0 = p0 + 64 * U;
+        const uint32_t nxt = np0 < we ? np0 : nws;
+        uint32_t nc[U], nr[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { nc[u] = ecol[nxt + u * 64 + lane]; nr[u] = erow[nxt + u * 64 + lane]; }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const uint32_t p = p0 + u * 64 + lane;
+          const bool valid = p < we;
+          const uint32_t id = valid ? (r[u] & 0x7fffu) : (0x10000u + lane);
+          const uint32_t prev = __shfl_up(id, 1);
+          const bool head = valid && (lane == 0 || id != prev);
+          const unsigned long long H = __ballot(head) | (__ballot(!valid));
+          const unsigned long long above = lane == 63 ? 0ull : (H >> (lane + 1));
+          const int runlen = above ? (__builtin_ctzll(above) + 1) : (64 - lane);
+          float v = 0.f;
+          if (head) v = (r[u] & 0x8000u) ? m[u] : acc[id] + m[u];
+          for (int k = 1; __ballot(head && k < runlen); k++) {
+            const float t = __shfl(m[u], (lane + k) & 63);
+            if (head && k < runlen) v += t;
+          }
+          if (head) acc[id] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) { c[u] = nc[u]; r[u] = nr[u]; }
+        pre = nxt;
+        p0 = np0;
+      }
+      const int step = pass * S + s;
+      if (BARRIER) __syncthreads();
+      if (window >= 0) {
+        // (BARRIER: ONE lane of the workgroup reports and waits, with a pause between two looks -- 512 waves of an XCD polling one line
+        // of the L2 keep the reports themselves from getting through -- and a second barrier hands the result to the other waves)
+        const int need = step + 1 - window;
+        const unsigned int target = nwg * (epoch + 1);
+        if (BARRIER) {
+          if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&mycnt[step], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (need >= 0)
+              for (int tries = 0; tries < 20000; tries++) {
+                if (__hip_atomic_load(&mycnt[need], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+                __builtin_amdgcn_s_sleep(4);
+              }
+          }
+          __syncthreads();
+        } else {
+          if (threadIdx.x == 0) __hip_atomic_fetch_add(&mycnt[step], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (need >= 0)
+            for (int tries = 0; tries < 20000; tries++)
+              if (__hip_atomic_load(&mycnt[need], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+        }
+      }
+      ws = nws; we = nwe;
+    }
+    if (has) {
+      const int r0 = blk * kRBW + wave * 2048;
+      for (int i = lane; i < 2048; i += 64) if (r0 + i < nrows) y[r0 + i] = acc[wave * 2048 + i];
+    }
+    if (BARRIER) __syncthreads();
+  }
+}
+
+template <int U, bool BARRIER>
+static void run_wg2(const char* what, const uint32_t* ecol, const uint16_t* erow, const uint32_t* woff, int S, int nblk, int64_t n, const float* x, float* y, const float* yref,
+                    int nrows, int reps, unsigned int* cnt, size_t cnt_words, int window) {
+  const size_t lds = (size_t)kRBW * 4;
+  OK(hipFuncSetAttribute((const void*)k_blocked_wg2<U, BARRIER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  OK(hipMemset(cnt, 0, cnt_words * 4));
+  OK(hipMemset(y, 0, (size_t)nrows * 4));
+  float best = 1e9f, sum = 0.f;
+  for (int it = 0; it < reps + 1; it++) {
+    OK(hipEventRecord(ev0, 0));
+    hipLaunchKernelGGL((k_blocked_wg2<U, BARRIER>), dim3(256), dim3(1024), lds, 0, ecol, erow, woff, S, nblk, x, y, nrows, cnt, window, (unsigned int)it);
+    OK(hipEventRecord(ev1, 0));
+    OK(hipEventSynchronize(ev1));
+    float ms; OK(hipEventElapsedTime(&ms, ev0, ev1));
+    if (it == 0) continue;
+    best = ms < best ? ms : best; sum += ms;
+  }
+  OK(hipGetLastError());
+  unsigned long long* d; OK(hipMalloc(&d, 8)); OK(hipMemset(d, 0, 8));
+  k_diff<<<(nrows + 255) / 256, 256>>>(y, yref, nrows, d);
+  unsigned long long h = 0; OK(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost)); OK(hipFree(d));
+  printf("%-44s U %d, window %2d: best %.3f ms, mean %.3f ms = %.2f ps per edge, %.1f G edges/s; %llu of %d rows differ from the serial fold\n", what, U, window, best, sum / reps,
+         best * 1e9 / (double)n, (double)n / best / 1e6, h, nrows);
+  fflush(stdout);
+}
+
+template <int U, int NT>
+static void run_wg(const char* what, const uint32_t* ecol, const uint16_t* erow, const uint32_t* woff, int S, int nblk, int64_t n, const float* x, float* y, const float* yref,
+                   int nrows, int reps, unsigned int* cnt, size_t cnt_words, int window) {
+  const size_t lds = (size_t)kRBW * 4;
+  OK(hipFuncSetAttribute((const void*)k_blocked_wg<U, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  OK(hipMemset(cnt, 0, cnt_words * 4));
+  OK(hipMemset(y, 0, (size_t)nrows * 4));
+  float best = 1e9f, sum = 0.f;
+  for (int it = 0; it < reps + 1; it++) {
+    OK(hipEventRecord(ev0, 0));
+    hipLaunchKernelGGL((k_blocked_wg<U, NT>), dim3(256), dim3(1024), lds, 0, ecol, erow, woff, S, nblk, x, y, nrows, cnt, window, (unsigned int)it);
+    OK(hipEventRecord(ev1, 0));
+    OK(hipEventSynchronize(ev1));
+    float ms; OK(hipEventElapsedTime(&ms, ev0, ev1));
+    if (it == 0) continue;
+    best = ms < best ? ms : best; sum += ms;
+  }
+  OK(hipGetLastError());
+  unsigned long long* d; OK(hipMalloc(&d, 8)); OK(hipMemset(d, 0, 8));
+  k_diff<<<(nrows + 255) / 256, 256>>>(y, yref, nrows, d);
+  unsigned long long h = 0; OK(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost)); OK(hipFree(d));
+  printf("%-44s U %d%s, window %2d: best %.3f ms, mean %.3f ms = %.2f ps per edge, %.1f G edges/s; %llu of %d rows differ from the serial fold\n", what, U, NT ? ", stream non-temporal" : "",
+         window, best, sum / reps, best * 1e9 / (double)n, (double)n / best / 1e6, h, nrows);
+  fflush(stdout);
+}
+
+static void build_and_run_wg(const int32_t* src, const int32_t* dst, int64_t ne, int scale, const int32_t* rank_of, int nrows, const int32_t* bound, int S, const uint32_t* rowmin,
+                             const float* x, int reps, unsigned long long* k1, unsigned long long* k1s, unsigned long long* scratch, int64_t nsel, const float* yref, float* y) {
+  const int cbits = scale, G = 4096;
+  k_edge_keys<<<G, 256>>>(src, dst, ne, rank_of, bound, S, kRBWBits, cbits, k1, scratch);
+  sort_keys(k1, k1s, (size_t)ne, 64);
+  const int nblk = (nrows + kRBW - 1) / kRBW;
+  const size_t nseg = (size_t)nblk * S;
+  uint32_t *ecol, *toff, *woff; uint16_t* erow;
+  OK(hipMalloc(&ecol, ((size_t)nsel + 64 * 64) * 4)); OK(hipMalloc(&erow, ((size_t)nsel + 64 * 64) * 2)); OK(hipMalloc(&toff, (nseg + 2) * 4)); OK(hipMalloc(&woff, (nseg + 1) * 17 * 4));
+  OK(hipMemset(ecol, 0, ((size_t)nsel + 64 * 64) * 4)); OK(hipMemset(erow, 0, ((size_t)nsel + 64 * 64) * 2)); OK(hipMemset(toff, 0xff, (nseg + 2) * 4));
+  k_entries_wg<<<G, 256>>>(k1s, nsel, cbits, S, rowmin, ecol, erow, toff);
+  OK(hipDeviceSynchronize());
+  {
+    std::vector<uint32_t> h(nseg + 1);
+    OK(hipMemcpy(h.data(), toff, nseg * 4, hipMemcpyDeviceToHost));
+    h[nseg] = (uint32_t)nsel;
+    for (size_t b = nseg; b-- > 0;) if (h[b] == 0xffffffffu) h[b] = h[b + 1];
+    OK(hipMemcpy(toff, h.data(), (nseg + 1) * 4, hipMemcpyHostToDevice));
+  }
+  k_wave_offsets<<<(unsigned)((nseg * 17 + 255) / 256), 256>>>(toff, erow, nseg, woff);
+  OK(hipDeviceSynchronize());
+  const int npass = (nblk + 255) / 256;
+  const size_t cnt_words = (size_t)8 * npass * S + 64;
+  unsigned int* cnt; OK(hipMalloc(&cnt, cnt_words * 4));
+  printf("workgroup-stationary form: blocks of %d rows: %d blocks = %d passes of 256 workgroups, %.0f entries per block and slice (%.1f us of L2-hit gathers per pass and slice chip-wide)\n", kRBW, nblk,
+         npass, (double)nsel / nblk / S, (double)nsel / npass / S / 200e3);
+  run_wg<4, 0>("workgroups in step", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 1);
+  run_wg<4, 0>("workgroups in step", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 2);
+  run_wg<4, 0>("workgroups in step", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 4);
+  run_wg<4, 1>("workgroups in step", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 2);
+  run_wg<2, 0>("workgroups in step", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 2);
+  run_wg<4, 0>("workgroups not kept in step", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, -1);
+  run_wg2<4, true>("in step, next batch prefetched", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 1);
+  run_wg2<4, true>("in step, next batch prefetched", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 2);
+  run_wg2<4, true>("in step, next batch prefetched", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 3);
+  run_wg2<2, true>("in step, next batch prefetched", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 2);
+  run_wg2<8, true>("in step, next batch prefetched", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 2);
+  if (getenv("BLOCKED_BENCH_ALL") == nullptr) { OK(hipFree(ecol)); OK(hipFree(erow)); OK(hipFree(toff)); OK(hipFree(woff)); OK(hipFree(cnt)); return; }
+  k_wave_offsets_by_row<<<(unsigned)((nseg * 17 + 255) / 256), 256>>>(toff, erow, nseg, woff);
+  OK(hipDeviceSynchronize());
+  run_wg2<4, false>("waves own rows, paced, no barrier", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 1);
+  run_wg2<4, false>("waves own rows, paced, no barrier", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 2);
+  run_wg2<4, false>("waves own rows, paced, no barrier", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 3);
+  run_wg2<2, false>("waves own rows, paced, no barrier", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 2);
+  run_wg2<8, false>("waves own rows, paced, no barrier", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 2);
+  run_wg2<4, false>("waves own rows, not paced", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, -1);
+  OK(hipFree(ecol)); OK(hipFree(erow)); OK(hipFree(toff)); OK(hipFree(woff)); OK(hipFree(cnt));
+}
+
 int main(int argc, char** argv) {
   const int scale = argc > 1 ? atoi(argv[1]) : 26;
   const int kind = argc > 2 ? atoi(argv[2]) : 0;
   const int S = argc > 3 ? atoi(argv[3]) : 128;
   const int reps = argc > 4 ? atoi(argv[4]) : 5;
   const int row_hi = argc > 5 ? atoi(argv[5]) : 64;
+  const int form = argc > 6 ? atoi(argv[6]) : 3;  // 1 = wave-stationary blocks, 2 = workgroup-stationary blocks kept in step, 3 = both
   if (S < 1 || S > kMaxS) { printf("slices: 1..%d\n", kMaxS); return 1; }
   const int nv = 1 << scale;
   const int64_t ne = 16ll * nv;
@@ -338,6 +652,8 @@ int main(int argc, char** argv) {
     OK(hipDeviceSynchronize());
     OK(hipFree(rowptr));
   }
+  if (form & 2) build_and_run_wg(src, dst, ne, scale, rank_of, nrows, bound, S, rowmin, x, reps, k1, k1s, k2, nsel, yref, y);
+  if (!(form & 1)) return 0;
   build_and_run<2048>(src, dst, ne, nv, scale, rank_of, nrows, bound, S, rowmin, x, reps, k1, k1s, k2, nsel, yref, y);
   build_and_run<1024>(src, dst, ne, nv, scale, rank_of, nrows, bound, S, rowmin, x, reps, k1, k1s, k2, nsel, yref, y);
   build_and_run<512>(src, dst, ne, nv, scale, rank_of, nrows, bound, S, rowmin, x, reps, k1, k1s, k2, nsel, yref, y);
