@@ -1641,7 +1641,10 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     // 2.17 / 2.09 / 2.05 / 2.15 ms for the swept rows, RMAT-25 (65 MiB) 32 / 64: 1.02 / 0.94 ms, RMAT-24 (34 MiB) 16 / 32 / 64: 0.79 / 0.80 / 0.92)
     int want_slices = g_sweep_slices >= 8 ? g_sweep_slices : (int)(mib_live / 1.3 + 0.5);
     want_slices = std::max(16, std::min(GM_MAX_SLICES, want_slices));
-    const int sub = g_sweep_slices != 0 ? std::max(1, std::min(GM_MAX_SLICES / T, (want_slices + T / 2) / T)) : 1;
+    // (an adjacency the sweep cannot take -- edge values that are not 4 bytes wide -- is only ever walked tile by tile: its order stays
+    // degree-ranked inside a whole TILE, so that the tile kernels' LDS hot sets hold the tile's busiest vertices, not one slice's)
+    const bool sweepable = !keeps_values || D.val_bytes == 4;
+    const int sub = (g_sweep_slices != 0 && sweepable) ? std::max(1, std::min(GM_MAX_SLICES / T, (want_slices + T / 2) / T)) : 1;
     const int TS = T * sub;
     hipLaunchKernelGGL(k_tile_of_ranked, dim3(grid_for(nv)), dim3(kT), 0, s, order.as<int32_t>(), nv, deg.as<uint32_t>(),
                        wpre.as<unsigned long long>(), total, TS, tk_in.as<uint8_t>());
