@@ -49,6 +49,11 @@ class Sweep(C.Structure):
                 ("ngiant_edges", C.c_int64), ("gcol", C.c_void_p), ("gval", C.c_void_p), ("gdst", C.c_void_p), ("gslice", C.c_void_p), ("gsrc_pos", C.c_void_p)]
 
 
+class Blocked(C.Structure):
+    _fields_ = [("nrows", C.c_int32), ("nblocks", C.c_int32), ("nslices", C.c_int32), ("short_row", C.c_int32), ("nsteps", C.c_int32), ("reserved_", C.c_int32),
+                ("nentries", C.c_int64), ("ecol", C.c_void_p), ("erow", C.c_void_p), ("woff", C.c_void_p), ("row_of", C.c_void_p), ("step_count", C.c_void_p)]
+
+
 class RunStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("send_ms", C.c_float), ("spmv_ms", C.c_float), ("apply_ms", C.c_float),
                 ("total_ms", C.c_float), ("spmv_launches", C.c_int32), ("rowblock_ms", C.c_float),
@@ -59,7 +64,7 @@ class RunStats(C.Structure):
 class EngineOptions(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("debug_flags", "wave16_form", "rowwave_form", "persist_per_cu", "giant_maps", "ordered_giant_two_pass",
                                          "fuse_apply_send", "untiled_pass_plain", "last_rows_lanes", "push_edge_permille", "bits_step_edges",
-                                         "sparse_step_edges", "iteration_trace", "ablate_cold_from", "ablate_cold_short", "two_stage_head_permille", "giant_stream", "sweep_form")] + [("reserved_", C.c_int32 * 14)]
+                                         "sparse_step_edges", "iteration_trace", "ablate_cold_from", "ablate_cold_short", "two_stage_head_permille", "giant_stream", "sweep_form", "blocked_form")] + [("reserved_", C.c_int32 * 13)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int))
@@ -84,6 +89,7 @@ SIGNATURES = {
     "gm_graph_desc": (C.c_int, [_P, C.POINTER(GraphDesc)]),
     "gm_graph_csr": (C.c_int, [_P, C.c_int, C.POINTER(Csr)]),
     "gm_graph_sweep": (C.c_int, [_P, C.POINTER(Sweep)]),
+    "gm_graph_blocked": (C.c_int, [_P, C.POINTER(Blocked)]),
     "gm_graph_rowbits_all": (C.c_int, [_P, C.POINTER(_P)]),
     "gm_graph_tiles": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
     "gm_graph_tile": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(Csr), C.POINTER(_P)]),

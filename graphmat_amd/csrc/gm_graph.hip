@@ -81,6 +81,15 @@ k_count_nonzero(const uint32_t* __restrict__ deg, int nv, unsigned long long* __
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
 }
 
+// out[0] += the degrees of all vertices, out[1] += the degrees of the vertices above `thr` (how much of the graph sits on busy vertices)
+__global__ void __launch_bounds__(kT)
+k_degree_mass(const uint32_t* __restrict__ deg, int nv, uint32_t thr, unsigned long long* __restrict__ out) {
+  unsigned long long all = 0, heavy = 0;
+  for (int v = blockIdx.x * kT + threadIdx.x; v < nv; v += gridDim.x * kT) { const uint32_t d = deg[v]; all += d; if (d > thr) heavy += d; }
+  for (int o = 32; o > 0; o >>= 1) { all += __shfl_down(all, o); heavy += __shfl_down(heavy, o); }
+  if ((threadIdx.x & 63) == 0) { if (all) atomicAdd(&out[0], all); if (heavy) atomicAdd(&out[1], heavy); }
+}
+
 __global__ void __launch_bounds__(kT)
 k_rank_keys(const uint32_t* __restrict__ deg, int nv, uint32_t* __restrict__ keys, int32_t* __restrict__ ids, uint32_t cap) {
   int v = blockIdx.x * kT + threadIdx.x;
@@ -1458,6 +1467,170 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
   return GM_OK;
 }
 
+// ---- the short rows of a graph without skew as a column-blocked stream (graphmat_hip.h: gm_blocked_t; kernels.hpp: k_spmv_blocked) ----
+int g_blocked_rows = 0;  // 0: automatic, 1: whenever the graph has slices, -1: never (gm_set_option("blocked_rows"))
+__global__ void __launch_bounds__(kT) k_blocked_flag(const int64_t* __restrict__ rowptr, int nrows, int short_row, unsigned char* __restrict__ flag) {
+  const int r = blockIdx.x * kT + threadIdx.x;
+  if (r < nrows) { const int64_t l = rowptr[r + 1] - rowptr[r]; flag[r] = (l >= 1 && l <= short_row) ? 1 : 0; }
+}
+// The short rows are dealt over the blocks in runs of 64 consecutive rows (run j -> block j % nblk): the device order is degree-ranked inside
+// a slice, so blocks of CONSECUTIVE rows would hold up to twice as many entries at the top of a slice as at its bottom -- and workgroups
+// that walk the slices in step wait for the heaviest block of the pass (measured on the uniform 2^26 graph: 14.3 ms against 11 for the
+// prototype's equal blocks).  A run's results are 256 contiguous bytes of y.
+__global__ void __launch_bounds__(kT) k_blocked_deal(const int32_t* __restrict__ rows, int ns, int nblk, int32_t* __restrict__ dealt) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= ns) return;
+  const int j = i >> 6;
+  dealt[(size_t)(j % nblk) * GM_BLOCKED_ROWS + (size_t)(j / nblk) * 64 + (i & 63)] = rows[i];
+}
+// (slots: the blocks' row slots, -1 = no row)
+__global__ void __launch_bounds__(kT) k_blocked_lens(const int32_t* __restrict__ slots, int n, const int64_t* __restrict__ rowptr, unsigned long long* __restrict__ len) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i < n) len[i] = slots[i] >= 0 ? (unsigned long long)(rowptr[slots[i] + 1] - rowptr[slots[i]]) : 0ull;
+}
+// key = block | slice (7 bits) | row slot inside the block (15 bits); value = the edge's position in the CSR
+__global__ void __launch_bounds__(kT)
+k_blocked_keys(const int32_t* __restrict__ slots, int n, const unsigned long long* __restrict__ off, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+               SweepSlices sl, int TS, unsigned long long* __restrict__ key, uint32_t* __restrict__ pos) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  const int r = slots[i];
+  if (r < 0) return;
+  const int64_t a = rowptr[r], e = rowptr[r + 1];
+  const unsigned long long hi = ((unsigned long long)(i / GM_BLOCKED_ROWS) << 22), lo = (unsigned long long)(i % GM_BLOCKED_ROWS);
+  unsigned long long o = off[i];
+  for (int64_t k = a; k < e; k++, o++) {
+    const int c = colidx[k];
+    int s0 = 0, s1 = TS;  // slice of column c: sl.b[s] <= c < sl.b[s + 1]
+    while (s1 - s0 > 1) { const int mid = (s0 + s1) / 2; if (sl.b[mid] <= c) s0 = mid; else s1 = mid; }
+    key[o] = hi | ((unsigned long long)s0 << 15) | lo;
+    pos[o] = (uint32_t)k;
+  }
+}
+__global__ void __launch_bounds__(kT)
+k_blocked_fill(const unsigned long long* __restrict__ key, const uint32_t* __restrict__ pos, int64_t n, const int32_t* __restrict__ slots, const int64_t* __restrict__ rowptr,
+               const int32_t* __restrict__ colidx, int TS, uint32_t* __restrict__ ecol, uint16_t* __restrict__ erow, uint32_t* __restrict__ toff) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = key[i];
+  const uint32_t local = (uint32_t)(k & 0x7fffu), slice = (uint32_t)(k >> 15) & 127u;
+  const size_t blk = (size_t)(k >> 22);
+  const int r = slots[blk * GM_BLOCKED_ROWS + local];
+  const uint32_t p = pos[i];
+  ecol[i] = (uint32_t)colidx[p];
+  erow[i] = (uint16_t)(local | ((int64_t)p == rowptr[r] ? 0x8000u : 0u));
+  if (i == 0 || (key[i - 1] >> 15) != (k >> 15)) toff[blk * (size_t)TS + slice] = (uint32_t)i;
+}
+// where the 16 waves of a workgroup start inside a (block, slice) segment: equal shares, moved forward to the next row border
+__global__ void __launch_bounds__(kT) k_blocked_wave_offsets(const uint32_t* __restrict__ toff, const uint16_t* __restrict__ erow, size_t nseg, uint32_t* __restrict__ woff) {
+  const size_t t = (size_t)blockIdx.x * kT + threadIdx.x;
+  if (t >= nseg * 17) return;
+  const size_t seg = t / 17;
+  const int w = (int)(t % 17);
+  const uint32_t a = toff[seg], e = toff[seg + 1];
+  uint32_t p = w == 16 ? e : a + (uint32_t)(((unsigned long long)(e - a) * (unsigned)w) / 16u);
+  while (p > a && p < e && (erow[p] & 0x7fffu) == (erow[p - 1] & 0x7fffu)) p++;
+  woff[t] = p;
+}
+static void free_blocked(gm_graph* g) {
+  gm_blocked_t& B = g->blocked;
+  const void* owned[] = {B.ecol, B.erow, B.woff, B.row_of, B.step_count};
+  for (const void* q : owned)
+    if (q) (void)hipFree((void*)q);
+  memset(&B, 0, sizeof(B));
+}
+static int build_blocked(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
+  memset(&g->blocked, 0, sizeof(g->blocked));
+  const int TS = g->nslices;
+  const int nrows = g->desc.row_hi - g->desc.row_lo;
+  if (g_blocked_rows < 0 || TS < 2 || TS > GM_MAX_SLICES || nrows <= 0 || whole->vals != nullptr || whole->view.nnz <= 0 || whole->view.nnz >= ((int64_t)1 << 32) - 65536 ||
+      g->desc.nshards > 1 || whole->view.short_row <= 0 || whole->view.short_row > 16384)
+    return GM_OK;
+  if (g_blocked_rows == 0 && (double)g->nlive * 4.0 < 48.0 * 1048576.0) return GM_OK;
+  const int64_t* rowptr = (const int64_t*)whole->rowptr;
+  const int32_t* colidx = (const int32_t*)whole->colidx;
+  int rc;
+  DevBuf flag, iota, rows, cnt, tmp, l64, off, dealt;
+  if ((rc = flag.alloc((size_t)nrows)) || (rc = iota.alloc((size_t)nrows * 4)) || (rc = rows.alloc((size_t)nrows * 4)) || (rc = cnt.alloc(16))) return rc;
+  hipLaunchKernelGGL(k_blocked_flag, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr, nrows, whole->view.short_row, flag.as<unsigned char>());
+  hipLaunchKernelGGL(k_sweep_iota, dim3(grid_for(nrows)), dim3(kT), 0, s, iota.as<int32_t>(), nrows);
+  size_t tb = 0;
+  GM_TRY_HIP(rocprim::select(nullptr, tb, iota.as<int32_t>(), flag.as<unsigned char>(), rows.as<int32_t>(), cnt.as<unsigned int>(), (size_t)nrows, s));
+  if ((rc = tmp.alloc(tb + 256))) return rc;
+  GM_TRY_HIP(rocprim::select(tmp.p, tb, iota.as<int32_t>(), flag.as<unsigned char>(), rows.as<int32_t>(), cnt.as<unsigned int>(), (size_t)nrows, s));
+  unsigned int ns = 0;
+  GM_TRY_HIP(hipMemcpyAsync(&ns, cnt.p, 4, hipMemcpyDeviceToHost, s));
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  iota.free(); flag.free();
+  if (ns == 0) return GM_OK;
+  const int nblk = (int)(((size_t)ns + GM_BLOCKED_ROWS - 1) / GM_BLOCKED_ROWS);
+  if (nblk >= (1 << 16)) return GM_OK;
+  const int nslots = nblk * GM_BLOCKED_ROWS;
+  if ((rc = dealt.alloc((size_t)nslots * 4))) return rc;
+  GM_TRY_HIP(hipMemsetAsync(dealt.p, 0xff, (size_t)nslots * 4, s));
+  hipLaunchKernelGGL(k_blocked_deal, dim3(grid_for((int)ns)), dim3(kT), 0, s, (const int32_t*)rows.as<int32_t>(), (int)ns, nblk, dealt.as<int32_t>());
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  rows.free();
+  if ((rc = l64.alloc(((size_t)nslots + 1) * 8)) || (rc = off.alloc(((size_t)nslots + 1) * 8))) return rc;
+  GM_TRY_HIP(hipMemsetAsync(l64.p, 0, ((size_t)nslots + 1) * 8, s));
+  hipLaunchKernelGGL(k_blocked_lens, dim3(grid_for(nslots)), dim3(kT), 0, s, (const int32_t*)dealt.as<int32_t>(), nslots, rowptr, l64.as<unsigned long long>());
+  if ((rc = sweep_excl_scan(l64.as<unsigned long long>(), off.as<unsigned long long>(), (size_t)nslots + 1, s))) return rc;
+  unsigned long long tot = 0;
+  GM_TRY_HIP(hipMemcpyAsync(&tot, off.as<unsigned long long>() + nslots, 8, hipMemcpyDeviceToHost, s));
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  l64.free();
+  const int64_t nent = (int64_t)tot;
+  // automatic: a graph without skew -- (nearly) every edge in a short row; with hot vertices the row-blocks and the sweep are faster
+  // (profiles/r05_short_rows_blocked_stream_prototype.md: RMAT-26's short rows 2.8-3.2 ms this way against 1.27-1.30)
+  if (nent <= 0 || (g_blocked_rows == 0 && (double)nent < 0.9 * (double)whole->view.nnz)) return GM_OK;
+  const size_t nseg = (size_t)nblk * TS;
+  DevBuf k_in, k_out, v_in, v_out;
+  if ((rc = k_in.alloc((size_t)nent * 8)) || (rc = k_out.alloc((size_t)nent * 8)) || (rc = v_in.alloc((size_t)nent * 4)) || (rc = v_out.alloc((size_t)nent * 4))) return rc;
+  SweepSlices sl;
+  memset(&sl, 0, sizeof(sl));
+  for (int t = 0; t <= TS; t++) sl.b[t] = g->slice_base[t];
+  hipLaunchKernelGGL(k_blocked_keys, dim3(grid_for(nslots)), dim3(kT), 0, s, (const int32_t*)dealt.as<int32_t>(), nslots, (const unsigned long long*)off.as<unsigned long long>(), rowptr,
+                     colidx, sl, TS, k_in.as<unsigned long long>(), v_in.as<uint32_t>());
+  GM_TRY_HIP(hipGetLastError());
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  off.free();
+  // stable: inside a (block, slice, row) the edges keep their CSR order = ascending native column
+  if ((rc = sweep_sort_pairs(k_in.as<unsigned long long>(), k_out.as<unsigned long long>(), v_in.as<uint32_t>(), v_out.as<uint32_t>(), (size_t)nent, 22 + bits_for((uint32_t)nblk), s))) return rc;
+  k_in.free(); v_in.free();
+  DevBuf ecol, erow, toff, woff, steps;
+  const int npass = (nblk + 255) / 256;
+  const int nsteps = npass * TS;
+  if ((rc = ecol.alloc(((size_t)nent + 64 * 64) * 4)) || (rc = erow.alloc(((size_t)nent + 64 * 64) * 2)) || (rc = toff.alloc((nseg + 2) * 4)) || (rc = woff.alloc((nseg + 1) * 17 * 4)) ||
+      (rc = steps.alloc((size_t)8 * nsteps * 4 + 256)))
+    return rc;
+  GM_TRY_HIP(hipMemsetAsync(ecol.p, 0, ((size_t)nent + 64 * 64) * 4, s));
+  GM_TRY_HIP(hipMemsetAsync(erow.p, 0, ((size_t)nent + 64 * 64) * 2, s));
+  GM_TRY_HIP(hipMemsetAsync(toff.p, 0xff, (nseg + 2) * 4, s));
+  GM_TRY_HIP(hipMemsetAsync(steps.p, 0, (size_t)8 * nsteps * 4 + 256, s));
+  hipLaunchKernelGGL(k_blocked_fill, dim3(grid_for(nent)), dim3(kT), 0, s, (const unsigned long long*)k_out.as<unsigned long long>(), (const uint32_t*)v_out.as<uint32_t>(), nent,
+                     (const int32_t*)dealt.as<int32_t>(), rowptr, colidx, TS, ecol.as<uint32_t>(), erow.as<uint16_t>(), toff.as<uint32_t>());
+  GM_TRY_HIP(hipGetLastError());
+  {
+    std::vector<uint32_t> h(nseg + 1);
+    GM_TRY_HIP(hipMemcpyAsync(h.data(), toff.p, nseg * 4, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    h[nseg] = (uint32_t)nent;
+    for (size_t b = nseg; b-- > 0;) if (h[b] == 0xffffffffu) h[b] = h[b + 1];
+    GM_TRY_HIP(hipMemcpyAsync(toff.p, h.data(), (nseg + 1) * 4, hipMemcpyHostToDevice, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+  }
+  k_out.free(); v_out.free();
+  hipLaunchKernelGGL(k_blocked_wave_offsets, dim3((unsigned)((nseg * 17 + kT - 1) / kT)), dim3(kT), 0, s, (const uint32_t*)toff.as<uint32_t>(), (const uint16_t*)erow.as<uint16_t>(), nseg,
+                     woff.as<uint32_t>());
+  GM_TRY_HIP(hipGetLastError());
+  GM_TRY_HIP(hipStreamSynchronize(s));
+  gm_blocked_t& B = g->blocked;
+  B.nrows = (int32_t)ns; B.nblocks = nblk; B.nslices = TS; B.short_row = whole->view.short_row; B.nsteps = nsteps; B.nentries = nent;
+  B.ecol = (const uint32_t*)ecol.release(); B.erow = (const uint16_t*)erow.release(); B.woff = (const uint32_t*)woff.release();
+  B.row_of = (const int32_t*)dealt.release(); B.step_count = (uint32_t*)steps.release();
+  return GM_OK;
+}
+
 static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* idx_sorted, unsigned long long kept,
                        const void* d_val, hipStream_t s, const CsrOwned* whole) {
   const int T = g->ntiles;
@@ -1533,6 +1706,7 @@ static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t*
   }
   GM_TRY_HIP(hipStreamSynchronize(s));
   if (g_sweep_slices != 0 && (rc = build_sweep(g, whole, s))) return rc;
+  if (g_sweep_slices != 0 && (rc = build_blocked(g, whole, s))) return rc;
   return GM_OK;
 }
 
@@ -1639,7 +1813,21 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     // (gm_graph_sweep: the order is cut k times finer than the tiles, a tile = k consecutive slices; about 1.3 MiB of live
     // messages per slice -- measured with the sweep's prototype, tools/sell_bench.hip: RMAT-26 (125 MiB) 64 / 80 / 96 / 128 slices
     // 2.17 / 2.09 / 2.05 / 2.15 ms for the swept rows, RMAT-25 (65 MiB) 32 / 64: 1.02 / 0.94 ms, RMAT-24 (34 MiB) 16 / 32 / 64: 0.79 / 0.80 / 0.92)
-    int want_slices = g_sweep_slices >= 8 ? g_sweep_slices : (int)(mib_live / 1.3 + 0.5);
+    // (a graph WITHOUT skew -- next to no edge on a vertex of more than 2 x short_row edges: the shape of the reference's test/generator.h --
+    // is multiplied by the column-blocked stream of its short rows, k_spmv_blocked, whose synchronised steps want fewer, larger slices:
+    // uniform 2^26, 32 / 48 / 56 / 64 / 72 / 96 / 128 slices: 12.9 / 10.5 / 9.7 / 9.0 / 10.0 / 10.1 / 12.0 ms; 2^25, 32 / 99: 4.24 / 4.71 -- about 4 MiB each)
+    bool no_skew = false;
+    if (g_sweep_slices == 1 && g_blocked_rows >= 0 && !keeps_values && nnz > 0) {
+      DevBuf mass;
+      if ((rc = mass.alloc(16))) return rc;
+      GM_TRY_HIP(hipMemsetAsync(mass.p, 0, 16, s));
+      hipLaunchKernelGGL(k_degree_mass, dim3(1024), dim3(kT), 0, s, deg.as<uint32_t>(), nv, (uint32_t)(2 * g_short_row), mass.as<unsigned long long>());
+      unsigned long long hm[2] = {0, 0};
+      GM_TRY_HIP(hipMemcpyAsync(hm, mass.p, 16, hipMemcpyDeviceToHost, s));
+      GM_TRY_HIP(hipStreamSynchronize(s));
+      no_skew = hm[0] > 0 && hm[1] * 10ull <= hm[0];
+    }
+    int want_slices = g_sweep_slices >= 8 ? g_sweep_slices : (int)(mib_live / (no_skew ? 4.0 : 1.3) + 0.5);
     want_slices = std::max(16, std::min(GM_MAX_SLICES, want_slices));
     // (an adjacency the sweep cannot take -- edge values that are not 4 bytes wide -- is only ever walked tile by tile: its order stays
     // degree-ranked inside a whole TILE, so that the tile kernels' LDS hot sets hold the tile's busiest vertices, not one slice's)
@@ -1747,6 +1935,7 @@ static void free_csr(CsrOwned* c) {
 
 static void free_tiles(gm_graph* g) {
   free_sweep(g);
+  free_blocked(g);
   if (g->out_tiles) {
     for (int t = 0; t < g->ntiles; t++) free_csr(&g->out_tiles[t]);
     delete[] g->out_tiles;
@@ -1776,6 +1965,11 @@ int gm_graph_sweep(const gm_graph_t* g, gm_sweep_t* out) {
   return GM_OK;
 }
 
+int gm_graph_blocked(const gm_graph_t* g, gm_blocked_t* out) {
+  if (!g || !out) { gm::set_error("gm_graph_blocked: null argument"); return GM_ERR_INVALID; }
+  *out = g->blocked;
+  return GM_OK;
+}
 int gm_graph_tile(const gm_graph_t* g, int direction, int tile, gm_csr_t* out, const uint32_t** d_prev_bits) {
   if (!g || !out) { gm::set_error("gm_graph_tile: null argument"); return GM_ERR_INVALID; }
   if (direction != GM_DIR_OUT || !g->out_tiles || tile < 0 || tile >= g->ntiles) {

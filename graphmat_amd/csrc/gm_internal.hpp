@@ -93,6 +93,7 @@ struct gm_graph {
   int32_t slice_base[GM_MAX_SLICES + 2];
   gm_sweep_t sweep;             // device arrays owned by the graph (nrows = 0: not built)
   int32_t* d_slice_base;
+  gm_blocked_t blocked;         // the short rows of a graph without skew as a column-blocked stream (nrows = 0: not built)
   // native RCCL exchange (gm_dist.hip): state behind xfn/xctx when gm_graph_use_rccl installed it
   int xcaps;                    // GM_XCAP_* of the installed exchange
   void* native_xchg;

@@ -20,7 +20,7 @@
 
 namespace gm {
 
-extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance, g_own_wave_row, g_sort_tile_lists, g_sweep_slices, g_sweep_acc_limit, g_sweep_long_limit, g_sweep_long_row, g_sweep_fold_share, g_sweep_border_factor;
+extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance, g_own_wave_row, g_sort_tile_lists, g_sweep_slices, g_sweep_acc_limit, g_sweep_long_limit, g_sweep_long_row, g_sweep_fold_share, g_sweep_border_factor, g_blocked_rows;
 static int g_force_ordered = 0;
 
 // ---------------- PageRank (reference: src/PageRank.cpp:34-112) ----------------------------
@@ -746,8 +746,9 @@ static const EngineKey kEngineKeys[] = {
   {"two_stage_head_permille", 15, 900, 100, 990},
   {"giant_stream", 16, 1, 0, 2},
   {"sweep_form", 17, 0, 0, 15},
+  {"blocked_form", 18, 2, 0, 31},
 };
-static_assert(offsetof(gm_engine_options_t, sweep_form) == 17 * sizeof(int32_t), "kEngineKeys follows the field order");
+static_assert(offsetof(gm_engine_options_t, blocked_form) == 18 * sizeof(int32_t), "kEngineKeys follows the field order");
 static bool engine_value_ok(const EngineKey& k, int v) {
   if (v < k.lo || v > k.hi) return false;
 #ifndef GRAPHMAT_ABLATION
@@ -831,6 +832,7 @@ int gm_reset_options(void) {
   gm::g_own_wave_row = 4096;
   gm::g_sort_tile_lists = 1;
   gm::g_sweep_slices = 1;
+  gm::g_blocked_rows = 0;
   gm::g_sweep_acc_limit = GM_SWEEP_ACC_ROWS;
   gm::g_sweep_long_limit = GM_SWEEP_LONG_SLOTS;
   gm::g_sweep_long_row = 0;
@@ -861,6 +863,7 @@ int gm_set_option(const char* key, int value) {
   // (0: no slices, no sweep; 1: automatic slice count; 8 .. GM_MAX_SLICES: about that many slices)
   if (key && !strcmp(key, "sweep_slices") && (value == 0 || value == 1 || (value >= 8 && value <= GM_MAX_SLICES))) { gm::g_sweep_slices = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_acc_rows") && value >= 1 && value <= GM_SWEEP_ACC_ROWS) { gm::g_sweep_acc_limit = value; return GM_OK; }
+  if (key && !strcmp(key, "blocked_rows") && value >= -1 && value <= 1) { gm::g_blocked_rows = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_long_row") && value >= 0 && value <= 8191) { gm::g_sweep_long_row = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_border_factor") && value >= 1 && value <= 64) { gm::g_sweep_border_factor = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_fold_share") && value >= 0 && value <= 100) { gm::g_sweep_fold_share = value; return GM_OK; }

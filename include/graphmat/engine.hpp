@@ -1280,14 +1280,18 @@ class Run {
       Launch La = L;
       La.aux = nullptr;
       La.tiled_untiled_pass = true;
-      const int where = gterms != nullptr ? 2 : (opt.sweep_form & 3);
+      // (a graph with few busy rows and a column-blocked stream of its short rows, graphmat_hip.h: gm_blocked_t: the stream instead of the
+      // row-blocks, on the main stream -- it wants the whole chip, like the sweep)
+      gm_blocked_t bl;
+      const bool shorts_blocked = blocked_usable(acc, &bl);
+      const int where = shorts_blocked ? 3 : (gterms != nullptr ? 2 : (opt.sweep_form & 3));  // (3: behind everything, below)
       if (where == 1) { La.s = aux.s; La.timer = nullptr; }
       auto short_rows = [&]() {
         if (As.nblk <= 0) return;
         launch_spmv_vp<P, T, U, V, E>(use_vp, La, pa, As, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
         if (where == 1) { GM_HIP_OK(hipEventRecord(aux.join, aux.s)); aux.pending = true; }
       };
-      if (where != 2) short_rows();
+      if (where < 2) short_rows();
       // the pool of LDS words is split between the slice's hot entries and the long rows' stage: a stage that takes the
       // largest block in one round where that leaves most of the pool to the hot set
       int stage = 64;
@@ -1325,9 +1329,73 @@ class Run {
       if (aux.pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
       aux.keep = aux.forked = aux.pending = false;
       timer.mark(TAG_GIANT);  // (the multiply ends when the auxiliary stream has joined: the wait is charged to the giant rows' passes)
+      if (shorts_blocked) {  // (with the chip to itself: its workgroups walk the slices in step only while all of them are resident)
+        launch_blocked(pa, bl);
+        st.spmv_launches += 1;
+        timer.mark(TAG_ROWBLOCK);
+      }
       check_probed(pa, Aout, Aout.rowbits, nullptr, acc, ybits, true);
     } else {
       (void)pa; (void)acc; (void)sw;
+    }
+  }
+
+  // Can this run's pull multiply of the OUT adjacency take the column-blocked stream of the short rows (graphmat_hip.h: gm_blocked_t;
+  // kernels.hpp: k_spmv_blocked)?  The conditions of the sweep; the structure exists only for graphs without skew that keep no edge values.
+  bool blocked_usable(int acc, gm_blocked_t* bl) {
+    if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
+      if (use_vp || xq == nullptr || xb != nullptr || d_want != nullptr || program_row_filter<P>::enabled || (acc & dev::ACC_READ_PREV)) return false;
+      if (!(rk == REDUCE_ORDERED || rk == REDUCE_F32_ADD || rk == REDUCE_COMMUTATIVE)) return false;
+      if (opt.debug_flags & dev::DBG_NO_TILES) return false;
+      if (Aout.vals != nullptr || gm_graph_blocked(g, bl) != GM_OK || bl->nrows <= 0 || bl->short_row != Aout.short_row) return false;
+      return true;
+    } else {
+      (void)acc; (void)bl;
+      return false;
+    }
+  }
+  // the launch of k_spmv_blocked on the run's stream (the kernel wants the whole chip: 256 workgroups x 128 KB of LDS)
+  void launch_blocked(const dev::ProgArg<P>& pa, const gm_blocked_t& bl) {
+    if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
+      static int cus = 0;  // (per instantiation: the kernels' 128 KB of dynamic LDS have to be allowed once)
+      if (cus == 0) {
+        GM_HIP_OK(hipFuncSetAttribute((const void*)&dev::k_spmv_blocked<P, T, U, V, E, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_BLOCKED_ROWS * 4));
+        GM_HIP_OK(hipFuncSetAttribute((const void*)&dev::k_spmv_blocked<P, T, U, V, E, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_BLOCKED_ROWS * 4));
+        int dev_id = 0, n = 0;
+        GM_HIP_OK(hipGetDevice(&dev_id));
+        GM_HIP_OK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev_id));
+        cus = n > 0 ? n : 1;
+      }
+      // workgroups that are not all resident at once (a partitioned or masked device) cannot walk the slices in step: they are not asked to
+      const int window = cus >= 256 ? (opt.blocked_form & 15) : 0;
+      if (window > 0) GM_HIP_OK(hipMemsetAsync(bl.step_count, 0, (size_t)8 * bl.nsteps * 4, s));
+      if (opt.blocked_form & 16)
+        hipLaunchKernelGGL((dev::k_spmv_blocked<P, T, U, V, E, 4>), dim3(256), dim3(1024), GM_BLOCKED_ROWS * 4, s, pa, bl.ecol, bl.erow, bl.woff, bl.nslices, bl.nblocks, bl.row_of,
+                           xq, y, bl.step_count, bl.nsteps, window);
+      else
+        hipLaunchKernelGGL((dev::k_spmv_blocked<P, T, U, V, E, 2>), dim3(256), dim3(1024), GM_BLOCKED_ROWS * 4, s, pa, bl.ecol, bl.erow, bl.woff, bl.nslices, bl.nblocks, bl.row_of,
+                           xq, y, bl.step_count, bl.nsteps, window);
+    } else {
+      (void)pa; (void)bl;
+    }
+  }
+  // The OUT adjacency of a graph without skew: the short rows -- (nearly) all of it -- through the column-blocked stream, whatever rows
+  // are longer through the whole-graph CSR's wave / giant kernels in front of it.  The row sets are disjoint.
+  void multiply_out_blocked(const dev::ProgArg<P>& pa, int acc, const gm_blocked_t& bl) {
+    if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
+      gm_csr_t Ar = Aout;  // the rows above the short-row limit
+      Ar.nblk = 0;
+      if (Ar.nmid > 0 || Ar.ngiant > 0) {
+        Launch La = launch_ctx();
+        La.aux = nullptr;  // (few rows, if any: everything on the run's stream)
+        launch_spmv_vp<P, T, U, V, E>(use_vp, La, pa, Ar, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
+      }
+      launch_blocked(pa, bl);
+      st.spmv_launches += 1;
+      timer.mark(TAG_ROWBLOCK);
+      check_probed(pa, Aout, Aout.rowbits, nullptr, acc, ybits, true);
+    } else {
+      (void)pa; (void)acc; (void)bl;
     }
   }
 
@@ -1440,8 +1508,11 @@ class Run {
       if (dense_x && !multi && row_bits == nullptr && rk != REDUCE_LAST && dev::stageable<T>::value && !(opt.debug_flags & dev::DBG_NO_TILES))
         gm_graph_tiles(g, GM_DIR_OUT, &ntile);
       gm_sweep_t sw;
+      gm_blocked_t bl;
       if (dense_x && !multi && row_bits == nullptr && sweep_usable(acc, &sw)) {
         multiply_out_swept(pa, acc, sw);
+      } else if (dense_x && !multi && row_bits == nullptr && blocked_usable(acc, &bl)) {
+        multiply_out_blocked(pa, acc, bl);
       } else if (ntile > 1) {
         multiply_out_tiled(pa, ntile, acc);
       } else {

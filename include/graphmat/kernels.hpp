@@ -1782,6 +1782,115 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
   }
 }
 
+// ------------------------------------------------------------------------------------
+// The short rows of a graph WITHOUT skew as a column-blocked stream (graphmat_hip.h: gm_blocked_t; built by gm_graph.hip:
+// build_blocked; prototype and measurements: tools/blocked_bench.hip, profiles/r05_short_rows_blocked_stream_prototype.md --
+// uniform 16-out-regular 2^26: 9.9-11 ms against 21 ms for the row-blocks, whose every gather misses).
+// Workgroup b of a pass owns GM_BLOCKED_ROWS short rows and keeps their running values in LDS from the first slice to the last; the
+// grid's workgroups take the blocks of a pass side by side and walk the slices TOGETHER: a workgroup that has finished step (pass,
+// slice) adds itself to its XCD's counter for that step (workgroups are dealt round-robin over the 8 XCDs), and nobody starts the next
+// slice before all workgroups of the XCD have finished step + 1 - window -- the XCD's L2 then holds window + 1 slices of x whatever
+// the workgroups' pace.  The wait is bounded: a workgroup that never arrives costs locality, not progress.  A (block, slice)
+// segment's entries are in (row, CSR order) order; the 16 waves take equal shares cut at row borders (woff), so inside a slice no
+// two waves touch the same running value; lanes holding the same row form a run whose head lane reads the running value, folds
+// the run's products one after the other and writes it back: ascending native column order, the reference's.
+// Dense x, 2-operand programs, 4-byte messages and reductions, no edge values (E()).
+template <class P, class T, class U, class V, class E, int UB = 2>
+__global__ void __launch_bounds__(1024)
+k_spmv_blocked(ProgArg<P> pa, const uint32_t* __restrict__ ecol, const uint16_t* __restrict__ erow, const uint32_t* __restrict__ woff, int nslices, int nblk,
+               const int32_t* __restrict__ row_of, const T* __restrict__ x, U* __restrict__ y, unsigned int* __restrict__ step_count, int nsteps, int window) {
+  static_assert(sizeof(T) == 4 && sizeof(U) == 4, "4-byte messages and reductions");
+  extern __shared__ uint32_t s_bacc[];  // GM_BLOCKED_ROWS running values
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned int nwg = (gridDim.x + 7 - (blockIdx.x & 7)) >> 3;  // workgroups of this XCD
+  unsigned int* const mycnt = step_count + (size_t)(blockIdx.x & 7) * nsteps;
+  const int npass = (nblk + (int)gridDim.x - 1) / (int)gridDim.x;
+  V no_vp;
+  auto as_u = [](uint32_t raw) { U u; __builtin_memcpy(&u, &raw, 4); return u; };
+  auto raw_u = [](const U& u) { uint32_t r; __builtin_memcpy(&r, &u, 4); return r; };
+  for (int pass = 0; pass < npass; pass++) {
+    const int blk = pass * (int)gridDim.x + (int)blockIdx.x;
+    const bool has_blk = blk < nblk;  // (a workgroup without a block in the last pass still reports its steps)
+    uint32_t ws = 0, we = 0;
+    if (has_blk) { const uint32_t* wo = woff + ((size_t)blk * nslices) * 17 + wave; ws = wo[0]; we = wo[1]; }
+    uint32_t c[UB], r[UB];
+    uint32_t pre = ws;
+#pragma unroll
+    for (int u = 0; u < UB; u++) { c[u] = ecol[pre + u * 64 + lane]; r[u] = erow[pre + u * 64 + lane]; }  // (both arrays are padded behind the last entry)
+    for (int sl = 0; sl < nslices; sl++) {
+      uint32_t nws = 0, nwe = 0;
+      if (has_blk && sl + 1 < nslices) { const uint32_t* wo = woff + ((size_t)blk * nslices + sl + 1) * 17 + wave; nws = wo[0]; nwe = wo[1]; }  // (the next slice's range: requested now)
+      if (pre != ws && ws < we) {  // (an empty range in between: the batch requested ahead is not this slice's first)
+        pre = ws;
+#pragma unroll
+        for (int u = 0; u < UB; u++) { c[u] = ecol[pre + u * 64 + lane]; r[u] = erow[pre + u * 64 + lane]; }
+      }
+      for (uint32_t p0 = ws; p0 < we;) {
+        T m[UB];
+#pragma unroll
+        for (int u = 0; u < UB; u++) m[u] = x[c[u]];
+        // the next batch -- of this slice or the next -- is requested before this one is folded
+        const uint32_t np0 = p0 + 64 * UB;
+        const uint32_t nxt = np0 < we ? np0 : nws;
+        uint32_t nc[UB], nr[UB];
+#pragma unroll
+        for (int u = 0; u < UB; u++) { nc[u] = ecol[nxt + u * 64 + lane]; nr[u] = erow[nxt + u * 64 + lane]; }
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+          const bool valid = p0 + u * 64 + lane < we;
+          const uint32_t id = valid ? (r[u] & 0x7fffu) : (0x10000u + lane);
+          const uint32_t prev = __shfl_up(id, 1);
+          const bool head = valid && (lane == 0 || id != prev);
+          const unsigned long long H = __ballot(head) | __ballot(!valid);  // (an entry past the range ends a run as a head would)
+          const unsigned long long above = lane == 63 ? 0ull : (H >> (lane + 1));
+          const int runlen = above ? (__builtin_ctzll(above) + 1) : (64 - lane);
+          U res;
+          __builtin_memset(&res, 0, 4);
+          if (valid) p.P::process_message(m[u], E(), no_vp, res);
+          const uint32_t rraw = raw_u(res);
+          U acc = res;
+          if (head && !(r[u] & 0x8000u)) { acc = as_u(s_bacc[id]); p.P::reduce_function(acc, res); }  // SPMV.h:54-59: c = a; reduce(c, b)
+          for (int k = 1; __ballot(head && k < runlen); k++) {
+            const U t = as_u(__shfl(rraw, (lane + k) & 63));
+            if (head && k < runlen) p.P::reduce_function(acc, t);
+          }
+          if (head) s_bacc[id] = raw_u(acc);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; u++) { c[u] = nc[u]; r[u] = nr[u]; }
+        pre = nxt;
+        p0 = np0;
+      }
+      __syncthreads();  // the slice is folded: the next one's shares cut the rows differently
+      if (window > 0) {
+        // ONE lane of the workgroup reports and waits, with a pause between two looks (all waves of an XCD polling one line of the
+        // L2 keep the reports themselves from getting through); the barrier hands the result to the other waves
+        const int step = pass * nslices + sl;
+        if (threadIdx.x == 0) {
+          __hip_atomic_fetch_add(&mycnt[step], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int need = step + 1 - window;
+          if (need >= 0)
+            for (int tries = 0; tries < 20000; tries++) {
+              if (__hip_atomic_load(&mycnt[need], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nwg) break;
+              __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        __syncthreads();
+      }
+      ws = nws; we = nwe;
+    }
+    if (has_blk) {
+      const int32_t* __restrict__ ro = row_of + (size_t)blk * GM_BLOCKED_ROWS;
+      for (int i = threadIdx.x; i < GM_BLOCKED_ROWS; i += 1024) {
+        const int row = ro[i];  // (-1: past the last short row; every short row has an edge: its value was assigned)
+        if (row >= 0) y[row] = as_u(s_bacc[i]);
+      }
+    }
+    __syncthreads();  // the next pass's first messages are assigned into the same words
+  }
+}
+
 // a=b programs, the wanted rows among a wave's 64 list entries: 64 / LPR rows at a time, LPR lanes each.
 // A bottom-up level is a chain of dependent loads per row (row pointers, column ids, summary bit, presence bit, the
 // winner's message) and most rows end in their last few edges, so what counts is how many rows a wave has in flight:

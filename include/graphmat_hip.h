@@ -326,6 +326,37 @@ typedef struct {
 #define GM_SWEEP_MAX_STAGE 14336 /* largest stage (words): larger blocks are staged in chunks */
 int gm_graph_sweep(const gm_graph_t* g, gm_sweep_t* out);
 int gm_graph_tile(const gm_graph_t* g, int direction, int tile, gm_csr_t* out, const uint32_t** d_prev_bits);
+/* ---- the short rows of a graph WITHOUT skew as a column-blocked stream (round 5, last session) -----------------------------
+ * When nearly every edge of a large single-shard graph sits in a short row (at most GM_SHORT_ROW edges: no vertex is hot, every
+ * gather of the row-block kernel misses -- the shape of the reference's test/generator.h:73-105) the library keeps the short
+ * rows' edges a second time, laid out for ONE persistent kernel (kernels.hpp: k_spmv_blocked): the short rows, in device order,
+ * are cut into BLOCKS of GM_BLOCKED_ROWS rows whose running values fill a workgroup's LDS; the 256 workgroups take the blocks of a
+ * PASS side by side and walk the graph's slices (gm_sweep_t.slice_base: ascending native ranges) together -- a per-XCD counter per
+ * (pass, slice) step keeps them within `window` slices of each other (bounded wait), so the slice everybody gathers from is L2
+ * resident.  A (block, slice) SEGMENT holds its entries row after row, a row's entries in CSR order (ascending native column):
+ * a row folded segment by segment is folded in the reference's order.  Entry i: ecol[i] = device column, erow[i] = row inside the
+ * block | 0x8000 for the row's first edge (its message is assigned, SPMV.h:54-59).  woff[(block * nslices + slice) * 17 + w] = where
+ * wave w of 16 starts inside the segment (equal shares moved to the next row border; [16] = the segment's end).
+ * row_of[block * GM_BLOCKED_ROWS + k] = the row (relative to row_lo) of the block's k-th row.  Graphs that keep edge values are
+ * not laid out this way.  gm_set_option("blocked_rows", 0 = automatic (>= 90 % of the edges in short rows, >= 48 MiB of live
+ * 4-byte messages), 1 = whenever the graph has slices, -1 = never).  nrows = 0: not built.  Prototype and measurements:
+ * tools/blocked_bench.hip, profiles/r05_short_rows_blocked_stream_prototype.md. */
+typedef struct gm_blocked {
+  int32_t nrows;      /* short rows covered (every row of 1 .. short_row edges) */
+  int32_t nblocks;    /* ceil(nrows / GM_BLOCKED_ROWS) */
+  int32_t nslices;
+  int32_t short_row;
+  int32_t nsteps;     /* passes * nslices: words per XCD of step_count */
+  int32_t reserved_;
+  int64_t nentries;
+  const uint32_t* ecol;
+  const uint16_t* erow;
+  const uint32_t* woff;
+  const int32_t* row_of;
+  uint32_t* step_count; /* 8 * nsteps words: workgroups of XCD k that have finished step t (cleared by the engine before a launch) */
+} gm_blocked_t;
+#define GM_BLOCKED_ROWS 32768
+int gm_graph_blocked(const gm_graph_t* g, gm_blocked_t* out);
 /* rowbits of GM_DIR_OUT | rowbits of GM_DIR_IN (graphs built with both directions; ALL_EDGES programs) */
 int gm_graph_rowbits_all(const gm_graph_t* g, const uint32_t** d_bits);
 /* Rebuild g's adjacency in the device order of `like` (same vertex count and nparts, single
@@ -548,7 +579,10 @@ typedef struct {
                                      in front of the sweep (default), 1 on the auxiliary stream behind the giant rows' passes (next to the sweep),
                                      2 on the main stream behind the sweep; bit 2 = the long rows staged in rounds of 1024 entries (tests); bit 3 = the
                                      giant rows gather for themselves on the auxiliary stream (k_giant_terms) instead of the sweep gathering for them */
-  int32_t reserved_[14];
+  int32_t blocked_form;           /* the column-blocked stream of the short rows (engine.hpp: multiply_out_blocked): bits 0-3 = window -- a workgroup starts a
+                                     slice when all workgroups of its XCD have finished the one `window` slices back (default 2; 0 = workgroups not
+                                     kept in step); bit 4 = batches of 4 x 64 entries instead of 2 x 64 */
+  int32_t reserved_[13];
 } gm_engine_options_t;
 /* the options a run on `g` uses (g may be NULL: the process defaults) */
 int gm_graph_engine_options(const gm_graph_t* g, gm_engine_options_t* out);

@@ -418,3 +418,96 @@ def test_row_stationary_sweep_bit_exact(env, scale, tiles, threads):
             assert seen_sets[0] > 1  # (several launches were exercised)
     finally:
         api._lib.check(L.gm_reset_options())
+
+
+def _blocked_info(g):
+    import ctypes as C
+    from graphmat_amd import _lib
+    bl = _lib.Blocked()
+    assert g.L.gm_graph_blocked(g.h, C.byref(bl)) == 0
+    return bl
+
+
+@pytest.mark.parametrize("kind,scale,tiles,threads", [("uniform", 14, 3, 1), ("uniform", 16, 4, 2), ("rmat", 15, 3, 1), ("rmat", 16, 4, 3), ("rmat+sweep", 15, 3, 2), ("rmat+sweep", 16, 4, 1)])
+def test_blocked_short_rows_bit_exact(env, kind, scale, tiles, threads):
+    """The column-blocked stream of the short rows (graphmat_hip.h gm_blocked_t, kernels.hpp k_spmv_blocked): forced on small graphs --
+    a graph without skew (every row short: the whole multiply goes through it), RMAT with the sweep switched off (the rows above
+    the short-row limit then take the wave / giant kernels in front of it) and RMAT with the sweep (medium rows swept, giant rows' passes, then the stream) --, its structure covers exactly the rows of 1 .. 64 edges, and
+    PageRank through it has the oracle's bits, which are also those of the row-blocks (blocked_rows -1)."""
+    api, ob = env
+    from graphmat_amd import _lib
+    L = _lib.lib()
+    if kind == "uniform":
+        nv, s, d, v = gen.uniform_out_regular_edges(1 << scale, 16, seed=3)
+    else:
+        nv, s, d, v = gen.rmat_edges(scale, 16, 7)
+    og = ob.OracleGraph(nv, s, d, None, ref_threads=threads)
+    odeg = og.degree()
+    opr, _, _ = og.pagerank(5, degree=odeg)
+    try:
+        for mode in (1, -1):
+            api._lib.check(L.gm_reset_options())
+            api._lib.check(L.gm_set_option(b"blocked_rows", mode))
+            if kind == "rmat":  # (debug_flags 16 = no auxiliary stream: the sweep, which needs one, is not taken)
+                api._lib.check(L.gm_set_option(b"debug_flags", 16))
+            g = api.Graph(nv, s, d, None, ref_threads=threads, keep_values=False, col_tiles=tiles)
+            assert g.col_tiles > 1
+            bl = _blocked_info(g)
+            rp, ci, _ = g.csr_to_host(api.GM_DIR_OUT)
+            rowlen = np.diff(rp)
+            short = np.nonzero((rowlen >= 1) & (rowlen <= 64))[0]
+            if mode == 1:
+                assert bl.nrows == len(short) and bl.nentries == int(rowlen[short].sum()) and bl.nblocks == -(-len(short) // 32768) and bl.nslices >= 2
+                row_of = np.zeros(bl.nblocks * 32768, np.int32)
+                api.copy_from_device(row_of, bl.row_of)
+                # the short rows are dealt over the blocks in runs of 64 (run j -> block j % nblocks)
+                i_ = np.arange(bl.nrows); j_ = i_ >> 6
+                slot_of = (j_ % bl.nblocks) * 32768 + (j_ // bl.nblocks) * 64 + (i_ & 63)
+                assert (row_of[slot_of] == short).all() and int((row_of >= 0).sum()) == bl.nrows
+                ecol = np.zeros(bl.nentries, np.uint32); erow = np.zeros(bl.nentries, np.uint16)
+                api.copy_from_device(ecol, bl.ecol); api.copy_from_device(erow, bl.erow)
+                assert int((erow >> 15).sum()) == bl.nrows  # one "first edge" per row
+                woff = np.zeros((bl.nblocks * bl.nslices + 1) * 17, np.uint32)
+                api.copy_from_device(woff, bl.woff)
+                w = woff[: bl.nblocks * bl.nslices * 17].reshape(-1, 17)
+                assert (np.diff(w.astype(np.int64), axis=1) >= 0).all() and w[0, 0] == 0 and w[-1, 16] == bl.nentries and (w[1:, 0] == w[:-1, 16]).all()
+                # a row's entries, in stream order, are its CSR columns in CSR order
+                for r in np.random.default_rng(2).choice(bl.nrows, size=40, replace=False):
+                    b, k = int(slot_of[r]) // 32768, int(slot_of[r]) % 32768
+                    seg = slice(int(w[b * bl.nslices, 0]), int(w[(b + 1) * bl.nslices - 1, 16]))
+                    mine = np.nonzero((erow[seg] & 0x7fff) == k)[0]
+                    row = int(short[r])
+                    assert (ecol[seg][mine] == ci[rp[row]: rp[row + 1]].astype(np.uint32)).all()
+                    assert (erow[seg][mine][0] >> 15) == 1 and ((erow[seg][mine][1:] >> 15) == 0).all()
+            else:
+                assert bl.nrows == 0
+            pr, deg, it = g.pagerank(5)
+            assert (deg == odeg).all() and it == 5
+            assert (f32bits(pr) == f32bits(opr)).all(), "%s scale %d blocked_rows %d" % (kind, scale, mode)
+            g.close()
+    finally:
+        api._lib.check(L.gm_reset_options())
+
+
+def test_blocked_short_rows_several_passes_equal_the_row_blocks(env):
+    """More short rows than one pass of 256 workgroups x 32768 holds (uniform 2^24: 512 blocks, two passes): the bits of the
+    row-block kernel (blocked_rows -1), which the small cases above tie to the oracle."""
+    import torch
+    api, _ = env
+    from graphmat_amd import _lib
+    L = _lib.lib()
+    nv, src, dst, _ = api.uniform_on_device(24, 16, 1)
+    res = {}
+    try:
+        for mode in (1, -1):
+            api._lib.check(L.gm_reset_options())
+            api._lib.check(L.gm_set_option(b"blocked_rows", mode))
+            g = api.Graph(nv, src, dst, None, keep_values=False)
+            bl = _blocked_info(g)
+            assert (bl.nrows > 256 * 32768 and bl.nblocks > 256) if mode == 1 else bl.nrows == 0
+            pr, deg, it = g.pagerank(4)
+            res[mode] = pr.copy()
+            g.close()
+    finally:
+        api._lib.check(L.gm_reset_options())
+    assert (f32bits(res[1]) == f32bits(res[-1])).all()
