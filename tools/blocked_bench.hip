@@ -279,7 +279,10 @@ static void build_and_run(const int32_t* src, const int32_t* dst, int64_t ne, in
 // side and walk the slices TOGETHER: a workgroup that has finished slice s tells its XCD's counter so, and nobody starts slice
 // s + 1 before every workgroup of the XCD has finished slice s + 1 - window -- the L2 then holds `window` + 1 slices of x, whatever the
 // workgroups' pace.  The wait is bounded: a workgroup that never arrives costs locality, not progress.
-constexpr int kRBW = 32768, kRBWBits = 15;
+#ifndef BB_WAVES
+#define BB_WAVES 16  // waves per workgroup (-DBB_WAVES=8: two workgroups of 512 threads and 16384 rows per CU, out of phase with each other)
+#endif
+constexpr int kWV = BB_WAVES, kRBW = kWV * 2048, kRBWBits = kWV == 16 ? 15 : 14, kWGT = kWV * 64, kGrid = 256 * (16 / kWV);
 __global__ void k_entries_wg(const unsigned long long* __restrict__ key, int64_t n, int cbits, int S, const uint32_t* __restrict__ rowmin,
                              uint32_t* __restrict__ ecol, uint16_t* __restrict__ erow, uint32_t* __restrict__ toff) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -298,12 +301,12 @@ __global__ void k_entries_wg(const unsigned long long* __restrict__ key, int64_t
 // where the 16 waves of a workgroup start inside a (block, slice) segment: equal shares, moved forward to the next row border
 __global__ void k_wave_offsets(const uint32_t* __restrict__ toff, const uint16_t* __restrict__ erow, size_t nseg, uint32_t* __restrict__ woff) {
   const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (t >= nseg * 17) return;
-  const size_t seg = t / 17;
-  const int w = (int)(t % 17);
+  if (t >= nseg * (kWV + 1)) return;
+  const size_t seg = t / (kWV + 1);
+  const int w = (int)(t % (kWV + 1));
   const uint32_t a = toff[seg], e = toff[seg + 1];
-  uint32_t p = a + (uint32_t)(((unsigned long long)(e - a) * (unsigned)w) / 16u);
-  if (w == 16) p = e;
+  uint32_t p = a + (uint32_t)(((unsigned long long)(e - a) * (unsigned)w) / (unsigned)kWV);
+  if (w == kWV) p = e;
   while (p > a && p < e && (erow[p] & 0x7fffu) == (erow[p - 1] & 0x7fffu)) p++;
   woff[t] = p;
 }
@@ -323,10 +326,10 @@ __global__ void __launch_bounds__(1024) k_blocked_wg(const uint32_t* __restrict_
     const int blk = pass * gridDim.x + blockIdx.x;
     const bool has = blk < nblk;
     uint32_t ws = 0, we = 0;
-    if (has) { const uint32_t* wo = woff + ((size_t)blk * S) * 17 + wave; ws = wo[0]; we = wo[1]; }
+    if (has) { const uint32_t* wo = woff + ((size_t)blk * S) * (kWV + 1) + wave; ws = wo[0]; we = wo[1]; }
     for (int s = 0; s < S; s++) {
       uint32_t nws = 0, nwe = 0;
-      if (has && s + 1 < S) { const uint32_t* wo = woff + ((size_t)blk * S + s + 1) * 17 + wave; nws = wo[0]; nwe = wo[1]; }  // (the next slice's range: requested now)
+      if (has && s + 1 < S) { const uint32_t* wo = woff + ((size_t)blk * S + s + 1) * (kWV + 1) + wave; nws = wo[0]; nwe = wo[1]; }  // (the next slice's range: requested now)
       for (uint32_t p0 = ws; p0 < we; p0 += 64 * U) {
         uint32_t c[U], r[U];
         float m[U];
@@ -372,7 +375,7 @@ __global__ void __launch_bounds__(1024) k_blocked_wg(const uint32_t* __restrict_
     }
     if (has) {
       const int r0 = blk * kRBW;
-      for (int i = threadIdx.x; i < kRBW; i += 1024) if (r0 + i < nrows) y[r0 + i] = acc[i];
+      for (int i = threadIdx.x; i < kRBW; i += kWGT) if (r0 + i < nrows) y[r0 + i] = acc[i];
     }
     __syncthreads();
   }
@@ -383,9 +386,9 @@ __global__ void __launch_bounds__(1024) k_blocked_wg(const uint32_t* __restrict_
 // slice or the next -- are requested before the current batch is folded; wave 0 reports the slice done, every wave paces itself.
 __global__ void k_wave_offsets_by_row(const uint32_t* __restrict__ toff, const uint16_t* __restrict__ erow, size_t nseg, uint32_t* __restrict__ woff) {
   const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (t >= nseg * 17) return;
-  const size_t seg = t / 17;
-  const uint32_t w = (uint32_t)(t % 17);
+  if (t >= nseg * (kWV + 1)) return;
+  const size_t seg = t / (kWV + 1);
+  const uint32_t w = (uint32_t)(t % (kWV + 1));
   const uint32_t a = toff[seg], e = toff[seg + 1];
   uint32_t lo = a, hi = e;  // first entry whose local row is >= w * 2048
   while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if ((uint32_t)(erow[mid] & 0x7fffu) >= w * 2048u) hi = mid; else lo = mid + 1; }
@@ -407,14 +410,14 @@ __global__ void __launch_bounds__(1024) k_blocked_wg2(const uint32_t* __restrict
     const int blk = pass * gridDim.x + blockIdx.x;
     const bool has = blk < nblk;
     uint32_t ws = 0, we = 0;
-    if (has) { const uint32_t* wo = woff + ((size_t)blk * S) * 17 + wave; ws = wo[0]; we = wo[1]; }
+    if (has) { const uint32_t* wo = woff + ((size_t)blk * S) * (kWV + 1) + wave; ws = wo[0]; we = wo[1]; }
     uint32_t c[U], r[U];
     uint32_t pre = ws;
 #pragma unroll
     for (int u = 0; u < U; u++) { c[u] = ecol[pre + u * 64 + lane]; r[u] = erow[pre + u * 64 + lane]; }
     for (int s = 0; s < S; s++) {
       uint32_t nws = 0, nwe = 0;
-      if (has && s + 1 < S) { const uint32_t* wo = woff + ((size_t)blk * S + s + 1) * 17 + wave; nws = wo[0]; nwe = wo[1]; }
+      if (has && s + 1 < S) { const uint32_t* wo = woff + ((size_t)blk * S + s + 1) * (kWV + 1) + wave; nws = wo[0]; nwe = wo[1]; }
       if (pre != ws && ws < we) {
         pre = ws;
 #pragma unroll
@@ -496,7 +499,7 @@ static void run_wg2(const char* what, const uint32_t* ecol, const uint16_t* erow
   float best = 1e9f, sum = 0.f;
   for (int it = 0; it < reps + 1; it++) {
     OK(hipEventRecord(ev0, 0));
-    hipLaunchKernelGGL((k_blocked_wg2<U, BARRIER>), dim3(256), dim3(1024), lds, 0, ecol, erow, woff, S, nblk, x, y, nrows, cnt, window, (unsigned int)it);
+    hipLaunchKernelGGL((k_blocked_wg2<U, BARRIER>), dim3(kGrid), dim3(kWGT), lds, 0, ecol, erow, woff, S, nblk, x, y, nrows, cnt, window, (unsigned int)it);
     OK(hipEventRecord(ev1, 0));
     OK(hipEventSynchronize(ev1));
     float ms; OK(hipEventElapsedTime(&ms, ev0, ev1));
@@ -522,7 +525,7 @@ static void run_wg(const char* what, const uint32_t* ecol, const uint16_t* erow,
   float best = 1e9f, sum = 0.f;
   for (int it = 0; it < reps + 1; it++) {
     OK(hipEventRecord(ev0, 0));
-    hipLaunchKernelGGL((k_blocked_wg<U, NT>), dim3(256), dim3(1024), lds, 0, ecol, erow, woff, S, nblk, x, y, nrows, cnt, window, (unsigned int)it);
+    hipLaunchKernelGGL((k_blocked_wg<U, NT>), dim3(kGrid), dim3(kWGT), lds, 0, ecol, erow, woff, S, nblk, x, y, nrows, cnt, window, (unsigned int)it);
     OK(hipEventRecord(ev1, 0));
     OK(hipEventSynchronize(ev1));
     float ms; OK(hipEventElapsedTime(&ms, ev0, ev1));
@@ -546,7 +549,7 @@ static void build_and_run_wg(const int32_t* src, const int32_t* dst, int64_t ne,
   const int nblk = (nrows + kRBW - 1) / kRBW;
   const size_t nseg = (size_t)nblk * S;
   uint32_t *ecol, *toff, *woff; uint16_t* erow;
-  OK(hipMalloc(&ecol, ((size_t)nsel + 64 * 64) * 4)); OK(hipMalloc(&erow, ((size_t)nsel + 64 * 64) * 2)); OK(hipMalloc(&toff, (nseg + 2) * 4)); OK(hipMalloc(&woff, (nseg + 1) * 17 * 4));
+  OK(hipMalloc(&ecol, ((size_t)nsel + 64 * 64) * 4)); OK(hipMalloc(&erow, ((size_t)nsel + 64 * 64) * 2)); OK(hipMalloc(&toff, (nseg + 2) * 4)); OK(hipMalloc(&woff, (nseg + 1) * (kWV + 1) * 4));
   OK(hipMemset(ecol, 0, ((size_t)nsel + 64 * 64) * 4)); OK(hipMemset(erow, 0, ((size_t)nsel + 64 * 64) * 2)); OK(hipMemset(toff, 0xff, (nseg + 2) * 4));
   k_entries_wg<<<G, 256>>>(k1s, nsel, cbits, S, rowmin, ecol, erow, toff);
   OK(hipDeviceSynchronize());
@@ -557,13 +560,13 @@ static void build_and_run_wg(const int32_t* src, const int32_t* dst, int64_t ne,
     for (size_t b = nseg; b-- > 0;) if (h[b] == 0xffffffffu) h[b] = h[b + 1];
     OK(hipMemcpy(toff, h.data(), (nseg + 1) * 4, hipMemcpyHostToDevice));
   }
-  k_wave_offsets<<<(unsigned)((nseg * 17 + 255) / 256), 256>>>(toff, erow, nseg, woff);
+  k_wave_offsets<<<(unsigned)((nseg * (kWV + 1) + 255) / 256), 256>>>(toff, erow, nseg, woff);
   OK(hipDeviceSynchronize());
-  const int npass = (nblk + 255) / 256;
+  const int npass = (nblk + kGrid - 1) / kGrid;
   const size_t cnt_words = (size_t)8 * npass * S + 64;
   unsigned int* cnt; OK(hipMalloc(&cnt, cnt_words * 4));
-  printf("workgroup-stationary form: blocks of %d rows: %d blocks = %d passes of 256 workgroups, %.0f entries per block and slice (%.1f us of L2-hit gathers per pass and slice chip-wide)\n", kRBW, nblk,
-         npass, (double)nsel / nblk / S, (double)nsel / npass / S / 200e3);
+  printf("workgroup-stationary form: blocks of %d rows: %d blocks = %d passes of %d workgroups, %.0f entries per block and slice (%.1f us of L2-hit gathers per pass and slice chip-wide)\n", kRBW, nblk,
+         npass, kGrid, (double)nsel / nblk / S, (double)nsel / npass / S / 200e3);
   run_wg<4, 0>("workgroups in step", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 1);
   run_wg<4, 0>("workgroups in step", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 2);
   run_wg<4, 0>("workgroups in step", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 4);
@@ -575,8 +578,10 @@ static void build_and_run_wg(const int32_t* src, const int32_t* dst, int64_t ne,
   run_wg2<4, true>("in step, next batch prefetched", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 3);
   run_wg2<2, true>("in step, next batch prefetched", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 2);
   run_wg2<8, true>("in step, next batch prefetched", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 2);
+  run_wg2<1, true>("in step, next batch prefetched", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 2);
+  run_wg2<3, true>("in step, next batch prefetched", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 2);
   if (getenv("BLOCKED_BENCH_ALL") == nullptr) { OK(hipFree(ecol)); OK(hipFree(erow)); OK(hipFree(toff)); OK(hipFree(woff)); OK(hipFree(cnt)); return; }
-  k_wave_offsets_by_row<<<(unsigned)((nseg * 17 + 255) / 256), 256>>>(toff, erow, nseg, woff);
+  k_wave_offsets_by_row<<<(unsigned)((nseg * (kWV + 1) + 255) / 256), 256>>>(toff, erow, nseg, woff);
   OK(hipDeviceSynchronize());
   run_wg2<4, false>("waves own rows, paced, no barrier", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 1);
   run_wg2<4, false>("waves own rows, paced, no barrier", ecol, erow, woff, S, nblk, nsel, x, y, yref, nrows, reps, cnt, cnt_words, 2);
