@@ -252,6 +252,42 @@ def extra_bfs(scale, edge_factor, seed, ref_threads, local_rank, rank):
             "runs": runs}
 
 
+def extra_uniform(scale, edge_factor, seed, local_rank, rank, iters=10):
+    """Not a BASELINE configuration: PageRank on a graph WITHOUT skew -- 2^scale vertices with `edge_factor` out-edges each to uniformly
+    drawn destinations, the shape of the reference's own random test graphs (test/generator.h:73-105) -- with the automatic policy
+    (the short rows as a column-blocked stream, kernels.hpp: k_spmv_blocked) and with gm_set_option("blocked_rows", -1) (the row-block
+    kernel, every gather of which misses on such a graph); the two runs' states are compared bit for bit."""
+    from graphmat_amd import api, _lib
+    L = _lib.lib()
+    nv, src, dst, _ = api.uniform_on_device(scale, edge_factor, seed, device=local_rank)
+    res = {}
+    states = {}
+    try:
+        for name, mode in (("column_blocked_stream", 0), ("row_blocks", -1)):
+            _lib.check(L.gm_set_option(b"blocked_rows", mode))
+            g = api.Graph(nv, src, dst, None, device=local_rank, keep_values=False)
+            st = g.new_pr_state()
+            g.run_degree(st)
+            g.run_pagerank(st, 2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            g.run_pagerank(st, iters)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3 / iters
+            res[name] = {"ms_per_iteration": round(ms, 4), "gteps": round(edge_factor * nv / ms / 1e6, 2)}
+            states[name] = g.to_vertex_order(st[:, 0].contiguous()).clone()  # (the two graphs' device orders differ: slices of ~4 MiB against ~1.3 MiB)
+            log(rank, "extra uniform 2^%d: %s %.3f ms/iteration = %.1f GTEPS" % (scale, name, ms, edge_factor * nv / ms / 1e6))
+            g.close()
+    finally:
+        _lib.check(L.gm_set_option(b"blocked_rows", 0))
+    same = bool((states["column_blocked_stream"] == states["row_blocks"]).all())
+    del src, dst, states
+    torch.cuda.empty_cache()
+    return {"workload": "PageRank (fp32, %d + 2 iterations) on a uniform random graph WITHOUT skew, 2^%d vertices x %d out-edges (NOT the metric's input)" % (iters, scale, edge_factor),
+            "V": nv, "E": edge_factor * nv, "bits_equal_between_the_two_paths": same,
+            "speedup": round(res["row_blocks"]["ms_per_iteration"] / res["column_blocked_stream"]["ms_per_iteration"], 2), **res}
+
+
 def sgd_sampled_rows_check(g, nv, src, dst, val, lat0, lat1, users, items, K, lam, step, nsample, dev):
     """One ALL_EDGES SGD iteration recomputed for `nsample` user rows and `nsample` item rows from the same initial
     state, independently of the kernels (torch elementwise ops only, nothing shared with the library or the oracle),
@@ -906,6 +942,10 @@ def main():
             extra["sgd_k128"] = extra_sgd(args.sgd_users, args.sgd_items, 100, 3, local_rank, rank)
         except Exception as e:  # pragma: no cover
             extra["sgd_k128"] = {"error": repr(e)}
+        try:
+            extra["pagerank_uniform25"] = extra_uniform(25, 16, 1, local_rank, rank)
+        except Exception as e:  # pragma: no cover
+            extra["pagerank_uniform25"] = {"error": repr(e)}
         out["extra"] = extra
     if rank == 0:
         r = roof or {}
