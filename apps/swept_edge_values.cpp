@@ -12,6 +12,7 @@
 // what is tested is WHICH values the multiply reads.  Prints "SWEPTEDGES PASS" and exits 0.
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "GraphMatRuntime.h"
@@ -70,13 +71,23 @@ static bool spmv_matches(GraphMat::Graph<float>& G, const edges_t& ed, int n, co
   G.setAllActive();
   GraphMat::run_graph_program(&prog, G, 1);
   bool ok = true;
-  for (int v = 1; v <= n; v++) ok &= (G.getVertexproperty(v) == (has[v] ? want[v] : x[v]));
+  int shown = 0;
+  std::vector<int> indeg(n + 1, 0);
+  for (auto& e : ed) indeg[e.dst]++;
+  for (int v = 1; v <= n; v++) {
+    const float got = G.getVertexproperty(v), exp = has[v] ? want[v] : x[v];
+    if (got != exp) { ok = false; if (shown++ < 8) printf("  vertex %d (in-degree %d): %g, expected %g\n", v, indeg[v], got, exp); }
+  }
   return ok;
 }
 
 int main(int argc, char** argv) {
   MPI_Init(&argc, &argv);
   setenv("GRAPHMAT_COL_TILES", "4", 1);
+  // "blocked": the rows of at most 64 edges also go through the column-blocked stream with their edge values (kernels.hpp: k_spmv_blocked<..., HAS_VALS = true>;
+  // gm_blocked_t.eval / epos), which the library builds by itself only for large graphs without skew
+  const bool blocked = argc > 1 && std::string(argv[1]) == "blocked";
+  if (blocked) CHECK(gm_set_option("blocked_rows", 1) == 0);
   const int n = 6000;
   std::vector<float> x(n + 1);
   for (int v = 1; v <= n; v++) x[v] = (float)(v % 7 + 1);
@@ -96,6 +107,10 @@ int main(int argc, char** argv) {
     printf("graph 1: %d column tiles, %d slices, sweep: %d rows (%d long), value bytes %d, %lld giant-row edges gathered by the sweep, %d giant rows\n", nt, sw.nslices, sw.nrows,
            sw.nrows_long, sw.val_bytes, (long long)sw.ngiant_edges, ca.ngiant);
     CHECK(nt > 1);
+    gm_blocked_t bl;
+    CHECK(gm_graph_blocked(G.A, &bl) == 0);
+    if (blocked) { printf("graph 1: column-blocked stream: %d short rows, %lld entries, value bytes %d\n", bl.nrows, (long long)bl.nentries, bl.val_bytes); CHECK(bl.nrows > 0 && bl.val_bytes == 4 && bl.eval && bl.epos); }
+    else CHECK(bl.nrows == 0);
     CHECK(sw.nrows > sw.nrows_long && sw.nrows_long > 0 && sw.val_bytes == 4 && ca.ngiant > 0 && sw.ngiant_edges > 0);
     CHECK(spmv_matches(G, ed, n, x, [](const GraphMat::edge_t<int>& e) { return (float)e.val; }));
     // device functor form: the whole-CSR values are rewritten in place, the tile copies must follow

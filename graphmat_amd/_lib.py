@@ -50,8 +50,9 @@ class Sweep(C.Structure):
 
 
 class Blocked(C.Structure):
-    _fields_ = [("nrows", C.c_int32), ("nblocks", C.c_int32), ("nslices", C.c_int32), ("short_row", C.c_int32), ("nsteps", C.c_int32), ("reserved_", C.c_int32),
-                ("nentries", C.c_int64), ("ecol", C.c_void_p), ("erow", C.c_void_p), ("woff", C.c_void_p), ("row_of", C.c_void_p), ("step_count", C.c_void_p)]
+    _fields_ = [("nrows", C.c_int32), ("nblocks", C.c_int32), ("nslices", C.c_int32), ("short_row", C.c_int32), ("nsteps", C.c_int32), ("val_bytes", C.c_int32),
+                ("nentries", C.c_int64), ("ecol", C.c_void_p), ("erow", C.c_void_p), ("woff", C.c_void_p), ("row_of", C.c_void_p), ("step_count", C.c_void_p),
+                ("eval", C.c_void_p), ("epos", C.c_void_p)]
 
 
 class RunStats(C.Structure):

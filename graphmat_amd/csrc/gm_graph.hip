@@ -1509,7 +1509,8 @@ k_blocked_keys(const int32_t* __restrict__ slots, int n, const unsigned long lon
 }
 __global__ void __launch_bounds__(kT)
 k_blocked_fill(const unsigned long long* __restrict__ key, const uint32_t* __restrict__ pos, int64_t n, const int32_t* __restrict__ slots, const int64_t* __restrict__ rowptr,
-               const int32_t* __restrict__ colidx, int TS, uint32_t* __restrict__ ecol, uint16_t* __restrict__ erow, uint32_t* __restrict__ toff) {
+               const int32_t* __restrict__ colidx, const uint32_t* __restrict__ vals, int TS, uint32_t* __restrict__ ecol, uint16_t* __restrict__ erow,
+               uint32_t* __restrict__ eval, uint32_t* __restrict__ toff) {
   const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
   if (i >= n) return;
   const unsigned long long k = key[i];
@@ -1518,6 +1519,7 @@ k_blocked_fill(const unsigned long long* __restrict__ key, const uint32_t* __res
   const int r = slots[blk * GM_BLOCKED_ROWS + local];
   const uint32_t p = pos[i];
   ecol[i] = (uint32_t)colidx[p];
+  if (eval) eval[i] = vals[p];
   erow[i] = (uint16_t)(local | ((int64_t)p == rowptr[r] ? 0x8000u : 0u));
   if (i == 0 || (key[i - 1] >> 15) != (k >> 15)) toff[blk * (size_t)TS + slice] = (uint32_t)i;
 }
@@ -1534,7 +1536,7 @@ __global__ void __launch_bounds__(kT) k_blocked_wave_offsets(const uint32_t* __r
 }
 static void free_blocked(gm_graph* g) {
   gm_blocked_t& B = g->blocked;
-  const void* owned[] = {B.ecol, B.erow, B.woff, B.row_of, B.step_count};
+  const void* owned[] = {B.ecol, B.erow, B.woff, B.row_of, B.step_count, B.eval, B.epos};
   for (const void* q : owned)
     if (q) (void)hipFree((void*)q);
   memset(&B, 0, sizeof(B));
@@ -1543,12 +1545,13 @@ static int build_blocked(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
   memset(&g->blocked, 0, sizeof(g->blocked));
   const int TS = g->nslices;
   const int nrows = g->desc.row_hi - g->desc.row_lo;
-  if (g_blocked_rows < 0 || TS < 2 || TS > GM_MAX_SLICES || nrows <= 0 || whole->vals != nullptr || whole->view.nnz <= 0 || whole->view.nnz >= ((int64_t)1 << 32) - 65536 ||
+  if (g_blocked_rows < 0 || TS < 2 || TS > GM_MAX_SLICES || nrows <= 0 || (whole->vals != nullptr && whole->view.val_bytes != 4) || whole->view.nnz <= 0 || whole->view.nnz >= ((int64_t)1 << 32) - 65536 ||
       g->desc.nshards > 1 || whole->view.short_row <= 0 || whole->view.short_row > 16384)
     return GM_OK;
   if (g_blocked_rows == 0 && (double)g->nlive * 4.0 < 48.0 * 1048576.0) return GM_OK;
   const int64_t* rowptr = (const int64_t*)whole->rowptr;
   const int32_t* colidx = (const int32_t*)whole->colidx;
+  const uint32_t* vals = (const uint32_t*)whole->vals;
   int rc;
   DevBuf flag, iota, rows, cnt, tmp, l64, off, dealt;
   if ((rc = flag.alloc((size_t)nrows)) || (rc = iota.alloc((size_t)nrows * 4)) || (rc = rows.alloc((size_t)nrows * 4)) || (rc = cnt.alloc(16))) return rc;
@@ -1597,7 +1600,9 @@ static int build_blocked(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
   // stable: inside a (block, slice, row) the edges keep their CSR order = ascending native column
   if ((rc = sweep_sort_pairs(k_in.as<unsigned long long>(), k_out.as<unsigned long long>(), v_in.as<uint32_t>(), v_out.as<uint32_t>(), (size_t)nent, 22 + bits_for((uint32_t)nblk), s))) return rc;
   k_in.free(); v_in.free();
-  DevBuf ecol, erow, toff, woff, steps;
+  DevBuf ecol, erow, toff, woff, steps, eval;
+  if (vals && (rc = eval.alloc(((size_t)nent + 64 * 64) * 4))) return rc;
+  if (vals) GM_TRY_HIP(hipMemsetAsync(eval.p, 0, ((size_t)nent + 64 * 64) * 4, s));
   const int npass = (nblk + 255) / 256;
   const int nsteps = npass * TS;
   if ((rc = ecol.alloc(((size_t)nent + 64 * 64) * 4)) || (rc = erow.alloc(((size_t)nent + 64 * 64) * 2)) || (rc = toff.alloc((nseg + 2) * 4)) || (rc = woff.alloc((nseg + 1) * 17 * 4)) ||
@@ -1608,7 +1613,8 @@ static int build_blocked(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
   GM_TRY_HIP(hipMemsetAsync(toff.p, 0xff, (nseg + 2) * 4, s));
   GM_TRY_HIP(hipMemsetAsync(steps.p, 0, (size_t)8 * nsteps * 4 + 256, s));
   hipLaunchKernelGGL(k_blocked_fill, dim3(grid_for(nent)), dim3(kT), 0, s, (const unsigned long long*)k_out.as<unsigned long long>(), (const uint32_t*)v_out.as<uint32_t>(), nent,
-                     (const int32_t*)dealt.as<int32_t>(), rowptr, colidx, TS, ecol.as<uint32_t>(), erow.as<uint16_t>(), toff.as<uint32_t>());
+                     (const int32_t*)dealt.as<int32_t>(), rowptr, colidx, vals, TS, ecol.as<uint32_t>(), erow.as<uint16_t>(), vals ? eval.as<uint32_t>() : (uint32_t*)nullptr,
+                     toff.as<uint32_t>());
   GM_TRY_HIP(hipGetLastError());
   {
     std::vector<uint32_t> h(nseg + 1);
@@ -1619,7 +1625,8 @@ static int build_blocked(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
     GM_TRY_HIP(hipMemcpyAsync(toff.p, h.data(), (nseg + 1) * 4, hipMemcpyHostToDevice, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
   }
-  k_out.free(); v_out.free();
+  k_out.free();
+  if (!vals) v_out.free();  // (with edge values: the entries' CSR positions stay, for gm_graph_sync_tile_vals)
   hipLaunchKernelGGL(k_blocked_wave_offsets, dim3((unsigned)((nseg * 17 + kT - 1) / kT)), dim3(kT), 0, s, (const uint32_t*)toff.as<uint32_t>(), (const uint16_t*)erow.as<uint16_t>(), nseg,
                      woff.as<uint32_t>());
   GM_TRY_HIP(hipGetLastError());
@@ -1628,6 +1635,7 @@ static int build_blocked(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
   B.nrows = (int32_t)ns; B.nblocks = nblk; B.nslices = TS; B.short_row = whole->view.short_row; B.nsteps = nsteps; B.nentries = nent;
   B.ecol = (const uint32_t*)ecol.release(); B.erow = (const uint16_t*)erow.release(); B.woff = (const uint32_t*)woff.release();
   B.row_of = (const int32_t*)dealt.release(); B.step_count = (uint32_t*)steps.release();
+  B.val_bytes = vals ? 4 : 0; B.eval = (const uint32_t*)eval.release(); B.epos = vals ? (const uint32_t*)v_out.release() : nullptr;
   return GM_OK;
 }
 
@@ -2241,6 +2249,11 @@ int gm_graph_relayout_like(gm_graph_t* g, const gm_graph_t* like, gm_stream_t st
   }
   g->ntiles = like_tiles;
   memcpy(g->tile_base, like->tile_base, sizeof(g->tile_base));
+  // (... and the finer cut of the adopted order: the slices are native ranges of LIKE's order -- this graph's own cuts, made for the order it
+  // had, are not: a row folded slice by slice through them would leave the ascending-native-column order, and the column-blocked stream,
+  // whose "first edge of the row" is the CSR's first, would assign it in the middle of a row)
+  g->nslices = like_tiles > 1 ? like->nslices : 0;
+  memcpy(g->slice_base, like->slice_base, sizeof(g->slice_base));
   g->nlive = like->nlive;
   g->desc.col_tiles = g->ntiles;
   // the other graph's order ranks ITS edges: this graph's vertices with edges may sit anywhere in it
@@ -2334,6 +2347,12 @@ int gm_graph_sync_tile_vals(gm_graph_t* g, gm_stream_t stream) {
     if (S.nrows > 0 && S.val_bytes == 4 && S.lval && S.lsrc_pos && S.nedges_long > 0)
       hipLaunchKernelGGL(gm::k_sweep_sync_vals, dim3(gm::grid_for(S.nedges_long)), dim3(gm::kT), 0, s, S.lsrc_pos, (size_t)S.nedges_long, (const uint32_t*)g->out.vals,
                          const_cast<uint32_t*>(S.lval));
+  }
+  {  // ... and the column-blocked stream's (gm_blocked_t.eval)
+    const gm_blocked_t& B = g->blocked;
+    if (B.nrows > 0 && B.val_bytes == 4 && B.eval && B.epos && B.nentries > 0)
+      hipLaunchKernelGGL(gm::k_sweep_sync_vals, dim3(gm::grid_for(B.nentries)), dim3(gm::kT), 0, s, B.epos, (size_t)B.nentries, (const uint32_t*)g->out.vals,
+                         const_cast<uint32_t*>(B.eval));
   }
   if (g->ntiles <= 1 || !g->out_tiles) { GM_TRY_HIP(hipGetLastError()); GM_TRY_HIP(hipStreamSynchronize(s)); return GM_OK; }
   const int nrows = g->out.view.nrows, vb = g->out.view.val_bytes;

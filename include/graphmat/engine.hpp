@@ -1342,12 +1342,14 @@ class Run {
 
   // Can this run's pull multiply of the OUT adjacency take the column-blocked stream of the short rows (graphmat_hip.h: gm_blocked_t;
   // kernels.hpp: k_spmv_blocked)?  The conditions of the sweep; the structure exists only for graphs without skew that keep no edge values.
+  bool said_blocked = false;
   bool blocked_usable(int acc, gm_blocked_t* bl) {
     if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
       if (use_vp || xq == nullptr || xb != nullptr || d_want != nullptr || program_row_filter<P>::enabled || (acc & dev::ACC_READ_PREV)) return false;
       if (!(rk == REDUCE_ORDERED || rk == REDUCE_F32_ADD || rk == REDUCE_COMMUTATIVE)) return false;
       if (opt.debug_flags & dev::DBG_NO_TILES) return false;
-      if (Aout.vals != nullptr || gm_graph_blocked(g, bl) != GM_OK || bl->nrows <= 0 || bl->short_row != Aout.short_row) return false;
+      if (gm_graph_blocked(g, bl) != GM_OK || bl->nrows <= 0 || bl->short_row != Aout.short_row) return false;
+      if (Aout.vals != nullptr && !(bl->val_bytes == 4 && bl->eval != nullptr && sizeof(E) == 4 && std::is_trivially_copyable<E>::value)) return false;
       return true;
     } else {
       (void)acc; (void)bl;
@@ -1358,23 +1360,38 @@ class Run {
   void launch_blocked(const dev::ProgArg<P>& pa, const gm_blocked_t& bl) {
     if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
       static int cus = 0;  // (per instantiation: the kernels' 128 KB of dynamic LDS have to be allowed once)
+      constexpr bool kValsOk = sizeof(E) == 4 && std::is_trivially_copyable<E>::value;
       if (cus == 0) {
-        GM_HIP_OK(hipFuncSetAttribute((const void*)&dev::k_spmv_blocked<P, T, U, V, E, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_BLOCKED_ROWS * 4));
-        GM_HIP_OK(hipFuncSetAttribute((const void*)&dev::k_spmv_blocked<P, T, U, V, E, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_BLOCKED_ROWS * 4));
+        GM_HIP_OK(hipFuncSetAttribute((const void*)&dev::k_spmv_blocked<P, T, U, V, E, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_BLOCKED_ROWS * 4));
+        GM_HIP_OK(hipFuncSetAttribute((const void*)&dev::k_spmv_blocked<P, T, U, V, E, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_BLOCKED_ROWS * 4));
+        if constexpr (kValsOk) {
+          GM_HIP_OK(hipFuncSetAttribute((const void*)&dev::k_spmv_blocked<P, T, U, V, E, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_BLOCKED_ROWS * 4));
+          GM_HIP_OK(hipFuncSetAttribute((const void*)&dev::k_spmv_blocked<P, T, U, V, E, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_BLOCKED_ROWS * 4));
+        }
         int dev_id = 0, n = 0;
         GM_HIP_OK(hipGetDevice(&dev_id));
         GM_HIP_OK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev_id));
         cus = n > 0 ? n : 1;
       }
+      if (verbose && !said_blocked) { printf("GraphMat(HIP):   the short rows take the column-blocked stream (%d rows, %lld edges%s)\n", bl.nrows, (long long)bl.nentries, Aout.vals ? ", with their edge values" : ""); said_blocked = true; }
       // workgroups that are not all resident at once (a partitioned or masked device) cannot walk the slices in step: they are not asked to
       const int window = cus >= 256 ? (opt.blocked_form & 15) : 0;
       if (window > 0) GM_HIP_OK(hipMemsetAsync(bl.step_count, 0, (size_t)8 * bl.nsteps * 4, s));
-      if (opt.blocked_form & 16)
-        hipLaunchKernelGGL((dev::k_spmv_blocked<P, T, U, V, E, 4>), dim3(256), dim3(1024), GM_BLOCKED_ROWS * 4, s, pa, bl.ecol, bl.erow, bl.woff, bl.nslices, bl.nblocks, bl.row_of,
-                           xq, y, bl.step_count, bl.nsteps, window);
-      else
-        hipLaunchKernelGGL((dev::k_spmv_blocked<P, T, U, V, E, 2>), dim3(256), dim3(1024), GM_BLOCKED_ROWS * 4, s, pa, bl.ecol, bl.erow, bl.woff, bl.nslices, bl.nblocks, bl.row_of,
-                           xq, y, bl.step_count, bl.nsteps, window);
+      auto launch = [&](auto vals_c, auto ub_c) {
+        constexpr bool HV = decltype(vals_c)::value;
+        constexpr int UBV = decltype(ub_c)::value;
+        hipLaunchKernelGGL((dev::k_spmv_blocked<P, T, U, V, E, HV, UBV>), dim3(256), dim3(1024), GM_BLOCKED_ROWS * 4, s, pa, bl.ecol, bl.erow, bl.eval, bl.woff, bl.nslices, bl.nblocks,
+                           bl.row_of, xq, y, bl.step_count, bl.nsteps, window);
+      };
+      const bool ub4 = (opt.blocked_form & 16) != 0;
+      bool launched = false;
+      if constexpr (kValsOk) {
+        if (Aout.vals != nullptr) {
+          if (ub4) launch(std::true_type(), std::integral_constant<int, 4>()); else launch(std::true_type(), std::integral_constant<int, 2>());
+          launched = true;
+        }
+      }
+      if (!launched) { if (ub4) launch(std::false_type(), std::integral_constant<int, 4>()); else launch(std::false_type(), std::integral_constant<int, 2>()); }
     } else {
       (void)pa; (void)bl;
     }

@@ -1795,9 +1795,9 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
 // two waves touch the same running value; lanes holding the same row form a run whose head lane reads the running value, folds
 // the run's products one after the other and writes it back: ascending native column order, the reference's.
 // Dense x, 2-operand programs, 4-byte messages and reductions, no edge values (E()).
-template <class P, class T, class U, class V, class E, int UB = 2>
+template <class P, class T, class U, class V, class E, bool HAS_VALS, int UB = 2>
 __global__ void __launch_bounds__(1024)
-k_spmv_blocked(ProgArg<P> pa, const uint32_t* __restrict__ ecol, const uint16_t* __restrict__ erow, const uint32_t* __restrict__ woff, int nslices, int nblk,
+k_spmv_blocked(ProgArg<P> pa, const uint32_t* __restrict__ ecol, const uint16_t* __restrict__ erow, const uint32_t* __restrict__ eval, const uint32_t* __restrict__ woff, int nslices, int nblk,
                const int32_t* __restrict__ row_of, const T* __restrict__ x, U* __restrict__ y, unsigned int* __restrict__ step_count, int nsteps, int window) {
   static_assert(sizeof(T) == 4 && sizeof(U) == 4, "4-byte messages and reductions");
   extern __shared__ uint32_t s_bacc[];  // GM_BLOCKED_ROWS running values
@@ -1809,22 +1809,23 @@ k_spmv_blocked(ProgArg<P> pa, const uint32_t* __restrict__ ecol, const uint16_t*
   V no_vp;
   auto as_u = [](uint32_t raw) { U u; __builtin_memcpy(&u, &raw, 4); return u; };
   auto raw_u = [](const U& u) { uint32_t r; __builtin_memcpy(&r, &u, 4); return r; };
+  auto as_e = [](uint32_t raw) { E e; if constexpr (HAS_VALS) __builtin_memcpy(&e, &raw, 4); else e = E(); return e; };
   for (int pass = 0; pass < npass; pass++) {
     const int blk = pass * (int)gridDim.x + (int)blockIdx.x;
     const bool has_blk = blk < nblk;  // (a workgroup without a block in the last pass still reports its steps)
     uint32_t ws = 0, we = 0;
     if (has_blk) { const uint32_t* wo = woff + ((size_t)blk * nslices) * 17 + wave; ws = wo[0]; we = wo[1]; }
-    uint32_t c[UB], r[UB];
+    uint32_t c[UB], r[UB], ev[UB];
     uint32_t pre = ws;
 #pragma unroll
-    for (int u = 0; u < UB; u++) { c[u] = ecol[pre + u * 64 + lane]; r[u] = erow[pre + u * 64 + lane]; }  // (both arrays are padded behind the last entry)
+    for (int u = 0; u < UB; u++) { c[u] = ecol[pre + u * 64 + lane]; r[u] = erow[pre + u * 64 + lane]; if constexpr (HAS_VALS) ev[u] = eval[pre + u * 64 + lane]; else ev[u] = 0u; }  // (both arrays are padded behind the last entry)
     for (int sl = 0; sl < nslices; sl++) {
       uint32_t nws = 0, nwe = 0;
       if (has_blk && sl + 1 < nslices) { const uint32_t* wo = woff + ((size_t)blk * nslices + sl + 1) * 17 + wave; nws = wo[0]; nwe = wo[1]; }  // (the next slice's range: requested now)
       if (pre != ws && ws < we) {  // (an empty range in between: the batch requested ahead is not this slice's first)
         pre = ws;
 #pragma unroll
-        for (int u = 0; u < UB; u++) { c[u] = ecol[pre + u * 64 + lane]; r[u] = erow[pre + u * 64 + lane]; }
+        for (int u = 0; u < UB; u++) { c[u] = ecol[pre + u * 64 + lane]; r[u] = erow[pre + u * 64 + lane]; if constexpr (HAS_VALS) ev[u] = eval[pre + u * 64 + lane]; else ev[u] = 0u; }
       }
       for (uint32_t p0 = ws; p0 < we;) {
         T m[UB];
@@ -1833,9 +1834,9 @@ k_spmv_blocked(ProgArg<P> pa, const uint32_t* __restrict__ ecol, const uint16_t*
         // the next batch -- of this slice or the next -- is requested before this one is folded
         const uint32_t np0 = p0 + 64 * UB;
         const uint32_t nxt = np0 < we ? np0 : nws;
-        uint32_t nc[UB], nr[UB];
+        uint32_t nc[UB], nr[UB], ne[UB];
 #pragma unroll
-        for (int u = 0; u < UB; u++) { nc[u] = ecol[nxt + u * 64 + lane]; nr[u] = erow[nxt + u * 64 + lane]; }
+        for (int u = 0; u < UB; u++) { nc[u] = ecol[nxt + u * 64 + lane]; nr[u] = erow[nxt + u * 64 + lane]; if constexpr (HAS_VALS) ne[u] = eval[nxt + u * 64 + lane]; else ne[u] = 0u; }
 #pragma unroll
         for (int u = 0; u < UB; u++) {
           const bool valid = p0 + u * 64 + lane < we;
@@ -1847,7 +1848,7 @@ k_spmv_blocked(ProgArg<P> pa, const uint32_t* __restrict__ ecol, const uint16_t*
           const int runlen = above ? (__builtin_ctzll(above) + 1) : (64 - lane);
           U res;
           __builtin_memset(&res, 0, 4);
-          if (valid) p.P::process_message(m[u], E(), no_vp, res);
+          if (valid) p.P::process_message(m[u], as_e(ev[u]), no_vp, res);
           const uint32_t rraw = raw_u(res);
           U acc = res;
           if (head && !(r[u] & 0x8000u)) { acc = as_u(s_bacc[id]); p.P::reduce_function(acc, res); }  // SPMV.h:54-59: c = a; reduce(c, b)
@@ -1858,7 +1859,7 @@ k_spmv_blocked(ProgArg<P> pa, const uint32_t* __restrict__ ecol, const uint16_t*
           if (head) s_bacc[id] = raw_u(acc);
         }
 #pragma unroll
-        for (int u = 0; u < UB; u++) { c[u] = nc[u]; r[u] = nr[u]; }
+        for (int u = 0; u < UB; u++) { c[u] = nc[u]; r[u] = nr[u]; ev[u] = ne[u]; }
         pre = nxt;
         p0 = np0;
       }

@@ -337,8 +337,8 @@ int gm_graph_tile(const gm_graph_t* g, int direction, int tile, gm_csr_t* out, c
  * a row folded segment by segment is folded in the reference's order.  Entry i: ecol[i] = device column, erow[i] = row inside the
  * block | 0x8000 for the row's first edge (its message is assigned, SPMV.h:54-59).  woff[(block * nslices + slice) * 17 + w] = where
  * wave w of 16 starts inside the segment (equal shares moved to the next row border; [16] = the segment's end).
- * row_of[block * GM_BLOCKED_ROWS + k] = the row (relative to row_lo) of the block's k-th row.  Graphs that keep edge values are
- * not laid out this way.  gm_set_option("blocked_rows", 0 = automatic (>= 90 % of the edges in short rows, >= 48 MiB of live
+ * row_of[block * GM_BLOCKED_ROWS + k] = the row (relative to row_lo) of the block's k-th row.  A graph that keeps 4-byte edge values
+ * carries them in the entries' positions (eval, +4 B per edge, and epos for refreshing them); other value widths are not laid out this way.  gm_set_option("blocked_rows", 0 = automatic (>= 90 % of the edges in short rows, >= 48 MiB of live
  * 4-byte messages), 1 = whenever the graph has slices, -1 = never).  nrows = 0: not built.  Prototype and measurements:
  * tools/blocked_bench.hip, profiles/r05_short_rows_blocked_stream_prototype.md. */
 typedef struct gm_blocked {
@@ -347,13 +347,15 @@ typedef struct gm_blocked {
   int32_t nslices;
   int32_t short_row;
   int32_t nsteps;     /* passes * nslices: words per XCD of step_count */
-  int32_t reserved_;
+  int32_t val_bytes;  /* 4: the entries carry the edge values (eval), 0: the graph keeps none */
   int64_t nentries;
   const uint32_t* ecol;
   const uint16_t* erow;
   const uint32_t* woff;
   const int32_t* row_of;
   uint32_t* step_count; /* 8 * nsteps words: workgroups of XCD k that have finished step t (cleared by the engine before a launch) */
+  const uint32_t* eval; /* val_bytes == 4: entry i's edge value */
+  const uint32_t* epos; /* val_bytes == 4: the CSR position entry i came from (gm_graph_sync_tile_vals refreshes eval through it) */
 } gm_blocked_t;
 #define GM_BLOCKED_ROWS 32768
 int gm_graph_blocked(const gm_graph_t* g, gm_blocked_t* out);

@@ -372,6 +372,19 @@ def test_edge_values_through_the_sweep():
 
 
 @pytest.mark.gpu
+def test_edge_values_through_the_column_blocked_stream():
+    """apps/swept_edge_values.cpp blocked: the same checks with the rows of at most 64 edges in the column-blocked stream WITH their edge
+    values (k_spmv_blocked<HAS_VALS>, gm_blocked_t.eval / epos; the sweep and the giant rows' passes in front of it): the values the
+    stream reads after applyToAllEdges rewrote them, and on the relayouted graphs; every vertex against a host evaluation."""
+    exe = _need(os.path.join(OWN_APPS, "swept_edge_values"))
+    out = subprocess.run([exe, "blocked"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=dict(os.environ, GRAPHMAT_VERBOSE="1"))
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "SWEPTEDGES PASS" in text, text[-2000:]
+    assert re.search(r"column-blocked stream: [1-9][0-9]* short rows, [1-9][0-9]* entries, value bytes 4", text), text[-2000:]
+    assert "the short rows take the column-blocked stream" in text and "with their edge values" in text, text[-2000:]
+
+
+@pytest.mark.gpu
 def test_reference_pagerank_timing_build_prints_the_per_iteration_lines(golden_dir, ref):
     """The reference's tracing flavour (-D__TIMING) of the UNCHANGED src/PageRank.cpp: per iteration the phase lines and
     "Iteration %d :: %f msec :: updated %d vertices :: changed %d vertices" (include/GraphMatRuntime.h:150-248 of the

@@ -428,7 +428,7 @@ def _blocked_info(g):
     return bl
 
 
-@pytest.mark.parametrize("kind,scale,tiles,threads", [("uniform", 14, 3, 1), ("uniform", 16, 4, 2), ("rmat", 15, 3, 1), ("rmat", 16, 4, 3), ("rmat+sweep", 15, 3, 2), ("rmat+sweep", 16, 4, 1)])
+@pytest.mark.parametrize("kind,scale,tiles,threads", [("uniform", 14, 3, 1), ("uniform", 15, 2, 1), ("uniform", 16, 4, 2), ("rmat", 15, 3, 1), ("rmat", 16, 4, 3), ("rmat+sweep", 15, 3, 2), ("rmat+sweep", 16, 4, 1)])
 def test_blocked_short_rows_bit_exact(env, kind, scale, tiles, threads):
     """The column-blocked stream of the short rows (graphmat_hip.h gm_blocked_t, kernels.hpp k_spmv_blocked): forced on small graphs --
     a graph without skew (every row short: the whole multiply goes through it), RMAT with the sweep switched off (the rows above
@@ -440,7 +440,7 @@ def test_blocked_short_rows_bit_exact(env, kind, scale, tiles, threads):
     if kind == "uniform":
         nv, s, d, v = gen.uniform_out_regular_edges(1 << scale, 16, seed=3)
     else:
-        nv, s, d, v = gen.rmat_edges(scale, 16, 7)
+        nv, s, d, v = gen.rmat_edges(scale, 16, 7, weights="hash")
     og = ob.OracleGraph(nv, s, d, None, ref_threads=threads)
     odeg = og.degree()
     opr, _, _ = og.pagerank(5, degree=odeg)
@@ -450,10 +450,11 @@ def test_blocked_short_rows_bit_exact(env, kind, scale, tiles, threads):
             api._lib.check(L.gm_set_option(b"blocked_rows", mode))
             if kind == "rmat":  # (debug_flags 16 = no auxiliary stream: the sweep, which needs one, is not taken)
                 api._lib.check(L.gm_set_option(b"debug_flags", 16))
-            g = api.Graph(nv, s, d, None, ref_threads=threads, keep_values=False, col_tiles=tiles)
+            keep = (scale % 2 == 1)  # (the odd scales keep 4-byte edge values: the entries then carry them)
+            g = api.Graph(nv, s, d, v if keep else None, ref_threads=threads, keep_values=keep, col_tiles=tiles)
             assert g.col_tiles > 1
             bl = _blocked_info(g)
-            rp, ci, _ = g.csr_to_host(api.GM_DIR_OUT)
+            rp, ci, vv = g.csr_to_host(api.GM_DIR_OUT)
             rowlen = np.diff(rp)
             short = np.nonzero((rowlen >= 1) & (rowlen <= 64))[0]
             if mode == 1:
@@ -467,6 +468,11 @@ def test_blocked_short_rows_bit_exact(env, kind, scale, tiles, threads):
                 ecol = np.zeros(bl.nentries, np.uint32); erow = np.zeros(bl.nentries, np.uint16)
                 api.copy_from_device(ecol, bl.ecol); api.copy_from_device(erow, bl.erow)
                 assert int((erow >> 15).sum()) == bl.nrows  # one "first edge" per row
+                assert bl.val_bytes == (4 if keep else 0)
+                if keep:
+                    ev = np.zeros(bl.nentries, np.int32); ep = np.zeros(bl.nentries, np.uint32)
+                    api.copy_from_device(ev, bl.eval); api.copy_from_device(ep, bl.epos)
+                    assert (ev == vv[ep]).all() and (ecol == ci[ep].astype(np.uint32)).all()
                 woff = np.zeros((bl.nblocks * bl.nslices + 1) * 17, np.uint32)
                 api.copy_from_device(woff, bl.woff)
                 w = woff[: bl.nblocks * bl.nslices * 17].reshape(-1, 17)
