@@ -1341,7 +1341,7 @@ class Run {
   }
 
   // Can this run's pull multiply of the OUT adjacency take the column-blocked stream of the short rows (graphmat_hip.h: gm_blocked_t;
-  // kernels.hpp: k_spmv_blocked)?  The conditions of the sweep; the structure exists only for graphs without skew that keep no edge values.
+  // kernels.hpp: k_spmv_blocked)?  The conditions of the sweep; the structure exists only for graphs without skew (edge values: none, or 4 bytes in its entries).
   bool said_blocked = false;
   bool blocked_usable(int acc, gm_blocked_t* bl) {
     if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
@@ -1359,8 +1359,12 @@ class Run {
   // the launch of k_spmv_blocked on the run's stream (the kernel wants the whole chip: 256 workgroups x 128 KB of LDS)
   void launch_blocked(const dev::ProgArg<P>& pa, const gm_blocked_t& bl) {
     if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
-      static int cus = 0;  // (per instantiation: the kernels' 128 KB of dynamic LDS have to be allowed once)
+      // (per instantiation and device: the kernels' 128 KB of dynamic LDS have to be allowed once, and the device's CU count is asked once)
+      static int cus_of[64] = {0};
       constexpr bool kValsOk = sizeof(E) == 4 && std::is_trivially_copyable<E>::value;
+      int dev_id = 0;
+      GM_HIP_OK(hipGetDevice(&dev_id));
+      int& cus = cus_of[dev_id & 63];
       if (cus == 0) {
         GM_HIP_OK(hipFuncSetAttribute((const void*)&dev::k_spmv_blocked<P, T, U, V, E, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_BLOCKED_ROWS * 4));
         GM_HIP_OK(hipFuncSetAttribute((const void*)&dev::k_spmv_blocked<P, T, U, V, E, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_BLOCKED_ROWS * 4));
@@ -1368,8 +1372,7 @@ class Run {
           GM_HIP_OK(hipFuncSetAttribute((const void*)&dev::k_spmv_blocked<P, T, U, V, E, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_BLOCKED_ROWS * 4));
           GM_HIP_OK(hipFuncSetAttribute((const void*)&dev::k_spmv_blocked<P, T, U, V, E, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GM_BLOCKED_ROWS * 4));
         }
-        int dev_id = 0, n = 0;
-        GM_HIP_OK(hipGetDevice(&dev_id));
+        int n = 0;
         GM_HIP_OK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev_id));
         cus = n > 0 ? n : 1;
       }

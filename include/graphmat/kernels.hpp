@@ -1785,7 +1785,7 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
 // ------------------------------------------------------------------------------------
 // The short rows of a graph WITHOUT skew as a column-blocked stream (graphmat_hip.h: gm_blocked_t; built by gm_graph.hip:
 // build_blocked; prototype and measurements: tools/blocked_bench.hip, profiles/r05_short_rows_blocked_stream_prototype.md --
-// uniform 16-out-regular 2^26: 9.9-11 ms against 21 ms for the row-blocks, whose every gather misses).
+// uniform 16-out-regular 2^26: 9.0-9.5 ms against 21 ms for the row-blocks, whose every gather misses).
 // Workgroup b of a pass owns GM_BLOCKED_ROWS short rows and keeps their running values in LDS from the first slice to the last; the
 // grid's workgroups take the blocks of a pass side by side and walk the slices TOGETHER: a workgroup that has finished step (pass,
 // slice) adds itself to its XCD's counter for that step (workgroups are dealt round-robin over the 8 XCDs), and nobody starts the next
@@ -1794,7 +1794,7 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
 // segment's entries are in (row, CSR order) order; the 16 waves take equal shares cut at row borders (woff), so inside a slice no
 // two waves touch the same running value; lanes holding the same row form a run whose head lane reads the running value, folds
 // the run's products one after the other and writes it back: ascending native column order, the reference's.
-// Dense x, 2-operand programs, 4-byte messages and reductions, no edge values (E()).
+// Dense x, 2-operand programs, 4-byte messages and reductions; edge values: none, or 4 bytes in the entries' positions (eval).
 template <class P, class T, class U, class V, class E, bool HAS_VALS, int UB = 2>
 __global__ void __launch_bounds__(1024)
 k_spmv_blocked(ProgArg<P> pa, const uint32_t* __restrict__ ecol, const uint16_t* __restrict__ erow, const uint32_t* __restrict__ eval, const uint32_t* __restrict__ woff, int nslices, int nblk,
