@@ -17,6 +17,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "gm_internal.hpp"
@@ -154,6 +155,24 @@ k_deal(const int32_t* __restrict__ order, int nv, int nshards, int S, int32_t* _
   if (k >= nv) return;
   int v = order[k];
   int d = (k % nshards) * S + k / nshards;
+  dev_of_native[v] = d;
+  native_of_dev[d] = v;
+}
+
+// Sharded graphs with slices (graphmat_hip.h: gm_sweep_t.nsub): position k of the list sorted by (slice, degree rank) -- the j-th
+// busiest vertex of slice t -- goes to owner (j + t) % G at position sb[t] + j / G of the owner's range (the rotation by t keeps
+// the slices' busiest vertices from all landing on owner 0); vertices without edges (key 255) follow the live part of every range.
+struct SliceDeal { int32_t hb[GM_MAX_SLICES + 2]; int32_t sb[GM_MAX_SLICES + 2]; };
+__global__ void __launch_bounds__(kT)
+k_deal_sliced(const int32_t* __restrict__ order, const uint8_t* __restrict__ key_sorted, int nv, int G, int S, int TS, SliceDeal sd,
+              int32_t* __restrict__ dev_of_native, int32_t* __restrict__ native_of_dev) {
+  const int k = blockIdx.x * kT + threadIdx.x;
+  if (k >= nv) return;
+  const int v = order[k];
+  const int t = key_sorted[k] == 255 ? TS : (int)key_sorted[k];
+  const int j = k - sd.hb[t];
+  const int owner = t == TS ? j % G : (j + t) % G;
+  const int d = owner * S + sd.sb[t] + j / G;
   dev_of_native[v] = d;
   native_of_dev[d] = v;
 }
@@ -426,6 +445,7 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
                       const void* d_val, hipStream_t s, CsrOwned* out, int tile_split = -1, const unsigned char* own_wave = nullptr);
 static int build_tiles(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* idx_sorted, unsigned long long kept,
                        const void* d_val, hipStream_t s, const CsrOwned* whole);
+static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s);
 
 // Sorts the edges of one direction into the reference's reduction order and builds its CSR
 // (and, for GM_DIR_OUT of a tiled graph, the per-tile CSRs from the same sorted keys).
@@ -463,6 +483,10 @@ static int build_direction(gm_graph* g, int by_dst, int64_t nnz, const int32_t* 
   const bool tiled = by_dst && g->ntiles > 1;
   if ((rc = finish_csr(g, keys_out.as<uint64_t>(), idx_out.as<uint32_t>(), kept, d_val, s, out, tiled ? g_tile_min_row : -1))) return rc;
   if (tiled) rc = build_tiles(g, keys_out.as<uint64_t>(), idx_out.as<uint32_t>(), kept, d_val, s, out);
+  else if (by_dst && D.nshards > 1 && g->nslices > 1 && g_sweep_slices != 0) {  // a shard's rows through the sweep (gm_sweep_t.nsub)
+    keys_out.free(); idx_out.free();
+    rc = build_sweep(g, out, s);
+  }
   return rc;
 }
 
@@ -613,7 +637,12 @@ static int build_direction_local(gm_graph* g, int by_dst, int64_t nnz, const int
   }
   GM_TRY_HIP(hipStreamSynchronize(s));
   rk_in.free(); ri_in.free(); tmp.free();
-  return finish_csr(g, rk_out.as<uint64_t>(), ri_out.as<uint32_t>(), (unsigned long long)kept, vb ? rvals.p : nullptr, s, out, -1);
+  if ((rc = finish_csr(g, rk_out.as<uint64_t>(), ri_out.as<uint32_t>(), (unsigned long long)kept, vb ? rvals.p : nullptr, s, out, -1))) return rc;
+  if (by_dst && N > 1 && g->nslices > 1 && g_sweep_slices != 0) {
+    rk_out.free(); ri_out.free(); rvals.free();
+    rc = build_sweep(g, out, s);
+  }
+  return rc;
 }
 
 // CSR arrays and work decomposition from `kept` sorted keys (row << 32 | native col) and, for the
@@ -922,7 +951,23 @@ __global__ void k_sweep_count_above(const uint32_t* __restrict__ len_desc, int n
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (len_desc[mid] > limit) lo = mid + 1; else hi = mid; }
   *out = (unsigned int)lo;
 }
-struct SweepSlices { int32_t b[GM_MAX_SLICES + 2]; };
+struct SweepSlices { int32_t b[GM_MAX_SLICES + 2]; int32_t nsub, stride, hot_words, pad_; };
+// slice of device column c: the last s with b[s] <= (position of c inside its owner's range)
+__device__ __forceinline__ int sweep_slice_of(const SweepSlices& sl, int nslices, int c) {
+  if (sl.nsub > 1) c -= (c / sl.stride) * sl.stride;
+  int lo = 0, hi = nslices;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sl.b[mid] <= c) lo = mid; else hi = mid; }
+  return lo;
+}
+// the entry the sweep keeps for column c of slice `slice`: byte offset into the message vector, or (sharded form) GM_SWEEP_HOT | byte
+// offset into the workgroup's LDS copy of the slice's busiest entries (graphmat_hip.h: gm_sweep_t.nsub)
+__device__ __forceinline__ uint32_t sweep_entry_of(const SweepSlices& sl, int slice, int c) {
+  if (sl.nsub <= 1) return (uint32_t)c << 2;
+  const int q = c / sl.stride, j = c - q * sl.stride - sl.b[slice];
+  const int slen = sl.b[slice + 1] - sl.b[slice], cap = sl.hot_words / sl.nsub;
+  const int hq = slen < cap ? slen : cap;
+  return j < hq ? (GM_SWEEP_HOT | ((uint32_t)(q * hq + j) << 2)) : ((uint32_t)c << 2);
+}
 // one wave per swept row (in length-rank order, the long rows first): its edges, keyed (set * 256 + workgroup, slice, slot), with
 // the CSR position as the value; the row's edges keep their CSR order in the key stream (ranked offsets `off`)
 __global__ void __launch_bounds__(kT)
@@ -945,9 +990,7 @@ k_sweep_keys(const int32_t* __restrict__ rows_ranked, int nswept, int nlong, int
   }
   const unsigned long long o = off[r];
   for (int64_t e = e0 + lane; e < e1; e += 64) {
-    const int c = colidx[e];
-    int lo = 0, hi = nslices;  // largest s with sl.b[s] <= c
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sl.b[mid] <= c) lo = mid; else hi = mid; }
+    const int lo = sweep_slice_of(sl, nslices, colidx[e]);
     key[o + (unsigned long long)(e - e0)] = (vw << 23) | ((unsigned long long)lo << 16) | slot;
     val[o + (unsigned long long)(e - e0)] = (uint32_t)e;
   }
@@ -1020,7 +1063,7 @@ k_sweep_fill(uint32_t ngroups, const uint32_t* __restrict__ gbase, const uint32_
     const uint32_t base = gbase[g], n = gbase[g + 1] - base;
     const uint32_t width = (n >> 6) - 1u;
     const uint32_t slice = b % (uint32_t)nslices, vw = b / (uint32_t)nslices;
-    const uint32_t pad = GM_SWEEP_PAD | ((uint32_t)sl.b[slice] << 2);
+    const uint32_t pad = sl.nsub > 1 ? (GM_SWEEP_PAD | GM_SWEEP_HOT) : (GM_SWEEP_PAD | ((uint32_t)sl.b[slice] << 2));
     const int lane = threadIdx.x & 63;
     const uint32_t q = q0 + lane;
     uint32_t ps = 0, len = 0;
@@ -1041,7 +1084,7 @@ k_sweep_fill(uint32_t ngroups, const uint32_t* __restrict__ gbase, const uint32_
         const uint32_t k = (j >> 6) - 1u;
         if (k < len) {
           sp_ = pos_sorted[ps + k];
-          c = (uint32_t)colidx[sp_] << 2;
+          c = sweep_entry_of(sl, (int)slice, colidx[sp_]);
           if (vals) v = vals[sp_];
         }
       }
@@ -1090,12 +1133,12 @@ k_sweep_long_starts(const unsigned long long* __restrict__ key, int64_t n, int n
   lps[e] = (uint32_t)lo;
 }
 __global__ void __launch_bounds__(kT)
-k_sweep_long_fill(const uint32_t* __restrict__ pos_sorted, int64_t n, const int32_t* __restrict__ colidx, const uint32_t* __restrict__ vals,
-                  uint32_t* __restrict__ lcol, uint32_t* __restrict__ lval) {
+k_sweep_long_fill(const unsigned long long* __restrict__ key_sorted, const uint32_t* __restrict__ pos_sorted, int64_t n, const int32_t* __restrict__ colidx,
+                  const uint32_t* __restrict__ vals, SweepSlices sl, uint32_t* __restrict__ lcol, uint32_t* __restrict__ lval) {
   const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
   if (i >= n) return;
   const uint32_t p = pos_sorted[i];
-  lcol[i] = (uint32_t)colidx[p] << 2;
+  lcol[i] = sweep_entry_of(sl, (int)((key_sorted[i] >> 16) & 127ull), colidx[p]);
   if (lval) lval[i] = vals[p];
 }
 __global__ void __launch_bounds__(kT)
@@ -1116,9 +1159,7 @@ k_sweep_giant_keys(const int32_t* __restrict__ giant_row, int ngiant, const int6
   const int row = giant_row[gi];
   const int64_t e0 = rowptr[row], e1 = rowptr[row + 1], o = gterm_off[gi];
   for (int64_t e = e0 + lane; e < e1; e += 64) {
-    const int c = colidx[e];
-    int lo = 0, hi = nslices;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sl.b[mid] <= c) lo = mid; else hi = mid; }
+    const int lo = sweep_slice_of(sl, nslices, colidx[e]);
     key[o + (e - e0)] = (uint8_t)lo;
     pos[o + (e - e0)] = (uint32_t)e;
     dst[o + (e - e0)] = (uint32_t)(o + (e - e0));
@@ -1126,12 +1167,12 @@ k_sweep_giant_keys(const int32_t* __restrict__ giant_row, int ngiant, const int6
 }
 // (gterm_off is padded per row to multiples of 64: slots between rows carry key 255 and sort to the end)
 __global__ void __launch_bounds__(kT)
-k_sweep_giant_fill(const uint32_t* __restrict__ pos_sorted, int64_t n, const int32_t* __restrict__ colidx, const uint32_t* __restrict__ vals,
-                   uint32_t* __restrict__ gcol, uint32_t* __restrict__ gval) {
+k_sweep_giant_fill(const uint8_t* __restrict__ key_sorted, const uint32_t* __restrict__ pos_sorted, int64_t n, const int32_t* __restrict__ colidx,
+                   const uint32_t* __restrict__ vals, SweepSlices sl, uint32_t* __restrict__ gcol, uint32_t* __restrict__ gval) {
   const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
   if (i >= n) return;
   const uint32_t p = pos_sorted[i];
-  gcol[i] = (uint32_t)colidx[p] << 2;
+  gcol[i] = sweep_entry_of(sl, (int)key_sorted[i], colidx[p]);
   if (gval) gval[i] = vals[p];
 }
 __global__ void k_sweep_giant_bounds(const uint8_t* __restrict__ key_sorted, int64_t n, int nslices, uint32_t* __restrict__ out) {
@@ -1178,6 +1219,15 @@ static int sweep_excl_scan(X* in, X* out, size_t n, hipStream_t s) {
   GM_TRY_HIP(hipStreamSynchronize(s));
   return GM_OK;
 }
+// LDS words of the long rows' stage (the rest of the pool holds a slice's hot entries): the largest block in one round where that
+// leaves most of the pool to the hot set
+static int sweep_stage_words(int nrows_long, int max_long_block) {
+  if (nrows_long <= 0) return 64;
+  int stage = (max_long_block + 63) / 64 * 64;
+  if (stage > GM_SWEEP_MAX_STAGE) stage = GM_SWEEP_MAX_STAGE;
+  if (stage < 1024) stage = 1024;
+  return stage;
+}
 static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
   memset(&g->sweep, 0, sizeof(g->sweep));
   const int TS = g->nslices;
@@ -1194,7 +1244,8 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
     g->sweep.slice_base = g->d_slice_base;
   }
   const int vb = whole->view.val_bytes;
-  if (nrows <= 0 || whole->view.nnz >= ((int64_t)1 << 32) || g->desc.ndevice >= (1 << 29) || (whole->vals != nullptr && vb != 4)) return GM_OK;
+  const int nsub = g->desc.nshards > 1 ? g->desc.nshards : 1;  // (sharded: slice_base holds positions inside an owner's range)
+  if (nrows <= 0 || whole->view.nnz >= ((int64_t)1 << 32) || g->desc.ndevice >= (nsub > 1 ? (1 << 28) : (1 << 29)) || (whole->vals != nullptr && vb != 4)) return GM_OK;
   const int64_t* rowptr = (const int64_t*)whole->rowptr;
   const int32_t* colidx = (const int32_t*)whole->colidx;
   const uint32_t* vals = (const uint32_t*)whole->vals;
@@ -1290,6 +1341,9 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
   SweepSlices sl;
   memset(&sl, 0, sizeof(sl));
   for (int t = 0; t <= TS; t++) sl.b[t] = g->slice_base[t];
+  sl.nsub = nsub;
+  sl.stride = nsub > 1 ? nrows : 0;
+  sl.hot_words = GM_SWEEP_POOL - 64;  // (settled below, once the long rows' largest block -- the stage it needs -- is known)
   GM_TRY_HIP(hipMemsetAsync(rslot.p, 0xff, nvw * GM_SWEEP_ACC_ROWS * 4, s));
   GM_TRY_HIP(hipMemsetAsync(lrslot.p, 0xff, nvw * GM_SWEEP_LONG_SLOTS * 4, s));
   hipLaunchKernelGGL(k_sweep_keys, dim3((nswept + (kT / 64) - 1) / (kT / 64)), dim3(kT), 0, s, (const int32_t*)ranked.as<int32_t>(), (int)nswept, (int)nlong, nsets,
@@ -1315,12 +1369,15 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
     if (vals && (rc = lval.alloc(((size_t)nedges_long + 64) * 4))) return rc;
     hipLaunchKernelGGL(k_sweep_long_starts, dim3(grid_for((int64_t)nent + 1)), dim3(kT), 0, s, (const unsigned long long*)k_out.as<unsigned long long>(), nedges_long, TS, nent,
                        lps.as<uint32_t>());
-    if (nedges_long > 0)
-      hipLaunchKernelGGL(k_sweep_long_fill, dim3(grid_for(nedges_long)), dim3(kT), 0, s, (const uint32_t*)v_out.as<uint32_t>(), nedges_long, colidx, vals, lcol.as<uint32_t>(),
-                         vals ? lval.as<uint32_t>() : (uint32_t*)nullptr);
     GM_TRY_HIP(hipMemsetAsync(cnt.p, 0, 4, s));
     hipLaunchKernelGGL(k_sweep_long_max, dim3(grid_for((int64_t)nblk)), dim3(kT), 0, s, (const uint32_t*)lps.as<uint32_t>(), nblk, cnt.as<unsigned int>());
     GM_TRY_HIP(hipMemcpyAsync(&max_block, cnt.p, 4, hipMemcpyDeviceToHost, s));
+    GM_TRY_HIP(hipStreamSynchronize(s));
+    // the LDS pool is shared by a slice's hot entries and the long rows' stage (engine.hpp: multiply_out_swept chooses the same stage)
+    sl.hot_words = GM_SWEEP_POOL - sweep_stage_words((int)nlong, (int)max_block);
+    if (nedges_long > 0)
+      hipLaunchKernelGGL(k_sweep_long_fill, dim3(grid_for(nedges_long)), dim3(kT), 0, s, (const unsigned long long*)k_out.as<unsigned long long>(), (const uint32_t*)v_out.as<uint32_t>(),
+                         nedges_long, colidx, vals, sl, lcol.as<uint32_t>(), vals ? lval.as<uint32_t>() : (uint32_t*)nullptr);
     if (keep_pos && nedges_long > 0) {
       if ((rc = lpos.alloc((size_t)nedges_long * 4))) return rc;
       GM_TRY_HIP(hipMemcpyAsync(lpos.p, v_out.p, (size_t)nedges_long * 4, hipMemcpyDeviceToDevice, s));
@@ -1445,8 +1502,8 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
     if ((rc = gcol.alloc(((size_t)nreal + 64) * 4))) return rc;
     if (vals && (rc = gval.alloc(((size_t)nreal + 64) * 4))) return rc;
     if (nreal > 0)
-      hipLaunchKernelGGL(k_sweep_giant_fill, dim3(grid_for((int64_t)nreal)), dim3(kT), 0, s, (const uint32_t*)gp_out.as<uint32_t>(), (int64_t)nreal, colidx, vals,
-                         gcol.as<uint32_t>(), vals ? gval.as<uint32_t>() : (uint32_t*)nullptr);
+      hipLaunchKernelGGL(k_sweep_giant_fill, dim3(grid_for((int64_t)nreal)), dim3(kT), 0, s, (const uint8_t*)gk_out.as<uint8_t>(), (const uint32_t*)gp_out.as<uint32_t>(), (int64_t)nreal,
+                         colidx, vals, sl, gcol.as<uint32_t>(), vals ? gval.as<uint32_t>() : (uint32_t*)nullptr);
     GM_TRY_HIP(hipGetLastError());
     GM_TRY_HIP(hipStreamSynchronize(s));
     gdst.p = gd_out.release();
@@ -1464,6 +1521,7 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
   S.lcol = (const uint32_t*)lcol.release(); S.lval = (const uint32_t*)lval.release(); S.lps = (const uint32_t*)lps.release();
   S.lrow_of_slot = (const int32_t*)lrslot.release(); S.slice_base = g->d_slice_base;
   S.src_pos = (const uint32_t*)spos.release(); S.lsrc_pos = (const uint32_t*)lpos.release();
+  S.nsub = nsub; S.stride = sl.stride; S.hot_words = sl.hot_words;
   return GM_OK;
 }
 
@@ -1724,15 +1782,13 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
   const int nv = D.nvertices, G = D.nshards;
   int S = (nv + G - 1) / G;
   if (G > 1) S = (S + 63) / 64 * 64;
-  const int vd = (G > 1) ? G * S : nv;
+  int vd = (G > 1) ? G * S : nv;  // (sharded graphs with slices: S and vd are settled once the slices are known, below)
   DevBuf deg, keys_in, keys_out, ids_in, order, tmp, don, nod;
   int rc;
   if ((rc = deg.alloc((size_t)nv * 4)) || (rc = keys_in.alloc((size_t)nv * 4)) || (rc = keys_out.alloc((size_t)nv * 4)) ||
-      (rc = ids_in.alloc((size_t)nv * 4)) || (rc = order.alloc((size_t)nv * 4)) || (rc = don.alloc((size_t)nv * 4)) ||
-      (rc = nod.alloc((size_t)vd * 4)))
+      (rc = ids_in.alloc((size_t)nv * 4)) || (rc = order.alloc((size_t)nv * 4)) || (rc = don.alloc((size_t)nv * 4)))
     return rc;
   GM_TRY_HIP(hipMemsetAsync(deg.p, 0, (size_t)nv * 4, s));
-  GM_TRY_HIP(hipMemsetAsync(nod.p, 0xff, (size_t)vd * 4, s));  // -1 = unused slot
   if (nnz > 0)
     hipLaunchKernelGGL(k_degree, dim3(grid_for(nnz)), dim3(kT), 0, s, d_src, d_dst, nnz, D.nparts, nv, D.ids_are_native,
                        deg.as<uint32_t>(), g_rank_by);
@@ -1787,9 +1843,18 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     if (g_sweep_slices != 0 && (!keeps_values || D.val_bytes == 4)) T = mib < 25.0 ? 1 : mib < 50.0 ? 2 : mib < 180.0 ? 3 : (int)(mib / 40.0 + 0.5);
     else if (keeps_values && mib < 100.0) T = 1;
   }
+  // Sharded graphs (round 6): no column tiles, but the same SLICES -- every owner's range of the device order becomes [slice][degree rank
+  // inside it], so that a slice of the message vector is the same sub-range of all G owners' ranges and the row-stationary sweep can walk
+  // a shard's rows (gm_sweep_t.nsub).  Whenever a single-shard graph of this size would be tiled (or the caller asks for tiles).
+  const bool sweepable_ = !keeps_values || D.val_bytes == 4;
+  const bool shard_slices = G > 1 && T > 1 && nz >= 2 && g_sweep_slices != 0 && sweepable_ && nnz >= 0 && nv < (1 << 28);
   if (T < 1 || G > 1 || nz < 2) T = 1;
   if (T > GM_MAX_TILES) T = GM_MAX_TILES;
-  if (T > 1) {
+  DevBuf slice_keys;  // sharded graphs with slices: the slice of every position of the sorted list (255 = no edges)
+  SliceDeal sd;
+  memset(&sd, 0, sizeof(sd));
+  int shard_TS = 0;
+  if (T > 1 || shard_slices) {
     // Tiles are contiguous NATIVE ranges cut so that every tile serves about the same number of gathers (a vertex weighs
     // as often as it is a column of the GM_DIR_OUT adjacency; on RMAT the busy tiles then hold fewer vertices, i.e. a
     // smaller slice of x where most gathers go).  gm_set_option("tile_balance", 0) cuts them into equally many vertices
@@ -1805,8 +1870,9 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     const int by_vertices = (g_tile_balance == 0 || nnz == 0) ? 1 : 0;
     const int pw100 = g_tile_balance >= 100000 ? g_tile_balance - 100000 : 100;
     const uint32_t addc = (g_tile_balance >= 2 && g_tile_balance <= 65536) ? (uint32_t)(g_tile_balance - 1) : 0u;
-    if (!by_vertices)
+    if (!by_vertices && nnz > 0)
       hipLaunchKernelGGL(k_col_weight, dim3(grid_for(nnz)), dim3(kT), 0, s, d_src, nnz, D.nparts, nv, D.ids_are_native, cnt.as<uint32_t>());
+    if (!by_vertices && D.edges_local && (rc = dist_all_reduce_sum_u32(cnt.as<uint32_t>(), (size_t)nv, s))) return rc;  // (every rank must cut the same slices)
     hipLaunchKernelGGL(k_tile_weight, dim3(grid_for(nv)), dim3(kT), 0, s, deg.as<uint32_t>(), cnt.as<uint32_t>(), nv, addc, pw100, by_vertices,
                        w.as<unsigned long long>());
     size_t sb = 0;
@@ -1825,7 +1891,7 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     // is multiplied by the column-blocked stream of its short rows, k_spmv_blocked, whose synchronised steps want fewer, larger slices:
     // uniform 2^26, 32 / 48 / 56 / 64 / 72 / 96 / 128 slices: 12.9 / 10.5 / 9.7 / 9.0 / 10.0 / 10.1 / 12.0 ms; 2^25, 32 / 99: 4.24 / 4.71 -- about 4 MiB each)
     bool no_skew = false;
-    if (g_sweep_slices == 1 && g_blocked_rows >= 0 && !keeps_values && nnz > 0) {
+    if (g_sweep_slices == 1 && g_blocked_rows >= 0 && !keeps_values && nnz > 0 && G == 1) {
       DevBuf mass;
       if ((rc = mass.alloc(16))) return rc;
       GM_TRY_HIP(hipMemsetAsync(mass.p, 0, 16, s));
@@ -1836,6 +1902,12 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
       no_skew = hm[0] > 0 && hm[1] * 10ull <= hm[0];
     }
     int want_slices = g_sweep_slices >= 8 ? g_sweep_slices : (int)(mib_live / (no_skew ? 4.0 : 1.3) + 0.5);
+    // (a shard of G holds 1 / G of the edges but walks the WHOLE message vector: what a slice costs a workgroup whatever it holds --
+    // two barriers, the hot-set load, the staging round -- weighs G times more against the gathers it makes cheaper, so a shard wants
+    // fewer, larger slices.  Shard 0 of RMAT-26, compute only, ms per iteration by slice count -- of 8: 16 / 20 / 24 / 28 / 32 / 48 / 64 / 96:
+    // 1.15 / 1.05 / 1.07 / 1.12 / 1.14 / 1.33 / 1.44 / 1.81; of 4: 16 / 24 / 32 / 96: 1.78 / 1.58 / 1.60 / 2.07; of 2: 24 / 32 / 48 / 96: 2.65 /
+    // 2.23 / 2.18 / 2.37 -- about G^-0.75 of the single shard's count; profiles/r06_shard_slice_counts.txt)
+    if (shard_slices && g_sweep_slices < 8) want_slices = (int)((double)want_slices / pow((double)G, 0.75) + 0.5);
     want_slices = std::max(16, std::min(GM_MAX_SLICES, want_slices));
     // (an adjacency the sweep cannot take -- edge values that are not 4 bytes wide -- is only ever walked tile by tile: its order stays
     // degree-ranked inside a whole TILE, so that the tile kernels' LDS hot sets hold the tile's busiest vertices, not one slice's)
@@ -1856,18 +1928,41 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     int64_t hb[GM_MAX_SLICES + 2];
     GM_TRY_HIP(hipMemcpyAsync(hb, bnd.p, (size_t)(TS + 1) * 8, hipMemcpyDeviceToHost, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
-    for (int t = 0; t <= T; t++) g->tile_base[t] = (int32_t)hb[t * sub];
-    g->nslices = sub > 1 ? TS : 0;
-    for (int t = 0; t <= TS; t++) g->slice_base[t] = (int32_t)hb[t];
+    if (!shard_slices) {
+      for (int t = 0; t <= T; t++) g->tile_base[t] = (int32_t)hb[t * sub];
+      g->nslices = sub > 1 ? TS : 0;
+      for (int t = 0; t <= TS; t++) g->slice_base[t] = (int32_t)hb[t];
+    } else {
+      // positions inside an owner's range: slice t takes ceil(n_t / G) of them in every owner
+      shard_TS = TS;
+      long long pos = 0;
+      for (int t = 0; t < TS; t++) { sd.hb[t] = (int32_t)hb[t]; sd.sb[t] = (int32_t)pos; pos += (hb[t + 1] - hb[t] + G - 1) / G; }
+      sd.hb[TS] = (int32_t)hb[TS];  // (= vertices with edges; the rest of the list has none)
+      sd.sb[TS] = (int32_t)pos;
+      const long long ndead = (long long)nv - hb[TS];
+      const long long need = pos + (ndead + G - 1) / G;
+      S = (int)((need + 63) / 64 * 64);
+      vd = G * S;
+      g->tile_base[0] = 0; g->tile_base[1] = (int32_t)pos;
+      g->nslices = TS;
+      for (int t = 0; t <= TS; t++) g->slice_base[t] = sd.sb[t];
+      slice_keys.p = tk_out.release();
+    }
   }
   g->ntiles = T;
   D.col_tiles = T;
-  hipLaunchKernelGGL(k_deal, dim3(grid_for(nv)), dim3(kT), 0, s, order.as<int32_t>(), nv, G, S, don.as<int32_t>(),
-                     nod.as<int32_t>());
+  if ((rc = nod.alloc((size_t)vd * 4))) return rc;
+  GM_TRY_HIP(hipMemsetAsync(nod.p, 0xff, (size_t)vd * 4, s));  // -1 = unused slot
+  if (shard_TS > 0)
+    hipLaunchKernelGGL(k_deal_sliced, dim3(grid_for(nv)), dim3(kT), 0, s, order.as<int32_t>(), (const uint8_t*)slice_keys.as<uint8_t>(), nv, G, S, shard_TS, sd,
+                       don.as<int32_t>(), nod.as<int32_t>());
+  else
+    hipLaunchKernelGGL(k_deal, dim3(grid_for(nv)), dim3(kT), 0, s, order.as<int32_t>(), nv, G, S, don.as<int32_t>(),
+                       nod.as<int32_t>());
   GM_TRY_HIP(hipGetLastError());
   GM_TRY_HIP(hipStreamSynchronize(s));
   {
-    long long per = ((long long)nz + G - 1) / G;
+    long long per = shard_TS > 0 ? (long long)sd.sb[shard_TS] : ((long long)nz + G - 1) / G;
     per = (per + 63) / 64 * 64;
     const long long slice = (G > 1) ? S : nv;
     D.xchg_rows = (int32_t)(per < slice ? per : slice);

@@ -957,8 +957,15 @@ class Run {
   // The stages send iteration i+1's messages before the hook of iteration i could run: only for programs that leave
   // do_every_iteration to the base class.
   bool two_stage_applies() const {
-    return multi && act == ALL_VERTICES && order == OUT_EDGES && iterations > 0 && !(opt.debug_flags & dev::DBG_NO_PIPELINE) && !trace &&
-           inherits_iteration_hook<P>();
+    if (!(multi && act == ALL_VERTICES && order == OUT_EDGES && iterations > 0 && !(opt.debug_flags & dev::DBG_NO_PIPELINE) && !trace && inherits_iteration_hook<P>()))
+      return false;
+    // a shard whose rows the sweep takes (gm_sweep_t.nsub): its device order is [slice][degree rank], the busy rows are no prefix of it
+    // -- the plain loop with the swept multiply (round 6)
+    if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
+      gm_sweep_t sw;
+      if (!use_vp && gm_graph_sweep(g, &sw) == GM_OK && sw.nrows > 0 && sw.nsub > 1 && !(opt.debug_flags & (dev::DBG_NO_TILES | dev::DBG_NO_OVERLAP))) return false;
+    }
+    return true;
   }
   // returns the iterations done, or -1 when the shards could not agree on a split (the caller runs the plain loop)
   int run_two_stage() {
@@ -1233,6 +1240,9 @@ class Run {
       if (opt.debug_flags & (dev::DBG_NO_TILES | dev::DBG_NO_OVERLAP)) return false;
       if (gm_graph_sweep(g, sw) != GM_OK || sw->nrows <= 0 || sw->acc_rows != GM_SWEEP_ACC_ROWS || sw->long_slots != GM_SWEEP_LONG_SLOTS) return false;
       if (sw->short_row != Aout.short_row) return false;
+      // a shard's rows (gm_sweep_t.nsub): the structure must describe THIS cut of the message vector; a single-shard structure is not
+      // used by a run that exchanges messages (a world of one rank: nothing to gain)
+      if (sw->nsub > 1 ? (sw->nsub != desc.nshards || sw->stride != n || sw->hot_words <= 0) : multi) return false;
       if (Aout.vals != nullptr && !(sw->val_bytes == 4 && sizeof(E) == 4 && std::is_trivially_copyable<E>::value)) return false;
       return true;
     } else {
@@ -1304,6 +1314,21 @@ class Run {
       for (int set = 0; set < sw.nsets; set++) {
         U* gt = set == 0 ? gterms : (U*)nullptr;  // (the first launch gathers for the giant rows)
         bool with_vals = false;
+        if (sw.nsub > 1) {  // a shard's rows: the message vector is made of nsub owners' ranges (kernels.hpp: k_spmv_sell_sharded)
+          if constexpr (sizeof(E) == 4 && std::is_trivially_copyable<E>::value) {
+            if (Aout.vals != nullptr) {
+              hipLaunchKernelGGL((dev::k_spmv_sell_sharded<P, T, U, V, E, true>), dim3(256), dim3(1024), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base,
+                                 sw.scol, sw.sval, sw.wrow, sw.row_of_slot, sw.lcol, sw.lval, sw.lps, sw.lrow_of_slot, sw.gcol, sw.gval, sw.gdst, sw.gslice, gt, xq, y,
+                                 sw.nsub, sw.stride, sw.hot_words);
+              with_vals = true;
+            }
+          }
+          if (!with_vals)
+            hipLaunchKernelGGL((dev::k_spmv_sell_sharded<P, T, U, V, E, false>), dim3(256), dim3(1024), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base,
+                               sw.scol, (const uint32_t*)nullptr, sw.wrow, sw.row_of_slot, sw.lcol, (const uint32_t*)nullptr, sw.lps, sw.lrow_of_slot, sw.gcol,
+                               (const uint32_t*)nullptr, sw.gdst, sw.gslice, gt, xq, y, sw.nsub, sw.stride, sw.hot_words);
+          continue;
+        }
         if constexpr (sizeof(E) == 4 && std::is_trivially_copyable<E>::value) {
           if (Aout.vals != nullptr) {
             hipLaunchKernelGGL((dev::k_spmv_sell<P, T, U, V, E, true>), dim3(256), dim3(1024), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base, sw.scol,
@@ -1529,7 +1554,7 @@ class Run {
         gm_graph_tiles(g, GM_DIR_OUT, &ntile);
       gm_sweep_t sw;
       gm_blocked_t bl;
-      if (dense_x && !multi && row_bits == nullptr && sweep_usable(acc, &sw)) {
+      if (dense_x && row_bits == nullptr && sweep_usable(acc, &sw)) {  // (sharded graphs too: gm_sweep_t.nsub)
         multiply_out_swept(pa, acc, sw);
       } else if (dense_x && !multi && row_bits == nullptr && blocked_usable(acc, &bl)) {
         multiply_out_blocked(pa, acc, bl);

@@ -1460,13 +1460,18 @@ static __device__ unsigned long long g_sell_phase_ticks[4096][8];
 #else
 #define GM_SELL_TICK(k) do { } while (0)
 #endif
-template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL = 0, int UBATCH = 7, int PIPE = 2, int POOLW = GM_SWEEP_POOL>
-__global__ void __launch_bounds__(1024)
-k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long, const int32_t* __restrict__ slice_base, const uint32_t* __restrict__ scol,
-            const uint32_t* __restrict__ sval, const uint32_t* __restrict__ wrow, const int32_t* __restrict__ row_of_slot, const uint32_t* __restrict__ lcol,
-            const uint32_t* __restrict__ lval, const uint32_t* __restrict__ lps, const int32_t* __restrict__ lrow_of_slot,
-            const uint32_t* __restrict__ gcol, const uint32_t* __restrict__ gval, const uint32_t* __restrict__ gdst, const uint32_t* __restrict__ gslice,
-            U* __restrict__ gterms /* products stream of the giant rows, or null: they gather for themselves */, const T* __restrict__ x, U* __restrict__ y) {
+// SHARDED (graphmat_hip.h: gm_sweep_t.nsub > 1; round 6): the rows are a shard's, the message vector is made of nsub owners' ranges of
+// `stride` entries, slice_base holds positions inside a range -- a slice is the same sub-range of every owner's range, its hot set the
+// first hq = min(slice length, hot_words / nsub) entries of each (LDS word q * hq + j) -- and the entries say at build time whether
+// their message is in LDS (GM_SWEEP_HOT | LDS byte offset) or in the message vector (byte offset): the gather decodes, nothing else changes.
+template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL, int UBATCH, int PIPE, int POOLW, bool SHARDED>
+__device__ __forceinline__ void
+sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows_long, const int32_t* __restrict__ slice_base, const uint32_t* __restrict__ scol,
+          const uint32_t* __restrict__ sval, const uint32_t* __restrict__ wrow, const int32_t* __restrict__ row_of_slot, const uint32_t* __restrict__ lcol,
+          const uint32_t* __restrict__ lval, const uint32_t* __restrict__ lps, const int32_t* __restrict__ lrow_of_slot,
+          const uint32_t* __restrict__ gcol, const uint32_t* __restrict__ gval, const uint32_t* __restrict__ gdst, const uint32_t* __restrict__ gslice,
+          U* __restrict__ gterms /* products stream of the giant rows, or null: they gather for themselves */, const T* __restrict__ x, U* __restrict__ y,
+          int nsub, int stride, int hot_words) {
   static_assert(sizeof(T) == 4 && sizeof(U) == 4, "4-byte messages and reductions");
   constexpr int BLOCK = 1024, W = BLOCK / 64, UB = UBATCH;
   constexpr int ACC = GM_SWEEP_ACC_ROWS, NLP = GM_SWEEP_LONG_SLOTS;
@@ -1542,17 +1547,33 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
   for (int sl = 0; sl < nslices; sl++) {
     const int base = slice_base[sl];
     const int slen = slice_base[sl + 1] - base;
-    const int nhot = slen < HOT ? slen : HOT;
+    int hq = 0;  // (sharded: hot entries per owner)
+    if constexpr (SHARDED) { const int cap = (hot_words < HOT ? hot_words : HOT) / nsub; hq = slen < cap ? slen : cap; }
+    const int nhot = SHARDED ? hq * nsub : (slen < HOT ? slen : HOT);
     const uint32_t base4 = (uint32_t)base << 2, nhot4 = (uint32_t)nhot << 2;
+    const uint32_t idle4 = SHARDED ? GM_SWEEP_HOT : base4;  // what a lane without an edge gathers (an LDS word / the slice's first entry)
     __syncthreads();  // the previous slice's folds are done: its hot set and stage may go, the running values are in s_acc
     GM_SELL_TICK(0);  // waiting for the other waves at the end of a slice
     // (requesting the hot entries before the barrier as well -- 12 of them per thread in registers -- was measured: 2.19 against
     // 2.09 ms, the kernel then needs all 128 VGPRs; the cold parts of the first staging round's and the giant rows' gathers
     // requested before the barriers: 2.15 against 2.10, with the giant rows 2.32 against 2.23)
-    for (int i = threadIdx.x; i < nhot; i += BLOCK) s_pool[i] = ((const uint32_t*)x)[base + i];
+    if constexpr (SHARDED) {
+      for (int q = 0; q < nsub; q++) {
+        const uint32_t* __restrict__ xq_ = (const uint32_t*)x + (size_t)q * (size_t)stride + (size_t)base;
+        for (int i = threadIdx.x; i < hq; i += BLOCK) s_pool[q * hq + i] = xq_[i];
+      }
+    } else {
+      for (int i = threadIdx.x; i < nhot; i += BLOCK) s_pool[i] = ((const uint32_t*)x)[base + i];
+    }
     __syncthreads();
     GM_SELL_TICK(1);  // hot set
     auto gather = [&](uint32_t c4) {  // (branch-free: lanes whose column is in LDS re-read the slice's first entry, an L1 hit)
+      if constexpr (SHARDED) {
+        const bool h = (c4 & GM_SWEEP_HOT) != 0u;
+        const uint32_t mh = *(const uint32_t*)((const char*)s_pool + (h ? (c4 & 0x3ffffffcu) : 0u));
+        const uint32_t mg = *(const uint32_t*)(xb + (h ? base4 : c4));
+        return h ? mh : mg;
+      } else {
       const uint32_t rel4 = c4 - base4;
       if constexpr ((ABL & 3) == 1) return c4;
       if constexpr ((ABL & 3) == 2) return *(const uint32_t*)((const char*)s_pool + (nhot4 ? (rel4 % nhot4) & ~3u : 0u));
@@ -1560,6 +1581,7 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
       const uint32_t mh = *(const uint32_t*)((const char*)s_pool + (h ? rel4 : 0u));
       const uint32_t mg = *(const uint32_t*)(xb + (h ? base4 : c4));
       return h ? mh : mg;
+      }
     };
     // the giant rows' share of this slice: their messages are requested here, next to the staging round's, and their products
     // go to the stream the giant rows' fold passes read (after the staging phase: by then they have arrived)
@@ -1676,7 +1698,7 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
       };
       auto gathers = [&](const uint32_t (&cx)[UB], uint32_t skip, uint32_t (&mx)[UB]) {
 #pragma unroll
-        for (int j = 0; j < UB; j++) mx[j] = gather(((skip >> j) & 1u) ? base4 : (cx[j] & 0x7fffffffu));
+        for (int j = 0; j < UB; j++) mx[j] = gather(((skip >> j) & 1u) ? idle4 : (cx[j] & 0x7fffffffu));
       };
       if (r < rend) {
         uint32_t skipA = 0, maskA = scan(r, cA, skipA);
@@ -1780,6 +1802,27 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
     const int row = lrow_of_slot[vw * NLP + lj];
     if (row >= 0 && lhas) y[row] = lacc;
   }
+}
+template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL = 0, int UBATCH = 7, int PIPE = 2, int POOLW = GM_SWEEP_POOL>
+__global__ void __launch_bounds__(1024)
+k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long, const int32_t* __restrict__ slice_base, const uint32_t* __restrict__ scol,
+            const uint32_t* __restrict__ sval, const uint32_t* __restrict__ wrow, const int32_t* __restrict__ row_of_slot, const uint32_t* __restrict__ lcol,
+            const uint32_t* __restrict__ lval, const uint32_t* __restrict__ lps, const int32_t* __restrict__ lrow_of_slot,
+            const uint32_t* __restrict__ gcol, const uint32_t* __restrict__ gval, const uint32_t* __restrict__ gdst, const uint32_t* __restrict__ gslice,
+            U* __restrict__ gterms, const T* __restrict__ x, U* __restrict__ y) {
+  sell_body<P, T, U, V, E, HAS_VALS, ABL, UBATCH, PIPE, POOLW, false>(pa, set, stage_words, nslices, nrows_long, slice_base, scol, sval, wrow, row_of_slot, lcol, lval, lps,
+                                                                       lrow_of_slot, gcol, gval, gdst, gslice, gterms, x, y, 1, 0, 0);
+}
+// the same sweep over a shard's rows (gm_sweep_t.nsub > 1)
+template <class P, class T, class U, class V, class E, bool HAS_VALS>
+__global__ void __launch_bounds__(1024)
+k_spmv_sell_sharded(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long, const int32_t* __restrict__ slice_base, const uint32_t* __restrict__ scol,
+                    const uint32_t* __restrict__ sval, const uint32_t* __restrict__ wrow, const int32_t* __restrict__ row_of_slot, const uint32_t* __restrict__ lcol,
+                    const uint32_t* __restrict__ lval, const uint32_t* __restrict__ lps, const int32_t* __restrict__ lrow_of_slot,
+                    const uint32_t* __restrict__ gcol, const uint32_t* __restrict__ gval, const uint32_t* __restrict__ gdst, const uint32_t* __restrict__ gslice,
+                    U* __restrict__ gterms, const T* __restrict__ x, U* __restrict__ y, int nsub, int stride, int hot_words) {
+  sell_body<P, T, U, V, E, HAS_VALS, 0, 7, 2, GM_SWEEP_POOL, true>(pa, set, stage_words, nslices, nrows_long, slice_base, scol, sval, wrow, row_of_slot, lcol, lval, lps,
+                                                                    lrow_of_slot, gcol, gval, gdst, gslice, gterms, x, y, nsub, stride, hot_words);
 }
 
 // ------------------------------------------------------------------------------------

@@ -317,7 +317,21 @@ typedef struct {
   const uint32_t* gdst;
   const uint32_t* gslice;
   const uint32_t* gsrc_pos;
+  /* SHARDED graphs (round 6; nsub = nshards > 1).  Every owner's range [q * stride, (q + 1) * stride) of the device order is laid
+     out [slice 0][slice 1] ... (busiest vertices first inside a slice), the j-th busiest vertex of slice t sitting at position
+     slice_base[t] + j / nsub of owner (j + t) % nsub: a slice of the message vector is then the SAME sub-range
+     [slice_base[t], slice_base[t + 1]) of all nsub owners' ranges (slice_base holds positions inside an owner's range, not device
+     ids), the structure is built from the shard's own rows, and the column entries (scol / lcol / gcol) carry the hot-set
+     decision made at build time: bit 30 set = the message is in the workgroup's LDS at byte offset (entry & 0x3ffffffc), i.e.
+     word q * hq + j for position slice_base[t] + j < hq of owner q, hq = min(slice length, hot_words / nsub); clear = byte offset
+     into the message vector (column << 2, columns below 2^28).  Padding = GM_SWEEP_PAD | bit 30.  nsub <= 1: the single-shard
+     form described above (hot entries are recognised by their offset). */
+  int32_t nsub;
+  int32_t stride;     /* rows per owner (= row_hi - row_lo) */
+  int32_t hot_words;  /* LDS words the build assumed for a slice's hot entries (the kernel must load at least as many) */
+  int32_t reserved_;
 } gm_sweep_t;
+#define GM_SWEEP_HOT 0x40000000u
 #define GM_MAX_SLICES 128
 #define GM_SWEEP_ACC_ROWS 10048
 #define GM_SWEEP_LONG_SLOTS 512

@@ -92,6 +92,28 @@ def test_native_exchange_several_ranks_over_shared_memory(world):
     assert out.returncode == 0 and "MULTI_OK" in text and "native-rccl" in text, text[-3000:]
 
 
+@pytest.mark.parametrize("world,exchange,scale", [(2, "callback", 15), (3, "callback", 15), (2, "native", 16), (3, "native", 16)])
+def test_sharded_sweep_matches_oracle(world, exchange, scale):
+    """The row-stationary sweep on a SHARD's rows (graphmat_hip.h: gm_sweep_t.nsub; kernels.hpp: k_spmv_sell_sharded; round 6): every
+    owner's range of the device order is [slice][degree rank], slices are ascending native ranges, the structure is built from the
+    shard's own rows (also by the distributed build), and PageRank through it -- with and without edge values, several launches,
+    long rows staged in one or several rounds, either giant-row form -- has the oracle's bits with 2 and 3 ranks, over the
+    torch.distributed callback and over the library's native exchange on the shared-memory stand-in for librccl
+    (tools/multi_sweep_check.py)."""
+    from graphmat_amd import build
+    build.build()
+    from oracle import binding
+    binding.build()
+    env = dict(os.environ, GM_BACKEND="gloo", GM_SCALE=str(scale), GM_EXCHANGE=exchange)
+    if exchange == "native":
+        env["GRAPHMAT_RCCL_LIBRARY"] = _shm_lib()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "multi_sweep_check.py")]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env, cwd=ROOT)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "SWEEP_MULTI_OK" in text, text[-3000:]
+
+
 def test_missing_stream_wait_is_caught():
     """Negative control for the multi-rank tests.  The shared-memory stand-in for librccl is stream-ordered (its collectives only
     enqueue copies, reductions and a spinning rendezvous kernel on the stream they are handed), so the ordering between

@@ -33,13 +33,19 @@ def main():
         g.run_pagerank(st, 2)
         g.enable_timing(True)
         torch.cuda.synchronize()
+        import ctypes as C
+        cnt = (C.c_int64 * 4)()
+        L.gm_debug_counters(cnt)  # (reset)
         g.run_pagerank(st, args.iters)
+        L.gm_debug_counters(cnt)
         s = g.last_stats()
         c = g.csr(api.GM_DIR_OUT)
         k = args.iters
         print("shard %d of %d (RMAT-%d): %d edges, %d giant rows; per iteration: total %.3f ms = send %.3f + rowblock %.3f + wave %.3f + apply %.3f; "
               "giant passes %.3f ms (overlapped on the auxiliary stream)" % (shard, args.nshards, args.scale, c.nnz, c.ngiant, s["total_ms"] / k,
               s["send_ms"] / k, s["rowblock_ms"] / k, s["wave_ms"] / k, s["apply_ms"] / k, s["giant_ms"] / k), flush=True)
+        print("   giant rows' exact replay per iteration: %d 16-product groups accepted by the parallel scan, %d folded serially, %d skipped by piece maps"
+              % (cnt[0] // k, cnt[1] // k, cnt[2] // k), flush=True)
         if args.staged:
             # a do-nothing exchange makes the run "sharded": the engine picks the two-stage schedule (needs the second
             # message buffer) or, with debug flag 128, the plain loop with one exchange per iteration
