@@ -642,10 +642,14 @@ def main():
     max_deg = int(degs.max()) if degs.size else 0
     del rowptr, degs
 
+    from graphmat_amd import _lib as _gl0
+    _sw0 = _gl0.Sweep()
+    sharded_sweep = world > 1 and _gl0.lib().gm_graph_sweep(g.h, C.byref(_sw0)) == 0 and int(_sw0.nsub) == world and int(_sw0.nslices) > 1
     # ---- state, Degree pass, warm-up ---------------------------------------------------------
     st = g.new_pr_state()
     g.run_degree(st)
     overlapped = False
+    forms_ms = None
 
     def parts_started():
         if native:
@@ -689,11 +693,13 @@ def main():
             overlapped = False
         elif overlapped and t_plain > 0 and t_two > t_plain * 1.02:
             # both schedules give the same bits; keep the faster one on this machine (max over ranks, 4 iterations each)
-            log(rank, "two-stage schedule %.3f ms/iteration vs plain %.3f: using the plain exchange" % (t_two / 4 * 1e3, t_plain / 4 * 1e3))
+            log(rank, "%s schedule %.3f ms/iteration vs plain %.3f: using the plain exchange" % ("sharded swept" if sharded_sweep else "two-stage", t_two / 4 * 1e3, t_plain / 4 * 1e3))
             args.debug_flags |= 128
             overlapped = False
         else:
-            log(rank, "two-stage schedule %.3f ms/iteration vs plain %.3f: using the two-stage schedule" % (t_two / 4 * 1e3, t_plain / 4 * 1e3))
+            log(rank, "%s schedule %.3f ms/iteration vs plain %.3f: using the %s" % ("sharded swept" if sharded_sweep else "two-stage", t_two / 4 * 1e3, t_plain / 4 * 1e3,
+                                                                                      "overlapped schedule" if overlapped else "plain loop (no overlapped schedule applies)"))
+        forms_ms = {"overlapped": round(t_two / 4 * 1e3, 4) if t_two > 0 else None, "plain": round(t_plain / 4 * 1e3, 4) if t_plain > 0 else None}
     if args.warmup > 0:
         if args.debug_flags & 128:
             L.gm_set_option(b"debug_flags", args.debug_flags)
@@ -733,18 +739,27 @@ def main():
                 return 0
             cb0 = _lib.EXCHANGE_FN(nothing)
             _lib.check(L.gm_graph_set_exchange(g.h, cb0, None))
+            _lib.check(L.gm_graph_set_exchange_caps(g.h, _lib.GM_XCAP_SPARSE))  # (the sharded swept schedule asks for the list exchange; this one moves nothing either)
             scratch = st.clone()
             g.enable_timing(False)
-            g.run_pagerank(scratch, 2)
-            dist.barrier()
-            torch.cuda.synchronize()
-            tc = time.perf_counter()
-            g.run_pagerank(scratch, args.steps)
-            torch.cuda.synchronize()
-            tc = time.perf_counter() - tc
-            tct = torch.tensor([tc], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(tct, op=dist.ReduceOp.MAX)
-            compute_ms = float(tct.item()) * 1e3 / args.steps
+
+            def compute_only(flags):
+                L.gm_set_option(b"debug_flags", flags)
+                g.run_pagerank(scratch, 2)
+                dist.barrier()
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
+                g.run_pagerank(scratch, args.steps)
+                torch.cuda.synchronize()
+                tc = time.perf_counter() - tc
+                tct = torch.tensor([tc], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(tct, op=dist.ReduceOp.MAX)
+                return float(tct.item()) * 1e3 / args.steps
+            compute_ms = compute_only(args.debug_flags)
+            # ... and of the OTHER form (overlapped / plain), so that the line carries what the exchange exposes in each
+            other_flags = (args.debug_flags & ~128) if (args.debug_flags & 128) else (args.debug_flags | 128)
+            compute_other_ms = compute_only(other_flags) if forms_ms is not None else None
+            L.gm_set_option(b"debug_flags", args.debug_flags)
             del scratch
             if native:
                 _lib.check(L.gm_graph_use_rccl(g.h))
@@ -760,6 +775,19 @@ def main():
                                                       "rowblock": round(stats["rowblock_ms"] / args.steps, 4), "wave": round(stats["wave_ms"] / args.steps, 4),
                                                       "giant_aux_stream": round(stats["giant_ms"] / args.steps, 4), "apply": round(stats["apply_ms"] / args.steps, 4)},
                           "note": "compute_only = the same schedule with an exchange callback that moves nothing (max over ranks); exposed = measured - compute_only"}
+            if forms_ms is not None:
+                # per form: measured (max over ranks; the chosen form over the timed region, the other one over the 4 iterations of the schedule check),
+                # compute only, and the difference = what the exchange adds on the critical path in that form
+                chosen = "plain" if (args.debug_flags & 128) else "overlapped"
+                other = "overlapped" if chosen == "plain" else "plain"
+                per_form = {chosen: {"ms_per_step": round(dt * 1e3 / args.steps, 4), "compute_only_ms_per_step": round(compute_ms, 4),
+                                     "exchange_ms_exposed": round(dt * 1e3 / args.steps - compute_ms, 4)}}
+                if forms_ms.get(other) is not None and compute_other_ms is not None:
+                    per_form[other] = {"ms_per_step": forms_ms[other], "compute_only_ms_per_step": round(compute_other_ms, 4),
+                                       "exchange_ms_exposed": round(forms_ms[other] - compute_other_ms, 4)}
+                multi_diag["forms"] = per_form
+                multi_diag["form_timed"] = chosen
+                multi_diag["overlapped_form"] = ("sharded swept schedule: the all-gather starts before the giant rows are folded" if sharded_sweep else "two-stage schedule: tail rows' messages travel while the head rows are multiplied")
             log(rank, "N=%d diagnostics: %.3f ms/step measured, %.3f ms/step compute only => %.3f ms of exchange exposed; %d bytes sent and %d received per rank and step"
                 % (world, dt * 1e3 / args.steps, compute_ms, dt * 1e3 / args.steps - compute_ms, live * 4, live * 4 * (world - 1)))
         except Exception as e:  # pragma: no cover
@@ -795,8 +823,8 @@ def main():
     # giant goes through it, the short rows through the row-block kernel, the giant rows through their own passes on the auxiliary stream
     from graphmat_amd import _lib as _gl
     sweep = _gl.Sweep()
-    if _gl.lib().gm_graph_sweep(g.h, C.byref(sweep)) != 0 or world > 1:
-        sweep.nrows = 0
+    if _gl.lib().gm_graph_sweep(g.h, C.byref(sweep)) != 0 or (world > 1 and int(sweep.nsub) != world):
+        sweep.nrows = 0  # (N > 1: rank 0's shard, when its rows go through the sharded sweep -- gm_sweep_t.nsub)
     swept = int(sweep.nrows) > 0
     roof = None
     name = max(kern, key=lambda k: kern[k][0])
@@ -905,8 +933,9 @@ def main():
                                 "vertices with %d out-edges each to uniformly drawn destinations, seed %d" % (args.scale, args.edge_factor, args.seed)),
                    "V": nv, "E": E, "parallelism": "1d-rows x%d" % world, "exchange": ((("native exchange (gm_dist.hip) over %s, " % ("%s [GRAPHMAT_RCCL_LIBRARY, not RCCL]" % os.path.basename(os.environ["GRAPHMAT_RCCL_LIBRARY"]) if os.environ.get("GRAPHMAT_RCCL_LIBRARY") else "RCCL"))
                                                                               if native else "torch.distributed callback, ") if world > 1 else "") +
-                                                                            ("two-stage overlapped all-gather" if overlapped else
-                                                                             ("all-gather between send and multiply" if world > 1 else "none")), "id_layout_nparts": nparts,
+                                                                            (("all-gather started before the giant rows are folded, their messages following as lists (sharded swept schedule)"
+                                                                              if sharded_sweep else "two-stage overlapped all-gather") if overlapped else
+                                                                             (("all-gather between send and multiply" + (" (sharded sweep)" if sharded_sweep else "")) if world > 1 else "none")), "id_layout_nparts": nparts,
                    "exchange_fell_back_to_broadcasts": bool(ex is not None and ex.no_fast_path and not native),
                    "device_order": "native" if args.native_layout else "degree-ranked, dealt over shards",
                    "col_tiles": int(g.col_tiles),

@@ -318,8 +318,10 @@ k_sgd_multiply(gm_csr_t A, const float* __restrict__ x, const float* __restrict_
   }
 }
 
-// ---- the dot products on the matrix cores (option "sgd_mfma"; NOT the default: sums are within 1e-6 of the reference's,
-// not its bits) --------------------------------------------------------------------------------------------------------
+// ---- the dot products on the matrix cores (option "sgd_mfma"; NOT the default, an opt-in MEASUREMENT form: the instruction sums
+// its partial dots in its own order, so results deviate from the reference's sequential K-term dot by up to ~1e-5 of the vectors'
+// scale -- outside north_star's 1e-6 bar and two orders of magnitude outside the reference's own fused-vs-unfused spread
+// (tests/test_gpu_parity.py::test_sgd_k128_matrix_core_option_deviation_bound, tests/test_oracle_golden.py) ------------------------
 // What a matrix core can do for this path at all: per edge the work is ONE K-term dot product of a gathered row with the
 // row's own vector -- no operand is shared between the edges of different rows, and at a ratings density of 1e-4 a
 // 32 x 32 (rows x columns) block of the matrix holds 0.1 ratings, so there is no dense tile to multiply.  The one

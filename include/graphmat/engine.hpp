@@ -686,6 +686,10 @@ class Run {
     setup();
     int it = -1;
     if (two_stage_applies()) it = run_two_stage();
+    if (it < 0) {
+      gm_sweep_t sw;
+      if (swept_pipeline_applies(&sw)) it = run_swept_sharded(sw);
+    }
     if (it < 0) it = run_loop();
     return it;
   }
@@ -838,7 +842,10 @@ class Run {
     if constexpr (std::is_same<U, float>::value && ((int)program_traits<P>::reduce == (int)REDUCE_AUTO || (int)program_traits<P>::reduce == (int)REDUCE_ORDERED)) {
       // (also for a program that DECLARES the ordered fold: the guess decides nothing about its bits, only which speculation its giant rows try)
       const char* off = getenv("GRAPHMAT_NO_PROBE");
-      guess_f32_add = rk == REDUCE_ORDERED && !(off && off[0] == '1') && probe_reduce_guess<P, U>(gp) == REDUCE_F32_ADD;
+      // (the host only calls the program's reduce_function with synthetic operands when the answer can be used at all: the adjacency has
+      // giant rows and the speculation on them is enabled -- round-5 advice; GRAPHMAT_NO_PROBE=1 switches it off altogether)
+      const bool has_giants = (order != IN_EDGES && Aout.ngiant > 0) || (order != OUT_EDGES && Ain.ngiant > 0);
+      guess_f32_add = rk == REDUCE_ORDERED && has_giants && opt.ordered_giant_two_pass >= 2 && !(off && off[0] == '1') && probe_reduce_guess<P, U>(gp) == REDUCE_F32_ADD;
     }
     tick("reduce_function probed", rk);
     if (verbose) printf("GraphMat(HIP): reduce strategy %d (0 ordered, 1 commutative, 2 last, 3 float add)\n", rk);
@@ -963,7 +970,9 @@ class Run {
     // -- the plain loop with the swept multiply (round 6)
     if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
       gm_sweep_t sw;
-      if (!use_vp && gm_graph_sweep(g, &sw) == GM_OK && sw.nrows > 0 && sw.nsub > 1 && !(opt.debug_flags & (dev::DBG_NO_TILES | dev::DBG_NO_OVERLAP))) return false;
+      // (decided by the LAYOUT -- sliced on every shard or on none -- not by whether this shard happens to hold swept rows: the shards
+      // must choose the same schedule)
+      if (!use_vp && gm_graph_sweep(g, &sw) == GM_OK && sw.nslices > 1 && desc.nshards > 1 && !(opt.debug_flags & (dev::DBG_NO_TILES | dev::DBG_NO_OVERLAP))) return false;
     }
     return true;
   }
@@ -1256,7 +1265,9 @@ class Run {
   // rows (row-blocks of the whole-graph CSR) and the sweep's launches on the main stream; joined before apply.  sweep_form:
   // 0 = short rows in front of the sweep, 1 = on the auxiliary stream behind the giant passes (next to the sweep), 2 = behind
   // the sweep.  The three row sets are disjoint, so no two kernels touch the same y entry.
-  void multiply_out_swept(const dev::ProgArg<P>& pa, int acc, const gm_sweep_t& sw) {
+  // defer_join: return without waiting for the auxiliary stream (the giant rows' fold passes): the caller joins (aux.wait_join) before it
+  // touches the giant rows' y entries -- the sharded swept schedule applies, sends and starts exchanging all other rows meanwhile
+  void multiply_out_swept(const dev::ProgArg<P>& pa, int acc, const gm_sweep_t& sw, bool defer_join = false) {
     if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
       const Launch L = launch_ctx();
       aux.keep = true;
@@ -1351,17 +1362,137 @@ class Run {
         launch_spmv_vp<P, T, U, V, E>(use_vp, Lg, pa, Ag, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
       }
       if (where == 2) short_rows();
-      if (aux.pending) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
+      if (aux.pending && !defer_join) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
       aux.keep = aux.forked = aux.pending = false;
-      timer.mark(TAG_GIANT);  // (the multiply ends when the auxiliary stream has joined: the wait is charged to the giant rows' passes)
+      timer.mark(defer_join ? TAG_ROWBLOCK : TAG_GIANT);  // (the multiply ends when the auxiliary stream has joined: the wait is charged to the giant rows' passes)
       if (shorts_blocked) {  // (with the chip to itself: its workgroups walk the slices in step only while all of them are resident)
         launch_blocked(pa, bl);
         st.spmv_launches += 1;
         timer.mark(TAG_ROWBLOCK);
       }
-      check_probed(pa, Aout, Aout.rowbits, nullptr, acc, ybits, true);
+      if (!defer_join) check_probed(pa, Aout, Aout.rowbits, nullptr, acc, ybits, true);
     } else {
-      (void)pa; (void)acc; (void)sw;
+      (void)pa; (void)acc; (void)sw; (void)defer_join;
+    }
+  }
+
+  // ---- schedule: the fixed-count loop of a SHARDED ALL_VERTICES run whose rows the sweep takes (round 6) ------------------------------
+  // A shard's iteration is sweep -> [short rows | the giant rows' fold passes on the auxiliary stream] -> apply -> send -> all-gather of x.
+  // The giant rows' passes are a serial chain that does not shrink with the number of shards (the hub row: ~0.5 ms on a shard of 8 of
+  // RMAT-26) during which most of the chip idles -- and they only hold up the apply of the giant rows themselves, a few hundred per shard.
+  // So: every OTHER row is applied and sends its next message as soon as the short rows are done, the all-gather of the whole live range
+  // starts on the exchange's side stream (GM_XCHG_PART into the second message buffer) and travels WHILE the giant rows fold; when they
+  // have joined, a list kernel applies them, sends their messages and packs them as (device id, message) entries, which one small
+  // all-gather of equal blocks (GM_XCHG_GATHER: the sparse exchange's mechanism) carries to every shard; GM_XCHG_WAIT puts the parts in
+  // place and the entries are scattered over them.  Every row is folded by the same kernels in the same order as in the plain loop: same
+  // bits.  Needs what the two-stage schedule needs (a second message buffer; a program that leaves do_every_iteration to the base class)
+  // plus the sparse exchange; DBG_NO_PIPELINE (128) keeps the plain loop.
+  bool swept_pipeline_applies(gm_sweep_t* sw) {
+    if constexpr (kSparseT && sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<U>::value) {
+      if (!(multi && act == ALL_VERTICES && order == OUT_EDGES && iterations > 1 && !(opt.debug_flags & dev::DBG_NO_PIPELINE) && !trace && inherits_iteration_hook<P>())) return false;
+      if (!(gm_graph_exchange_caps(g) & GM_XCAP_SPARSE) || rk_unverified || opt.fuse_apply_send == 0) return false;
+      xq = x;
+      xb = nullptr;
+      // (everything above is the same on every shard; what follows is not -- a shard may hold no swept row -- and the shards must take the
+      // same schedule, or their collectives do not match: MIN over the shards of "fine here")
+      int fine = (sweep_usable(dev::ACC_STATIC_BITS, sw) && sw->nsub > 1 && Aout.ngiant <= dev::kSparseListCap && n_live >= 64) ? 1 : 0;
+      gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &fine);
+      return fine == 1;
+    } else {
+      (void)sw;
+      return false;
+    }
+  }
+  // returns the iterations done, or -1 when the schedule cannot run here (the caller runs the plain loop)
+  int run_swept_sharded(const gm_sweep_t& sw) {
+    if constexpr (kSparseT && sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<U>::value) {
+      void* x2v = nullptr;
+      size_t x2_bytes = 0;
+      int x2_ext = 0;
+      bool have_x2 = gm_graph_workspace_info(g, 9, &x2v, &x2_bytes, &x2_ext) == GM_OK && x2_ext && x2v != nullptr && x2_bytes >= (size_t)desc.ndevice * sizeof(T);
+      if (!have_x2 && gm_graph_exchange_is_native(g)) have_x2 = gm_graph_workspace(g, 9, (size_t)desc.ndevice * sizeof(T) + 64, &x2v) == GM_OK && x2v != nullptr;
+      // the shards' blocks of the gather buffer are equally long: the largest giant-row count, agreed once per graph (note 2; 0 = the
+      // schedule cannot run: no shard has a giant row, or one has no second message buffer)
+      int cap = 0;
+      int64_t agreed = 0;
+      if (gm_graph_note_get(g, 2, &agreed) == GM_OK) {
+        cap = (int)agreed;
+      } else {
+        int mine = have_x2 ? -Aout.ngiant : -(1 << 30);  // (MIN over the shards of -count = -(largest count); a shard without the buffer makes it too large)
+        gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &mine);
+        cap = (-mine >= (1 << 30)) ? 0 : (-mine + 63) / 64 * 64;
+        gm_graph_note_set(g, 2, (int64_t)cap);
+      }
+      if (cap <= 0 || cap > dev::kSparseListCap) return -1;
+      void *pg = nullptr, *pm = nullptr;
+      if (gm_graph_workspace(g, GM_WS_GATHER, (size_t)desc.nshards * (size_t)cap * sizeof(xentry_t) + 256, &pg) != GM_OK) pg = nullptr;
+      const size_t mwords = (size_t)nwords + 2;
+      if (gm_graph_workspace(g, 8, 2 * mwords * 4, &pm) != GM_OK) pm = nullptr;
+      {  // (a shard that could not get its buffers takes the others with it: they must issue the same collectives)
+        int fine = (pg != nullptr && pm != nullptr) ? 1 : 0;
+        gm_graph_exchange(g, GM_XCHG_CONVERGED, nullptr, 0, nullptr, &fine);
+        if (!fine) return -1;
+      }
+      xentry_t* gather = (xentry_t*)pg;
+      uint32_t *bits_rest = (uint32_t*)pm, *bits_giant = (uint32_t*)pm + mwords;
+      GM_HIP_OK(hipMemcpyAsync(bits_rest, Aout.rowbits, (size_t)nwords * 4, hipMemcpyDeviceToDevice, s));
+      GM_HIP_OK(hipMemsetAsync(bits_giant, 0, mwords * 4, s));
+      if (Aout.ngiant > 0)  // (a shard without a giant row takes part with an empty list)
+        hipLaunchKernelGGL(dev::k_split_row_bits, dim3(grid_for(Aout.ngiant)), dim3(dev::kBlock), 0, s, Aout.giant_row, Aout.ngiant, bits_rest, bits_giant);
+      if (verbose) printf("GraphMat(HIP): sharded swept schedule: %d giant rows here, blocks of %d entries; the all-gather travels while they fold\n", Aout.ngiant, cap);
+      T* xcur = x;
+      T* xnext = (T*)x2v;
+      const int ag = grid_for(n_live) < dev::kApplyMaxBlocks ? grid_for(n_live) : dev::kApplyMaxBlocks;
+      int it = 0;
+      {
+        dev::ProgArg<P> pa = dev::make_prog_arg(gp);
+        timer.mark(TAG_START);
+        send_all(pa, nullptr, xcur);
+        if (gm_graph_exchange(g, GM_XCHG_MESSAGES, xcur, (int64_t)sizeof(T), xbits, nullptr) != 0) die("message exchange callback failed");
+        timer.mark(TAG_SEND);
+      }
+      for (; it < iterations; it++) {
+        dev::ProgArg<P> pa = dev::make_prog_arg(gp);
+        const bool more = it + 1 < iterations;
+        timer.mark(TAG_START);
+        xq = xcur;
+        xb = nullptr;
+        multiply_out_swept(pa, dev::ACC_STATIC_BITS, sw, more);
+        if (more) {
+          // every row but the giant ones: apply, the next message, and off they go
+          hipLaunchKernelGGL((dev::k_apply_send<P, T, U, V>), dim3(ag), dim3(dev::kBlock), 0, s, pa, (const U*)y, (const uint32_t*)bits_rest, d_vp, d_active, n_live, d_changed,
+                             (uint32_t*)nullptr, xnext, xbits, desc.row_lo);
+          timer.mark(TAG_APPLY);
+          int part[2] = {0, n_live};
+          if (gm_graph_exchange(g, GM_XCHG_PART, xnext, (int64_t)sizeof(T), nullptr, part) != 0) die("partial message exchange failed");
+          timer.mark(TAG_SEND);
+          // the giant rows, once their folds have joined
+          aux.wait_join(s);
+          timer.mark(TAG_GIANT);
+          hipLaunchKernelGGL((dev::k_apply_send_list<P, T, U, V>), dim3(grid_for(cap)), dim3(dev::kBlock), 0, s, pa, (const U*)y, (const uint32_t*)bits_giant, d_vp, d_active,
+                             Aout.giant_row, Aout.ngiant, d_changed, xnext, desc.row_lo, gather + (size_t)desc.shard * cap, cap);
+          timer.mark(TAG_APPLY);
+          int hf[2] = {cap, 0};
+          if (gm_graph_exchange(g, GM_XCHG_GATHER, gather, (int64_t)sizeof(xentry_t), nullptr, hf) != 0) die("giant rows' message exchange failed");
+          if (gm_graph_exchange(g, GM_XCHG_WAIT, xnext, (int64_t)sizeof(T), nullptr, nullptr) != 0) die("message exchange wait failed");
+          const int64_t nall = (int64_t)desc.nshards * cap;
+          hipLaunchKernelGGL((dev::k_unpack_frontier<T>), dim3(grid_for(nall)), dim3(dev::kBlock), 0, s, (const xentry_t*)gather, nall, xnext, xbits);
+          timer.mark(TAG_SEND);
+        } else {
+          hipLaunchKernelGGL((dev::k_apply<P, U, V, false>), dim3(ag), dim3(dev::kBlock), 0, s, pa, (const U*)y, Aout.rowbits, d_vp, d_active, n_live, d_changed,
+                             (const int64_t*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, (unsigned int*)nullptr);
+          timer.mark(TAG_APPLY);
+        }
+        if (n_live < n && it == 0) GM_HIP_OK(hipMemsetAsync(d_active + n_live / 32, 0, (size_t)(nwords - n_live / 32) * 4, s));
+        gp->do_every_iteration(it);  // (the base class's empty hook: this schedule is only taken by programs that do not override it)
+        T* t = xcur; xcur = xnext; xnext = t;
+      }
+      fill_active();
+      finish(it);
+      return it;
+    } else {
+      (void)sw;
+      return -1;
     }
   }
 
@@ -1403,7 +1534,17 @@ class Run {
       }
       if (verbose && !said_blocked) { printf("GraphMat(HIP):   the short rows take the column-blocked stream (%d rows, %lld edges%s)\n", bl.nrows, (long long)bl.nentries, Aout.vals ? ", with their edge values" : ""); said_blocked = true; }
       // workgroups that are not all resident at once (a partitioned or masked device) cannot walk the slices in step: they are not asked to
-      const int window = cus >= 256 ? (opt.blocked_form & 15) : 0;
+      // -- the device must have a CU per workgroup AND the runtime must say that a workgroup of this kernel (1024 threads, 128 KB of LDS)
+      // fits a CU (round-5 advice; the kernel's own wait is bounded and sticky on top of that)
+      static int fits_of[64] = {0};  // 0: not asked yet, 1: fits, -1: does not
+      int& fits = fits_of[dev_id & 63];
+      if (fits == 0) {
+        int per_cu = 0;
+        const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)&dev::k_spmv_blocked<P, T, U, V, E, false, 2>, 1024, (size_t)GM_BLOCKED_ROWS * 4);
+        fits = (oe == hipSuccess && per_cu >= 1) ? 1 : -1;
+        (void)hipGetLastError();
+      }
+      const int window = (cus >= 256 && fits > 0) ? (opt.blocked_form & 15) : 0;
       if (window > 0) GM_HIP_OK(hipMemsetAsync(bl.step_count, 0, (size_t)8 * bl.nsteps * 4, s));
       auto launch = [&](auto vals_c, auto ub_c) {
         constexpr bool HV = decltype(vals_c)::value;

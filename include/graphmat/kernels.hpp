@@ -1476,6 +1476,7 @@ sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows
   constexpr int BLOCK = 1024, W = BLOCK / 64, UB = UBATCH;
   constexpr int ACC = GM_SWEEP_ACC_ROWS, NLP = GM_SWEEP_LONG_SLOTS;
   constexpr int KMAX = GM_SWEEP_MAX_STAGE / BLOCK;  // entries of a staging round per thread
+  static_assert((POOLW + GM_SWEEP_ACC_ROWS) * 4 <= 160 * 1024, "k_spmv_sell: the pool and the accumulators must fit gfx950's 160 KB of LDS per workgroup");
   __shared__ uint32_t s_pool[POOLW];  // [hot entries of the slice | stage of the long rows' products]
   __shared__ uint32_t s_acc[ACC];
   const P& p = *reinterpret_cast<const P*>(pa.b);
@@ -1850,6 +1851,7 @@ k_spmv_blocked(ProgArg<P> pa, const uint32_t* __restrict__ ecol, const uint16_t*
   unsigned int* const mycnt = step_count + (size_t)(blockIdx.x & 7) * nsteps;
   const int npass = (nblk + (int)gridDim.x - 1) / (int)gridDim.x;
   V no_vp;
+  bool gave_up = false;  // (thread 0: a wait for the XCD's other workgroups timed out once -- no more waiting in this launch)
   auto as_u = [](uint32_t raw) { U u; __builtin_memcpy(&u, &raw, 4); return u; };
   auto raw_u = [](const U& u) { uint32_t r; __builtin_memcpy(&r, &u, 4); return r; };
   auto as_e = [](uint32_t raw) { E e; if constexpr (HAS_VALS) __builtin_memcpy(&e, &raw, 4); else e = E(); return e; };
@@ -1914,11 +1916,17 @@ k_spmv_blocked(ProgArg<P> pa, const uint32_t* __restrict__ ecol, const uint16_t*
         if (threadIdx.x == 0) {
           __hip_atomic_fetch_add(&mycnt[step], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const int need = step + 1 - window;
-          if (need >= 0)
-            for (int tries = 0; tries < 20000; tries++) {
+          // (the wait is bounded -- ~1000 looks, a few hundred microseconds, several times a step's duration -- and STICKY: a workgroup
+          // that once waited in vain (its XCD's workgroups are not all resident: a masked or shared device) stops waiting for the rest
+          // of the launch instead of paying the timeout at every step; it keeps reporting, so the others are not held up by it)
+          if (need >= 0 && !gave_up) {
+            int tries = 0;
+            for (; tries < 1000; tries++) {
               if (__hip_atomic_load(&mycnt[need], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nwg) break;
               __builtin_amdgcn_s_sleep(4);
             }
+            if (tries == 1000) gave_up = true;
+          }
         }
         __syncthreads();
       }
@@ -3321,6 +3329,50 @@ k_unpack_frontier(const sparse_entry<T>* __restrict__ all, int64_t n, T* __restr
   memcpy(&m, e.msg, sizeof(T));
   x[e.idx] = m;
   atomicOr(&xbits[e.idx >> 5], 1u << (e.idx & 31));
+}
+
+// ---- the sharded swept schedule (engine.hpp: run_swept_sharded; round 6) ---------------------------------------------------------------
+// nog = bits & ~(bits of the listed rows), only = bits of the listed rows: the rows every shard applies while its giant rows' fold
+// passes are still running, and the giant rows themselves (both arrays initialised by the caller: nog = a copy of bits, only = 0)
+__global__ void __launch_bounds__(kBlock)
+k_split_row_bits(const int32_t* __restrict__ list, int nlist, uint32_t* __restrict__ nog, uint32_t* __restrict__ only) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nlist) return;
+  const int r = list[i];
+  const uint32_t b = 1u << (r & 31);
+  if (atomicAnd(&nog[r >> 5], ~b) & b) atomicOr(&only[r >> 5], b);
+}
+// apply + send of the NEXT iteration for the listed rows (the shard's giant rows, once their folds have joined), the new message also
+// packed as a (device id, message) entry of this shard's block of the gather buffer (entries past the list: id -1).  Same arithmetic as
+// k_apply_send: apply on a private copy of the program, send with the program as captured.
+template <class P, class T, class U, class V>
+__global__ void __launch_bounds__(kBlock)
+k_apply_send_list(ProgArg<P> pa, const U* __restrict__ y, const uint32_t* __restrict__ ybits, V* __restrict__ vp, uint32_t* __restrict__ active,
+                  const int32_t* __restrict__ list, int nlist, int* __restrict__ changed_flag, T* __restrict__ x, int row_base, sparse_entry<T>* __restrict__ block, int cap) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= cap) return;
+  sparse_entry<T> e;
+  memset(&e, 0, sizeof(e));
+  e.idx = -1;
+  if (i < nlist) {
+    const int r = list[i];
+    ProgArg<P> local = pa;
+    P& p = *reinterpret_cast<P*>(local.b);
+    V cur = vp[r];
+    if (bit_get(ybits, r)) {
+      V old_prop = cur;
+      p.P::apply(y[r], cur);
+      vp[r] = cur;
+      if (old_prop != cur) { atomicOr(&active[r >> 5], 1u << (r & 31)); *changed_flag = 1; }
+    }
+    const P& ps = *reinterpret_cast<const P*>(pa.b);
+    T m;
+    ps.P::send_message(cur, m);
+    x[(size_t)row_base + r] = m;
+    e.idx = row_base + r;
+    memcpy(e.msg, &m, sizeof(T));
+  }
+  block[i] = e;
 }
 
 // ------------------------------------------------------------------------------------

@@ -546,7 +546,8 @@ int gm_run_sgd_bipartite(gm_graph_t* g, void* d_latent, int K, int real_bytes, c
  * graph is created): "short_row", "giant_row", "rank_by", "rank_cap", "col_tiles", "tile_min_row", "long_mid" (wave rows
  * of more than this many edges get a wave each instead of sharing one 16 to a wave; 0 = GM_LONG_MID rule), "tile_balance"
  * (1: column tiles serve equally many gathers, the default; 0: they hold equally many vertices with edges); "sgd_mfma"
- * (0/1: the dot products of K = 128 fp32 SGD on the matrix cores, within 1e-6 of the vector form instead of its bits).
+ * (0/1: the dot products of K = 128 fp32 SGD on the matrix cores: an opt-in measurement form whose results deviate from the vector
+ * form's -- the reference's -- bits by up to ~1e-5 of the vectors' scale, outside the 1e-6 bar; slower as well).
  * Every field of gm_engine_options_t below is also a key: gm_set_option then sets the PROCESS default, which a graph
  * uses unless gm_graph_set_option gave it a value of its own; the environment variable GRAPHMAT_OPTIONS="key=value,..."
  * sets such defaults for applications that cannot call this themselves (the reference's unchanged sources). */

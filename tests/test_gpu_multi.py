@@ -173,3 +173,29 @@ def test_bench_two_ranks_distributed_build_and_native_exchange():
     for k in ("E", "V", "rows_per_shard", "exchanged_rows_per_shard", "max_in_degree_rank0"):
         assert a["config"][k] == b["config"][k], k
     assert a["value"] > 0 and a["steps"] == 3
+
+
+def test_bench_four_ranks_sharded_sweep_both_forms():
+    """bench.py at N = 4 on this 1-GPU box (gloo + the shared-memory stand-in for librccl) with --col-tiles 3, so that the shards' device
+    order is sliced and their rows go through the SHARDED SWEEP (gm_sweep_t.nsub = 4): the line must say so, carry both schedule forms
+    (the sharded swept schedule, whose all-gather starts before the giant rows are folded, and the plain loop -- bench.py itself checks that
+    they give the same bits) with the exchange time each exposes, and a roofline entry for the sweep kernel on rank 0's shard."""
+    import json
+    from graphmat_amd import build
+    build.build()
+    env = dict(os.environ, GM_BENCH_BACKEND="gloo", GRAPHMAT_RCCL_LIBRARY=_shm_lib())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--scale", "18", "--steps", "3",
+           "--warmup", "1", "--cpu-scale", "0", "--col-tiles", "3"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env, cwd=ROOT)
+    text = out.stdout.decode()
+    assert out.returncode == 0, (text + out.stderr.decode())[-3000:]
+    js = [json.loads(l) for l in text.splitlines() if l.startswith("{")]
+    assert len(js) == 1, text[-2000:]
+    j = js[0]
+    assert j["n_gpus"] == 4 and "native exchange" in j["config"]["exchange"] and "sharded swe" in j["config"]["exchange"], j["config"]["exchange"]
+    forms = j["multi_gpu"]["forms"]
+    assert set(forms) == {"plain", "overlapped"} and all("exchange_ms_exposed" in f for f in forms.values())
+    assert j["multi_gpu"]["overlapped_parts_total"] > 0  # (the sharded swept schedule ran: one part per iteration but the last)
+    assert "disagrees" not in out.stderr.decode()
+    assert j["roofline"] is not None and "k_spmv_sell" in j["roofline"]["kernel"]

@@ -117,15 +117,29 @@ def main():
             if (tail >= 0).any() and live[tail[tail >= 0]].any():
                 fail("a vertex with edges sits behind owner %d's live part (%s)" % (q, tag))
         attach(g)
+        c = g.csr(api.GM_DIR_OUT)
+        ng = torch.tensor([c.ngiant], dtype=torch.int64)
+        dist.all_reduce(ng, op=dist.ReduceOp.MAX)
         p0 = parts_of(g)
+        # fixed count, ALL_VERTICES: the sharded swept schedule (engine.hpp: run_swept_sharded) -- the all-gather of every iteration but the
+        # last starts before the giant rows have been folded (one GM_XCHG_PART each), their messages follow as lists -- when some shard has a
+        # giant row; the plain swept loop otherwise
         pr, dg, it = g.pagerank(6)
-        if parts_of(g) != p0:
-            fail("the two-stage schedule ran instead of the swept plain loop (%s)" % tag)
+        want_parts = 5 if int(ng) > 0 else 0
+        if parts_of(g) - p0 != want_parts:
+            fail("the sharded swept schedule started %d parts, expected %d (%s; most giant rows per shard: %d)" % (parts_of(g) - p0, want_parts, tag, int(ng)))
         st = g.last_stats()
         if not ((dg == odeg).all() and it == oit == 6 and (pr.view(np.uint32) == opr.view(np.uint32)).all()):
             fail("PageRank through the sharded sweep differs from the oracle (%s): %d of %d values" % (tag, int((pr.view(np.uint32) != opr.view(np.uint32)).sum()), nv))
         if st["spmv_launches"] < 6 * sw.nsets:
             fail("fewer multiply launches than the sweep needs (%s)" % tag)
+        # ... and the plain loop (all-gather between send and multiply) through the same sweep
+        p1 = parts_of(g)
+        _lib.check(L.gm_set_option(b"debug_flags", 128))
+        pr_p, _, it_p = g.pagerank(6)
+        _lib.check(L.gm_set_option(b"debug_flags", 0))
+        if parts_of(g) != p1 or it_p != 6 or not (pr_p.view(np.uint32) == opr.view(np.uint32)).all():
+            fail("the plain swept loop differs from the oracle or started parts (%s)" % tag)
         g.close()
     if seen_sets < 2 and world <= 2:  # (a shard of three of a small graph has too few rows for a second launch)
         fail("several launches (sets) were never exercised")
