@@ -819,9 +819,10 @@ static int finish_csr(gm_graph* g, const uint64_t* keys_sorted, const uint32_t* 
     GM_TRY_HIP(hipMemcpyAsync(gce.p, h_gce.data(), h_gce.size() * 8, hipMemcpyHostToDevice, s));
   }
   GM_TRY_HIP(hipMemcpyAsync(gto.p, h_gto.data(), h_gto.size() * 8, hipMemcpyHostToDevice, s));
-  DevBuf gst;  // per-piece records of the giant-row kernels (no hints yet)
-  if ((rc = gst.alloc(h_gcr.size() * 16 + 16))) return rc;
-  GM_TRY_HIP(hipMemsetAsync(gst.p, 0, h_gcr.size() * 16 + 16, s));
+  DevBuf gst;  // 32-byte records of the giant-row kernels, one per 512-product sub-piece = 8 per piece (kernels.hpp: gchunk_state; no hints yet)
+  const size_t gst_bytes = h_gcr.size() * (GM_GIANT_CHUNK / 512) * 32 + 64;  // (32-byte records: a hint and the maps of three binades)
+  if ((rc = gst.alloc(gst_bytes))) return rc;
+  GM_TRY_HIP(hipMemsetAsync(gst.p, 0, gst_bytes, s));
   GM_TRY_HIP(hipStreamSynchronize(s));
 
   out->rowptr = (int64_t*)rowptr.release();

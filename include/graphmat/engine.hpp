@@ -397,20 +397,28 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
           if (xbits == nullptr && want == nullptr && L.opt.giant_maps != 0) maps = (dev::gchunk_state*)A.gchunk_state;
         }
         if (L.terms_ready) {
-          if (maps != nullptr) {  // the pieces' ulp-maps from the products the sweep wrote
-            hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP, true>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa, A, x, xbits, vp, terms, tpres
-                               GM_DBG_ARG(L.opt.debug_flags), maps);
-            (*launches)++;
-          }
+          // (the products are in the stream already -- the sweep gathered them: nothing to do here)
         } else {
           hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa, A, x, xbits, vp, terms, tpres
                              GM_DBG_ARG(L.opt.debug_flags), maps);
           (*launches)++;
         }
       }
-      hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa,
-                         A, x, xbits, vp, y, ybits, accumulate GM_DBG_ARG(L.opt.debug_flags), (const U*)terms,
-                         (const unsigned long long*)tpres, want, maps);
+      bool replayed = false;
+      if constexpr (RK == REDUCE_F32_ADD && std::is_same<U, float>::value) {
+        if (maps != nullptr) {  // the sub-pieces' maps for the binades predicted from this pass's products, then one wave per row walks them (kernels.hpp: gchunk_state)
+          hipLaunchKernelGGL(dev::k_giant_sums, dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, A, (const float*)terms, maps);
+          hipLaunchKernelGGL(dev::k_giant_maps, dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, A, (const float*)terms, maps, (const float*)y, (const uint32_t*)ybits, accumulate);
+          hipLaunchKernelGGL((dev::k_giant_replay_maps<P, U>), dim3(A.ngiant), dim3(64), 0, gs, pa, A, y, ybits, accumulate, (const U*)terms, (const dev::gchunk_state*)maps,
+                             (unsigned long long*)nullptr, (const int32_t*)nullptr);
+          (*launches) += 2;
+          replayed = true;
+        }
+      }
+      if (!replayed)
+        hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, RK>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa,
+                           A, x, xbits, vp, y, ybits, accumulate GM_DBG_ARG(L.opt.debug_flags), (const U*)terms,
+                           (const unsigned long long*)tpres, want, (dev::gchunk_state*)nullptr);
     } else {
       // plain ordered fold (any reduce_function): products spread over the chip by k_giant_terms, then one wave per row
       // folds the dense products stream in stored order (kernels.hpp: k_giant_fold_ordered).  Larger reduction types keep
@@ -436,14 +444,17 @@ void launch_spmv_rk(const Launch& L, const dev::ProgArg<P>& pa, const gm_csr_t& 
             hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa, A, x, xbits, vp, terms,
                                (unsigned long long*)nullptr GM_DBG_ARG(L.opt.debug_flags), maps);
             (*launches)++;
-          } else if (maps != nullptr) {
-            hipLaunchKernelGGL((dev::k_giant_terms<P, T, U, V, E, USE_VP, true>), dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, pa, A, x, xbits, vp, terms,
-                               (unsigned long long*)nullptr GM_DBG_ARG(L.opt.debug_flags), maps);
-            (*launches)++;
           }
-          hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, REDUCE_F32_ADD>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa, A, x, xbits, vp, y,
-                             ybits, accumulate GM_DBG_ARG(L.opt.debug_flags), (const U*)terms, (const unsigned long long*)nullptr, want, maps, bounds,
-                             (const int32_t*)L.spec_off);
+          if (maps != nullptr) {
+            hipLaunchKernelGGL(dev::k_giant_sums, dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, A, (const float*)terms, maps);
+            hipLaunchKernelGGL(dev::k_giant_maps, dim3(A.ngchunk), dim3(dev::kBlock), 0, gs, A, (const float*)terms, maps, (const float*)y, (const uint32_t*)ybits, accumulate);
+            hipLaunchKernelGGL((dev::k_giant_replay_maps<P, U>), dim3(A.ngiant), dim3(64), 0, gs, pa, A, y, ybits, accumulate, (const U*)terms, (const dev::gchunk_state*)maps, bounds,
+                               (const int32_t*)L.spec_off);
+            (*launches) += 2;
+          } else
+            hipLaunchKernelGGL((dev::k_spmv_giant<P, T, U, V, E, USE_VP, REDUCE_F32_ADD>), dim3(A.ngiant), dim3(dev::kGiant), 0, gs, pa, A, x, xbits, vp, y,
+                               ybits, accumulate GM_DBG_ARG(L.opt.debug_flags), (const U*)terms, (const unsigned long long*)nullptr, want, (dev::gchunk_state*)nullptr,
+                               bounds, (const int32_t*)L.spec_off);
           hipLaunchKernelGGL((dev::k_giant_verify_chunks<P, U>), dim3((A.ngchunk + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, (const U*)terms,
                              (const unsigned long long*)bounds, (const U*)y, redo, L.spec_off);
           hipLaunchKernelGGL((dev::k_giant_fold_ordered<P, U, V>), dim3((A.ngiant + WPB - 1) / WPB), dim3(dev::kBlock), 0, gs, pa, A, vp, y, ybits,

@@ -2123,11 +2123,25 @@ __device__ __forceinline__ bool ulp_term(uint32_t abits, int eS, ulp_map& out) {
 // the exact S it has reached really is in that binade and really stays there (S + delta < 2^24 ulps; S only grows:
 // terms are non-negative or the piece has no map) -- otherwise, and around every binade crossing, it replays the chunk
 // itself as before.  The hint decides only WHICH pieces get a map, never a value: the bits are the serial loop's.
+// (round 6: one record per SUB-PIECE of kGiantSub = 512 products, 8 per piece, and the replay is k_giant_replay_maps: one WAVE per row
+// walks the records 64 at a time -- a wave scan composes the maps and finds the first one that does not apply -- and replays only that
+// sub-piece, with wave scans and no barrier.  On a shard of 8 of RMAT-26 the hub row's chain fell from ~0.45 ms to ~0.1 ms.)
+constexpr int kGiantSub = 512;
+// Which binade will S be in?  (Rounds 2-5 took the binade of the PREVIOUS pass as a hint; while a run's values still move -- the first
+// ten PageRank iterations -- the places where S crosses into the next binade move by many sub-pieces from one pass to the next, every
+// sub-piece in between saw S off its hint, and the replay of the hub row took 0.3-2.6 ms instead of 0.2.)  Round 6 PREDICTS it from
+// this pass's own products: k_giant_sums adds up every sub-piece in double, k_giant_predict scans the sums along the row -- the double
+// prefix differs from the float sum S by accumulated rounding only, ~1e-4 relative at worst -- and a sub-piece whose predicted S has the
+// same binade at its start and at its end gets its map composed for that binade (k_giant_maps).  A wrong prediction (S within ~1e-4 of a
+// power of two) costs the replay of one sub-piece, never a bit: the replay applies a map only when the EXACT S is in the map's binade
+// and stays there.  No state survives a pass.
 struct gchunk_state {
-  int32_t e_hint;     // written by k_spmv_giant: biased exponent S had throughout this piece's chunk last time; 0 = none
-  int32_t e_map;      // written by k_giant_terms: the binade de/dod hold for; 0 = no map this pass
-  uint32_t de, dod;   // ulps the piece adds when the incoming S is even / odd
+  double sum;         // k_giant_sums: the sub-piece's products added up in double
+  int32_t e_map;      // k_giant_predict: the binade S is expected to have throughout the sub-piece (0: none); k_giant_maps clears it when a term has no map
+  uint32_t de, dod;   // k_giant_maps: ulps the sub-piece adds when the incoming S is even / odd
+  uint32_t pad_[3];
 };
+static_assert(sizeof(gchunk_state) == 32, "gchunk_state: 32-byte records (gm_graph.hip allocates them)");
 
 // ------------------------------------------------------------------------------------
 // giant rows, pass 1 (REDUCE_F32_ADD): the gathers and products of a giant row are spread
@@ -2167,14 +2181,7 @@ k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t
 #pragma unroll
   for (int j = 0; j < PER; j++)
     if (!FROM_TERMS && c[j] >= 0) { if ((dbg & DBG_SKIP_GATHER) || GM_ABL_COLD(c[j], A)) memset(&m[j], 0, sizeof(T)); else m[j] = x[c[j]]; }
-  // the exact replay spread over the chip (see gchunk_state): with a hint of the binade S will be in, the piece's
-  // products are also composed into one ulp-map here, where they are in registers anyway
-  constexpr bool kMaps = std::is_same<U, float>::value;
-  __shared__ float s_prod[kMaps ? GM_GIANT_CHUNK : 1];
-  int ehint = 0;
-  if constexpr (kMaps) {
-    if (state != nullptr) ehint = state[blockIdx.x].e_hint;
-  }
+  (void)state;  // (the sub-pieces' ulp-maps are composed by k_giant_sums / k_giant_predict / k_giant_maps since round 6)
 #pragma unroll
   for (int j = 0; j < PER; j++) {
     int k = threadIdx.x + j * kBlock;
@@ -2186,53 +2193,128 @@ k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t
         p.P::process_message(m[j], edge_at<E>(A.vals, eb + k), vprow, t);
         terms[out0 + k] = t;
       }
-      if constexpr (kMaps) { if (ehint > 0) s_prod[k] = t; }
     }
     if (tpres != nullptr) {
       unsigned long long w = __ballot(c[j] >= 0);
       if ((threadIdx.x & 63) == 0 && (k & ~63) < n) tpres[(out0 + (k & ~63)) >> 6] = w;
     }
   }
-  if constexpr (kMaps) {
-    if (state == nullptr) return;
-    if (ehint <= 0) {
-      if (threadIdx.x == 0) { state[blockIdx.x].e_map = 0; }
-      return;
-    }
-    __shared__ ulp_map s_wave[kBlock / 64];
-    __shared__ int s_bad;
-    if (threadIdx.x == 0) s_bad = 0;
-    __syncthreads();
-    const int k0 = threadIdx.x * PER, lane = threadIdx.x & 63;
-    ulp_map mine = {0u, 0u};
-    bool ok = true;
+}
+
+__device__ __forceinline__ int lower_piece(const int32_t* __restrict__ gchunk_row, int n, int gi) {  // first piece of giant row gi
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (gchunk_row[mid] < gi) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// ---- the sub-pieces' maps of a pass (float sums over a dense x; see gchunk_state) ------------------------------------------------------
+// one workgroup per 4096-product piece, a sub-piece = 32 consecutive threads x 16 consecutive products
+// (1) the products of every sub-piece added up in double
+__global__ void __launch_bounds__(kBlock)
+k_giant_sums(gm_csr_t A, const float* __restrict__ terms, gchunk_state* __restrict__ state) {
+  constexpr int PER = GM_GIANT_CHUNK / kBlock, kSubs = GM_GIANT_CHUNK / kGiantSub, kLanesPerSub = kGiantSub / PER;
+  static_assert(kLanesPerSub == 32 && kSubs * kLanesPerSub == kBlock, "a sub-piece is half a wave's products");
+  const int gi = A.gchunk_row[blockIdx.x];
+  const int row = A.giant_row[gi];
+  const int64_t eb = A.gchunk_edge[blockIdx.x], e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
+  const int n = (int)((e1 - eb) < GM_GIANT_CHUNK ? (e1 - eb) : GM_GIANT_CHUNK);
+  const float* __restrict__ t = terms + A.gterm_off[gi] + (eb - e0);
+  const int k0 = threadIdx.x * PER;
+  double acc = 0.0;
+  if (k0 < n) {  // (16 consecutive products as four 16-byte loads: a row's slots are padded to multiples of 64, so the last ones may lie past n but not past the row)
+    const float4* __restrict__ t4 = reinterpret_cast<const float4*>(t + k0);
+    float4 q[PER / 4];
 #pragma unroll
-    for (int j = 0; j < PER; j++) {
-      if (k0 + j < n) {
-        ulp_map t;
-        if (!ulp_term(__float_as_uint(s_prod[k0 + j]), ehint, t)) ok = false; else mine = ulp_compose(mine, t);
+    for (int j = 0; j < PER / 4; j++) q[j] = t4[j];
+#pragma unroll
+    for (int j = 0; j < PER / 4; j++) {
+      const float f[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (k0 + 4 * j + i < n) acc += (double)f[i];
+    }
+  }
+#pragma unroll
+  for (int off = kLanesPerSub / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & (kLanesPerSub - 1)) == 0) state[(size_t)blockIdx.x * kSubs + threadIdx.x / kLanesPerSub].sum = acc;
+}
+// (2) which binade is S expected to have?  the double prefix of the sums along the row (it differs from the float sum S by accumulated
+// rounding only)
+__device__ __forceinline__ int f32_binade_of(double d) {
+  if (!(d > 0.0)) return 0;
+  const float f = (float)d;
+  const uint32_t b = __float_as_uint(f);
+  const int e = (int)((b >> 23) & 0xff);
+  return (e > 0 && e < 255) ? e : 0;
+}
+// (3) the map of every sub-piece whose S is expected to start and end in the same binade of a positive normal number.  The workgroup of a
+// piece adds up the sums of the row's EARLIER sub-pieces itself (the hub row's last piece: 1664 doubles, seven loads per thread) instead of
+// waiting for a scan kernel in between: a separate one-wave-per-row scan took 55 us for the hub row.
+__global__ void __launch_bounds__(kBlock)
+k_giant_maps(gm_csr_t A, const float* __restrict__ terms, gchunk_state* __restrict__ state, const float* __restrict__ y, const uint32_t* __restrict__ ybits,
+             int accumulate) {
+  constexpr int PER = GM_GIANT_CHUNK / kBlock, kSubs = GM_GIANT_CHUNK / kGiantSub, kLanesPerSub = kGiantSub / PER;
+  const int gi = A.gchunk_row[blockIdx.x];
+  const int row = A.giant_row[gi];
+  const int64_t eb = A.gchunk_edge[blockIdx.x], e0 = A.rowptr[row], e1 = A.rowptr[row + 1];
+  const int n = (int)((e1 - eb) < GM_GIANT_CHUNK ? (e1 - eb) : GM_GIANT_CHUNK);
+  const float* __restrict__ t = terms + A.gterm_off[gi] + (eb - e0);
+  const int k0 = threadIdx.x * PER, lane = threadIdx.x & 63, sub = threadIdx.x / kLanesPerSub;
+  gchunk_state* const rec = state + (size_t)blockIdx.x * kSubs + sub;
+  // the expected S at this piece's start: what y holds (a pass that continues a fold) + the sums of the row's earlier sub-pieces
+  __shared__ double s_part[kBlock / 64];
+  {
+    const int nbefore = (int)((eb - e0) / kGiantSub);  // (pieces of a row are consecutive: its first piece's records start nbefore records back)
+    const gchunk_state* __restrict__ first = state + (size_t)blockIdx.x * kSubs - nbefore;
+    double part = 0.0;
+    for (int i = threadIdx.x; i < nbefore; i += kBlock) part += first[i].sum;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (lane == 0) s_part[threadIdx.x >> 6] = part;
+    __syncthreads();
+  }
+  double s_start = ((accumulate & ACC_READ_PREV) && bit_get(ybits, row)) ? (double)y[row] : 0.0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; w++) s_start += s_part[w];
+  for (int u = 0; u < sub; u++) s_start += state[(size_t)blockIdx.x * kSubs + u].sum;
+  const double s_end = s_start + rec->sum;
+  const int ea = f32_binade_of(s_start), ee = f32_binade_of(s_end);
+  const int e = (ea > 0 && ea == ee) ? ea : 0;  // (the same for the 32 threads of a sub-piece)
+  ulp_map mine = {0u, 0u};
+  bool ok = true;
+  if (e > 0 && k0 < n) {
+    const float4* __restrict__ t4 = reinterpret_cast<const float4*>(t + k0);
+    float4 q[PER / 4];
+#pragma unroll
+    for (int j = 0; j < PER / 4; j++) q[j] = t4[j];
+#pragma unroll
+    for (int j = 0; j < PER / 4; j++) {
+      const float f[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (k0 + 4 * j + i < n) {
+          ulp_map m;
+          if (!ulp_term(__float_as_uint(f[i]), e, m)) ok = false; else mine = ulp_compose(mine, m);
+        }
       }
     }
-    if (!ok) atomicOr(&s_bad, 1);
-    ulp_map v = mine;
+  }
+  ulp_map v = mine;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      ulp_map o;
-      o.de = __shfl_up(v.de, off, 64);
-      o.dod = __shfl_up(v.dod, off, 64);
-      if (lane >= off) v = ulp_compose(o, v);
-    }
-    if (lane == 63) s_wave[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      ulp_map tot = {0u, 0u};
-      for (int w = 0; w < kBlock / 64; w++) tot = ulp_compose(tot, s_wave[w]);
-      gchunk_state st = state[blockIdx.x];
-      st.e_map = s_bad ? 0 : ehint;
-      st.de = tot.de;
-      st.dod = tot.dod;
-      state[blockIdx.x] = st;
-    }
+  for (int off = 1; off < kLanesPerSub; off <<= 1) {
+    ulp_map o;
+    o.de = __shfl_up(v.de, off, 64);
+    o.dod = __shfl_up(v.dod, off, 64);
+    if ((lane & (kLanesPerSub - 1)) >= off) v = ulp_compose(o, v);
+  }
+  const unsigned long long badm = __ballot(!ok);
+  const bool bad = ((badm >> (lane & ~(kLanesPerSub - 1))) & 0xffffffffull) != 0ull;
+  if ((lane & (kLanesPerSub - 1)) == kLanesPerSub - 1) {
+    rec->e_map = (e > 0 && !bad && sub * kGiantSub < n) ? e : 0;
+    rec->de = v.de;
+    rec->dod = v.dod;
   }
 }
 
@@ -2352,14 +2434,6 @@ constexpr int kGiant = 512;                     // threads per workgroup of k_sp
 constexpr int kLongPer = 16;                    // consecutive edges per lane and chunk
 constexpr int kLongChunk = kLongPer * kGiant;   // 8192 edges per chunk
 
-__device__ __forceinline__ int lower_piece(const int32_t* __restrict__ gchunk_row, int n, int gi) {  // first piece of giant row gi
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (gchunk_row[mid] < gi) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
 
 template <class P, class T, class U, class V, class E, bool USE_VP, int RK>
 __global__ void __launch_bounds__(kGiant)
@@ -2474,84 +2548,15 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
       }
     };
     float term[PER], pre[PER];
-    // this row's piece maps (k_giant_terms), composed per 8192-product chunk and staged in LDS
-    constexpr int kMapsLds = 256;
-    struct chunk_rec { int32_t e; uint32_t de, dod; };
-    __shared__ chunk_rec s_maps[kMapsLds];
-    __shared__ int s_skip;
-    const int nchunks = (int)((deg + CH - 1) / CH);
-    const int npieces = (int)((deg + GM_GIANT_CHUNK - 1) / GM_GIANT_CHUNK);
-    const bool mapped = maps != nullptr && nchunks <= kMapsLds && !(dbg & DBG_NO_REPLAY);
+    // (the per-sub-piece ulp-maps of float sums over a dense x are walked by k_giant_replay_maps since round 6: this kernel is the replay
+    // WITHOUT maps -- sparse x, a row filter, giant_maps = 0)
+    (void)maps;
     int piece0 = 0;
-    if (mapped || bounds != nullptr) piece0 = lower_piece(A.gchunk_row, A.ngchunk, (int)blockIdx.x);
-    if (mapped) {
-      for (int c = tid; c < nchunks; c += kGiant) {
-        const gchunk_state a = maps[piece0 + 2 * c];
-        chunk_rec r = {a.e_map, a.de, a.dod};
-        if (2 * c + 1 < npieces) {
-          const gchunk_state b = maps[piece0 + 2 * c + 1];
-          if (a.e_map > 0 && b.e_map == a.e_map) {
-            const ulp_map ab = ulp_compose(ulp_map{a.de, a.dod}, ulp_map{b.de, b.dod});
-            r.de = ab.de;
-            r.dod = ab.dod;
-          } else {
-            r.e = 0;
-          }
-        }
-        s_maps[c] = r;
-      }
-    } else {
-      load_chunk(0, pre);
-    }
-    // (lane 0 only) the chunk being replayed and the binade S was in when it started: its hint for the next pass
-    int pend_c = -1, pend_e = 0;
-    auto leave_hint = [&](int c, int e) {  // both pieces of chunk c
-      maps[piece0 + 2 * c].e_hint = e;
-      if (2 * c + 1 < npieces) maps[piece0 + 2 * c + 1].e_hint = e;
-    };
+    if (bounds != nullptr) piece0 = lower_piece(A.gchunk_row, A.ngchunk, (int)blockIdx.x);
+    load_chunk(0, pre);
     for (int64_t base = e0; base < e1; base += CH) {
       __syncthreads();  // previous chunk fully consumed (and, first time round, s_maps / s_Sbits / s_has written)
-      if (mapped) {
-        // Chunks whose map applies -- the exact S is in the binade the map was composed for and stays in it -- are
-        // not even loaded: one lane walks them, however many follow each other, and the workgroup resumes at the
-        // first chunk it has to replay itself (a binade crossing, or a chunk without a map).
-        if (tid == 0) {
-          int c = (int)((base - e0) / CH), skipped = 0;
-          uint32_t sbm = s_Sbits;
-          const bool h = s_has[0] != 0;
-          if (pend_c >= 0) {  // the chunk just replayed: a hint only if S stayed in one binade
-            const int eo = (h && !(sbm >> 31)) ? (int)((sbm >> 23) & 0xff) : 0;
-            leave_hint(pend_c, (pend_e > 0 && eo == pend_e && eo < 255) ? eo : 0);
-            pend_c = -1;
-          }
-          if (h) {
-            while (c < nchunks) {
-              const chunk_rec rec = s_maps[c];
-              const uint32_t Sint = (sbm & 0x7fffffu) | 0x800000u;
-              const uint32_t Safter = Sint + ((Sint & 1u) ? rec.dod : rec.de);
-              if (!(rec.e > 0 && !(sbm >> 31) && (int)((sbm >> 23) & 0xff) == rec.e && Safter < 0x1000000u)) break;
-              if (bounds != nullptr) bounds[piece0 + 2 * c] = (unsigned long long)sbm | (1ull << 32);
-              sbm = (sbm & 0xff800000u) | (Safter & 0x7fffffu);  // (same binade: the hint stays what it is)
-              c++;
-              skipped++;
-            }
-          }
-          if (skipped) {
-            s_Sbits = sbm;
-            atomicAdd(&g_longrow_counters[2], (unsigned long long)skipped * (CH / PER));
-          }
-          s_skip = skipped;
-          if (c < nchunks) {
-            if (bounds != nullptr) bounds[piece0 + 2 * c] = (unsigned long long)sbm | ((unsigned long long)(h ? 1 : 0) << 32);
-            pend_c = c;
-            pend_e = (h && !(sbm >> 31)) ? (int)((sbm >> 23) & 0xff) : 0;
-          }
-        }
-        __syncthreads();
-        base += (int64_t)s_skip * CH;
-        if (base >= e1) break;
-        load_chunk(base - e0, pre);
-      } else if (bounds != nullptr && tid == 0) {
+      if (bounds != nullptr && tid == 0) {
         bounds[piece0 + 2 * (int)((base - e0) / CH)] = (unsigned long long)s_Sbits | ((unsigned long long)(s_has[0] != 0 ? 1 : 0) << 32);
       }
       const int n = (int)((e1 - base) < CH ? (e1 - base) : CH);
@@ -2559,7 +2564,7 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
       const int64_t rel = base - e0;
 #pragma unroll
       for (int j = 0; j < PER; j++) s_term[j * kGiant + tid] = pre[j];  // linear: slot(k) = k
-      if (!mapped) load_chunk(rel + CH, pre);
+      load_chunk(rel + CH, pre);
       uint32_t presmask = 0;
       if (k0 < n) {
         const int cnt = (n - k0) < PER ? (n - k0) : PER;
@@ -2681,16 +2686,187 @@ k_spmv_giant(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t*
       if (dbg & DBG_FIRST_CHUNK_ONLY) break;
     }
     __syncthreads();
-    if (mapped && tid == 0 && pend_c >= 0) {
-      const uint32_t sbm = s_Sbits;
-      const int eo = (s_has[0] != 0 && !(sbm >> 31)) ? (int)((sbm >> 23) & 0xff) : 0;
-      leave_hint(pend_c, (pend_e > 0 && eo == pend_e && eo < 255) ? eo : 0);
-    }
     if (tid == 0 && s_has[0]) {
       uint32_t sb = s_Sbits;
       U r;
       memcpy(&r, &sb, 4);
       y[row] = r;
+      if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// The exact replay of a giant row's float sum from its products stream and its sub-pieces' ulp-maps (gchunk_state; REDUCE_F32_ADD,
+// every x entry present): ONE WAVE per row, no LDS, no barrier.
+//   * walk: the records of the next 64 sub-pieces, one per lane; a record applies when it was composed for the binade S is in and
+//     S stays in it (S + delta < 2^24 ulps; S only grows: a map exists only for non-negative terms).  Records that do not apply
+//     count as saturating maps, an ordered wave scan composes them, and the first lane whose composed delta leaves the binade ends
+//     the accepted run -- up to 64 x 512 products per step;
+//   * replay of the sub-piece where the run stopped (a binade crossing, a sub-piece without a map, the row's start): lane l holds 8
+//     consecutive products; the same ulp-map scan over the lanes accepts the longest prefix that stays in S's binade, the lane where
+//     it stops is folded serially with the program's own reduce_function (that is where S changes binade), and the scan resumes.
+// Every accepted step adds exactly what the serial loop would have added (kernels.hpp: ulp_term / ulp_compose): the bits are the serial
+// loop's.  bounds (speculating runs): the running sum at the start of every 8192-product chunk, for k_giant_verify_chunks.
+template <class P, class U>
+__global__ void __launch_bounds__(64)
+k_giant_replay_maps(ProgArg<P> pa, gm_csr_t A, U* __restrict__ y, uint32_t* __restrict__ ybits, int accumulate, const U* __restrict__ terms,
+                    const gchunk_state* __restrict__ maps, unsigned long long* __restrict__ bounds, const int32_t* __restrict__ spec_off) {
+  static_assert(std::is_same<U, float>::value, "k_giant_replay_maps: float sums");
+  constexpr int PER = kGiantSub / 64;                    // products per lane of a replayed sub-piece
+  constexpr int kSubs = GM_GIANT_CHUNK / kGiantSub;      // records per piece
+  constexpr int kSubsPerChunk = 8192 / kGiantSub;        // (bounds are kept per 8192-product chunk = two pieces)
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  if (spec_off != nullptr && spec_off[0] != 0) return;
+  const int row = A.giant_row[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int64_t deg = A.rowptr[row + 1] - A.rowptr[row];
+  const int64_t t0 = A.gterm_off[blockIdx.x];
+  const int piece0 = lower_piece(A.gchunk_row, A.ngchunk, (int)blockIdx.x);
+  const gchunk_state* const rec0 = maps + (size_t)piece0 * kSubs;
+  const int nsub = (int)((deg + kGiantSub - 1) / kGiantSub);
+  bool has = (accumulate & ACC_READ_PREV) && bit_get(ybits, row);
+  uint32_t sb = 0;  // bits of S (wave-uniform)
+  if (has) sb = __float_as_uint(y[row]);
+  unsigned long long n_skip = 0, n_par = 0, n_ser = 0;
+  int sub = 0, pre_sub = -1, rbase = -(1 << 30);
+  float pre[kGiantSub / 64];
+  int rc_e = 0;  // record rbase + lane of the window: its binade and map
+  uint32_t rc_de = 0u, rc_dod = 0u;
+  while (sub < nsub) {
+    if (has) {
+      // ---- walk: which of the next 64 records apply, one after the other, to the S we have?
+      const int j = sub + lane;
+      const int eS = (int)((sb >> 23) & 0xff);
+      // (the records are read 64 at a time and kept: this pass never changes a record's map, and after every replayed sub-piece the
+      // walk resumes inside the window it already holds -- no load, and no scan either when the very next record does not apply)
+      if (sub < rbase || sub >= rbase + 64) {
+        rbase = sub;
+        rc_e = 0; rc_de = 0u; rc_dod = 0u;
+        if (rbase + lane < nsub) { const gchunk_state* r = rec0 + rbase + lane; rc_e = r->e_map; rc_de = r->de; rc_dod = r->dod; }
+      }
+      const int src = lane + (sub - rbase);  // the lane of the window that holds record j
+      const int e_j = __shfl(rc_e, src & 63, 64);
+      const uint32_t de_j = (uint32_t)__shfl((int)rc_de, src & 63, 64), dod_j = (uint32_t)__shfl((int)rc_dod, src & 63, 64);
+      const bool applies = src < 64 && j < nsub && !(sb >> 31) && eS > 0 && eS < 255 && e_j == eS;
+      if (!(__ballot(applies) & 1ull)) goto replay;  // (the next record is for another binade, or there is none: replay the sub-piece)
+      ulp_map m = {kUlpSat, kUlpSat};
+      if (applies) { m.de = de_j; m.dod = dod_j; }
+      ulp_map v = m;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        ulp_map o;
+        o.de = __shfl_up(v.de, off, 64);
+        o.dod = __shfl_up(v.dod, off, 64);
+        if (lane >= off) v = ulp_compose(o, v);
+      }
+      const uint32_t Sint = (sb & 0x7fffffu) | 0x800000u;
+      const uint32_t Safter = Sint + ((Sint & 1u) ? v.dod : v.de);  // (deltas saturate at 2^24: no wrap)
+      const unsigned long long stop = __ballot(!(Safter < 0x1000000u));
+      const int cnt = stop ? (int)__ffsll((long long)stop) - 1 : 64;
+      if (cnt > 0) {
+        if (bounds != nullptr) {  // (wave-uniform) the running sum at the start of every 8192-product chunk inside the accepted run
+          uint32_t pde = (uint32_t)__shfl_up(v.de, 1, 64), pdod = (uint32_t)__shfl_up(v.dod, 1, 64);
+          if (lane == 0) { pde = 0u; pdod = 0u; }
+          const uint32_t Sbefore = Sint + ((Sint & 1u) ? pdod : pde);
+          if (lane < cnt && (j % kSubsPerChunk) == 0) bounds[piece0 + j / kSubs] = (unsigned long long)((sb & 0xff800000u) | (Sbefore & 0x7fffffu)) | (1ull << 32);
+        }
+        const uint32_t Slast = (uint32_t)__shfl((int)Safter, cnt - 1, 64);
+        sb = (sb & 0xff800000u) | (Slast & 0x7fffffu);  // (same binade: the hints of the skipped sub-pieces stay what they are)
+        sub += cnt;
+        n_skip += (unsigned long long)cnt;
+        continue;
+      }
+    }
+  replay:
+    // ---- replay sub-piece `sub`
+    if (bounds != nullptr && lane == 0 && (sub % kSubsPerChunk) == 0) bounds[piece0 + sub / kSubs] = (unsigned long long)sb | ((unsigned long long)(has ? 1 : 0) << 32);
+    const int64_t base = (int64_t)sub * kGiantSub;
+    const int n = (int)((deg - base) < kGiantSub ? (deg - base) : kGiantSub);
+    const int ngroups = (n + PER - 1) / PER;
+    const int k0 = lane * PER;
+    float term[PER];
+    if (pre_sub == sub) {
+#pragma unroll
+      for (int i = 0; i < PER; i++) term[i] = pre[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < PER; i++) term[i] = (k0 + i < n) ? terms[t0 + base + k0 + i] : 0.f;
+    }
+    if (sub + 1 < nsub) {  // (the next sub-piece's products are requested now: replays come in runs -- a row's start, a pass without hints)
+      const int64_t nb = base + kGiantSub;
+#pragma unroll
+      for (int i = 0; i < PER; i++) pre[i] = (nb + k0 + i < deg) ? terms[t0 + nb + k0 + i] : 0.f;
+      pre_sub = sub + 1;
+    }
+    int g0 = 0, span = 1;
+    while (g0 < ngroups) {
+      const int eS = (int)((sb >> 23) & 0xff);
+      const bool s_ok = has && !(sb >> 31) && eS > 0 && eS < 255;
+      int fail = g0;
+      if (s_ok) {
+        ulp_map mine = {0u, 0u};
+        bool ok = true;
+        if (lane >= g0 && lane < ngroups) {
+#pragma unroll
+          for (int i = 0; i < PER; i++)
+            if (k0 + i < n) {
+              ulp_map t;
+              if (!ulp_term(__float_as_uint(term[i]), eS, t)) ok = false; else mine = ulp_compose(mine, t);
+            }
+        }
+        ulp_map v = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          ulp_map o;
+          o.de = __shfl_up(v.de, off, 64);
+          o.dod = __shfl_up(v.dod, off, 64);
+          if (lane >= off) v = ulp_compose(o, v);
+        }
+        const uint32_t Sint = (sb & 0x7fffffu) | 0x800000u;
+        const uint32_t Safter = Sint + ((Sint & 1u) ? v.dod : v.de);
+        // (a lane that cannot be taken poisons every later prefix: take the first such lane)
+        const unsigned long long badm = __ballot(lane >= g0 && lane < ngroups && (!ok || Safter >= 0x1000000u));
+        fail = badm ? (int)__ffsll((long long)badm) - 1 : ngroups;
+        if (fail > g0) {
+          const uint32_t Slast = (uint32_t)__shfl((int)Safter, fail - 1, 64);
+          sb = (sb & 0xff800000u) | (Slast & 0x7fffffu);
+          n_par += (unsigned long long)(fail - g0);
+        }
+      }
+      if (fail < ngroups) {
+        // `span` lanes from `fail` on are folded in order with the program's own function; the span doubles while the scan makes no
+        // progress (a row's start, terms as large as S, negative terms) and goes back to one lane when it does
+        int nspan = (fail > g0) ? 1 : span;
+        if (!has && nspan < 4) nspan = 4;
+        const int gend = fail + nspan < ngroups ? fail + nspan : ngroups;
+        U S = __uint_as_float(sb);
+        for (int l = fail; l < gend; l++) {
+#pragma unroll
+          for (int i = 0; i < PER; i++) {
+            const U t = wave_bcast(term[i], l);
+            if (l * PER + i < n) {
+              if (!has) { S = t; has = true; } else p.P::reduce_function(S, t);
+            }
+          }
+        }
+        sb = __float_as_uint(S);
+        n_ser += (unsigned long long)(gend - fail);
+        span = (fail > g0) ? 1 : (nspan * 2 > 64 ? 64 : nspan * 2);
+        g0 = gend;
+      } else {
+        g0 = ngroups;
+      }
+    }
+    sub++;
+  }
+  if (lane == 0) {
+    // (counters in 16-product groups, as the workgroup replay counts them)
+    if (n_par) atomicAdd(&g_longrow_counters[0], n_par * PER / 16);
+    if (n_ser) atomicAdd(&g_longrow_counters[1], (n_ser * PER + 15) / 16);
+    if (n_skip) atomicAdd(&g_longrow_counters[2], n_skip * (kGiantSub / 16));
+    if (has) {
+      y[row] = __uint_as_float(sb);
       if (!(accumulate & ACC_STATIC_BITS)) atomicOr(&ybits[row >> 5], 1u << (row & 31));
     }
   }

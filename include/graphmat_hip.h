@@ -197,8 +197,8 @@ typedef struct {
   int32_t hot_stride;         /*   so the busiest entries are the first ones of EVERY slice: the hot set is the first
                                  kHot / hot_slices entries of each slice [q * hot_stride, ...), q < hot_slices (1 / 0:
                                  one slice)                                                                           */
-  void* gchunk_state;         /* [ngchunk] 16-byte records the giant-row kernels keep between passes (kernels.hpp: gchunk_state:
-                                 binade hints and per-piece maps of the exact float replay); scratch owned by the graph */
+  void* gchunk_state;         /* [ngchunk * 8] 32-byte records the giant-row kernels keep between passes, one per 512-product sub-piece
+                                 (kernels.hpp: gchunk_state: binade hints and ulp-maps of the exact float replay); scratch owned by the graph */
   int64_t edges_blk;          /* edges of this adjacency by the kernel class that multiplies them: row-blocks (rows of up   */
   int64_t edges_wave16;       /*   to short_row edges), 16-rows-per-wave rows, one-wave-per-row rows (nmid_long), and -- the */
   int64_t edges_wave;         /*   rest of nnz -- giant rows                                                                */
