@@ -461,7 +461,7 @@ def main():
     ap.add_argument("--native-layout", action="store_true", help="device order = native order (single GPU; for A/B)")
     ap.add_argument("--tile-min-row", type=int, default=-1, help="experiment: rows of more than this many edges are tiled (0 = all rows)")
     ap.add_argument("--col-tiles", type=int, default=-1, help="column tiles of the OUT adjacency (-1 = default for the scale, 1 = none)")
-    ap.add_argument("--graph", choices=("rmat", "uniform"), default="rmat", help="rmat = the metric's input; uniform = every vertex with edge-factor out-edges to uniformly drawn destinations (the reference's test/generator.h:73-105 shape): policy robustness runs")
+    ap.add_argument("--graph", choices=("rmat", "uniform", "rmat-scrambled"), default="rmat", help="rmat = the metric's input; uniform = every vertex with edge-factor out-edges to uniformly drawn destinations (the reference's test/generator.h:73-105 shape): policy robustness runs")
     ap.add_argument("--lib-option", action="append", default=[], metavar="KEY=VALUE", help="gm_set_option(KEY, VALUE) before the graph is built (experiments)")
     ap.add_argument("--debug-flags", type=int, default=0, help="ablation only (results become invalid): 1 skip fold, 2 skip gathers")
     args = ap.parse_args()
@@ -538,6 +538,15 @@ def main():
         else:
             nv_, src_, dst_, _ = api.rmat_on_device(args.scale, args.edge_factor, args.seed, weights=False, device=local_rank,
                                                     part=((rank, world) if local else None))
+            if args.graph == "rmat-scrambled":
+                # the same power-law graph with its vertex ids passed through a random permutation: degree rank and native id -- which the
+                # slices of the device order are ranges of -- no longer have anything to do with each other (policy robustness runs)
+                gen_ = torch.Generator(device=src_.device)
+                gen_.manual_seed(1234567 + int(args.seed))
+                perm_ = (torch.randperm(nv_, device=src_.device, generator=gen_) + 1).to(torch.int32)
+                src_ = perm_[(src_ - 1).long()]
+                dst_ = perm_[(dst_ - 1).long()]
+                del perm_
         # device order chosen by the library: degree-ranked, dealt over the `world` shards
         g_ = api.Graph(nv_, src_, dst_, None, ref_threads=args.ref_threads, device=local_rank, keep_values=False,
                        layout=(_lib.GM_LAYOUT_NATIVE if args.native_layout else _lib.GM_LAYOUT_DEGREE), nshards=world, shard=rank,
@@ -640,6 +649,8 @@ def main():
     e_mid = int(degs[degs > (args.short_row or 64)].sum()) - e_giant
     e_long = e_mid + e_giant
     max_deg = int(degs.max()) if degs.size else 0
+    n_short_rows = int(((degs > 0) & (degs <= (args.short_row or 64))).sum())  # rows the row-block kernel folds (rank 0's shard)
+    n_giant_rows = int(c_out.ngiant)
     del rowptr, degs
 
     from graphmat_amd import _lib as _gl0
@@ -866,7 +877,7 @@ def main():
                 if tj.get("kernels_fingerprint") == kernels_fingerprint() and tj.get("col_tiles", {}).get("scale%d" % args.scale) == int(g.col_tiles):
                     # (large graphs run the persistent forms k_spmv_rowwave / k_spmv_wave16p instead of, or next to, the plain ones)
                     names = {"k_spmv_rowblock": ["k_spmv_rowblock", "k_spmv_rowwave"], "k_spmv_wave": ["k_spmv_wave", "k_spmv_wave16", "k_spmv_wave16p"],
-                             "k_spmv_sell": ["k_spmv_sell"],
+                             "k_spmv_sell": ["k_spmv_sell", "k_spmv_sell_sharded"],
                              "multiply": ["k_spmv_rowblock", "k_spmv_rowwave", "k_spmv_wave", "k_spmv_wave16", "k_spmv_wave16p"]}.get(name, [name])
                     parts = [per.get(k + "_bytes_per_iteration") for k in names]
                     traffic = int(sum(v for v in parts if v is not None)) if any(v is not None for v in parts) else None
@@ -894,15 +905,38 @@ def main():
         # fold passes run on the auxiliary stream next to the row-block kernel: their time overlaps it; the sweep's time includes
         # the gathers it does for the giant rows.)
         steps_ = max(args.steps, 1)
-        def kfrac(edges, ms_total):
+        pmc_per = {}   # raw counter bytes per iteration and kernel, when the PMC passes on record were taken on these kernels
+        pmc_cal = None
+        if traffic_raw is not None:
+            pmc_per = tj.get("scale%d" % args.scale, {})
+            pmc_cal = tj.get("calibration", {}).get("FETCH_SIZE_reported_over_known_coalesced_stream")
+
+        def kfrac(edges, ms_total, alg_bytes_k, pmc_names=(), stream_bytes=0):
+            # frac: 4 B per edge (the column id / the gathered message: round 1-5's figure); frac_alg_bytes: DESIGN §4's algorithmic bytes of the
+            # kernel (the row-block kernel also reads 8 B of row pointer and writes 4 B per row it folds, the sweep 8 B per row); traffic: the
+            # counters' bytes of its launches + the uncounted half of its coalesced streams (FETCH_SIZE tallies those at half: calibration)
             t = ms_total / steps_
+            raw = [pmc_per.get(k + "_bytes_per_iteration") for k in pmc_names]
+            raw = int(sum(v for v in raw if v is not None)) if any(v is not None for v in raw) else None
+            tr = int(raw + (1.0 - pmc_cal) * stream_bytes) if (raw is not None and pmc_cal) else raw
             return {"edges": int(edges), "avg_ms": round(t, 4), "gbps": round(4 * edges / (t * 1e-3) / 1e9, 1) if t > 0 else None,
-                    "frac": round(4 * edges / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if t > 0 else None}
-        per_kernel = ({"k_spmv_rowblock (rows of up to 64 edges)": kfrac(by_kernel[0], stats["rowblock_ms"]),
-                       "k_spmv_sell (rows of 65 .. giant-limit edges)": kfrac(by_kernel[1], stats["wave_ms"]),
-                       "k_giant_terms (maps only) + k_spmv_giant: the giant rows' fold passes (auxiliary stream, next to the row-block kernel; their gathers are done by the sweep)": kfrac(by_kernel[3], stats["giant_ms"])} if swept else
-                      {"k_spmv_rowblock": kfrac(by_kernel[0], stats["rowblock_ms"]), "k_spmv_wave16+k_spmv_wave": kfrac(by_kernel[1] + by_kernel[2], stats["wave_ms"]),
-                       "k_giant_terms+k_spmv_giant (auxiliary stream, overlapped)": kfrac(by_kernel[3], stats["giant_ms"])})
+                    "frac": round(4 * edges / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if t > 0 else None,
+                    "alg_bytes": int(alg_bytes_k), "frac_alg_bytes": round(alg_bytes_k / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if t > 0 else None,
+                    "traffic": tr, "traffic_raw_counters": raw, "traffic_over_alg_bytes": round(tr / alg_bytes_k, 2) if (tr and alg_bytes_k) else None}
+        if swept:
+            sweep_stream = 4 * (int(sweep.nentries) + int(sweep.nedges_long) + int(sweep.ngiant_edges) * 2) * (2 if int(sweep.val_bytes) else 1)
+            per_kernel = {"k_spmv_rowblock (rows of up to 64 edges)": kfrac(by_kernel[0], stats["rowblock_ms"], 4 * by_kernel[0] + 12 * n_short_rows,
+                                                                             ("k_spmv_rowblock", "k_spmv_rowwave"), 4 * by_kernel[0] + 8 * n_short_rows),
+                          "k_spmv_sell (rows of 65 .. giant-limit edges)": kfrac(by_kernel[1], stats["wave_ms"], 4 * by_kernel[1] + 8 * int(sweep.nrows), ("k_spmv_sell", "k_spmv_sell_sharded"), sweep_stream),
+                          "k_giant_sums + k_giant_maps + k_giant_replay_maps: the giant rows' fold passes (auxiliary stream, next to the row-block kernel; their gathers are done by the sweep, "
+                          "they read the products stream twice and the replayed sub-pieces once more)":
+                              kfrac(by_kernel[3], stats["giant_ms"], 8 * by_kernel[3] + 8 * n_giant_rows, ("k_giant_sums", "k_giant_maps", "k_giant_replay_maps"), 8 * by_kernel[3])}
+        else:
+            per_kernel = {"k_spmv_rowblock": kfrac(by_kernel[0], stats["rowblock_ms"], 4 * by_kernel[0] + 12 * n_short_rows, ("k_spmv_rowblock", "k_spmv_rowwave"), 4 * by_kernel[0] + 8 * n_short_rows),
+                          "k_spmv_wave16+k_spmv_wave": kfrac(by_kernel[1] + by_kernel[2], stats["wave_ms"], 4 * (by_kernel[1] + by_kernel[2]) + 12 * int(c_out.nmid),
+                                                           ("k_spmv_wave", "k_spmv_wave16", "k_spmv_wave16p"), 4 * (by_kernel[1] + by_kernel[2])),
+                          "k_giant_terms+k_spmv_giant (auxiliary stream, overlapped)": kfrac(by_kernel[3], stats["giant_ms"], 8 * by_kernel[3] + 8 * n_giant_rows,
+                                                                                              ("k_giant_terms", "k_spmv_giant", "k_giant_sums", "k_giant_maps", "k_giant_replay_maps"), 8 * by_kernel[3])}
         roof = {"bound": "hbm", "kernel": kname + "<PageRank>", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_raw_counters": traffic_raw, "traffic_source": traffic_note,
                 "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg_bytes,
@@ -922,13 +956,16 @@ def main():
                                "measurement forms (tools/sweep_lib_bench.hip, profiles/r05_sweep_phase_clocks.md): the L1-miss path of the CUs for the gathers "
                                "the LDS hot sets do not serve, and the per-slice latency chains")}
     iter_bytes = 4 * E + 48 * nv
+    live_vertices = min(nv, int(g.xchg_rows) * world)
     out = {
-        "metric": "GTEPS (edges/s) per iter + achieved HBM GB/s, PageRank %s-%d" % ("RMAT" if args.graph == "rmat" else "uniform", args.scale),
+        "metric": "GTEPS (edges/s) per iter + achieved HBM GB/s, PageRank %s-%d" % ({"rmat": "RMAT", "uniform": "uniform", "rmat-scrambled": "RMAT(scrambled ids)"}[args.graph], args.scale),
         "value": round(gteps, 3), "unit": "GTEPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("PageRank (alpha=0.3, fp32, fixed iteration count) on RMAT scale-%d, a/b/c=.57/.19/.19, "
                                 "edge factor %d, seed %d, duplicates and self loops kept" % (args.scale, args.edge_factor, args.seed)) if args.graph == "rmat" else
+                               ("PageRank (alpha=0.3, fp32, fixed iteration count) on RMAT scale-%d (a/b/c=.57/.19/.19, edge factor %d, seed %d) with the vertex ids SCRAMBLED by a "
+                                "random permutation (NOT the metric's input: policy robustness run)" % (args.scale, args.edge_factor, args.seed)) if args.graph == "rmat-scrambled" else
                                ("PageRank (alpha=0.3, fp32, fixed iteration count) on a UNIFORM random graph (NOT the metric's input: policy robustness run), 2^%d "
                                 "vertices with %d out-edges each to uniformly drawn destinations, seed %d" % (args.scale, args.edge_factor, args.seed)),
                    "V": nv, "E": E, "parallelism": "1d-rows x%d" % world, "exchange": ((("native exchange (gm_dist.hip) over %s, " % ("%s [GRAPHMAT_RCCL_LIBRARY, not RCCL]" % os.path.basename(os.environ["GRAPHMAT_RCCL_LIBRARY"]) if os.environ.get("GRAPHMAT_RCCL_LIBRARY") else "RCCL"))
@@ -947,6 +984,10 @@ def main():
                    "giant_row_groups_replayed": int(cnt64[0]), "giant_row_groups_serial": int(cnt64[1])},
         "iter_hbm_gbps": round(iter_bytes / (ms_per_step * 1e-3) / 1e9, 1),
         "iter_hbm_frac": round(iter_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4),
+        # the same with the vertices that have an edge only (the degree-ranked device order puts the others behind every shard's live rows:
+        # nothing of theirs is read or written): what the layout actually touches
+        "iter_hbm_frac_live_vertices": round((4 * E + 48 * live_vertices) / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 4),
+        "live_vertices": live_vertices,
         "roofline": roof,
     }
     if multi_diag is not None:

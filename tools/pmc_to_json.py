@@ -18,7 +18,9 @@ def per_iteration(path, counter):
     several times per iteration: once per column tile)"""
     out = {}
     for line in open(path):
-        m = re.match(r"\| `(k_\w+)<gm::PageRankP.*` \| %s \| \d+ \| ([^|]+) \| [^|]+ \|" % counter, line)
+        m = re.match(r"\| `(?:GraphMat::dev::)?(k_\w+)(?:<gm::PageRankP.*)?` \| %s \| \d+ \| ([^|]+) \| [^|]+ \|" % counter, line)
+        if m and "<" not in line.split("`")[1] and not m.group(1).startswith("k_giant_"):
+            m = None  # (kernels without the program in their name: only the giant rows' k_giant_sums / k_giant_maps belong to the iteration)
         if m:
             out[m.group(1)] = out.get(m.group(1), 0.0) + float(m.group(2)) / ITERATIONS
     return out
