@@ -66,7 +66,7 @@ class RunStats(C.Structure):
 class EngineOptions(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("debug_flags", "wave16_form", "rowwave_form", "persist_per_cu", "giant_maps", "ordered_giant_two_pass",
                                          "fuse_apply_send", "untiled_pass_plain", "last_rows_lanes", "push_edge_permille", "bits_step_edges",
-                                         "sparse_step_edges", "iteration_trace", "ablate_cold_from", "ablate_cold_short", "two_stage_head_permille", "giant_stream", "sweep_form", "blocked_form")] + [("reserved_", C.c_int32 * 13)]
+                                         "sparse_step_edges", "iteration_trace", "ablate_cold_from", "ablate_cold_short", "two_stage_head_permille", "giant_stream", "sweep_form", "blocked_form", "guided_pull")] + [("reserved_", C.c_int32 * 12)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int))

@@ -747,10 +747,11 @@ static const EngineKey kEngineKeys[] = {
   {"ablate_cold_short", 14, 0, 0, 0x7fffffff},
   {"two_stage_head_permille", 15, 900, 100, 990},
   {"giant_stream", 16, 1, 0, 2},
-  {"sweep_form", 17, 0, 0, 15},
+  {"sweep_form", 17, 0, 0, 31},
   {"blocked_form", 18, 2, 0, 31},
+  {"guided_pull", 19, 1, 0, 2},
 };
-static_assert(offsetof(gm_engine_options_t, blocked_form) == 18 * sizeof(int32_t), "kEngineKeys follows the field order");
+static_assert(offsetof(gm_engine_options_t, guided_pull) == 19 * sizeof(int32_t), "kEngineKeys follows the field order");
 static bool engine_value_ok(const EngineKey& k, int v) {
   if (v < k.lo || v > k.hi) return false;
 #ifndef GRAPHMAT_ABLATION

@@ -736,6 +736,8 @@ class Run {
   bool rk_unverified = false;  // a probed strategy still to be cross-checked on the device (k_check_rows)
   bool guess_f32_add = false;  // rk is the ordered fold and reduce_function answers like a float addition: speculation for the giant rows only, proven chunk by chunk
   bool can_push = false, xsparse_ok = false, lazy_send = false;
+  bool guided = false;         // an ORDERED fold over a sparse x on a large unsharded graph: levels with small active sets only fold the rows that have an active in-neighbour
+  uint32_t* d_mark = nullptr;  // ... their bitmap (workspace slot 8)
   const int32_t *dev_of_native = nullptr, *native_of_dev = nullptr;
   xentry_t* d_gather = nullptr;
   unsigned long long* d_best = nullptr;
@@ -881,6 +883,21 @@ class Run {
     lazy_send = rk == REDUCE_LAST && sizeof(U) <= 8 && std::is_trivially_copyable<U>::value && !multi && act == ACTIVE_ONLY && order == OUT_EDGES &&
                 desc.row_lo == 0 && desc.row_hi == desc.ndevice && !(opt.debug_flags & dev::DBG_NO_LAZY_SEND);
     if (verbose && lazy_send) printf("GraphMat(HIP): messages are evaluated on demand (no send pass)\n");
+    // Guided pull (round 6).  A program whose reduce_function nothing is known about folds, in every iteration, every row's present
+    // messages in stored order -- and finds them by testing the presence bit of every edge of the graph: 11 ms per BFS / SSSP level at
+    // RMAT-26 however few vertices are active.  While the active set owns few out-edges the rows that can receive a message at all are
+    // marked first (k_mark_rows_of_active: one atomic per out-edge of an active vertex) and only those are folded -- by the same kernels,
+    // in the same order: the bits cannot change.  Large unsharded graphs only (below 2^27 edges the statistics' host round trip costs
+    // more than the full scan: RMAT-22 SSSP 7.0 -> 13 ms when round 3 tried this on every graph).
+    guided = !can_push && !multi && !lazy_send && act == ACTIVE_ONLY && iterations <= 0 && order == OUT_EDGES && rk != REDUCE_LAST &&
+             !program_row_filter<P>::enabled && desc.row_lo == 0 && desc.row_hi == desc.ndevice && opt.guided_pull != 0 &&
+             (Aout.nnz >= (1ll << 27) || opt.guided_pull >= 2) &&
+             !(opt.debug_flags & dev::DBG_NO_PUSH) && gm_graph_csr(g, GM_DIR_IN, &Asrc) == GM_OK;
+    if (guided) {
+      void* pm = nullptr;
+      if (gm_graph_workspace(g, 8, ((size_t)(n + 31) / 32 + 2) * 4, &pm) == GM_OK) d_mark = (uint32_t*)pm; else guided = false;
+    }
+    if (verbose && guided) printf("GraphMat(HIP): guided pull: iterations whose active set owns few out-edges only fold the rows it reaches\n");
 
     gm_graph_workspace(g, 0, 4096, &flag_v);
     // (the changed flag sits directly in front of the striped statistics, so that one memset clears and one copy fetches
@@ -903,12 +920,13 @@ class Run {
       if (gm_graph_workspace(g, GM_WS_GATHER, (size_t)desc.nshards * dev::kSparseListCap * sizeof(xentry_t) + 256, &pg) == GM_OK) d_gather = (xentry_t*)pg;
       else xsparse_ok = false;  // (an adopted buffer that is too small: dense exchanges only)
     }
-    if (can_push || xsparse_ok) {
+    if (can_push || xsparse_ok || guided) {
       void *pb = nullptr, *pl = nullptr, *pt = nullptr;
       if (gm_graph_workspace(g, 7, (size_t)n * 4 + 1024 + ((size_t)dev::kSparseListCap + 64 + dev::kSparseListCap / dev::kBlock + 64) * 4, &pl) != GM_OK ||
           (can_push && (gm_graph_workspace(g, 6, (size_t)n * 8 + 64, &pb) != GM_OK || gm_graph_workspace(g, 10, (size_t)n * 4 + 1024, &pt) != GM_OK))) {
         can_push = false;
         xsparse_ok = false;
+        guided = false;
       } else {
         d_best = (unsigned long long*)pb;
         d_list = (int32_t*)pl;
@@ -1333,8 +1351,11 @@ class Run {
         if (stage < 1024) stage = 1024;
         if (opt.sweep_form & 4) stage = 1024;  // (tests: blocks staged in several rounds)
       }
+      // (sweep_form bit 4: the giant rows' gathers in a kernel of their own behind the sweep -- k_giant_gather_sliced on the auxiliary stream, next
+      // to the short rows -- instead of inside it; single-shard structures only)
+      const bool gather_apart = gterms != nullptr && sw.nsub <= 1 && (opt.sweep_form & 16) != 0;
       for (int set = 0; set < sw.nsets; set++) {
-        U* gt = set == 0 ? gterms : (U*)nullptr;  // (the first launch gathers for the giant rows)
+        U* gt = (set == 0 && !gather_apart) ? gterms : (U*)nullptr;  // (the first launch gathers for the giant rows)
         bool with_vals = false;
         if (sw.nsub > 1) {  // a shard's rows: the message vector is made of nsub owners' ranges (kernels.hpp: k_spmv_sell_sharded)
           if constexpr (sizeof(E) == 4 && std::is_trivially_copyable<E>::value) {
@@ -1368,6 +1389,18 @@ class Run {
       if (gterms != nullptr) {  // the giant rows' fold passes behind the sweep, on the auxiliary stream next to the short rows
         GM_HIP_OK(hipEventRecord(aux.fork, s));
         GM_HIP_OK(hipStreamWaitEvent(aux.s, aux.fork, 0));
+        if (gather_apart) {
+          bool done = false;
+          if constexpr (sizeof(E) == 4 && std::is_trivially_copyable<E>::value) {
+            if (Aout.vals != nullptr && sw.gval != nullptr) {
+              hipLaunchKernelGGL((dev::k_giant_gather_sliced<P, T, U, V, E, true>), dim3(2048), dim3(dev::kBlock), 0, aux.s, pa, sw.gcol, sw.gval, sw.gdst, (int64_t)sw.ngiant_edges, xq, gterms);
+              done = true;
+            }
+          }
+          if (!done)
+            hipLaunchKernelGGL((dev::k_giant_gather_sliced<P, T, U, V, E, false>), dim3(2048), dim3(dev::kBlock), 0, aux.s, pa, sw.gcol, (const uint32_t*)nullptr, sw.gdst, (int64_t)sw.ngiant_edges, xq, gterms);
+          st.spmv_launches++;
+        }
         Launch Lg = L;
         Lg.terms_ready = true;
         launch_spmv_vp<P, T, U, V, E>(use_vp, Lg, pa, Ag, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
@@ -1685,6 +1718,27 @@ class Run {
     xb = dense_x ? nullptr : (lazy_send ? (const uint32_t*)d_active : (const uint32_t*)xbits);
     const uint32_t* apply_bits = ybits;
     const uint32_t* row_bits = d_want;  // which rows the multiply works on
+    bool guided_few = true;
+    if (guided && !dense_push && !xsp && frontier_v > 0 && frontier_e * 50ull < (unsigned long long)Aout.nnz) {
+      // few out-edges leave the active set: mark the rows they reach, fold only those (same kernels, same order)
+      GM_HIP_OK(hipMemsetAsync(d_mark, 0, ((size_t)(n + 31) / 32 + 2) * 4, s));
+      if (frontier_v <= (unsigned long long)dev::kSparseListCap) {  // few vertices: from their list, a workgroup per 1024 out-edges (a hub is spread over the chip)
+        list_active_set();
+        const int nf = (int)frontier_v;
+        const unsigned pieces = (unsigned)(frontier_e / dev::kPieceEdges + frontier_v);
+        piece_offsets(nf);
+        hipLaunchKernelGGL(dev::k_mark_rows_of_list, dim3(pieces > 0 ? pieces : 1), dim3(dev::kBlock), 0, s, Asrc, (const int32_t*)d_list, nf, (const unsigned int*)d_off, d_mark);
+      } else {
+        const int mgrid = grid_for(n_live) < 4096 ? grid_for(n_live) : 4096;
+        hipLaunchKernelGGL(dev::k_mark_rows_of_active, dim3(mgrid), dim3(dev::kBlock), 0, s, Asrc, (const uint32_t*)d_active, n_live, d_mark);
+      }
+      row_bits = d_mark;
+      // (the kernel that takes 64 list entries per wave and works on the wanted ones one after the other pays for a handful of wanted rows;
+      // with thousands of them the 16-rows-per-wave kernels, which skip unwanted rows as well, are several times faster: RMAT-26 BFS level
+      // with 857 K out-edges 14.3 ms against ~4)
+      guided_few = frontier_e <= 4096ull;
+      if (verbose) printf("GraphMat(HIP):   guided pull: %llu active vertices, %llu out-edges\n", frontier_v, frontier_e);
+    }
     if (dense_push) {
       multiply_dense_push(pa);
     } else if (order == OUT_EDGES || order == ALL_EDGES) {
@@ -1713,7 +1767,7 @@ class Run {
       } else if (ntile > 1) {
         multiply_out_tiled(pa, ntile, acc);
       } else {
-        launch_spmv_vp<P, T, U, V, E>(use_vp, launch_ctx(), pa, Aout, xq, xb, (const V*)d_vp, y, ybits, acc, rk, row_bits, grouped_waves, xsum);
+        launch_spmv_vp<P, T, U, V, E>(use_vp, launch_ctx(), pa, Aout, xq, xb, (const V*)d_vp, y, ybits, acc, rk, row_bits, grouped_waves && guided_few, xsum);
         check_probed(pa, Aout, static_bits ? Aout.rowbits : (const uint32_t*)ybits, row_bits, acc, ybits, dense_x);
       }
       if (static_bits) apply_bits = Aout.rowbits;
@@ -1772,7 +1826,7 @@ class Run {
       tr_updated = -1;
       if (verbose && can_push) printf("GraphMat(HIP):   active set: %llu vertices, %llu out-edges (max %llu)\n", frontier_v, frontier_e, frontier_maxdeg);
       dev::ProgArg<P> pa = dev::make_prog_arg(gp);  // re-captured every iteration (do_every_iteration may change it)
-      const bool want_stats = (can_push || xsparse_ok) && iterations <= 0;
+      const bool want_stats = (can_push || xsparse_ok || guided) && iterations <= 0;
       // the changed flag and, for steered runs, the striped statistics behind it (k_apply / k_push_finish add to them);
       // a fixed-count run never reads the flag (:254-256), so it is not cleared either: one tiny fill kernel less per iteration
       if (iterations <= 0) GM_HIP_OK(hipMemsetAsync(d_changed, 0, want_stats ? sizeof(int) + striped_bytes : sizeof(int), s));

@@ -1814,6 +1814,28 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
   sell_body<P, T, U, V, E, HAS_VALS, ABL, UBATCH, PIPE, POOLW, false>(pa, set, stage_words, nslices, nrows_long, slice_base, scol, sval, wrow, row_of_slot, lcol, lval, lps,
                                                                        lrow_of_slot, gcol, gval, gdst, gslice, gterms, x, y, 1, 0, 0);
 }
+// The giant rows' gathers in a kernel of their own (engine option sweep_form bit 4): gm_sweep_t.gcol is sorted by slice, so a grid-stride
+// walk keeps all workgroups inside about one slice of the message vector at a time (L2-resident) without hot sets.  Runs on the auxiliary
+// stream behind the sweep, next to the short rows' kernel, in front of the giant rows' fold passes: the sweep is then free of their 36 M
+// (RMAT-26) gathers and stores.  Single-shard structures only (a shard's entries carry LDS offsets).
+template <class P, class T, class U, class V, class E, bool HAS_VALS>
+__global__ void __launch_bounds__(kBlock)
+k_giant_gather_sliced(ProgArg<P> pa, const uint32_t* __restrict__ gcol, const uint32_t* __restrict__ gval, const uint32_t* __restrict__ gdst, int64_t n,
+                      const T* __restrict__ x, U* __restrict__ gterms) {
+  static_assert(sizeof(T) == 4 && sizeof(U) == 4, "4-byte messages and reductions");
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  V no_vp;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const uint32_t c4 = __builtin_nontemporal_load(&gcol[i]), d = __builtin_nontemporal_load(&gdst[i]);
+    E ev = E();
+    if constexpr (HAS_VALS) { const uint32_t raw = __builtin_nontemporal_load(&gval[i]); __builtin_memcpy(&ev, &raw, 4); }
+    const T m = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(x) + c4);
+    U res;
+    p.P::process_message(m, ev, no_vp, res);
+    gterms[d] = res;
+  }
+}
+
 // the same sweep over a shard's rows (gm_sweep_t.nsub > 1)
 template <class P, class T, class U, class V, class E, bool HAS_VALS>
 __global__ void __launch_bounds__(1024)
@@ -3505,6 +3527,44 @@ k_unpack_frontier(const sparse_entry<T>* __restrict__ all, int64_t n, T* __restr
   memcpy(&m, e.msg, sizeof(T));
   x[e.idx] = m;
   atomicOr(&xbits[e.idx >> 5], 1u << (e.idx & 31));
+}
+
+// ---- rows with an active in-neighbour (engine.hpp: guided pull; round 6) -----------------------------------------------------------------
+// mark[v] := 1 for every destination v of an out-edge of an active vertex (S: rows = sources).  One lane per vertex of the active bitmap; a
+// vertex of more than 32 out-edges is walked by its whole wave.  The pull multiply of an ORDERED program then folds only the marked rows --
+// every other row has no present message -- and folds them exactly as before.
+__global__ void __launch_bounds__(kBlock)
+k_mark_rows_of_active(gm_csr_t S, const uint32_t* __restrict__ active, int n, uint32_t* __restrict__ mark) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n; base += (int64_t)gridDim.x * kBlock) {
+    const int i = (int)base + (int)threadIdx.x;
+    const bool act = i < n && bit_get(active, i);
+    long long e0 = 0, e1 = 0;
+    if (act) { e0 = S.rowptr[i]; e1 = S.rowptr[i + 1]; }
+    const bool big = act && e1 - e0 > 32;
+    if (act && !big)
+      for (long long e = e0; e < e1; e++) { const int c = S.colidx[e]; if (!((mark[c >> 5] >> (c & 31)) & 1u)) atomicOr(&mark[c >> 5], 1u << (c & 31)); }
+    unsigned long long todo = __ballot(big);
+    while (todo) {
+      const int l = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const long long b0 = __shfl(e0, l, 64), b1 = __shfl(e1, l, 64);
+      for (long long e = b0 + lane; e < b1; e += 64) { const int c = S.colidx[e]; if (!((mark[c >> 5] >> (c & 31)) & 1u)) atomicOr(&mark[c >> 5], 1u << (c & 31)); }
+    }
+  }
+}
+// the same from the LIST of the active vertices (while they are few): one workgroup per 1024-edge piece of a listed vertex's out-edges
+// (k_piece_offsets), so that a hub's 10^6 out-edges are spread over the chip instead of being walked by one wave (6 ms for RMAT-26's)
+__global__ void __launch_bounds__(kBlock)
+k_mark_rows_of_list(gm_csr_t S, const int32_t* __restrict__ list, int nlist, const unsigned int* __restrict__ off, uint32_t* __restrict__ mark) {
+  int u;
+  int64_t e0, e1;
+  if (!piece_of_block(S, list, nlist, off, blockIdx.x, &u, &e0, &e1)) return;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int64_t e = e0 + threadIdx.x + j * kBlock;
+    if (e < e1) { const int c = S.colidx[e]; if (!((mark[c >> 5] >> (c & 31)) & 1u)) atomicOr(&mark[c >> 5], 1u << (c & 31)); }
+  }
 }
 
 // ---- the sharded swept schedule (engine.hpp: run_swept_sharded; round 6) ---------------------------------------------------------------

@@ -595,11 +595,15 @@ typedef struct {
   int32_t sweep_form;             /* the swept multiply (engine.hpp: multiply_out_swept): bits 0-1 = where the short rows' pass runs: 0 on the main stream
                                      in front of the sweep (default), 1 on the auxiliary stream behind the giant rows' passes (next to the sweep),
                                      2 on the main stream behind the sweep; bit 2 = the long rows staged in rounds of 1024 entries (tests); bit 3 = the
-                                     giant rows gather for themselves on the auxiliary stream (k_giant_terms) instead of the sweep gathering for them */
+                                     giant rows gather for themselves on the auxiliary stream (k_giant_terms) instead of the sweep gathering for them; bit 4 = the giant rows' gathers in a
+                                     kernel of their own behind the sweep (k_giant_gather_sliced: their entries in slice order, on the auxiliary stream next to the short rows) */
   int32_t blocked_form;           /* the column-blocked stream of the short rows (engine.hpp: multiply_out_blocked): bits 0-3 = window -- a workgroup starts a
                                      slice when all workgroups of its XCD have finished the one `window` slices back (default 2; 0 = workgroups not
                                      kept in step); bit 4 = batches of 4 x 64 entries instead of 2 x 64 */
-  int32_t reserved_[13];
+  int32_t guided_pull;            /* ORDERED folds over a sparse x (ACTIVE_ONLY programs that declare nothing, running until convergence, unsharded): while the active
+                                     set owns less than 2 % of the edges, the rows it reaches are marked first and only those are folded (engine.hpp: guided pull).
+                                     0 = never, 1 = on graphs of at least 2^27 edges (default), 2 = on graphs of any size (tests) */
+  int32_t reserved_[12];
 } gm_engine_options_t;
 /* the options a run on `g` uses (g may be NULL: the process defaults) */
 int gm_graph_engine_options(const gm_graph_t* g, gm_engine_options_t* out);

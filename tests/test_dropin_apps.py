@@ -29,8 +29,9 @@ def test_apps_compile_for_gfx950():
             assert os.path.exists(os.path.join(REF_APPS, app))
 
 
-def _run(exe, *args):
-    out = subprocess.run([exe] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+def _run(exe, *args, env=None):
+    out = subprocess.run([exe] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
+                         env=(dict(os.environ, **env) if env else None))
     text = out.stdout.decode()
     assert out.returncode == 0, text
     return text
@@ -181,6 +182,15 @@ def test_untraited_programs_on_a_graph_with_giant_rows():
     degs = np.array([int(x) for _, x, _ in gotp], dtype=np.int64)
     assert (degs == odeg).all()
     assert (bits == np.ascontiguousarray(opr, np.float32).view(np.uint32)).all()
+    # The GUIDED PULL (engine.hpp; round 6): on large graphs the levels of an undeclared ACTIVE_ONLY program whose active set owns few
+    # out-edges only fold the rows that set reaches (marked first, then the same kernels in the same order).  Forced here on the small
+    # graph (guided_pull = 2): every line of the output must be the same, and the path must really have been taken.
+    text2 = _run(exe, path, 5, 6, env={"GRAPHMAT_OPTIONS": "guided_pull=2", "GRAPHMAT_VERBOSE": "1"})
+    assert "guided pull: " in text2 and text2.count("   guided pull:") >= 4, text2[:2000]
+    keep = lambda t: sorted(l for l in t.splitlines() if re.match(r"^(bfs|sssp|pr) ", l))
+    assert keep(text2) == keep(text)
+    text0 = _run(exe, path, 5, 6, env={"GRAPHMAT_OPTIONS": "guided_pull=0", "GRAPHMAT_VERBOSE": "1"})
+    assert "guided pull" not in text0 and keep(text0) == keep(text)
 
 
 @pytest.mark.gpu
