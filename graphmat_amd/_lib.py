@@ -47,7 +47,7 @@ class Sweep(C.Structure):
                 ("row_of_slot", C.c_void_p), ("lcol", C.c_void_p), ("lval", C.c_void_p), ("lps", C.c_void_p), ("lrow_of_slot", C.c_void_p),
                 ("slice_base", C.c_void_p), ("src_pos", C.c_void_p), ("lsrc_pos", C.c_void_p),
                 ("ngiant_edges", C.c_int64), ("gcol", C.c_void_p), ("gval", C.c_void_p), ("gdst", C.c_void_p), ("gslice", C.c_void_p), ("gsrc_pos", C.c_void_p),
-                ("nsub", C.c_int32), ("stride", C.c_int32), ("hot_words", C.c_int32), ("reserved_", C.c_int32)]
+                ("nsub", C.c_int32), ("stride", C.c_int32), ("hot_words", C.c_int32), ("waves", C.c_int32)]
 
 
 class Blocked(C.Structure):

@@ -34,6 +34,7 @@ int g_long_mid = 0;  // > 0: experiment -- wave rows of more than this many edge
 int g_sweep_slices = 1;  // 1: cut the device order into ntiles * k <= 64 slices and build the row-stationary sweep of the medium rows (gm_graph_sweep)
 int g_sort_tile_lists = 1;  // column tiles: the wave-row lists by descending piece length (sort_rows_by_length)
 int g_sweep_border_factor = 4;  // the medium / long border is lowered while it exceeds this many times a wave's share of a block per slice
+int g_sweep_waves = 16;  // waves per workgroup the sweep's blocks are dealt over (16; 12: a 768-thread sweep that leaves room on every CU for the short rows' kernel beside it -- experiment of round 6)
 int g_sweep_fold_share = 50;  // share (percent of an equal share) of a block's groups that the waves folding the long rows get
 int g_sweep_long_row = 0;  // the sweep's medium / long border (edges per row): 0 = chosen per graph (build_sweep)
 int g_sweep_acc_limit = GM_SWEEP_ACC_ROWS, g_sweep_long_limit = GM_SWEEP_LONG_SLOTS;  // rows per workgroup and launch of the sweep (tests force several launches with small values)
@@ -1099,10 +1100,11 @@ k_sweep_fill(uint32_t ngroups, const uint32_t* __restrict__ gbase, const uint32_
 // rows of the block first: as many waves as the workgroup's long rows need lanes) get fold_share percent of an equal share
 __global__ void __launch_bounds__(64)
 k_sweep_wave_ranges(const uint32_t* __restrict__ grp_first, int nblk, const uint32_t* __restrict__ gbase, uint32_t* __restrict__ wfirst, uint32_t* __restrict__ wrow,
-                    int fold_share, int fold_waves) {
+                    int fold_share, int fold_waves, int nwaves) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= nblk) return;
-  constexpr int W = 16;
+  constexpr int WS = 16;  // (entries per block in wfirst / wrow: WS + 1, whatever W)
+  const int W = nwaves;
   const int FW = fold_waves;
   const uint32_t g0 = grp_first[b], g1 = grp_first[b + 1];
   unsigned long long total = 0;
@@ -1111,14 +1113,16 @@ k_sweep_wave_ranges(const uint32_t* __restrict__ grp_first, int nblk, const uint
   uint32_t g = g0;
   unsigned long long acc = 0, share = 0;
   for (int w = 0; w < W; w++) {
-    wfirst[(size_t)b * (W + 1) + w] = g;
-    wrow[(size_t)b * (W + 1) + w] = gbase[g] >> 6;
+    wfirst[(size_t)b * (WS + 1) + w] = g;
+    wrow[(size_t)b * (WS + 1) + w] = gbase[g] >> 6;
     share += w >= W - FW ? (unsigned)fold_share : 100u;
     const unsigned long long want = total * share / units;
     while (g < g1 && acc + ((gbase[g + 1] - gbase[g]) / 64u + 1u + 1u) / 2u <= want) { acc += (gbase[g + 1] - gbase[g]) / 64u + 1u; g++; }
   }
-  wfirst[(size_t)b * (W + 1) + W] = g1;
-  wrow[(size_t)b * (W + 1) + W] = gbase[g1] >> 6;
+  for (int w = W; w <= WS; w++) {  // (entry W ends the block; the entries behind it repeat the end)
+    wfirst[(size_t)b * (WS + 1) + w] = g1;
+    wrow[(size_t)b * (WS + 1) + w] = gbase[g1] >> 6;
+  }
 }
 // long rows: entry e = ((set * 256 + w) * nslices + slice) * long_slots + j -> first position of that piece in the sorted keys
 __global__ void __launch_bounds__(kT)
@@ -1460,7 +1464,7 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
                        vals ? sval.as<uint32_t>() : (uint32_t*)nullptr, vals ? spos.as<uint32_t>() : (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_sweep_wave_ranges, dim3((unsigned)((nblk + 63) / 64)), dim3(64), 0, s, (const uint32_t*)grp_first.as<uint32_t>(), (int)nblk,
                        (const uint32_t*)gbase.as<uint32_t>(), wfirst.as<uint32_t>(), wrow.as<uint32_t>(), nlong > 0 ? g_sweep_fold_share : 100,
-                       (int)std::min(8, (((per_wg_long + nsets - 1) / nsets) + 63) / 64));
+                       (int)std::min(8, (((per_wg_long + nsets - 1) / nsets) + 63) / 64), (g_sweep_waves == 12 || g_sweep_waves == 8) ? g_sweep_waves : 16);
     GM_TRY_HIP(hipGetLastError());
     GM_TRY_HIP(hipStreamSynchronize(s));
   } else {
@@ -1523,6 +1527,7 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
   S.lrow_of_slot = (const int32_t*)lrslot.release(); S.slice_base = g->d_slice_base;
   S.src_pos = (const uint32_t*)spos.release(); S.lsrc_pos = (const uint32_t*)lpos.release();
   S.nsub = nsub; S.stride = sl.stride; S.hot_words = sl.hot_words;
+  S.waves = (g_sweep_waves == 12 || g_sweep_waves == 8) ? g_sweep_waves : 16;
   return GM_OK;
 }
 

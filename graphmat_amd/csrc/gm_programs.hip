@@ -20,7 +20,7 @@
 
 namespace gm {
 
-extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance, g_own_wave_row, g_sort_tile_lists, g_sweep_slices, g_sweep_acc_limit, g_sweep_long_limit, g_sweep_long_row, g_sweep_fold_share, g_sweep_border_factor, g_blocked_rows;
+extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance, g_own_wave_row, g_sort_tile_lists, g_sweep_slices, g_sweep_acc_limit, g_sweep_long_limit, g_sweep_long_row, g_sweep_fold_share, g_sweep_border_factor, g_blocked_rows, g_sweep_waves;
 static int g_force_ordered = 0;
 
 // ---------------- PageRank (reference: src/PageRank.cpp:34-112) ----------------------------
@@ -840,6 +840,7 @@ int gm_reset_options(void) {
   gm::g_sweep_long_limit = GM_SWEEP_LONG_SLOTS;
   gm::g_sweep_long_row = 0;
   gm::g_sweep_fold_share = 50;
+  gm::g_sweep_waves = 16;
   gm::g_sweep_border_factor = 4;
   gm::g_col_tiles = 0;
   return GM_OK;
@@ -870,6 +871,7 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "sweep_long_row") && value >= 0 && value <= 8191) { gm::g_sweep_long_row = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_border_factor") && value >= 1 && value <= 64) { gm::g_sweep_border_factor = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_fold_share") && value >= 0 && value <= 100) { gm::g_sweep_fold_share = value; return GM_OK; }
+  if (key && !strcmp(key, "sweep_waves") && (value == 16 || value == 12 || value == 8)) { gm::g_sweep_waves = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_long_slots") && value >= 1 && value <= GM_SWEEP_LONG_SLOTS) { gm::g_sweep_long_limit = value; return GM_OK; }
   gm::set_error("gm_set_option: unknown option");
   return GM_ERR_INVALID;

@@ -1281,6 +1281,7 @@ class Run {
       // a shard's rows (gm_sweep_t.nsub): the structure must describe THIS cut of the message vector; a single-shard structure is not
       // used by a run that exchanges messages (a world of one rank: nothing to gain)
       if (sw->nsub > 1 ? (sw->nsub != desc.nshards || sw->stride != n || sw->hot_words <= 0) : multi) return false;
+      if (sw->waves != 0 && sw->waves != 16 && !(sw->waves == 12 && sw->nsub <= 1)) return false;  // (a block's groups dealt over a wave count no kernel here has)
       if (Aout.vals != nullptr && !(sw->val_bytes == 4 && sizeof(E) == 4 && std::is_trivially_copyable<E>::value)) return false;
       return true;
     } else {
@@ -1334,7 +1335,33 @@ class Run {
       // row-blocks, on the main stream -- it wants the whole chip, like the sweep)
       gm_blocked_t bl;
       const bool shorts_blocked = blocked_usable(acc, &bl);
-      const int where = shorts_blocked ? 3 : (gterms != nullptr ? 2 : (opt.sweep_form & 3));  // (3: behind everything, below)
+      // The 768-thread form (gm_sweep_t.waves = 12; experiment of round 6): the sweep leaves every CU a quarter of its registers and 36 KB of LDS,
+      // and EVERYTHING else runs beside it on the auxiliary stream from the moment x is complete: the giant rows' gathers in slice order
+      // (k_giant_gather_sliced), their fold passes, then the short rows' kernel.
+      const bool w12 = sw.waves == 12 && sw.nsub <= 1 && !shorts_blocked && !defer_join;
+      // (the giant rows' gathers in a kernel of their own instead of inside the sweep: sweep_form bit 4, or the 768-thread form)
+      const bool gather_apart = gterms != nullptr && sw.nsub <= 1 && ((opt.sweep_form & 16) != 0 || w12);
+      auto giant_gather = [&]() {
+        bool done = false;
+        if constexpr (sizeof(E) == 4 && std::is_trivially_copyable<E>::value) {
+          if (Aout.vals != nullptr && sw.gval != nullptr) {
+            hipLaunchKernelGGL((dev::k_giant_gather_sliced<P, T, U, V, E, true>), dim3(2048), dim3(dev::kBlock), 0, aux.s, pa, sw.gcol, sw.gval, sw.gdst, (int64_t)sw.ngiant_edges, xq, gterms);
+            done = true;
+          }
+        }
+        if (!done)
+          hipLaunchKernelGGL((dev::k_giant_gather_sliced<P, T, U, V, E, false>), dim3(2048), dim3(dev::kBlock), 0, aux.s, pa, sw.gcol, (const uint32_t*)nullptr, sw.gdst, (int64_t)sw.ngiant_edges, xq, gterms);
+        st.spmv_launches++;
+      };
+      bool chain_done = false;
+      if (w12 && gterms != nullptr) {  // gathers and fold passes of the giant rows right away, beside the sweep
+        giant_gather();
+        Launch Lg = L;
+        Lg.terms_ready = true;
+        launch_spmv_vp<P, T, U, V, E>(use_vp, Lg, pa, Ag, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
+        chain_done = true;
+      }
+      const int where = shorts_blocked ? 3 : (w12 ? 1 : (gterms != nullptr ? 2 : (opt.sweep_form & 3)));  // (3: behind everything, below)
       if (where == 1) { La.s = aux.s; La.timer = nullptr; }
       auto short_rows = [&]() {
         if (As.nblk <= 0) return;
@@ -1351,9 +1378,7 @@ class Run {
         if (stage < 1024) stage = 1024;
         if (opt.sweep_form & 4) stage = 1024;  // (tests: blocks staged in several rounds)
       }
-      // (sweep_form bit 4: the giant rows' gathers in a kernel of their own behind the sweep -- k_giant_gather_sliced on the auxiliary stream, next
-      // to the short rows -- instead of inside it; single-shard structures only)
-      const bool gather_apart = gterms != nullptr && sw.nsub <= 1 && (opt.sweep_form & 16) != 0;
+      if (w12 && stage > GM_SWEEP_MAX_STAGE_W12) stage = GM_SWEEP_MAX_STAGE_W12;
       for (int set = 0; set < sw.nsets; set++) {
         U* gt = (set == 0 && !gather_apart) ? gterms : (U*)nullptr;  // (the first launch gathers for the giant rows)
         bool with_vals = false;
@@ -1372,6 +1397,20 @@ class Run {
                                (const uint32_t*)nullptr, sw.gdst, sw.gslice, gt, xq, y, sw.nsub, sw.stride, sw.hot_words);
           continue;
         }
+        if (w12) {  // 768-thread workgroups (kernels.hpp: k_spmv_sell_w12)
+          if constexpr (sizeof(E) == 4 && std::is_trivially_copyable<E>::value) {
+            if (Aout.vals != nullptr) {
+              hipLaunchKernelGGL((dev::k_spmv_sell_w12<P, T, U, V, E, true>), dim3(256), dim3(768), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base, sw.scol,
+                                 sw.sval, sw.wrow, sw.row_of_slot, sw.lcol, sw.lval, sw.lps, sw.lrow_of_slot, sw.gcol, sw.gval, sw.gdst, sw.gslice, gt, xq, y);
+              with_vals = true;
+            }
+          }
+          if (!with_vals)
+            hipLaunchKernelGGL((dev::k_spmv_sell_w12<P, T, U, V, E, false>), dim3(256), dim3(768), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base, sw.scol,
+                               (const uint32_t*)nullptr, sw.wrow, sw.row_of_slot, sw.lcol, (const uint32_t*)nullptr, sw.lps, sw.lrow_of_slot, sw.gcol,
+                               (const uint32_t*)nullptr, sw.gdst, sw.gslice, gt, xq, y);
+          continue;
+        }
         if constexpr (sizeof(E) == 4 && std::is_trivially_copyable<E>::value) {
           if (Aout.vals != nullptr) {
             hipLaunchKernelGGL((dev::k_spmv_sell<P, T, U, V, E, true>), dim3(256), dim3(1024), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base, sw.scol,
@@ -1386,21 +1425,10 @@ class Run {
       }
       st.spmv_launches += sw.nsets;
       timer.mark(TAG_WAVE);
-      if (gterms != nullptr) {  // the giant rows' fold passes behind the sweep, on the auxiliary stream next to the short rows
+      if (gterms != nullptr && !chain_done) {  // the giant rows' fold passes behind the sweep, on the auxiliary stream next to the short rows
         GM_HIP_OK(hipEventRecord(aux.fork, s));
         GM_HIP_OK(hipStreamWaitEvent(aux.s, aux.fork, 0));
-        if (gather_apart) {
-          bool done = false;
-          if constexpr (sizeof(E) == 4 && std::is_trivially_copyable<E>::value) {
-            if (Aout.vals != nullptr && sw.gval != nullptr) {
-              hipLaunchKernelGGL((dev::k_giant_gather_sliced<P, T, U, V, E, true>), dim3(2048), dim3(dev::kBlock), 0, aux.s, pa, sw.gcol, sw.gval, sw.gdst, (int64_t)sw.ngiant_edges, xq, gterms);
-              done = true;
-            }
-          }
-          if (!done)
-            hipLaunchKernelGGL((dev::k_giant_gather_sliced<P, T, U, V, E, false>), dim3(2048), dim3(dev::kBlock), 0, aux.s, pa, sw.gcol, (const uint32_t*)nullptr, sw.gdst, (int64_t)sw.ngiant_edges, xq, gterms);
-          st.spmv_launches++;
-        }
+        if (gather_apart) giant_gather();
         Launch Lg = L;
         Lg.terms_ready = true;
         launch_spmv_vp<P, T, U, V, E>(use_vp, Lg, pa, Ag, xq, xb, (const V*)d_vp, y, ybits, acc, rk);

@@ -1464,7 +1464,7 @@ static __device__ unsigned long long g_sell_phase_ticks[4096][8];
 // `stride` entries, slice_base holds positions inside a range -- a slice is the same sub-range of every owner's range, its hot set the
 // first hq = min(slice length, hot_words / nsub) entries of each (LDS word q * hq + j) -- and the entries say at build time whether
 // their message is in LDS (GM_SWEEP_HOT | LDS byte offset) or in the message vector (byte offset): the gather decodes, nothing else changes.
-template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL, int UBATCH, int PIPE, int POOLW, bool SHARDED>
+template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL, int UBATCH, int PIPE, int POOLW, bool SHARDED, int BLOCKT = 1024>
 __device__ __forceinline__ void
 sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows_long, const int32_t* __restrict__ slice_base, const uint32_t* __restrict__ scol,
           const uint32_t* __restrict__ sval, const uint32_t* __restrict__ wrow, const int32_t* __restrict__ row_of_slot, const uint32_t* __restrict__ lcol,
@@ -1473,9 +1473,12 @@ sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows
           U* __restrict__ gterms /* products stream of the giant rows, or null: they gather for themselves */, const T* __restrict__ x, U* __restrict__ y,
           int nsub, int stride, int hot_words) {
   static_assert(sizeof(T) == 4 && sizeof(U) == 4, "4-byte messages and reductions");
-  constexpr int BLOCK = 1024, W = BLOCK / 64, UB = UBATCH;
+  constexpr int BLOCK = BLOCKT, W = BLOCK / 64, UB = UBATCH;
+  constexpr int WS = 16;  // (wrow keeps WS + 1 entries per block whatever the workgroup's size: gm_sweep_t.waves)
   constexpr int ACC = GM_SWEEP_ACC_ROWS, NLP = GM_SWEEP_LONG_SLOTS;
-  constexpr int KMAX = GM_SWEEP_MAX_STAGE / BLOCK;  // entries of a staging round per thread
+  // entries of a staging round per thread (a smaller workgroup stages in rounds of at most 12 per thread: the engine caps its stage)
+  constexpr int KMAX = BLOCK == 1024 ? GM_SWEEP_MAX_STAGE / BLOCK : 12;
+  static_assert(BLOCK >= NLP && BLOCK % 64 == 0, "the last GM_SWEEP_LONG_SLOTS threads fold the long rows");
   static_assert((POOLW + GM_SWEEP_ACC_ROWS) * 4 <= 160 * 1024, "k_spmv_sell: the pool and the accumulators must fit gfx950's 160 KB of LDS per workgroup");
   __shared__ uint32_t s_pool[POOLW];  // [hot entries of the slice | stage of the long rows' products]
   __shared__ uint32_t s_acc[ACC];
@@ -1502,7 +1505,7 @@ sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows
   uint32_t pr = 0, prend = 0, pl0 = 0, pl1 = 0, pps = 0, ppe = 0, pga = 0, pgb = 0;
   auto prefetch = [&](int sl) {
     const size_t blk = vw * (size_t)nslices + (size_t)sl;
-    const uint32_t* __restrict__ wr = wrow + blk * (W + 1);
+    const uint32_t* __restrict__ wr = wrow + blk * (WS + 1);
     pr = __builtin_amdgcn_readfirstlane(wr[wv]);
     prend = __builtin_amdgcn_readfirstlane(wr[wv + 1]);
 #pragma unroll
@@ -1834,6 +1837,19 @@ k_giant_gather_sliced(ProgArg<P> pa, const uint32_t* __restrict__ gcol, const ui
     p.P::process_message(m, ev, no_vp, res);
     gterms[d] = res;
   }
+}
+
+// The sweep in 768-thread workgroups (gm_sweep_t.waves = 12) with a smaller LDS pool: 12 waves x 128 VGPRs and ~124 KB of LDS leave every CU a
+// quarter of its register file and 36 KB of LDS, so that the short rows' row-block kernel can run BESIDE the sweep (experiment of round 6)
+template <class P, class T, class U, class V, class E, bool HAS_VALS>
+__global__ void __launch_bounds__(768)
+k_spmv_sell_w12(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long, const int32_t* __restrict__ slice_base, const uint32_t* __restrict__ scol,
+                const uint32_t* __restrict__ sval, const uint32_t* __restrict__ wrow, const int32_t* __restrict__ row_of_slot, const uint32_t* __restrict__ lcol,
+                const uint32_t* __restrict__ lval, const uint32_t* __restrict__ lps, const int32_t* __restrict__ lrow_of_slot,
+                const uint32_t* __restrict__ gcol, const uint32_t* __restrict__ gval, const uint32_t* __restrict__ gdst, const uint32_t* __restrict__ gslice,
+                U* __restrict__ gterms, const T* __restrict__ x, U* __restrict__ y) {
+  sell_body<P, T, U, V, E, HAS_VALS, 0, 7, 2, GM_SWEEP_POOL_W12, false, 768>(pa, set, stage_words, nslices, nrows_long, slice_base, scol, sval, wrow, row_of_slot, lcol, lval, lps,
+                                                                             lrow_of_slot, gcol, gval, gdst, gslice, gterms, x, y, 1, 0, 0);
 }
 
 // the same sweep over a shard's rows (gm_sweep_t.nsub > 1)

@@ -329,7 +329,8 @@ typedef struct {
   int32_t nsub;
   int32_t stride;     /* rows per owner (= row_hi - row_lo) */
   int32_t hot_words;  /* LDS words the build assumed for a slice's hot entries (the kernel must load at least as many) */
-  int32_t reserved_;
+  int32_t waves;      /* waves per workgroup the blocks' groups are dealt over (wrow / wfirst keep 17 entries per block): 16, or 12 / 8 with
+                         gm_set_option("sweep_waves"): a smaller sweep workgroup that leaves room on every CU for another kernel */
 } gm_sweep_t;
 #define GM_SWEEP_HOT 0x40000000u
 #define GM_MAX_SLICES 128
@@ -338,6 +339,8 @@ typedef struct {
 #define GM_SWEEP_PAD 0x80000000u
 #define GM_SWEEP_POOL 30848      /* 4-byte LDS words shared by the slice's hot entries and the long rows' stage */
 #define GM_SWEEP_MAX_STAGE 14336 /* largest stage (words): larger blocks are staged in chunks */
+#define GM_SWEEP_POOL_W12 21504  /* the pool of the 768-thread form (gm_sweep_t.waves = 12): with the accumulators 126 208 bytes of LDS */
+#define GM_SWEEP_MAX_STAGE_W12 9216
 int gm_graph_sweep(const gm_graph_t* g, gm_sweep_t* out);
 int gm_graph_tile(const gm_graph_t* g, int direction, int tile, gm_csr_t* out, const uint32_t** d_prev_bits);
 /* ---- the short rows of a graph WITHOUT skew as a column-blocked stream (round 5, last session) -----------------------------

@@ -420,6 +420,32 @@ def test_row_stationary_sweep_bit_exact(env, scale, tiles, threads):
         api._lib.check(L.gm_reset_options())
 
 
+@pytest.mark.parametrize("keep", [False, True])
+def test_sweep_in_768_thread_workgroups_bit_exact(env, keep):
+    """gm_set_option("sweep_waves", 12): the blocks' groups dealt over 12 waves and the sweep run by k_spmv_sell_w12 (768-thread workgroups, a smaller
+    LDS pool) with the giant rows' gathers (k_giant_gather_sliced), their fold passes and the short rows' kernel BESIDE it on the auxiliary stream -- an
+    experiment of round 6 that does not pay (RMAT-26 3.82 against 3.77 ms: the two kernels share the CUs' vector-memory path, their times add) and stays
+    an option.  Same bits as the oracle."""
+    import ctypes as C
+    api, ob = env
+    from graphmat_amd import _lib
+    L = _lib.lib()
+    nv, s, d, v = gen.rmat_edges(16, 16, 5, weights="hash")
+    opr, _, _ = ob.OracleGraph(nv, s, d, None, ref_threads=1).pagerank(6)
+    try:
+        api._lib.check(L.gm_reset_options())
+        api._lib.check(L.gm_set_option(b"sweep_waves", 12))
+        api._lib.check(L.gm_set_option(b"sweep_long_row", 256))
+        g = api.Graph(nv, s, d, v if keep else None, ref_threads=1, keep_values=keep, col_tiles=4)
+        sw = _lib.Sweep()
+        assert L.gm_graph_sweep(g.h, C.byref(sw)) == 0 and sw.nrows > 0 and sw.waves == 12 and sw.nrows_long > 0
+        pr, deg, it = g.pagerank(6)
+        assert it == 6 and (f32bits(pr) == f32bits(opr)).all()
+        g.close()
+    finally:
+        api._lib.check(L.gm_reset_options())
+
+
 def _blocked_info(g):
     import ctypes as C
     from graphmat_amd import _lib
