@@ -978,6 +978,7 @@ class Run {
 
   void finish(int it) {
     GM_HIP_OK(hipStreamSynchronize(s));
+    gm_graph_note_set(g, 3, (int64_t)sparse_sweeps);
     tick("loop done", it);
     aux.finish();
     st.iterations = it;
@@ -1273,7 +1274,7 @@ class Run {
   // the whole-graph CSR's short-row pass and giant passes leave out.
   bool sweep_usable(int acc, gm_sweep_t* sw) {
     if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
-      if (aux.s == nullptr || use_vp || xq == nullptr || xb != nullptr || d_want != nullptr || program_row_filter<P>::enabled || (acc & dev::ACC_READ_PREV)) return false;
+      if (aux.s == nullptr || use_vp || xq == nullptr || d_want != nullptr || program_row_filter<P>::enabled || (acc & dev::ACC_READ_PREV)) return false;
       if (!(rk == REDUCE_ORDERED || rk == REDUCE_F32_ADD || rk == REDUCE_COMMUTATIVE)) return false;
       if (opt.debug_flags & (dev::DBG_NO_TILES | dev::DBG_NO_OVERLAP)) return false;
       if (gm_graph_sweep(g, sw) != GM_OK || sw->nrows <= 0 || sw->acc_rows != GM_SWEEP_ACC_ROWS || sw->long_slots != GM_SWEEP_LONG_SLOTS) return false;
@@ -1282,6 +1283,8 @@ class Run {
       // used by a run that exchanges messages (a world of one rank: nothing to gain)
       if (sw->nsub > 1 ? (sw->nsub != desc.nshards || sw->stride != n || sw->hot_words <= 0) : multi) return false;
       if (sw->waves != 0 && sw->waves != 16 && !(sw->waves == 12 && sw->nsub <= 1)) return false;  // (a block's groups dealt over a wave count no kernel here has)
+      // a SPARSE message vector (ACTIVE_ONLY programs; round 6): k_spmv_sell_sparse -- single-shard structures, 16 waves, not under the static presence bits of a dense x
+      if (xb != nullptr && (sw->nsub > 1 || (sw->waves != 0 && sw->waves != 16) || (acc & dev::ACC_STATIC_BITS) || (opt.sweep_form & 32))) return false;
       if (Aout.vals != nullptr && !(sw->val_bytes == 4 && sizeof(E) == 4 && std::is_trivially_copyable<E>::value)) return false;
       return true;
     } else {
@@ -1316,7 +1319,7 @@ class Run {
         // 459 ms with its chain behind the sweep, 444 with it beside everything)
         const bool two_pass = rk == REDUCE_F32_ADD && std::is_same<U, float>::value;
         void* p6 = nullptr;
-        if (two_pass && Aout.ngiant > 0 && sw.ngiant_edges > 0 && sw.gcol != nullptr && !(opt.sweep_form & 8) &&
+        if (two_pass && xb == nullptr && Aout.ngiant > 0 && sw.ngiant_edges > 0 && sw.gcol != nullptr && !(opt.sweep_form & 8) &&
             gm_graph_workspace(g, 6, (size_t)Aout.giant_edges * sizeof(U) + 64, &p6) == GM_OK)
           gterms = (U*)p6;
       }
@@ -1338,7 +1341,7 @@ class Run {
       // The 768-thread form (gm_sweep_t.waves = 12; experiment of round 6): the sweep leaves every CU a quarter of its registers and 36 KB of LDS,
       // and EVERYTHING else runs beside it on the auxiliary stream from the moment x is complete: the giant rows' gathers in slice order
       // (k_giant_gather_sliced), their fold passes, then the short rows' kernel.
-      const bool w12 = sw.waves == 12 && sw.nsub <= 1 && !shorts_blocked && !defer_join;
+      const bool w12 = sw.waves == 12 && sw.nsub <= 1 && !shorts_blocked && !defer_join && xb == nullptr;
       // (the giant rows' gathers in a kernel of their own instead of inside the sweep: sweep_form bit 4, or the 768-thread form)
       const bool gather_apart = gterms != nullptr && sw.nsub <= 1 && ((opt.sweep_form & 16) != 0 || w12);
       auto giant_gather = [&]() {
@@ -1397,6 +1400,21 @@ class Run {
                                (const uint32_t*)nullptr, sw.gdst, sw.gslice, gt, xq, y, sw.nsub, sw.stride, sw.hot_words);
           continue;
         }
+        if (xb != nullptr) {  // a sparse message vector: presence tests per entry, y's presence bits OR-ed in (kernels.hpp: k_spmv_sell_sparse)
+          if (verbose && !said_sparse_sweep) { printf("GraphMat(HIP):   sparse message vector through the sweep (k_spmv_sell_sparse)\n"); said_sparse_sweep = true; }
+          if (set == 0) sparse_sweeps++;
+          if constexpr (sizeof(E) == 4 && std::is_trivially_copyable<E>::value) {
+            if (Aout.vals != nullptr) {
+              hipLaunchKernelGGL((dev::k_spmv_sell_sparse<P, T, U, V, E, true>), dim3(256), dim3(1024), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base, sw.scol,
+                                 sw.sval, sw.wrow, sw.row_of_slot, sw.lcol, sw.lval, sw.lps, sw.lrow_of_slot, xq, xb, y, ybits);
+              with_vals = true;
+            }
+          }
+          if (!with_vals)
+            hipLaunchKernelGGL((dev::k_spmv_sell_sparse<P, T, U, V, E, false>), dim3(256), dim3(1024), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base, sw.scol,
+                               (const uint32_t*)nullptr, sw.wrow, sw.row_of_slot, sw.lcol, (const uint32_t*)nullptr, sw.lps, sw.lrow_of_slot, xq, xb, y, ybits);
+          continue;
+        }
         if (w12) {  // 768-thread workgroups (kernels.hpp: k_spmv_sell_w12)
           if constexpr (sizeof(E) == 4 && std::is_trivially_copyable<E>::value) {
             if (Aout.vals != nullptr) {
@@ -1442,7 +1460,7 @@ class Run {
         st.spmv_launches += 1;
         timer.mark(TAG_ROWBLOCK);
       }
-      if (!defer_join) check_probed(pa, Aout, Aout.rowbits, nullptr, acc, ybits, true);
+      if (!defer_join) check_probed(pa, Aout, xb != nullptr ? (const uint32_t*)ybits : Aout.rowbits, nullptr, acc, ybits, xb == nullptr);
     } else {
       (void)pa; (void)acc; (void)sw; (void)defer_join;
     }
@@ -1570,7 +1588,8 @@ class Run {
 
   // Can this run's pull multiply of the OUT adjacency take the column-blocked stream of the short rows (graphmat_hip.h: gm_blocked_t;
   // kernels.hpp: k_spmv_blocked)?  The conditions of the sweep; the structure exists only for graphs without skew (edge values: none, or 4 bytes in its entries).
-  bool said_blocked = false;
+  bool said_blocked = false, said_sparse_sweep = false;
+  int sparse_sweeps = 0;  // multiplies of this run that took a sparse x through the sweep (note 3 of the graph: tests read it)
   bool blocked_usable(int acc, gm_blocked_t* bl) {
     if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
       if (use_vp || xq == nullptr || xb != nullptr || d_want != nullptr || program_row_filter<P>::enabled || (acc & dev::ACC_READ_PREV)) return false;
@@ -1788,7 +1807,7 @@ class Run {
         gm_graph_tiles(g, GM_DIR_OUT, &ntile);
       gm_sweep_t sw;
       gm_blocked_t bl;
-      if (dense_x && row_bits == nullptr && sweep_usable(acc, &sw)) {  // (sharded graphs too: gm_sweep_t.nsub)
+      if (row_bits == nullptr && !xsp && sweep_usable(acc, &sw)) {  // (sharded graphs too: gm_sweep_t.nsub; a sparse x too: k_spmv_sell_sparse)
         multiply_out_swept(pa, acc, sw);
       } else if (dense_x && !multi && row_bits == nullptr && blocked_usable(acc, &bl)) {
         multiply_out_blocked(pa, acc, bl);

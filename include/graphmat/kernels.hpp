@@ -1464,15 +1464,20 @@ static __device__ unsigned long long g_sell_phase_ticks[4096][8];
 // `stride` entries, slice_base holds positions inside a range -- a slice is the same sub-range of every owner's range, its hot set the
 // first hq = min(slice length, hot_words / nsub) entries of each (LDS word q * hq + j) -- and the entries say at build time whether
 // their message is in LDS (GM_SWEEP_HOT | LDS byte offset) or in the message vector (byte offset): the gather decodes, nothing else changes.
-template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL, int UBATCH, int PIPE, int POOLW, bool SHARDED, int BLOCKT = 1024>
+// SPARSE (round 6; ACTIVE_ONLY programs: x has presence bits): an entry only counts when its column's bit is set -- the message of an absent
+// column is not even gathered --, the FIRST PRESENT message of a row assigns (the build's first-piece flags say nothing), so every accumulator
+// slot has a "has a value" bit in LDS next to it and the long rows' stage a presence bit per product; rows that received nothing leave y and its
+// presence bits alone.  Single-shard structures, two batches deep.
+template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL, int UBATCH, int PIPE, int POOLW, bool SHARDED, int BLOCKT = 1024, bool SPARSE = false>
 __device__ __forceinline__ void
 sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows_long, const int32_t* __restrict__ slice_base, const uint32_t* __restrict__ scol,
           const uint32_t* __restrict__ sval, const uint32_t* __restrict__ wrow, const int32_t* __restrict__ row_of_slot, const uint32_t* __restrict__ lcol,
           const uint32_t* __restrict__ lval, const uint32_t* __restrict__ lps, const int32_t* __restrict__ lrow_of_slot,
           const uint32_t* __restrict__ gcol, const uint32_t* __restrict__ gval, const uint32_t* __restrict__ gdst, const uint32_t* __restrict__ gslice,
           U* __restrict__ gterms /* products stream of the giant rows, or null: they gather for themselves */, const T* __restrict__ x, U* __restrict__ y,
-          int nsub, int stride, int hot_words) {
+          int nsub, int stride, int hot_words, const uint32_t* __restrict__ xbits = nullptr, uint32_t* __restrict__ ybits = nullptr) {
   static_assert(sizeof(T) == 4 && sizeof(U) == 4, "4-byte messages and reductions");
+  static_assert(!SPARSE || (PIPE == 2 && !SHARDED && ABL == 0), "the sparse form: single shard, two batches deep");
   constexpr int BLOCK = BLOCKT, W = BLOCK / 64, UB = UBATCH;
   constexpr int WS = 16;  // (wrow keeps WS + 1 entries per block whatever the workgroup's size: gm_sweep_t.waves)
   constexpr int ACC = GM_SWEEP_ACC_ROWS, NLP = GM_SWEEP_LONG_SLOTS;
@@ -1482,6 +1487,12 @@ sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows
   static_assert((POOLW + GM_SWEEP_ACC_ROWS) * 4 <= 160 * 1024, "k_spmv_sell: the pool and the accumulators must fit gfx950's 160 KB of LDS per workgroup");
   __shared__ uint32_t s_pool[POOLW];  // [hot entries of the slice | stage of the long rows' products]
   __shared__ uint32_t s_acc[ACC];
+  __shared__ uint32_t s_hasbits[SPARSE ? (ACC + 31) / 32 : 1];             // SPARSE: slot holds a value
+  __shared__ uint32_t s_stagebits[SPARSE ? GM_SWEEP_MAX_STAGE / 32 : 1];   // SPARSE: staged product is present
+  if constexpr (SPARSE) {
+    for (int i = threadIdx.x; i < (ACC + 31) / 32; i += BLOCKT) s_hasbits[i] = 0u;  // (the first slice's barrier orders this before any use)
+  }
+  auto present = [&](uint32_t c4) { return ((xbits[c4 >> 7] >> ((c4 >> 2) & 31u)) & 1u) != 0u; };
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int wg = blockIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int HOT = POOLW - stage_words;
@@ -1615,7 +1626,18 @@ sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows
         uint32_t m[KMAX];
 #pragma unroll
         for (int j = 0; j < KMAX; j++)
-          if ((uint32_t)(j * BLOCK) < n) m[j] = gather(lc[j]);
+          if ((uint32_t)(j * BLOCK) < n) {
+            if constexpr (SPARSE) {
+              const uint32_t i = (uint32_t)(j * BLOCK) + threadIdx.x;
+              const bool pr = i < n && present(lc[j]);
+              m[j] = gather(pr ? lc[j] : idle4);
+              const unsigned long long pm = __ballot(pr);  // the wave's 64 consecutive stage entries
+              if (lane == 0) s_stagebits[(i >> 5)] = (uint32_t)pm;
+              if (lane == 32) s_stagebits[(i >> 5)] = (uint32_t)(pm >> 32);
+            } else {
+              m[j] = gather(lc[j]);
+            }
+          }
 #pragma unroll
         for (int j = 0; j < KMAX; j++) {
           const uint32_t i = (uint32_t)(j * BLOCK) + threadIdx.x;
@@ -1630,6 +1652,14 @@ sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows
         if (lj >= 0) {
           uint32_t k = ps > c0 ? ps : c0;
           const uint32_t ke = pe_ < c0 + n ? pe_ : c0 + n;
+          if constexpr (SPARSE) {
+            for (; k < ke; k++) {
+              const uint32_t i = k - c0;
+              if ((s_stagebits[i >> 5] >> (i & 31u)) & 1u) {
+                if (lhas) p.P::reduce_function(lacc, as_u(s_stage[i])); else { lacc = as_u(s_stage[i]); lhas = true; }
+              }
+            }
+          }
           if (k < ke && !lhas) { lacc = as_u(s_stage[k - c0]); lhas = true; k++; }
           for (; k + 4 <= ke; k += 4) {
             uint32_t r[4];
@@ -1700,30 +1730,45 @@ sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows
         skip |= mask;
         return mask;
       };
-      auto gathers = [&](const uint32_t (&cx)[UB], uint32_t skip, uint32_t (&mx)[UB]) {
+      auto gathers = [&](const uint32_t (&cx)[UB], uint32_t skip, uint32_t (&mx)[UB], uint32_t& px) {
+        px = 0u;  // SPARSE: bit j = the lane's entry of row j is a real edge whose column is present
 #pragma unroll
-        for (int j = 0; j < UB; j++) mx[j] = gather(((skip >> j) & 1u) ? idle4 : (cx[j] & 0x7fffffffu));
+        for (int j = 0; j < UB; j++) {
+          if constexpr (SPARSE) {
+            const bool real = !((skip >> j) & 1u) && (int32_t)cx[j] >= 0;
+            const bool pr = real && present(cx[j]);
+            px |= pr ? (1u << j) : 0u;
+            mx[j] = gather(pr ? cx[j] : idle4);
+          } else {
+            mx[j] = gather(((skip >> j) & 1u) ? idle4 : (cx[j] & 0x7fffffffu));
+          }
+        }
       };
       if (r < rend) {
-        uint32_t skipA = 0, maskA = scan(r, cA, skipA);
-        gathers(cA, skipA, mA);
+        uint32_t skipA = 0, maskA = scan(r, cA, skipA), pA = 0u;
+        gathers(cA, skipA, mA, pA);
         load_entries(r + UB, cB, eB);
         while (true) {
           const uint32_t rn = r + UB;
           uint32_t mB[UB], cC[UB], eC[UB];
           uint32_t skipB = 0;
           const uint32_t maskB = scan(rn, cB, skipB);
-          gathers(cB, skipB, mB);
+          uint32_t pB = 0u;
+          gathers(cB, skipB, mB, pB);
           load_entries(rn + UB, cC, eC);
 #pragma unroll
           for (int j = 0; j < UB; j++) {
             if (r + j < rend) {
               if ((maskA >> j) & 1u) {  // a new group: the previous group's running values go back to LDS, this one's come out
-                if (slot != 0x7fff) s_acc[slot] = raw_u(acc);
+                if (slot != 0x7fff) {
+                  s_acc[slot] = raw_u(acc);
+                  if constexpr (SPARSE) { if (has) atomicOr(&s_hasbits[slot >> 5], 1u << (slot & 31)); }
+                }
                 slot = (int)(cA[j] & 0x7fffu);
-                has = !(cA[j] & 0x8000u);
+                if constexpr (SPARSE) has = slot != 0x7fff && ((s_hasbits[slot >> 5] >> (slot & 31)) & 1u) != 0u;
+                else has = !(cA[j] & 0x8000u);
                 acc = as_u(slot != 0x7fff ? s_acc[slot] : 0u);
-              } else if ((int32_t)cA[j] >= 0) {
+              } else if (SPARSE ? ((pA >> j) & 1u) != 0u : (int32_t)cA[j] >= 0) {
                 U res;
                 p.P::process_message(as_t(mA[j]), as_e(eA[j]), no_vp, res);
                 if (has) p.P::reduce_function(acc, res);
@@ -1735,6 +1780,7 @@ sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows
           r = rn;
           if (r >= rend) break;
           maskA = maskB;
+          pA = pB;
 #pragma unroll
           for (int j = 0; j < UB; j++) { cA[j] = cB[j]; eA[j] = eB[j]; mA[j] = mB[j]; cB[j] = cC[j]; eB[j] = eC[j]; }
         }
@@ -1792,7 +1838,10 @@ sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows
         left = l;
       }
     }
-    if (slot != 0x7fff) s_acc[slot] = raw_u(acc);
+    if (slot != 0x7fff) {
+      s_acc[slot] = raw_u(acc);
+      if constexpr (SPARSE) { if (has) atomicOr(&s_hasbits[slot >> 5], 1u << (slot & 31)); }
+    }
     GM_SELL_TICK(4);  // groups
     if (sl + 1 < nslices) prefetch(sl + 1);  // (in flight while this wave waits for the others at the barrier)
     GM_SELL_TICK(5);
@@ -1800,11 +1849,18 @@ sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows
   __syncthreads();
   for (int i = threadIdx.x; i < ACC; i += BLOCK) {
     const int row = row_of_slot[vw * ACC + i];  // (-1: no row in this slot; every row of the sweep has edges)
-    if (row >= 0) y[row] = as_u(s_acc[i]);
+    if constexpr (SPARSE) {
+      if (row >= 0 && ((s_hasbits[i >> 5] >> (i & 31)) & 1u)) { y[row] = as_u(s_acc[i]); atomicOr(&ybits[row >> 5], 1u << (row & 31)); }
+    } else {
+      if (row >= 0) y[row] = as_u(s_acc[i]);
+    }
   }
   if (lj >= 0 && nrows_long > 0) {
     const int row = lrow_of_slot[vw * NLP + lj];
-    if (row >= 0 && lhas) y[row] = lacc;
+    if (row >= 0 && lhas) {
+      y[row] = lacc;
+      if constexpr (SPARSE) atomicOr(&ybits[row >> 5], 1u << (row & 31));
+    }
   }
 }
 template <class P, class T, class U, class V, class E, bool HAS_VALS, int ABL = 0, int UBATCH = 7, int PIPE = 2, int POOLW = GM_SWEEP_POOL>
@@ -1850,6 +1906,17 @@ k_spmv_sell_w12(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_
                 U* __restrict__ gterms, const T* __restrict__ x, U* __restrict__ y) {
   sell_body<P, T, U, V, E, HAS_VALS, 0, 7, 2, GM_SWEEP_POOL_W12, false, 768>(pa, set, stage_words, nslices, nrows_long, slice_base, scol, sval, wrow, row_of_slot, lcol, lval, lps,
                                                                              lrow_of_slot, gcol, gval, gdst, gslice, gterms, x, y, 1, 0, 0);
+}
+
+// the sweep over a SPARSE message vector (ACTIVE_ONLY programs; single shard): xbits = the presence bits of x, ybits = those of y (OR-ed in)
+template <class P, class T, class U, class V, class E, bool HAS_VALS>
+__global__ void __launch_bounds__(1024)
+k_spmv_sell_sparse(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long, const int32_t* __restrict__ slice_base, const uint32_t* __restrict__ scol,
+                   const uint32_t* __restrict__ sval, const uint32_t* __restrict__ wrow, const int32_t* __restrict__ row_of_slot, const uint32_t* __restrict__ lcol,
+                   const uint32_t* __restrict__ lval, const uint32_t* __restrict__ lps, const int32_t* __restrict__ lrow_of_slot, const T* __restrict__ x,
+                   const uint32_t* __restrict__ xbits, U* __restrict__ y, uint32_t* __restrict__ ybits) {
+  sell_body<P, T, U, V, E, HAS_VALS, 0, 7, 2, GM_SWEEP_POOL_SPARSE, false, 1024, true>(pa, set, stage_words, nslices, nrows_long, slice_base, scol, sval, wrow, row_of_slot, lcol, lval,
+                                                                                        lps, lrow_of_slot, nullptr, nullptr, nullptr, nullptr, (U*)nullptr, x, y, 1, 0, 0, xbits, ybits);
 }
 
 // the same sweep over a shard's rows (gm_sweep_t.nsub > 1)
@@ -2168,14 +2235,14 @@ constexpr int kGiantSub = 512;
 // Which binade will S be in?  (Rounds 2-5 took the binade of the PREVIOUS pass as a hint; while a run's values still move -- the first
 // ten PageRank iterations -- the places where S crosses into the next binade move by many sub-pieces from one pass to the next, every
 // sub-piece in between saw S off its hint, and the replay of the hub row took 0.3-2.6 ms instead of 0.2.)  Round 6 PREDICTS it from
-// this pass's own products: k_giant_sums adds up every sub-piece in double, k_giant_predict scans the sums along the row -- the double
+// this pass's own products: k_giant_sums adds up every sub-piece in double, k_giant_maps adds the sums of the row's earlier sub-pieces -- the double
 // prefix differs from the float sum S by accumulated rounding only, ~1e-4 relative at worst -- and a sub-piece whose predicted S has the
 // same binade at its start and at its end gets its map composed for that binade (k_giant_maps).  A wrong prediction (S within ~1e-4 of a
 // power of two) costs the replay of one sub-piece, never a bit: the replay applies a map only when the EXACT S is in the map's binade
 // and stays there.  No state survives a pass.
 struct gchunk_state {
   double sum;         // k_giant_sums: the sub-piece's products added up in double
-  int32_t e_map;      // k_giant_predict: the binade S is expected to have throughout the sub-piece (0: none); k_giant_maps clears it when a term has no map
+  int32_t e_map;      // k_giant_maps: the binade S is expected to have throughout the sub-piece and the map was composed for (0: none)
   uint32_t de, dod;   // k_giant_maps: ulps the sub-piece adds when the incoming S is even / odd
   uint32_t pad_[3];
 };
@@ -2186,13 +2253,11 @@ static_assert(sizeof(gchunk_state) == 32, "gchunk_state: 32-byte records (gm_gra
 // over many workgroups (one per GM_GIANT_CHUNK edges) because a single CU can only issue
 // about one gather per 2.7 cycles; the products go to a scratch stream in edge order
 // (plus presence words when x is sparse) that the ordered fold of pass 2 merely streams.
-// (FROM_TERMS: the products are in `terms` already -- the sweep, k_spmv_sell, gathered them slice by slice with its hot sets --
-// and only the pieces' ulp-maps are composed here)
-template <class P, class T, class U, class V, class E, bool USE_VP, bool FROM_TERMS = false>
+template <class P, class T, class U, class V, class E, bool USE_VP>
 __global__ void __launch_bounds__(kBlock)
 k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t* __restrict__ xbits,
               const V* __restrict__ vp, U* __restrict__ terms, unsigned long long* __restrict__ tpres GM_DBG_PARAM,
-              gchunk_state* __restrict__ state /* per piece: exponent hint in, composed ulp-map out (float sums over a dense x), or null */) {
+              gchunk_state* __restrict__ state /* unused since round 6 (kept so that the call sites keep their shape) */) {
   constexpr int PER = GM_GIANT_CHUNK / kBlock;
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int gi = A.gchunk_row[blockIdx.x];
@@ -2207,10 +2272,9 @@ k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t
 #pragma unroll
   for (int j = 0; j < PER; j++) {
     int k = threadIdx.x + j * kBlock;
-    if constexpr (FROM_TERMS) c[j] = (k < n) ? 0 : -1;
-    else c[j] = (k < n) ? stream_load(&A.colidx[eb + k]) : -1;
+    c[j] = (k < n) ? stream_load(&A.colidx[eb + k]) : -1;
   }
-  if (!FROM_TERMS && xbits != nullptr) {
+  if (xbits != nullptr) {
 #pragma unroll
     for (int j = 0; j < PER; j++)
       if (c[j] >= 0 && !bit_get(xbits, c[j])) c[j] = -1;
@@ -2218,19 +2282,15 @@ k_giant_terms(ProgArg<P> pa, gm_csr_t A, const T* __restrict__ x, const uint32_t
   T m[PER];
 #pragma unroll
   for (int j = 0; j < PER; j++)
-    if (!FROM_TERMS && c[j] >= 0) { if ((dbg & DBG_SKIP_GATHER) || GM_ABL_COLD(c[j], A)) memset(&m[j], 0, sizeof(T)); else m[j] = x[c[j]]; }
-  (void)state;  // (the sub-pieces' ulp-maps are composed by k_giant_sums / k_giant_predict / k_giant_maps since round 6)
+    if (c[j] >= 0) { if ((dbg & DBG_SKIP_GATHER) || GM_ABL_COLD(c[j], A)) memset(&m[j], 0, sizeof(T)); else m[j] = x[c[j]]; }
+  (void)state;  // (the sub-pieces' ulp-maps are composed by k_giant_sums / k_giant_maps since round 6)
 #pragma unroll
   for (int j = 0; j < PER; j++) {
     int k = threadIdx.x + j * kBlock;
     if (c[j] >= 0) {
       U t;
-      if constexpr (FROM_TERMS) {
-        t = terms[out0 + k];
-      } else {
-        p.P::process_message(m[j], edge_at<E>(A.vals, eb + k), vprow, t);
-        terms[out0 + k] = t;
-      }
+      p.P::process_message(m[j], edge_at<E>(A.vals, eb + k), vprow, t);
+      terms[out0 + k] = t;
     }
     if (tpres != nullptr) {
       unsigned long long w = __ballot(c[j] >= 0);

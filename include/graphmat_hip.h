@@ -339,6 +339,7 @@ typedef struct {
 #define GM_SWEEP_PAD 0x80000000u
 #define GM_SWEEP_POOL 30848      /* 4-byte LDS words shared by the slice's hot entries and the long rows' stage */
 #define GM_SWEEP_MAX_STAGE 14336 /* largest stage (words): larger blocks are staged in chunks */
+#define GM_SWEEP_POOL_SPARSE (GM_SWEEP_POOL - 768) /* the pool of the sparse-x form: 314 + 448 words go to its presence bits */
 #define GM_SWEEP_POOL_W12 21504  /* the pool of the 768-thread form (gm_sweep_t.waves = 12): with the accumulators 126 208 bytes of LDS */
 #define GM_SWEEP_MAX_STAGE_W12 9216
 int gm_graph_sweep(const gm_graph_t* g, gm_sweep_t* out);
@@ -599,7 +600,8 @@ typedef struct {
                                      in front of the sweep (default), 1 on the auxiliary stream behind the giant rows' passes (next to the sweep),
                                      2 on the main stream behind the sweep; bit 2 = the long rows staged in rounds of 1024 entries (tests); bit 3 = the
                                      giant rows gather for themselves on the auxiliary stream (k_giant_terms) instead of the sweep gathering for them; bit 4 = the giant rows' gathers in a
-                                     kernel of their own behind the sweep (k_giant_gather_sliced: their entries in slice order, on the auxiliary stream next to the short rows) */
+                                     kernel of their own behind the sweep (k_giant_gather_sliced: their entries in slice order, on the auxiliary stream next to the short rows); bit 5 = a SPARSE
+                                     message vector (ACTIVE_ONLY programs) does not take the sweep (k_spmv_sell_sparse) */
   int32_t blocked_form;           /* the column-blocked stream of the short rows (engine.hpp: multiply_out_blocked): bits 0-3 = window -- a workgroup starts a
                                      slice when all workgroups of its XCD have finished the one `window` slices back (default 2; 0 = workgroups not
                                      kept in step); bit 4 = batches of 4 x 64 entries instead of 2 x 64 */

@@ -446,6 +446,46 @@ def test_sweep_in_768_thread_workgroups_bit_exact(env, keep):
         api._lib.check(L.gm_reset_options())
 
 
+@pytest.mark.parametrize("scale,tiles,threads", [(13, 3, 1), (15, 3, 2), (16, 4, 1)])
+def test_sparse_message_vector_through_the_sweep(env, scale, tiles, threads):
+    """ACTIVE_ONLY programs on a swept graph (round 6; kernels.hpp: k_spmv_sell_sparse): the pull steps of SSSP (uint32 messages, int edge values
+    carried by the structure, min) go through the sweep with a presence test per entry, the first PRESENT message of a row assigning, and y's
+    presence bits produced by the kernel.  Distances and iteration counts must be the oracle's -- from several sources, so that the active sets
+    range from a handful of vertices to most of the graph -- and the same with the sweep refused for sparse vectors (sweep_form bit 5); the
+    path must really have been taken."""
+    import ctypes as C
+    api, ob = env
+    from graphmat_amd import _lib
+    L = _lib.lib()
+    nv, s, d, v = gen.rmat_edges(scale, 16, 7, weights="hash")
+    og = ob.OracleGraph(nv, s, d, v, ref_threads=threads)
+    try:
+        api._lib.check(L.gm_reset_options())
+        api._lib.check(L.gm_set_option(b"sweep_long_row", 256))
+        # (top-down steps off: every iteration is a pull step, whatever the size of its active set)
+        api._lib.check(L.gm_set_option(b"debug_flags", 32))
+        g = api.Graph(nv, s, d, v, ref_threads=threads, col_tiles=tiles)
+        sw = _lib.Sweep()
+        assert L.gm_graph_sweep(g.h, C.byref(sw)) == 0 and sw.nrows > 0 and sw.val_bytes == 4
+        taken = 0
+        for src in (1, 2, 77):
+            od, oit = og.sssp(src)
+            dist, it = g.sssp(src)
+            n3 = C.c_int64(0)
+            assert L.gm_graph_note_get(g.h, 3, C.byref(n3)) == 0
+            taken += n3.value
+            assert it == oit and (dist == od).all(), "source %d" % src
+            api._lib.check(L.gm_set_option(b"sweep_form", 32))
+            dist2, it2 = g.sssp(src)
+            api._lib.check(L.gm_set_option(b"sweep_form", 0))
+            assert L.gm_graph_note_get(g.h, 3, C.byref(n3)) == 0 and n3.value == 0
+            assert it2 == oit and (dist2 == od).all()
+        assert taken >= 3
+        g.close()
+    finally:
+        api._lib.check(L.gm_reset_options())
+
+
 def _blocked_info(g):
     import ctypes as C
     from graphmat_amd import _lib
