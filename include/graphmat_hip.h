@@ -58,7 +58,7 @@ typedef void* gm_stream_t; /* hipStream_t */
 typedef struct gm_graph gm_graph_t;
 
 const char* gm_last_error(void);
-int gm_version(void);
+int gm_version(void); /* 100 + the build round whose struct layouts these are (106: gm_sweep_t with nsub / stride / hot_words / waves, 32-byte gchunk_state records) */
 int gm_device_count(int* count);
 int gm_set_device(int device);
 

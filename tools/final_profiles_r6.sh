@@ -33,7 +33,7 @@ python tools/prof_timeline.py $out/kt_shard_results.db --match "k_spmv|k_giant|k
 rm -f $out/kt_shard_results.db
 # BFS RMAT-26, level by level
 timeout 900 rocprofv3 --kernel-trace -d $out -o bfs -- python tools/bfs_bench.py --scale 26 > $out/bfs.log 2> $out/bfs.err
-python tools/prof_timeline.py $out/bfs_results.db --match "^(?!.*(at::native|rocprim|copyBuffer))" --last 90 > $out/${tag}_bfs_timeline_scale26.md
+python tools/prof_timeline.py $out/bfs_results.db --match "^(?!.*(at::native|rocprim|copyBuffer))" --last 150 | grep -v "at::native" > $out/${tag}_bfs_timeline_scale26.md
 tail -n 4 $out/bfs.log > $out/${tag}_bfs_bench_scale26.txt
 rm -f $out/bfs_results.db
 {
