@@ -1846,7 +1846,14 @@ static int build_degree_layout(gm_graph* g, int64_t nnz, const int32_t* d_src, c
     // 228 / 308 / 283 / 281 ms; RMAT-26 1 / 3 / 8: 641 / 582 / 506 ms.)
     // (round 5: the sweep -- kernels.hpp: k_spmv_sell -- also takes the rows of more than own_wave_row edges and adjacencies that keep
     // 4-byte edge values; the tiles are only walked by programs the sweep does not cover, and get the same count)
-    if (g_sweep_slices != 0 && (!keeps_values || D.val_bytes == 4)) T = mib < 25.0 ? 1 : mib < 50.0 ? 2 : mib < 180.0 ? 3 : (int)(mib / 40.0 + 0.5);
+    // (round 6: with the giant rows' passes down to a third -- they were what the small graphs' iterations waited for -- the sweep pays from ~7 MiB on:
+    // RMAT-22 (9 MiB) 0.445 -> 0.384 ms, RMAT-23 (18 MiB) 0.813 -> 0.589 ms with 2 x 8 slices; RMAT-21 (5 MiB) 0.295 -> 0.321, RMAT-20 0.207 -> 0.307:
+    // profiles/r06_small_scales_sweep.txt.  The [slice][degree rank] order the sweep needs spreads the hub columns over the slices, which the
+    // gather kernels of the programs that do NOT take the sweep pay for: unchanged SSSP.cpp RMAT-22 6.4 -> 7.8 ms, RMAT-23 11.4 -> 13.4 ms,
+    // BFS.cpp +3..5 %, against PageRank.cpp 24.3 -> 24.8 ms (RMAT-22) and 52.3 -> 44.4 ms (RMAT-23) -- so the rule starts at 12 MiB, where PageRank
+    // gains 28 %, not at 7.  Shards keep the 25 MiB rule: nothing smaller was measured on them.)
+    const double sweep_from = G > 1 ? 25.0 : 12.0;
+    if (g_sweep_slices != 0 && (!keeps_values || D.val_bytes == 4)) T = mib < sweep_from ? 1 : mib < 50.0 ? 2 : mib < 180.0 ? 3 : (int)(mib / 40.0 + 0.5);
     else if (keeps_values && mib < 100.0) T = 1;
   }
   // Sharded graphs (round 6): no column tiles, but the same SLICES -- every owner's range of the device order becomes [slice][degree rank

@@ -1284,7 +1284,11 @@ class Run {
       if (sw->nsub > 1 ? (sw->nsub != desc.nshards || sw->stride != n || sw->hot_words <= 0) : multi) return false;
       if (sw->waves != 0 && sw->waves != 16 && !(sw->waves == 12 && sw->nsub <= 1)) return false;  // (a block's groups dealt over a wave count no kernel here has)
       // a SPARSE message vector (ACTIVE_ONLY programs; round 6): k_spmv_sell_sparse -- single-shard structures, 16 waves, not under the static presence bits of a dense x
-      if (xb != nullptr && (sw->nsub > 1 || (sw->waves != 0 && sw->waves != 16) || (acc & dev::ACC_STATIC_BITS) || (opt.sweep_form & 32))) return false;
+      // (large graphs only -- the sweep walks all its slices however few columns are present: unchanged SSSP.cpp RMAT-22 6.5 -> 12.3 ms and
+      // RMAT-23 11.5 -> 14.4 ms when it was taken there, 21.6 -> 20.0 ms at RMAT-24, 84 -> 60 ms at RMAT-26; sweep_form bit 6 lifts the size
+      // limit for tests, bit 5 refuses the form)
+      if (xb != nullptr && (sw->nsub > 1 || (sw->waves != 0 && sw->waves != 16) || (acc & dev::ACC_STATIC_BITS) || (opt.sweep_form & 32) ||
+                            (Aout.nnz < 200000000ll && !(opt.sweep_form & 64)))) return false;
       if (Aout.vals != nullptr && !(sw->val_bytes == 4 && sizeof(E) == 4 && std::is_trivially_copyable<E>::value)) return false;
       return true;
     } else {

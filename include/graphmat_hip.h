@@ -131,8 +131,8 @@ typedef struct {
                             each slice.  Multiple of 64; = slice size for GM_LAYOUT_NATIVE.   */
   int32_t col_tiles;     /* column tiles of the GM_DIR_OUT adjacency (see gm_graph_tile): 0 = library default
                             (gm_set_option("col_tiles"), else environment GRAPHMAT_COL_TILES, else automatic:
-                            by the live part of a 4-byte message vector: two tiles from 25 MiB, three from 50 MiB, one per 40 MiB
-                            from 180 MiB on, i.e. none up to RMAT-23, 2 at RMAT-24, 3 at RMAT-25 and RMAT-26, 6 at RMAT-27 -- the
+                            by the live part of a 4-byte message vector: two tiles from 12 MiB (25 MiB on a sharded graph), three from 50 MiB, one per 40 MiB
+                            from 180 MiB on, i.e. none up to RMAT-21, 2 at RMAT-22 .. 24, 3 at RMAT-25 and RMAT-26, 6 at RMAT-27 -- the
                             medium rows are swept over ~64 slices whatever the tile count (gm_graph_sweep), tiles only cut the longer
                             rows; with gm_set_option("sweep_slices", 0): one tile per 17 MiB once the live part reaches 60 MiB; with
                             edge values kept (such an adjacency is not swept): the same from 100 MiB on),
@@ -601,7 +601,7 @@ typedef struct {
                                      2 on the main stream behind the sweep; bit 2 = the long rows staged in rounds of 1024 entries (tests); bit 3 = the
                                      giant rows gather for themselves on the auxiliary stream (k_giant_terms) instead of the sweep gathering for them; bit 4 = the giant rows' gathers in a
                                      kernel of their own behind the sweep (k_giant_gather_sliced: their entries in slice order, on the auxiliary stream next to the short rows); bit 5 = a SPARSE
-                                     message vector (ACTIVE_ONLY programs) does not take the sweep (k_spmv_sell_sparse) */
+                                     message vector (ACTIVE_ONLY programs) does not take the sweep (k_spmv_sell_sparse); bit 6 = it does on graphs of any size (default: from 2e8 edges on) */
   int32_t blocked_form;           /* the column-blocked stream of the short rows (engine.hpp: multiply_out_blocked): bits 0-3 = window -- a workgroup starts a
                                      slice when all workgroups of its XCD have finished the one `window` slices back (default 2; 0 = workgroups not
                                      kept in step); bit 4 = batches of 4 x 64 entries instead of 2 x 64 */

@@ -193,7 +193,7 @@ def test_untraited_programs_on_a_graph_with_giant_rows():
     assert "guided pull" not in text0 and keep(text0) == keep(text)
     # ... and on a graph with slices (forced here: GRAPHMAT_COL_TILES) the undeclared SSSP's sparse message vector goes through the sweep
     # (k_spmv_sell_sparse: 4-byte messages, int edge values in the structure, the program's own min as an ordered fold): same lines again
-    text3 = _run(exe, path, 5, 6, env={"GRAPHMAT_COL_TILES": "3", "GRAPHMAT_VERBOSE": "1"})
+    text3 = _run(exe, path, 5, 6, env={"GRAPHMAT_COL_TILES": "3", "GRAPHMAT_VERBOSE": "1", "GRAPHMAT_OPTIONS": "sweep_form=64"})
     assert "sparse message vector through the sweep" in text3 and keep(text3) == keep(text)
 
 

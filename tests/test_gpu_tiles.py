@@ -464,6 +464,7 @@ def test_sparse_message_vector_through_the_sweep(env, scale, tiles, threads):
         api._lib.check(L.gm_set_option(b"sweep_long_row", 256))
         # (top-down steps off: every iteration is a pull step, whatever the size of its active set)
         api._lib.check(L.gm_set_option(b"debug_flags", 32))
+        api._lib.check(L.gm_set_option(b"sweep_form", 64))  # (the form is taken from 2^27 edges on; bit 6 lifts the limit)
         g = api.Graph(nv, s, d, v, ref_threads=threads, col_tiles=tiles)
         sw = _lib.Sweep()
         assert L.gm_graph_sweep(g.h, C.byref(sw)) == 0 and sw.nrows > 0 and sw.val_bytes == 4
@@ -477,7 +478,7 @@ def test_sparse_message_vector_through_the_sweep(env, scale, tiles, threads):
             assert it == oit and (dist == od).all(), "source %d" % src
             api._lib.check(L.gm_set_option(b"sweep_form", 32))
             dist2, it2 = g.sssp(src)
-            api._lib.check(L.gm_set_option(b"sweep_form", 0))
+            api._lib.check(L.gm_set_option(b"sweep_form", 64))
             assert L.gm_graph_note_get(g.h, 3, C.byref(n3)) == 0 and n3.value == 0
             assert it2 == oit and (dist2 == od).all()
         assert taken >= 3
