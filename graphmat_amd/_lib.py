@@ -47,7 +47,10 @@ class Sweep(C.Structure):
                 ("row_of_slot", C.c_void_p), ("lcol", C.c_void_p), ("lval", C.c_void_p), ("lps", C.c_void_p), ("lrow_of_slot", C.c_void_p),
                 ("slice_base", C.c_void_p), ("src_pos", C.c_void_p), ("lsrc_pos", C.c_void_p),
                 ("ngiant_edges", C.c_int64), ("gcol", C.c_void_p), ("gval", C.c_void_p), ("gdst", C.c_void_p), ("gslice", C.c_void_p), ("gsrc_pos", C.c_void_p),
-                ("nsub", C.c_int32), ("stride", C.c_int32), ("hot_words", C.c_int32), ("waves", C.c_int32)]
+                ("nsub", C.c_int32), ("stride", C.c_int32), ("hot_words", C.c_int32), ("waves", C.c_int32),
+                ("nstream", C.c_int64), ("nstream_slots", C.c_int64), ("nshort_rows", C.c_int32), ("nbins", C.c_int32), ("bin_cap", C.c_int32),
+                ("stream_width", C.c_int32), ("srow", C.c_void_p), ("soff", C.c_void_p), ("sbin_row", C.c_void_p), ("schunk", C.c_void_p), ("sinv", C.c_void_p),
+                ("wrow_stream", C.c_void_p)]
 
 
 class Blocked(C.Structure):

@@ -98,7 +98,7 @@ struct MapPop { __device__ long long operator()(uint32_t v) const { return (long
 extern "C" {
 
 const char* gm_last_error(void) { return gm::g_err; }
-int gm_version(void) { return 106; }  // 100 + the round whose ABI this is ("ABI changes by round")
+int gm_version(void) { return 107; }  // 100 + the round whose ABI this is ("ABI changes by round")
 
 int gm_device_count(int* count) {
   if (!count) { gm::set_error("gm_device_count: null argument"); return GM_ERR_INVALID; }

@@ -34,6 +34,7 @@ int g_long_mid = 0;  // > 0: experiment -- wave rows of more than this many edge
 int g_sweep_slices = 1;  // 1: cut the device order into ntiles * k <= 64 slices and build the row-stationary sweep of the medium rows (gm_graph_sweep)
 int g_sort_tile_lists = 1;  // column tiles: the wave-row lists by descending piece length (sort_rows_by_length)
 int g_sweep_border_factor = 4;  // the medium / long border is lowered while it exceeds this many times a wave's share of a block per slice
+int g_sweep_stream = 1;  // the short rows ride the sweep as stream groups (gm_sweep_t.nstream; round 6, last session); 0: none built
 int g_sweep_waves = 16;  // waves per workgroup the sweep's blocks are dealt over (16; 12: a 768-thread sweep that leaves room on every CU for the short rows' kernel beside it -- experiment of round 6)
 int g_sweep_fold_share = 50;  // share (percent of an equal share) of a block's groups that the waves folding the long rows get
 int g_sweep_long_row = 0;  // the sweep's medium / long border (edges per row): 0 = chosen per graph (build_sweep)
@@ -1037,10 +1038,21 @@ __global__ void __launch_bounds__(kT) k_sweep_block_groups(const int32_t* __rest
 // group g of block b = pieces q0 .. q0 + 63 of the block's sorted order; entries = 64 x its first (longest) piece
 __global__ void __launch_bounds__(64)
 k_sweep_group_sizes(const int32_t* __restrict__ blk_first, const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ sp,
-                    const uint32_t* __restrict__ piece_start, unsigned long long* __restrict__ gsize, uint32_t* __restrict__ gq0, uint32_t* __restrict__ gblk) {
+                    const uint32_t* __restrict__ piece_start, unsigned long long* __restrict__ gsize, uint32_t* __restrict__ gq0, uint32_t* __restrict__ gblk,
+                    const uint32_t* __restrict__ stream_first /* [nstream_blk + 1] first stream entry of the block, or null */, int nstream_blk) {
   const int b = blockIdx.x;
   const uint32_t g0 = grp_first[b], g1 = grp_first[b + 1];
+  const uint32_t nm = (uint32_t)(blk_first[b + 1] - blk_first[b] + 63) / 64u;  // medium groups; behind them the block's stream groups
   for (uint32_t g = g0 + threadIdx.x; g < g1; g += 64) {
+    if (g - g0 >= nm) {  // stream group j of the block: GM_STREAM_WIDTH rows of 64 of the block's short-row edges (the last one: what is left)
+      const uint32_t j = g - g0 - nm;
+      const uint32_t rows = (stream_first[b + 1] - stream_first[b] + 63u) / 64u;
+      const uint32_t w = rows - j * GM_STREAM_WIDTH < GM_STREAM_WIDTH ? rows - j * GM_STREAM_WIDTH : GM_STREAM_WIDTH;
+      gsize[g] = ((unsigned long long)w + 1ull) * 64ull;
+      gq0[g] = j;
+      gblk[g] = (uint32_t)b | 0x80000000u;
+      continue;
+    }
     const uint32_t q0 = (uint32_t)blk_first[b] + (g - g0) * 64u;
     const uint32_t p = sp[q0];
     gsize[g] = ((unsigned long long)(piece_start[p + 1] - piece_start[p]) + 1ull) * 64ull;  // (a meta row, then the longest piece's rows)
@@ -1061,6 +1073,7 @@ k_sweep_fill(uint32_t ngroups, const uint32_t* __restrict__ gbase, const uint32_
              const uint32_t* __restrict__ vals, SweepSlices sl, int nslices, const int* __restrict__ rowmin, uint32_t* __restrict__ scol,
              uint32_t* __restrict__ sval, uint32_t* __restrict__ src_pos) {
   for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    if (gblk[g] & 0x80000000u) continue;  // (a stream group: k_stream_fill)
     const uint32_t b = gblk[g], q0 = gq0[g], qe = (uint32_t)blk_first[b + 1];
     const uint32_t base = gbase[g], n = gbase[g + 1] - base;
     const uint32_t width = (n >> 6) - 1u;
@@ -1096,17 +1109,123 @@ k_sweep_fill(uint32_t ngroups, const uint32_t* __restrict__ gbase, const uint32_
     }
   }
 }
+// ---- the short rows as stream groups of the sweep (graphmat_hip.h: gm_sweep_t.nstream) ----
+__global__ void __launch_bounds__(kT) k_stream_flag(const int64_t* __restrict__ rowptr, int nrows, int short_row, unsigned char* __restrict__ flag) {
+  const int r = blockIdx.x * kT + threadIdx.x;
+  if (r < nrows) { const int64_t l = rowptr[r + 1] - rowptr[r]; flag[r] = (l >= 1 && l <= short_row) ? 1 : 0; }
+}
+// one thread per short row (device order): its edges keyed (workgroup = bin % 256, slice, bin), value = the edge's index in the short rows'
+// own CSR order (soff), spos[that index] = its position in the graph's CSR
+__global__ void __launch_bounds__(kT)
+k_stream_keys(const int32_t* __restrict__ srow, int nshort, const uint32_t* __restrict__ soff, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+              SweepSlices sl, int nslices, unsigned long long* __restrict__ key, uint32_t* __restrict__ val, uint32_t* __restrict__ spos) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= nshort) return;
+  const int row = srow[i];
+  const int64_t e0 = rowptr[row];
+  const uint32_t o = soff[i], n = soff[i + 1] - o;
+  const unsigned long long bin = o / (uint32_t)GM_STREAM_BIN, wg = bin & 255ull;
+  for (uint32_t k = 0; k < n; k++) {
+    const int lo = sweep_slice_of(sl, nslices, colidx[e0 + k]);
+    key[o + k] = (wg << 31) | ((unsigned long long)lo << 24) | bin;
+    val[o + k] = o + k;
+    spos[o + k] = (uint32_t)(e0 + k);
+  }
+}
+__device__ __forceinline__ uint32_t stream_lower_bound(const unsigned long long* __restrict__ key, uint32_t n, unsigned long long want) {
+  uint32_t lo = 0, hi = n;  // first index with key >= want
+  while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (key[mid] < want) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+// first[b] = first sorted entry of block b = workgroup * nslices + slice (first[nblk] = n); rows[b] = 64-entry rows the block's products take
+__global__ void __launch_bounds__(kT)
+k_stream_block_starts(const unsigned long long* __restrict__ key, uint32_t n, int nslices, int nblk, uint32_t* __restrict__ first) {
+  const int b = blockIdx.x * kT + threadIdx.x;
+  if (b > nblk) return;
+  if (b == nblk) { first[b] = n; return; }
+  const unsigned long long wg = (unsigned)b / (unsigned)nslices, sl = (unsigned)b % (unsigned)nslices;
+  first[b] = stream_lower_bound(key, n, (wg << 31) | (sl << 24));
+}
+__global__ void __launch_bounds__(kT) k_stream_block_rows(const uint32_t* __restrict__ first, int nblk, uint32_t* __restrict__ rows, uint32_t* __restrict__ groups) {
+  const int b = blockIdx.x * kT + threadIdx.x;
+  if (b > nblk) return;
+  const uint32_t r = b < nblk ? (first[b + 1] - first[b] + 63u) / 64u : 0u;
+  rows[b] = r;
+  groups[b] = (r + GM_STREAM_WIDTH - 1) / GM_STREAM_WIDTH;
+}
+__global__ void __launch_bounds__(kT) k_stream_add_groups(const uint32_t* __restrict__ groups, int nblk, uint32_t* __restrict__ ng) {
+  const int b = blockIdx.x * kT + threadIdx.x;
+  if (b < nblk) ng[b] += groups[b];
+}
+// schunk[(bin * nslices + slice) * 2] = where the bin's products of that slice start in the products stream, [.. + 1] = how many
+__global__ void __launch_bounds__(kT)
+k_stream_chunks(const unsigned long long* __restrict__ key, uint32_t n, int nslices, int nbins, const uint32_t* __restrict__ first, const uint32_t* __restrict__ row_base,
+                uint32_t* __restrict__ schunk) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i >= (int64_t)nbins * nslices) return;
+  const unsigned long long bin = (unsigned long long)(i / nslices), sl = (unsigned long long)(i % nslices), wg = bin & 255ull;
+  const unsigned long long k0 = (wg << 31) | (sl << 24) | bin;
+  const uint32_t lo = stream_lower_bound(key, n, k0), hi = stream_lower_bound(key, n, k0 + 1ull);
+  const uint32_t b = (uint32_t)(wg * (unsigned long long)nslices + sl);
+  schunk[i * 2] = row_base[b] * 64u + (lo - first[b]);
+  schunk[i * 2 + 1] = hi - lo;
+}
+__global__ void __launch_bounds__(kT) k_stream_bin_rows(const uint32_t* __restrict__ soff, int nshort, int nbins, uint32_t* __restrict__ bin_row) {
+  const int b = blockIdx.x * kT + threadIdx.x;
+  if (b > nbins) return;
+  if (b == nbins) { bin_row[b] = (uint32_t)nshort; return; }
+  const uint32_t want = (uint32_t)b * (uint32_t)GM_STREAM_BIN;
+  uint32_t lo = 0, hi = (uint32_t)nshort;  // first row with soff >= want
+  while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (soff[mid] < want) lo = mid + 1; else hi = mid; }
+  bin_row[b] = lo;
+}
+// the entries of the stream groups (k_sweep_fill skips them), and where each product belongs in its bin (sinv)
+__global__ void __launch_bounds__(kT)
+k_stream_fill(uint32_t ngroups, const uint32_t* __restrict__ gbase, const uint32_t* __restrict__ gq0, const uint32_t* __restrict__ gblk,
+              const uint32_t* __restrict__ first, const uint32_t* __restrict__ row_base, const unsigned long long* __restrict__ key_sorted,
+              const uint32_t* __restrict__ idx_sorted, const uint32_t* __restrict__ spos, const int32_t* __restrict__ colidx, const uint32_t* __restrict__ vals,
+              SweepSlices sl, int nslices, uint32_t* __restrict__ scol, uint32_t* __restrict__ sval, uint32_t* __restrict__ src_pos, uint16_t* __restrict__ sinv) {
+  for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    if (!(gblk[g] & 0x80000000u)) continue;
+    const uint32_t b = gblk[g] & 0x7fffffffu, j = gq0[g];
+    const uint32_t base = gbase[g], n = gbase[g + 1] - base, width = (n >> 6) - 1u;
+    const uint32_t slice = b % (uint32_t)nslices;
+    const uint32_t e_lo = first[b] + j * (GM_STREAM_WIDTH * 64u), e_end = first[b + 1];
+    const uint32_t drow = row_base[b] + j * GM_STREAM_WIDTH;
+    const uint32_t pad = GM_SWEEP_PAD | ((uint32_t)sl.b[slice] << 2);
+    for (uint32_t t = threadIdx.x; t < n; t += kT) {
+      uint32_t c = pad, v = 0u, sp_ = 0xffffffffu;
+      if (t < 64) {
+        c = GM_SWEEP_PAD | 0x40000000u | (width << 16) | 0x7fffu | ((t < 32 && ((drow >> t) & 1u)) ? 0x8000u : 0u);
+      } else {
+        const uint32_t i = e_lo + (t - 64u);
+        if (i < e_end) {
+          const uint32_t k = idx_sorted[i];
+          sp_ = spos[k];
+          c = sweep_entry_of(sl, (int)slice, colidx[sp_]);
+          if (vals) v = vals[sp_];
+          const uint32_t bin = (uint32_t)(key_sorted[i] & 0xffffffull);
+          sinv[(size_t)drow * 64 + (t - 64u)] = (uint16_t)(k - bin * (uint32_t)GM_STREAM_BIN);
+        }
+      }
+      scol[base + t] = c;
+      if (sval) sval[base + t] = v;
+      if (src_pos) src_pos[base + t] = sp_;
+    }
+  }
+}
 // contiguous ranges of a block's groups for the 16 waves (wfirst: groups; wrow: 64-entry rows of scol), balanced by rows + 1 per group; the last waves (they fold the long
 // rows of the block first: as many waves as the workgroup's long rows need lanes) get fold_share percent of an equal share
 __global__ void __launch_bounds__(64)
 k_sweep_wave_ranges(const uint32_t* __restrict__ grp_first, int nblk, const uint32_t* __restrict__ gbase, uint32_t* __restrict__ wfirst, uint32_t* __restrict__ wrow,
-                    int fold_share, int fold_waves, int nwaves) {
+                    int fold_share, int fold_waves, int nwaves, const uint32_t* __restrict__ skip_groups /* per block: groups at its end to leave out, or null */,
+                    int nskip_blk) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= nblk) return;
   constexpr int WS = 16;  // (entries per block in wfirst / wrow: WS + 1, whatever W)
   const int W = nwaves;
   const int FW = fold_waves;
-  const uint32_t g0 = grp_first[b], g1 = grp_first[b + 1];
+  const uint32_t g0 = grp_first[b], g1 = grp_first[b + 1] - ((skip_groups != nullptr && b < nskip_blk) ? skip_groups[b] : 0u);
   unsigned long long total = 0;
   for (uint32_t g = g0; g < g1; g++) total += (gbase[g + 1] - gbase[g]) / 64u + 1u;
   const unsigned long long units = (unsigned long long)(W - FW) * 100ull + (unsigned long long)FW * (unsigned)fold_share;
@@ -1195,7 +1314,8 @@ k_sweep_sync_vals(const uint32_t* __restrict__ src_pos, size_t n, const uint32_t
 }
 static void free_sweep(gm_graph* g) {
   gm_sweep_t& S = g->sweep;
-  const void* owned[] = {S.gcol, S.gval, S.gdst, S.gslice, S.gsrc_pos, S.scol, S.sval, S.gbase, S.wrow, S.wfirst, S.row_of_slot, S.lcol, S.lval, S.lps, S.lrow_of_slot, S.src_pos, S.lsrc_pos};
+  const void* owned[] = {S.gcol, S.gval, S.gdst, S.gslice, S.gsrc_pos, S.scol, S.sval, S.gbase, S.wrow, S.wfirst, S.row_of_slot, S.lcol, S.lval, S.lps, S.lrow_of_slot, S.src_pos, S.lsrc_pos,
+                         S.srow, S.soff, S.sbin_row, S.schunk, S.sinv, S.wrow_stream};
   for (const void* q : owned)
     if (q) (void)hipFree((void*)q);
   if (g->d_slice_base) (void)hipFree(g->d_slice_base);
@@ -1391,6 +1511,10 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
   }
   // ---- the medium rows: pieces, groups of 64 pieces of similar length, transposed entries
   DevBuf scol, sval, spos, gbase, wrow, wfirst;
+  DevBuf st_srow, st_soff, st_keys, st_idx, st_spos, st_first, st_rowbase, st_binrow, st_chunk, st_inv, st_sgroups, st_wrow, st_wfirst;  // the short rows' stream groups (below)
+  uint32_t st_nshort = 0, st_edges = 0, st_rows_total = 0;
+  int st_nbins = 0;
+  bool st_built = false;
   uint32_t ngroups = 0;
   unsigned long long nentries = 0;
   if (nedges > 0) {
@@ -1439,6 +1563,61 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
     if ((rc = ng.alloc((nblk + 1) * 4)) || (rc = grp_first.alloc((nblk + 1) * 4))) return rc;
     GM_TRY_HIP(hipMemsetAsync(ng.p, 0, (nblk + 1) * 4, s));
     hipLaunchKernelGGL(k_sweep_block_groups, dim3(grid_for((int64_t)nblk)), dim3(kT), 0, s, (const int32_t*)bfirst.as<int32_t>(), (int)nblk, ng.as<uint32_t>());
+    // ---- the short rows (1 .. short_row edges) as STREAM groups behind the medium groups of the first launch's blocks (gm_sweep_t.nstream):
+    // listed in device order, cut into bins of ~GM_STREAM_BIN edges, bin b -> workgroup b % 256; their edges sorted (workgroup, slice, bin, row,
+    // column) -- stable, so a row's edges keep their ascending native column order inside every (bin, slice) chunk
+    if (g_sweep_stream != 0 && nsub == 1) {
+      const int nsblk = 256 * TS;
+      DevBuf sflag, siota, scnt, slen, kin, vin, srows_;
+      DevBuf& sgroups = st_sgroups;
+      if ((rc = sflag.alloc((size_t)nrows)) || (rc = siota.alloc((size_t)nrows * 4)) || (rc = st_srow.alloc((size_t)nrows * 4 + 4)) || (rc = scnt.alloc(16))) return rc;
+      hipLaunchKernelGGL(k_stream_flag, dim3(grid_for(nrows)), dim3(kT), 0, s, rowptr, nrows, whole->view.short_row, sflag.as<unsigned char>());
+      hipLaunchKernelGGL(k_sweep_iota, dim3(grid_for(nrows)), dim3(kT), 0, s, siota.as<int32_t>(), nrows);
+      tb = 0;
+      GM_TRY_HIP(rocprim::select(nullptr, tb, siota.as<int32_t>(), sflag.as<unsigned char>(), st_srow.as<int32_t>(), scnt.as<unsigned int>(), (size_t)nrows, s));
+      if ((rc = tmp.alloc(tb + 256))) return rc;
+      GM_TRY_HIP(rocprim::select(tmp.p, tb, siota.as<int32_t>(), sflag.as<unsigned char>(), st_srow.as<int32_t>(), scnt.as<unsigned int>(), (size_t)nrows, s));
+      GM_TRY_HIP(hipMemcpyAsync(&st_nshort, scnt.p, 4, hipMemcpyDeviceToHost, s));
+      GM_TRY_HIP(hipStreamSynchronize(s));
+      sflag.free(); siota.free();
+      if (st_nshort > 0) {
+        if ((rc = slen.alloc(((size_t)st_nshort + 1) * 4)) || (rc = st_soff.alloc(((size_t)st_nshort + 1) * 4))) return rc;
+        GM_TRY_HIP(hipMemsetAsync(slen.p, 0, ((size_t)st_nshort + 1) * 4, s));
+        hipLaunchKernelGGL(k_sweep_lens, dim3(grid_for((int)st_nshort)), dim3(kT), 0, s, (const int32_t*)st_srow.as<int32_t>(), (int)st_nshort, rowptr, slen.as<uint32_t>());
+        if ((rc = sweep_excl_scan(slen.as<uint32_t>(), st_soff.as<uint32_t>(), (size_t)st_nshort + 1, s))) return rc;
+        GM_TRY_HIP(hipMemcpyAsync(&st_edges, st_soff.as<uint32_t>() + st_nshort, 4, hipMemcpyDeviceToHost, s));
+        GM_TRY_HIP(hipStreamSynchronize(s));
+        slen.free();
+      }
+      st_nbins = (int)(((unsigned long long)st_edges + GM_STREAM_BIN - 1) / GM_STREAM_BIN);
+      if (st_edges > 0 && st_nbins < (1 << 24)) {
+        if ((rc = kin.alloc((size_t)st_edges * 8)) || (rc = st_keys.alloc((size_t)st_edges * 8)) || (rc = vin.alloc((size_t)st_edges * 4)) ||
+            (rc = st_idx.alloc((size_t)st_edges * 4)) || (rc = st_spos.alloc((size_t)st_edges * 4)))
+          return rc;
+        hipLaunchKernelGGL(k_stream_keys, dim3(grid_for((int)st_nshort)), dim3(kT), 0, s, (const int32_t*)st_srow.as<int32_t>(), (int)st_nshort, (const uint32_t*)st_soff.as<uint32_t>(),
+                           rowptr, colidx, sl, TS, kin.as<unsigned long long>(), vin.as<uint32_t>(), st_spos.as<uint32_t>());
+        GM_TRY_HIP(hipGetLastError());
+        if ((rc = sweep_sort_pairs(kin.as<unsigned long long>(), st_keys.as<unsigned long long>(), vin.as<uint32_t>(), st_idx.as<uint32_t>(), (size_t)st_edges, 39, s))) return rc;
+        kin.free(); vin.free();
+        if ((rc = st_first.alloc(((size_t)nsblk + 2) * 4)) || (rc = srows_.alloc(((size_t)nsblk + 2) * 4)) || (rc = sgroups.alloc(((size_t)nsblk + 2) * 4)) ||
+            (rc = st_rowbase.alloc(((size_t)nsblk + 2) * 4)) || (rc = st_binrow.alloc(((size_t)st_nbins + 2) * 4)) || (rc = st_chunk.alloc((size_t)st_nbins * TS * 8 + 64)))
+          return rc;
+        hipLaunchKernelGGL(k_stream_block_starts, dim3(grid_for(nsblk + 1)), dim3(kT), 0, s, (const unsigned long long*)st_keys.as<unsigned long long>(), st_edges, TS, nsblk,
+                           st_first.as<uint32_t>());
+        hipLaunchKernelGGL(k_stream_block_rows, dim3(grid_for(nsblk + 1)), dim3(kT), 0, s, (const uint32_t*)st_first.as<uint32_t>(), nsblk, srows_.as<uint32_t>(), sgroups.as<uint32_t>());
+        if ((rc = sweep_excl_scan(srows_.as<uint32_t>(), st_rowbase.as<uint32_t>(), (size_t)nsblk + 1, s))) return rc;
+        GM_TRY_HIP(hipMemcpyAsync(&st_rows_total, st_rowbase.as<uint32_t>() + nsblk, 4, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(k_stream_add_groups, dim3(grid_for(nsblk)), dim3(kT), 0, s, (const uint32_t*)sgroups.as<uint32_t>(), nsblk, ng.as<uint32_t>());
+        hipLaunchKernelGGL(k_stream_bin_rows, dim3(grid_for(st_nbins + 1)), dim3(kT), 0, s, (const uint32_t*)st_soff.as<uint32_t>(), (int)st_nshort, st_nbins, st_binrow.as<uint32_t>());
+        hipLaunchKernelGGL(k_stream_chunks, dim3(grid_for((int64_t)st_nbins * TS)), dim3(kT), 0, s, (const unsigned long long*)st_keys.as<unsigned long long>(), st_edges, TS, st_nbins,
+                           (const uint32_t*)st_first.as<uint32_t>(), (const uint32_t*)st_rowbase.as<uint32_t>(), st_chunk.as<uint32_t>());
+        GM_TRY_HIP(hipGetLastError());
+        GM_TRY_HIP(hipStreamSynchronize(s));
+        if ((rc = st_inv.alloc((size_t)st_rows_total * 64 * 2 + 64))) return rc;
+        GM_TRY_HIP(hipMemsetAsync(st_inv.p, 0xff, (size_t)st_rows_total * 64 * 2 + 64, s));
+        st_built = true;
+      }
+    }
     if ((rc = sweep_excl_scan(ng.as<uint32_t>(), grp_first.as<uint32_t>(), nblk + 1, s))) return rc;
     GM_TRY_HIP(hipMemcpyAsync(&ngroups, grp_first.as<uint32_t>() + nblk, 4, hipMemcpyDeviceToHost, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
@@ -1448,7 +1627,8 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
       return rc;
     GM_TRY_HIP(hipMemsetAsync(gsize.p, 0, ((size_t)ngroups + 1) * 8, s));
     hipLaunchKernelGGL(k_sweep_group_sizes, dim3((unsigned)nblk), dim3(64), 0, s, (const int32_t*)bfirst.as<int32_t>(), (const uint32_t*)grp_first.as<uint32_t>(),
-                       (const uint32_t*)sp.as<uint32_t>(), (const uint32_t*)pstart.as<uint32_t>(), gsize.as<unsigned long long>(), gq0.as<uint32_t>(), gblk.as<uint32_t>());
+                       (const uint32_t*)sp.as<uint32_t>(), (const uint32_t*)pstart.as<uint32_t>(), gsize.as<unsigned long long>(), gq0.as<uint32_t>(), gblk.as<uint32_t>(),
+                       st_built ? (const uint32_t*)st_first.as<uint32_t>() : (const uint32_t*)nullptr, 256 * TS);
     if ((rc = sweep_excl_scan(gsize.as<unsigned long long>(), gb64.as<unsigned long long>(), (size_t)ngroups + 1, s))) return rc;
     GM_TRY_HIP(hipMemcpyAsync(&nentries, gb64.as<unsigned long long>() + ngroups, 8, hipMemcpyDeviceToHost, s));
     GM_TRY_HIP(hipStreamSynchronize(s));
@@ -1462,9 +1642,21 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
                        (const uint32_t*)gblk.as<uint32_t>(), (const int32_t*)bfirst.as<int32_t>(), (const uint32_t*)sp.as<uint32_t>(), (const uint32_t*)pstart.as<uint32_t>(),
                        (const uint16_t*)pslot16.as<uint16_t>(), mpos, colidx, vals, sl, TS, (const int*)rowmin.as<int>(), scol.as<uint32_t>(),
                        vals ? sval.as<uint32_t>() : (uint32_t*)nullptr, vals ? spos.as<uint32_t>() : (uint32_t*)nullptr);
+    if (st_built)
+      hipLaunchKernelGGL(k_stream_fill, dim3(65536), dim3(kT), 0, s, ngroups, (const uint32_t*)gbase.as<uint32_t>(), (const uint32_t*)gq0.as<uint32_t>(),
+                         (const uint32_t*)gblk.as<uint32_t>(), (const uint32_t*)st_first.as<uint32_t>(), (const uint32_t*)st_rowbase.as<uint32_t>(),
+                         (const unsigned long long*)st_keys.as<unsigned long long>(), (const uint32_t*)st_idx.as<uint32_t>(), (const uint32_t*)st_spos.as<uint32_t>(), colidx, vals, sl, TS,
+                         scol.as<uint32_t>(), vals ? sval.as<uint32_t>() : (uint32_t*)nullptr, vals ? spos.as<uint32_t>() : (uint32_t*)nullptr, st_inv.as<uint16_t>());
     hipLaunchKernelGGL(k_sweep_wave_ranges, dim3((unsigned)((nblk + 63) / 64)), dim3(64), 0, s, (const uint32_t*)grp_first.as<uint32_t>(), (int)nblk,
                        (const uint32_t*)gbase.as<uint32_t>(), wfirst.as<uint32_t>(), wrow.as<uint32_t>(), nlong > 0 ? g_sweep_fold_share : 100,
-                       (int)std::min(8, (((per_wg_long + nsets - 1) / nsets) + 63) / 64), (g_sweep_waves == 12 || g_sweep_waves == 8) ? g_sweep_waves : 16);
+                       (int)std::min(8, (((per_wg_long + nsets - 1) / nsets) + 63) / 64), (g_sweep_waves == 12 || g_sweep_waves == 8) ? g_sweep_waves : 16,
+                       st_built ? (const uint32_t*)st_sgroups.as<uint32_t>() : (const uint32_t*)nullptr, 256 * TS);
+    if (st_built) {  // the ranges WITH the stream groups (gm_sweep_t.wrow_stream): the kernel form that stores their products walks these
+      if ((rc = st_wrow.alloc(nblk * 17 * 4)) || (rc = st_wfirst.alloc(nblk * 17 * 4))) return rc;
+      hipLaunchKernelGGL(k_sweep_wave_ranges, dim3((unsigned)((nblk + 63) / 64)), dim3(64), 0, s, (const uint32_t*)grp_first.as<uint32_t>(), (int)nblk,
+                         (const uint32_t*)gbase.as<uint32_t>(), st_wfirst.as<uint32_t>(), st_wrow.as<uint32_t>(), nlong > 0 ? g_sweep_fold_share : 100,
+                         (int)std::min(8, (((per_wg_long + nsets - 1) / nsets) + 63) / 64), 16, (const uint32_t*)nullptr, 0);
+    }
     GM_TRY_HIP(hipGetLastError());
     GM_TRY_HIP(hipStreamSynchronize(s));
   } else {
@@ -1528,6 +1720,12 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
   S.src_pos = (const uint32_t*)spos.release(); S.lsrc_pos = (const uint32_t*)lpos.release();
   S.nsub = nsub; S.stride = sl.stride; S.hot_words = sl.hot_words;
   S.waves = (g_sweep_waves == 12 || g_sweep_waves == 8) ? g_sweep_waves : 16;
+  if (st_built) {
+    S.nstream = (int64_t)st_edges; S.nstream_slots = (int64_t)st_rows_total * 64; S.nshort_rows = (int32_t)st_nshort; S.nbins = st_nbins;
+    S.bin_cap = GM_STREAM_BIN; S.stream_width = GM_STREAM_WIDTH;
+    S.srow = (const int32_t*)st_srow.release(); S.soff = (const uint32_t*)st_soff.release(); S.sbin_row = (const uint32_t*)st_binrow.release();
+    S.schunk = (const uint32_t*)st_chunk.release(); S.sinv = (const uint16_t*)st_inv.release(); S.wrow_stream = (const uint32_t*)st_wrow.release();
+  }
   return GM_OK;
 }
 

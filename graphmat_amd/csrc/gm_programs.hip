@@ -20,7 +20,7 @@
 
 namespace gm {
 
-extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance, g_own_wave_row, g_sort_tile_lists, g_sweep_slices, g_sweep_acc_limit, g_sweep_long_limit, g_sweep_long_row, g_sweep_fold_share, g_sweep_border_factor, g_blocked_rows, g_sweep_waves;
+extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance, g_own_wave_row, g_sort_tile_lists, g_sweep_slices, g_sweep_acc_limit, g_sweep_long_limit, g_sweep_long_row, g_sweep_fold_share, g_sweep_border_factor, g_blocked_rows, g_sweep_waves, g_sweep_stream;
 static int g_force_ordered = 0;
 
 // ---------------- PageRank (reference: src/PageRank.cpp:34-112) ----------------------------
@@ -747,7 +747,7 @@ static const EngineKey kEngineKeys[] = {
   {"ablate_cold_short", 14, 0, 0, 0x7fffffff},
   {"two_stage_head_permille", 15, 900, 100, 990},
   {"giant_stream", 16, 1, 0, 2},
-  {"sweep_form", 17, 0, 0, 127},
+  {"sweep_form", 17, 0, 0, 255},
   {"blocked_form", 18, 2, 0, 31},
   {"guided_pull", 19, 1, 0, 2},
 };
@@ -841,6 +841,7 @@ int gm_reset_options(void) {
   gm::g_sweep_long_row = 0;
   gm::g_sweep_fold_share = 50;
   gm::g_sweep_waves = 16;
+  gm::g_sweep_stream = 1;
   gm::g_sweep_border_factor = 4;
   gm::g_col_tiles = 0;
   return GM_OK;
@@ -871,6 +872,7 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "sweep_long_row") && value >= 0 && value <= 8191) { gm::g_sweep_long_row = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_border_factor") && value >= 1 && value <= 64) { gm::g_sweep_border_factor = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_fold_share") && value >= 0 && value <= 100) { gm::g_sweep_fold_share = value; return GM_OK; }
+  if (key && !strcmp(key, "sweep_stream") && (value == 0 || value == 1)) { gm::g_sweep_stream = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_waves") && (value == 16 || value == 12 || value == 8)) { gm::g_sweep_waves = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_long_slots") && value >= 1 && value <= GM_SWEEP_LONG_SLOTS) { gm::g_sweep_long_limit = value; return GM_OK; }
   gm::set_error("gm_set_option: unknown option");

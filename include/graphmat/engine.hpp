@@ -979,6 +979,7 @@ class Run {
   void finish(int it) {
     GM_HIP_OK(hipStreamSynchronize(s));
     gm_graph_note_set(g, 3, (int64_t)sparse_sweeps);
+    gm_graph_note_set(g, 4, (int64_t)short_folds);
     tick("loop done", it);
     aux.finish();
     st.iterations = it;
@@ -1368,7 +1369,17 @@ class Run {
         launch_spmv_vp<P, T, U, V, E>(use_vp, Lg, pa, Ag, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
         chain_done = true;
       }
-      const int where = shorts_blocked ? 3 : (w12 ? 1 : (gterms != nullptr ? 2 : (opt.sweep_form & 3)));  // (3: behind everything, below)
+      // The short rows through the sweep (gm_sweep_t.nstream; round 6, last session): their edges sit in STREAM groups of the first launch's
+      // blocks, the sweep gathers for them -- from ~1.3 MB of x at a time and its LDS hot sets, where the row-block kernel gathers from the
+      // whole message vector -- and leaves the products in a stream that k_short_fold folds bin by bin behind the sweep.  Dense x, 16 waves,
+      // single-shard structures; sweep_form bit 7 keeps the row-block kernel (every other form walks wrow, which leaves the groups out).
+      U* sterms = nullptr;
+      if (sw.nstream > 0 && sw.sinv != nullptr && sw.wrow_stream != nullptr && sw.nsub <= 1 && xb == nullptr && !w12 && !shorts_blocked && !(opt.sweep_form & 128) &&
+          sw.bin_cap == GM_STREAM_BIN) {
+        void* p16 = nullptr;
+        if (gm_graph_workspace(g, 16, (size_t)sw.nstream_slots * sizeof(U) + 256, &p16) == GM_OK) sterms = (U*)p16;
+      }
+      const int where = sterms != nullptr ? 4 : shorts_blocked ? 3 : (w12 ? 1 : (gterms != nullptr ? 2 : (opt.sweep_form & 3)));  // (3: behind everything, below; 4: folded from the sweep's products)
       if (where == 1) { La.s = aux.s; La.timer = nullptr; }
       auto short_rows = [&]() {
         if (As.nblk <= 0) return;
@@ -1433,6 +1444,20 @@ class Run {
                                (const uint32_t*)nullptr, sw.gdst, sw.gslice, gt, xq, y);
           continue;
         }
+        if (sterms != nullptr && set == 0) {  // the launch that holds the short rows' stream groups stores their products
+          if constexpr (sizeof(E) == 4 && std::is_trivially_copyable<E>::value) {
+            if (Aout.vals != nullptr) {
+              hipLaunchKernelGGL((dev::k_spmv_sell_stream<P, T, U, V, E, true>), dim3(256), dim3(1024), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base, sw.scol,
+                                 sw.sval, sw.wrow_stream, sw.row_of_slot, sw.lcol, sw.lval, sw.lps, sw.lrow_of_slot, sw.gcol, sw.gval, sw.gdst, sw.gslice, gt, xq, y, sterms);
+              with_vals = true;
+            }
+          }
+          if (!with_vals)
+            hipLaunchKernelGGL((dev::k_spmv_sell_stream<P, T, U, V, E, false>), dim3(256), dim3(1024), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base, sw.scol,
+                               (const uint32_t*)nullptr, sw.wrow_stream, sw.row_of_slot, sw.lcol, (const uint32_t*)nullptr, sw.lps, sw.lrow_of_slot, sw.gcol,
+                               (const uint32_t*)nullptr, sw.gdst, sw.gslice, gt, xq, y, sterms);
+          continue;
+        }
         if constexpr (sizeof(E) == 4 && std::is_trivially_copyable<E>::value) {
           if (Aout.vals != nullptr) {
             hipLaunchKernelGGL((dev::k_spmv_sell<P, T, U, V, E, true>), dim3(256), dim3(1024), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base, sw.scol,
@@ -1456,6 +1481,12 @@ class Run {
         launch_spmv_vp<P, T, U, V, E>(use_vp, Lg, pa, Ag, xq, xb, (const V*)d_vp, y, ybits, acc, rk);
       }
       if (where == 2) short_rows();
+      if (where == 4) {  // the short rows' fold from the products the sweep left (next to the giant rows' fold passes on the auxiliary stream)
+        hipLaunchKernelGGL((dev::k_short_fold<P, U>), dim3((unsigned)sw.nbins), dim3(512), 0, s, pa, (const U*)sterms, sw.sinv, sw.schunk, sw.nslices, sw.bin_cap, sw.sbin_row,
+                           sw.soff, sw.srow, y, (acc & dev::ACC_STATIC_BITS) ? (uint32_t*)nullptr : ybits, getenv("GM_FOLD_ABL") ? atoi(getenv("GM_FOLD_ABL")) : 0);
+        st.spmv_launches++;
+        short_folds++;
+      }
       if (aux.pending && !defer_join) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
       aux.keep = aux.forked = aux.pending = false;
       timer.mark(defer_join ? TAG_ROWBLOCK : TAG_GIANT);  // (the multiply ends when the auxiliary stream has joined: the wait is charged to the giant rows' passes)
@@ -1594,6 +1625,7 @@ class Run {
   // kernels.hpp: k_spmv_blocked)?  The conditions of the sweep; the structure exists only for graphs without skew (edge values: none, or 4 bytes in its entries).
   bool said_blocked = false, said_sparse_sweep = false;
   int sparse_sweeps = 0;  // multiplies of this run that took a sparse x through the sweep (note 3 of the graph: tests read it)
+  int short_folds = 0;    // multiplies of this run whose short rows were folded from the sweep's products stream (note 4)
   bool blocked_usable(int acc, gm_blocked_t* bl) {
     if constexpr (sizeof(T) == 4 && sizeof(U) == 4 && std::is_trivially_copyable<T>::value && std::is_trivially_copyable<U>::value) {
       if (use_vp || xq == nullptr || xb != nullptr || d_want != nullptr || program_row_filter<P>::enabled || (acc & dev::ACC_READ_PREV)) return false;

@@ -1475,7 +1475,8 @@ sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows
           const uint32_t* __restrict__ lval, const uint32_t* __restrict__ lps, const int32_t* __restrict__ lrow_of_slot,
           const uint32_t* __restrict__ gcol, const uint32_t* __restrict__ gval, const uint32_t* __restrict__ gdst, const uint32_t* __restrict__ gslice,
           U* __restrict__ gterms /* products stream of the giant rows, or null: they gather for themselves */, const T* __restrict__ x, U* __restrict__ y,
-          int nsub, int stride, int hot_words, const uint32_t* __restrict__ xbits = nullptr, uint32_t* __restrict__ ybits = nullptr) {
+          int nsub, int stride, int hot_words, const uint32_t* __restrict__ xbits = nullptr, uint32_t* __restrict__ ybits = nullptr,
+          U* __restrict__ sterms = nullptr /* products stream of the short rows' STREAM groups, or null: nothing is stored for them */) {
   static_assert(sizeof(T) == 4 && sizeof(U) == 4, "4-byte messages and reductions");
   static_assert(!SPARSE || (PIPE == 2 && !SHARDED && ABL == 0), "the sparse form: single shard, two batches deep");
   constexpr int BLOCK = BLOCKT, W = BLOCK / 64, UB = UBATCH;
@@ -1700,6 +1701,11 @@ sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows
     int slot = 0x7fff;
     U acc;
     bool has = false;
+    // STREAM groups (graphmat_hip.h: gm_sweep_t.nstream): bit 30 of the meta row; no lane has a slot, the products of row k of the group go
+    // to sterms[(first + k) * 64 + lane], `first` spelled by bit 15 of lanes 0..31 -- the short rows' edges ride the sweep for their gathers
+    // and are folded from that stream afterwards (k_short_fold)
+    bool streaming = false;
+    uint32_t srow = 0;
     if constexpr (PIPE == 2) {
       // Two batches deep: while batch k is folded, the messages of batch k + 1 and the entries of batch k + 2 are in flight (one
       // wait per iteration -- for the entries requested last, which the earlier gathers precede -- instead of entries, then
@@ -1765,9 +1771,18 @@ sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows
                   if constexpr (SPARSE) { if (has) atomicOr(&s_hasbits[slot >> 5], 1u << (slot & 31)); }
                 }
                 slot = (int)(cA[j] & 0x7fffu);
+                streaming = ((uint32_t)__builtin_amdgcn_readfirstlane((int)cA[j]) & 0x40000000u) != 0u;
+                if (streaming) srow = (uint32_t)__ballot(((cA[j] >> 15) & 1u) != 0u);
                 if constexpr (SPARSE) has = slot != 0x7fff && ((s_hasbits[slot >> 5] >> (slot & 31)) & 1u) != 0u;
                 else has = !(cA[j] & 0x8000u);
                 acc = as_u(slot != 0x7fff ? s_acc[slot] : 0u);
+              } else if (streaming) {
+                if (!SPARSE && sterms != nullptr && (int32_t)cA[j] >= 0) {
+                  U res;
+                  p.P::process_message(as_t(mA[j]), as_e(eA[j]), no_vp, res);
+                  sterms[(size_t)srow * 64 + lane] = res;
+                }
+                srow++;
               } else if (SPARSE ? ((pA >> j) & 1u) != 0u : (int32_t)cA[j] >= 0) {
                 U res;
                 p.P::process_message(as_t(mA[j]), as_e(eA[j]), no_vp, res);
@@ -1872,6 +1887,114 @@ k_spmv_sell(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long
             U* __restrict__ gterms, const T* __restrict__ x, U* __restrict__ y) {
   sell_body<P, T, U, V, E, HAS_VALS, ABL, UBATCH, PIPE, POOLW, false>(pa, set, stage_words, nslices, nrows_long, slice_base, scol, sval, wrow, row_of_slot, lcol, lval, lps,
                                                                        lrow_of_slot, gcol, gval, gdst, gslice, gterms, x, y, 1, 0, 0);
+}
+// ... with the short rows' STREAM groups stored (gm_sweep_t.nstream; the first launch holds them all)
+template <class P, class T, class U, class V, class E, bool HAS_VALS>
+__global__ void __launch_bounds__(1024)
+k_spmv_sell_stream(ProgArg<P> pa, int set, int stage_words, int nslices, int nrows_long, const int32_t* __restrict__ slice_base, const uint32_t* __restrict__ scol,
+                   const uint32_t* __restrict__ sval, const uint32_t* __restrict__ wrow, const int32_t* __restrict__ row_of_slot, const uint32_t* __restrict__ lcol,
+                   const uint32_t* __restrict__ lval, const uint32_t* __restrict__ lps, const int32_t* __restrict__ lrow_of_slot,
+                   const uint32_t* __restrict__ gcol, const uint32_t* __restrict__ gval, const uint32_t* __restrict__ gdst, const uint32_t* __restrict__ gslice,
+                   U* __restrict__ gterms, const T* __restrict__ x, U* __restrict__ y, U* __restrict__ sterms) {
+  sell_body<P, T, U, V, E, HAS_VALS, 0, 7, 2, GM_SWEEP_POOL, false>(pa, set, stage_words, nslices, nrows_long, slice_base, scol, sval, wrow, row_of_slot, lcol, lval, lps,
+                                                                     lrow_of_slot, gcol, gval, gdst, gslice, gterms, x, y, 1, 0, 0, nullptr, nullptr, sterms);
+}
+// The short rows' fold behind the sweep (gm_sweep_t.nstream): workgroup = one BIN of consecutive short rows (at most bin_cap + 63 products).
+// The sweep left the bin's products in nslices chunks of the stream, (row, column) order inside a chunk; sinv says where each belongs in the
+// bin's CSR order, the products are put there in LDS -- all chunks' entries dealt flat over the threads -- and one thread per row folds its run
+// in ascending native column order: the first message assigns (spmspv.h:73-77), like every other kernel of the path.  ybits = nullptr: the
+// presence bits are the graph's static ones.
+template <class P, class U>
+__global__ void __launch_bounds__(512)
+k_short_fold(ProgArg<P> pa, const U* __restrict__ sterms, const uint16_t* __restrict__ sinv, const uint32_t* __restrict__ schunk, int nslices, int cap,
+             const uint32_t* __restrict__ sbin_row, const uint32_t* __restrict__ soff, const int32_t* __restrict__ srow_id, U* __restrict__ y,
+             uint32_t* __restrict__ ybits, int abl = 0) {
+  static_assert(sizeof(U) == 4, "4-byte reductions");
+  __shared__ uint32_t s_prod[GM_STREAM_BIN + 64];
+  __shared__ uint32_t s_cpos[GM_MAX_SLICES], s_cpre[GM_MAX_SLICES + 1];
+  const P& p = *reinterpret_cast<const P*>(pa.b);
+  const int b = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t* __restrict__ raw = reinterpret_cast<const uint32_t*>(sterms);
+  const uint32_t i0 = sbin_row[b], i1 = sbin_row[b + 1], base = (uint32_t)b * (uint32_t)cap;
+  // this thread's first rows are requested while the products arrive
+  constexpr int RK = 4;
+  uint32_t ro0[RK], ro1[RK];
+  int rid[RK];
+#pragma unroll
+  for (int j = 0; j < RK; j++) {
+    const uint32_t i = i0 + (uint32_t)(j * 512) + threadIdx.x;
+    if (i < i1) { ro0[j] = soff[i]; ro1[j] = soff[i + 1]; rid[j] = srow_id[i]; }
+  }
+  if ((int)threadIdx.x < nslices) {  // where the bin's products of every slice are, and how many
+    const uint2 pn = *reinterpret_cast<const uint2*>(&schunk[((size_t)b * nslices + threadIdx.x) * 2]);
+    s_cpos[threadIdx.x] = pn.x;
+    s_cpre[threadIdx.x] = pn.y;
+  }
+  __syncthreads();
+  // wave w takes the chunks w, w + 8, ...: six chunks' first 256 products are requested before any of them is awaited
+  constexpr int CB = 6, CK = 4;
+  if (!(abl & 1))
+  for (int c0 = wv; c0 < nslices; c0 += 8 * CB) {
+    uint32_t vv[CB][CK];
+    uint16_t qq[CB][CK];
+    uint32_t cp[CB], cn[CB];
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+      const int sl = c0 + 8 * c;
+      cp[c] = sl < nslices ? s_cpos[sl] : 0u;
+      cn[c] = sl < nslices ? s_cpre[sl] : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+#pragma unroll
+      for (int k = 0; k < CK; k++) {
+        const uint32_t i = (uint32_t)(k * 64 + lane);
+        if (i < cn[c]) {
+          vv[c][k] = __builtin_nontemporal_load(&raw[cp[c] + i]);
+          qq[c][k] = __builtin_nontemporal_load(&sinv[cp[c] + i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+#pragma unroll
+      for (int k = 0; k < CK; k++)
+        if ((uint32_t)(k * 64 + lane) < cn[c]) s_prod[qq[c][k]] = vv[c][k];
+      for (uint32_t i = (uint32_t)(CK * 64 + lane); i < cn[c]; i += 64u) s_prod[sinv[cp[c] + i]] = raw[cp[c] + i];  // (a chunk of more than 256 products)
+    }
+  }
+  __syncthreads();
+  auto as_u = [](uint32_t r) { U u; __builtin_memcpy(&u, &r, 4); return u; };
+  if (abl & 4) return;
+  for (uint32_t ii = i0 + (uint32_t)(wv * 64), jj = 0; ii < ((abl & 2) ? i0 : i1); ii += 512u, jj++) {
+    const uint32_t i = ii + (uint32_t)lane;
+    const bool valid = i < i1;
+    int row = 0;
+    if (valid) {
+      uint32_t o0, o1;
+      if (jj < RK) {
+        o0 = ro0[0]; o1 = ro1[0]; row = rid[0];
+#pragma unroll
+        for (int j = 1; j < RK; j++) if ((int)jj == j) { o0 = ro0[j]; o1 = ro1[j]; row = rid[j]; }
+      } else { o0 = soff[i]; o1 = soff[i + 1]; row = srow_id[i]; }
+      o0 -= base; o1 -= base;
+      U acc = as_u(s_prod[o0]);
+      for (uint32_t k = o0 + 1; k < o1; k++) p.P::reduce_function(acc, as_u(s_prod[k]));
+      y[row] = acc;
+    }
+    if (ybits != nullptr) {  // (rows of a run are consecutive device ids: three words per wave instead of 64 atomics)
+      const int r0 = __builtin_amdgcn_readfirstlane(row);
+      if (__all(!valid || row == r0 + lane)) {
+        const unsigned long long hb = __ballot(valid);
+        const int sh = r0 & 31;
+        const unsigned long long lo = hb << sh, hi = sh ? (hb >> (64 - sh)) : 0ull;
+        const uint32_t w = lane == 0 ? (uint32_t)lo : lane == 1 ? (uint32_t)(lo >> 32) : lane == 2 ? (uint32_t)hi : 0u;
+        if (lane < 3 && w != 0u) atomicOr(&ybits[(r0 >> 5) + lane], w);
+      } else if (valid) {
+        atomicOr(&ybits[row >> 5], 1u << (row & 31));
+      }
+    }
+  }
 }
 // The giant rows' gathers in a kernel of their own (engine option sweep_form bit 4): gm_sweep_t.gcol is sorted by slice, so a grid-stride
 // walk keeps all workgroups inside about one slice of the message vector at a time (L2-resident) without hot sets.  Runs on the auxiliary

@@ -58,7 +58,7 @@ typedef void* gm_stream_t; /* hipStream_t */
 typedef struct gm_graph gm_graph_t;
 
 const char* gm_last_error(void);
-int gm_version(void); /* 100 + the build round whose struct layouts these are (106: gm_sweep_t with nsub / stride / hot_words / waves, 32-byte gchunk_state records) */
+int gm_version(void); /* 100 + the build round whose struct layouts these are (107: gm_sweep_t with nsub / stride / hot_words / waves and the short rows' stream groups, 32-byte gchunk_state records) */
 int gm_device_count(int* count);
 int gm_set_device(int device);
 
@@ -331,7 +331,34 @@ typedef struct {
   int32_t hot_words;  /* LDS words the build assumed for a slice's hot entries (the kernel must load at least as many) */
   int32_t waves;      /* waves per workgroup the blocks' groups are dealt over (wrow / wfirst keep 17 entries per block): 16, or 12 / 8 with
                          gm_set_option("sweep_waves"): a smaller sweep workgroup that leaves room on every CU for another kernel */
+  /* SHORT rows riding the sweep (round 6, last session; single-shard structures; gm_set_option("sweep_stream", 0) builds none).  The rows of
+     1 .. short_row edges -- 15 % of RMAT-26's edges, whose gathers from the whole message vector cost the row-block kernel 35 % of an iteration --
+     are listed in device order (srow[i], i < nshort_rows; soff[i] = edges of the rows before i) and cut into BINS of consecutive rows (bin b =
+     the rows with soff[i] / bin_cap == b: at most bin_cap + 63 edges; sbin_row[b] = its first row).  Bin b belongs to workgroup b % 256 of the
+     FIRST launch, whose (workgroup, slice) blocks get extra STREAM groups behind their medium groups: meta row = GM_SWEEP_PAD | bit 30 | width
+     << 16 | 0x7fff in every lane (no lane has a slot), bit 15 of lanes 0 .. 31 spelling the group's first row `first` of the products stream;
+     the `width` <= stream_width rows that follow hold the block's short-row edges, 64 per row, in (bin, row, ascending native column) order
+     (padding only behind the block's last edge).  wrow_stream = the waves' row ranges WITH those groups (wrow: without -- kernel forms that do
+     not store products never see them).  The sweep gathers for the stream rows like for any entry and stores the product of row k, lane l at
+     sterms[(first + k) * 64 + l] (nstream_slots entries; kernels.hpp: k_spmv_sell_stream); a block's products are contiguous, so bin b's
+     products of slice s are the schunk[(b * nslices + s) * 2 + 1] entries from schunk[(b * nslices + s) * 2] on, and sinv[that position] =
+     where the product belongs in the bin's CSR order (soff of its row + index in the row - b * bin_cap).  kernels.hpp: k_short_fold
+     folds a bin from there in ascending native column order.  nstream = 0: none built. */
+  int64_t nstream;        /* edges of the short rows */
+  int64_t nstream_slots;  /* entries of the products stream */
+  int32_t nshort_rows;
+  int32_t nbins;
+  int32_t bin_cap;        /* = GM_STREAM_BIN */
+  int32_t stream_width;   /* rows of a full stream group (= GM_STREAM_WIDTH) */
+  const int32_t* srow;       /* [nshort_rows] local row ids, ascending */
+  const uint32_t* soff;      /* [nshort_rows + 1] */
+  const uint32_t* sbin_row;  /* [nbins + 1] */
+  const uint32_t* schunk;    /* [nbins * nslices * 2] */
+  const uint16_t* sinv;      /* [nstream_slots] */
+  const uint32_t* wrow_stream; /* [nsets * 256 * nslices * 17] */
 } gm_sweep_t;
+#define GM_STREAM_BIN 12288   /* edges of a bin of short rows (k_short_fold keeps a bin's products in LDS) */
+#define GM_STREAM_WIDTH 8     /* rows (of 64 entries) of a full stream group */
 #define GM_SWEEP_HOT 0x40000000u
 #define GM_MAX_SLICES 128
 #define GM_SWEEP_ACC_ROWS 10048
@@ -636,7 +663,7 @@ int gm_graph_last_stats(const gm_graph_t* g, gm_run_stats_t* out);
  * Device scratch owned by the graph, grown on demand and reused across runs (the
  * reference allocates x/y per run_graph_program call, GraphMatRuntime.h:110-120).
  * slot in [0, GM_WS_SLOTS). */
-#define GM_WS_SLOTS 16
+#define GM_WS_SLOTS 20
 int gm_graph_workspace(gm_graph_t* g, int slot, size_t bytes, void** d_ptr);
 /* Let the caller provide a scratch slot (e.g. a torch tensor it also hands to its collective
  * library): slot 1 = message values x (nvertices * elt bytes), slot 2 = x presence bits

@@ -299,10 +299,13 @@ def _check_sweep_structure(api, g, sw, keep_values, rng, own=4096):
     assert sw.nedges == int(ln[med].sum()) and sw.nedges_long == int(ln[lng].sum())
     gb, wf = A["gbase"].astype(np.int64), A["wfirst"].reshape(-1, 17)
     assert gb[0] == 0 and gb[-1] == sw.nentries and (np.diff(gb) >= 128).all() and (np.diff(gb) % 64 == 0).all()
-    assert (np.diff(wf, axis=1).astype(np.int64) >= 0).all() and wf[0, 0] == 0 and wf[-1, 16] == sw.ngroups and (wf[1:, 0] == wf[:-1, 16]).all()
+    # (the short rows' stream groups -- gm_sweep_t.nstream, their own test below -- sit behind a block's medium groups; wfirst / wrow leave them out)
+    assert (np.diff(wf, axis=1).astype(np.int64) >= 0).all() and wf[0, 0] == 0 and wf[-1, 16] <= sw.ngroups and (wf[1:, 0] >= wf[:-1, 16]).all()
+    if sw.nstream == 0:
+        assert wf[-1, 16] == sw.ngroups and (wf[1:, 0] == wf[:-1, 16]).all()
     assert (A["wrow"].astype(np.int64) == gb[A["wfirst"]] // 64).all()
     # every edge exactly once: entries without the pad bit (meta rows and padding carry it); checked per piece below on a sample
-    assert int((A["scol"][: sw.nentries] >> 31 == 0).sum()) == sw.nedges
+    assert int((A["scol"][: sw.nentries] >> 31 == 0).sum()) == sw.nedges + sw.nstream
     def row_part(row, sl):
         whole = ci[rp[row]: rp[row + 1]]
         sel = (whole >= cuts[sl]) & (whole < cuts[sl + 1])
@@ -316,6 +319,11 @@ def _check_sweep_structure(api, g, sw, keep_values, rng, own=4096):
         grp = A["scol"][gb[gI]: gb[gI + 1]].reshape(width + 1, 64)
         metas, ent = grp[0], grp[1:]
         assert (metas >> 31).all() and (((metas >> 16) & 0x1fff) == width).all()
+        if (metas >> 30 & 1).any():  # a stream group: no lane has a slot, full rows of entries up to the block's last edge
+            flat = ent.reshape(-1)
+            nreal = int((flat >> 31 == 0).sum())
+            assert (metas >> 30 & 1).all() and ((metas & 0x7fff) == 0x7fff).all() and 1 <= width <= 8 and (flat[:nreal] >> 31 == 0).all() and nreal > (width - 1) * 64
+            continue
         lens = []
         for lane in range(64):
             meta = int(metas[lane]) & 0xffff
@@ -441,6 +449,85 @@ def test_sweep_in_768_thread_workgroups_bit_exact(env, keep):
         assert L.gm_graph_sweep(g.h, C.byref(sw)) == 0 and sw.nrows > 0 and sw.waves == 12 and sw.nrows_long > 0
         pr, deg, it = g.pagerank(6)
         assert it == 6 and (f32bits(pr) == f32bits(opr)).all()
+        g.close()
+    finally:
+        api._lib.check(L.gm_reset_options())
+
+
+@pytest.mark.parametrize("scale,tiles,threads,keep", [(13, 2, 1, False), (15, 3, 2, True), (16, 4, 1, False), (16, 3, 2, True)])
+def test_short_rows_ride_the_sweep(env, scale, tiles, threads, keep):
+    """The rows of 1 .. 64 edges as STREAM groups of the sweep (graphmat_hip.h: gm_sweep_t.nstream; kernels.hpp: k_spmv_sell_stream + k_short_fold):
+    the structure lists every short row once, in device order, its bins cover the short rows' edges exactly, every (bin, slice) chunk lies inside
+    the products stream, the stream groups are the only difference between wrow and wrow_stream, and sinv is a permutation inside every bin; PageRank through it -- with and without edge values -- has the oracle's bits,
+    the path was really taken (note 4 of the graph), and the same graph with the row-block kernel kept (sweep_form bit 7) or without the structure
+    (gm_set_option("sweep_stream", 0)) gives the same bits."""
+    import ctypes as C
+    api, ob = env
+    from graphmat_amd import _lib
+    L = _lib.lib()
+    nv, s, d, v = gen.rmat_edges(scale, 16, 11, weights="hash")
+    og = ob.OracleGraph(nv, s, d, v if keep else None, ref_threads=threads)
+    opr, oit, _ = og.pagerank(7)
+    try:
+        api._lib.check(L.gm_reset_options())
+        api._lib.check(L.gm_set_option(b"sweep_long_row", 256))
+        g = api.Graph(nv, s, d, v if keep else None, ref_threads=threads, keep_values=keep, col_tiles=tiles)
+        sw = _lib.Sweep()
+        assert L.gm_graph_sweep(g.h, C.byref(sw)) == 0 and sw.nrows > 0
+        assert sw.nstream > 0 and sw.nbins > 0 and sw.bin_cap == 12288 and sw.nstream_slots % 64 == 0 and sw.nstream_slots >= sw.nstream and sw.wrow_stream
+        c = g.csr(api.GM_DIR_OUT)
+        rp = np.zeros(c.nrows + 1, np.int64)
+        api.copy_from_device(rp, c.rowptr)
+        lens = np.diff(rp)
+        short = np.nonzero((lens >= 1) & (lens <= sw.short_row))[0]
+        srow = np.zeros(sw.nshort_rows, np.int32)
+        api.copy_from_device(srow, sw.srow)
+        soff = np.zeros(sw.nshort_rows + 1, np.uint32)
+        api.copy_from_device(soff, sw.soff)
+        assert (srow == short).all() and int(soff[-1]) == sw.nstream == int(lens[short].sum()) and (np.diff(soff.astype(np.int64)) == lens[short]).all()
+        binrow = np.zeros(sw.nbins + 1, np.uint32)
+        api.copy_from_device(binrow, sw.sbin_row)
+        assert binrow[0] == 0 and binrow[-1] == sw.nshort_rows and (np.diff(binrow.astype(np.int64)) >= 0).all()
+        chunk = np.zeros(sw.nbins * sw.nslices * 2, np.uint32)
+        api.copy_from_device(chunk, sw.schunk)
+        chunk = chunk.reshape(sw.nbins, sw.nslices, 2).astype(np.int64)
+        assert int(chunk[:, :, 1].sum()) == sw.nstream and ((chunk[:, :, 0] + chunk[:, :, 1]) <= sw.nstream_slots).all()
+        # the stream groups sit behind the medium groups of the first launch's blocks: wrow (every other kernel form) ends a block in front of
+        # them, wrow_stream behind them, and exactly the stream rows lie between
+        wr = np.zeros(sw.nsets * 256 * sw.nslices * 17, np.uint32)
+        ws = np.zeros_like(wr)
+        api.copy_from_device(wr, sw.wrow)
+        api.copy_from_device(ws, sw.wrow_stream)
+        wr, ws = wr.reshape(-1, 17).astype(np.int64), ws.reshape(-1, 17).astype(np.int64)
+        assert (wr[:, 0] == ws[:, 0]).all() and (ws[:, 16] >= wr[:, 16]).all()
+        extra_rows = int((ws[:, 16] - wr[:, 16]).sum())  # meta rows + product rows
+        assert extra_rows >= sw.nstream_slots // 64 and (ws[256 * sw.nslices:, 16] == wr[256 * sw.nslices:, 16]).all()
+        sinv = np.zeros(sw.nstream_slots, np.uint16)
+        api.copy_from_device(sinv, sw.sinv)
+        for b in range(sw.nbins):
+            i0, i1 = int(binrow[b]), int(binrow[b + 1])
+            want = int(soff[i1]) - int(soff[i0])
+            assert int(chunk[b, :, 1].sum()) == want and int(soff[i0]) >= b * sw.bin_cap and (i1 == i0 or int(soff[i1 - 1]) < (b + 1) * sw.bin_cap)
+            pos = np.concatenate([np.arange(p0, p0 + n) for p0, n in chunk[b]]) if want else np.zeros(0, np.int64)
+            got = np.sort(sinv[pos].astype(np.int64))
+            assert (got == np.arange(int(soff[i0]) - b * sw.bin_cap, int(soff[i0]) - b * sw.bin_cap + want)).all(), "sinv is no permutation inside bin %d" % b
+        n4 = C.c_int64(-1)
+        pr, _, it = g.pagerank(7)
+        assert it == oit == 7 and (f32bits(pr) == f32bits(opr)).all()
+        assert L.gm_graph_note_get(g.h, 4, C.byref(n4)) == 0 and n4.value == 7
+        api._lib.check(L.gm_set_option(b"sweep_form", 128))  # the row-block kernel for the short rows
+        pr2, _, _ = g.pagerank(7)
+        assert (f32bits(pr2) == f32bits(opr)).all() and L.gm_graph_note_get(g.h, 4, C.byref(n4)) == 0 and n4.value == 0
+        api._lib.check(L.gm_set_option(b"sweep_form", 0))
+        pru, itu, _ = og.pagerank(-1)
+        pr3, _, it3 = g.pagerank(-1)  # (until convergence: ACTIVE_ONLY-free program, but the iteration count must agree too)
+        assert it3 == itu and (f32bits(pr3) == f32bits(pru)).all()
+        g.close()
+        api._lib.check(L.gm_set_option(b"sweep_stream", 0))
+        g = api.Graph(nv, s, d, v if keep else None, ref_threads=threads, keep_values=keep, col_tiles=tiles)
+        assert L.gm_graph_sweep(g.h, C.byref(sw)) == 0 and sw.nrows > 0 and sw.nstream == 0 and not sw.sinv
+        pr4, _, _ = g.pagerank(7)
+        assert (f32bits(pr4) == f32bits(opr)).all()
         g.close()
     finally:
         api._lib.check(L.gm_reset_options())
