@@ -837,6 +837,10 @@ def main():
     if _gl.lib().gm_graph_sweep(g.h, C.byref(sweep)) != 0 or (world > 1 and int(sweep.nsub) != world):
         sweep.nrows = 0  # (N > 1: rank 0's shard, when its rows go through the sharded sweep -- gm_sweep_t.nsub)
     swept = int(sweep.nrows) > 0
+    # (round 6, last session: the short rows' gathers ride the sweep as stream groups -- gm_sweep_t.nstream -- and k_short_fold folds their
+    # products behind it; note 4 of the graph = multiplies of the last run that went that way)
+    n4 = C.c_int64(0)
+    streamed = swept and int(sweep.nstream) > 0 and _gl.lib().gm_graph_note_get(g.h, 4, C.byref(n4)) == 0 and n4.value > 0
     roof = None
     name = max(kern, key=lambda k: kern[k][0])
     ms, launches, alg_bytes = kern[name]
@@ -848,6 +852,8 @@ def main():
         ms, launches = stats["wave_ms"], stats["wave_launches"]
         swept_edges = int(sweep.nedges) + int(sweep.nedges_long)
         alg_bytes = 4 * swept_edges + 8 * int(sweep.nrows)
+        if streamed:  # + the short rows' edges: 4 B column id read, 4 B product written
+            alg_bytes += 8 * int(sweep.nstream)
         by_kernel = [int(c_out.edges_blk), swept_edges, 0, int(c_out.nnz) - int(c_out.edges_blk) - swept_edges]
     elif tiled:
         # column tiles: a row's pieces are spread over T launches of every kernel class (and per tile the long wave rows
@@ -877,7 +883,7 @@ def main():
                 if tj.get("kernels_fingerprint") == kernels_fingerprint() and tj.get("col_tiles", {}).get("scale%d" % args.scale) == int(g.col_tiles):
                     # (large graphs run the persistent forms k_spmv_rowwave / k_spmv_wave16p instead of, or next to, the plain ones)
                     names = {"k_spmv_rowblock": ["k_spmv_rowblock", "k_spmv_rowwave"], "k_spmv_wave": ["k_spmv_wave", "k_spmv_wave16", "k_spmv_wave16p"],
-                             "k_spmv_sell": ["k_spmv_sell", "k_spmv_sell_sharded"],
+                             "k_spmv_sell": ["k_spmv_sell", "k_spmv_sell_sharded", "k_spmv_sell_stream"],
                              "multiply": ["k_spmv_rowblock", "k_spmv_rowwave", "k_spmv_wave", "k_spmv_wave16", "k_spmv_wave16p"]}.get(name, [name])
                     parts = [per.get(k + "_bytes_per_iteration") for k in names]
                     traffic = int(sum(v for v in parts if v is not None)) if any(v is not None for v in parts) else None
@@ -901,6 +907,9 @@ def main():
                  (" over %d column tiles" % int(g.col_tiles) if tiled else "")}.get(name, name)
         if swept:
             kname = "k_spmv_sell (row-stationary sweep over %d slices, %d launch(es) per iteration)" % (int(sweep.nslices), int(sweep.nsets))
+            if streamed:
+                kname = "k_spmv_sell_stream (row-stationary sweep over %d slices, %d launch(es) per iteration; also gathers for the rows of up to 64 edges and writes their products)" % (
+                    int(sweep.nslices), int(sweep.nsets))
         # every multiply kernel of the iteration by itself: edges x 4 B / its average time / the HBM peak.  (The giant rows'
         # fold passes run on the auxiliary stream next to the row-block kernel: their time overlaps it; the sweep's time includes
         # the gathers it does for the giant rows.)
@@ -925,12 +934,21 @@ def main():
                     "traffic": tr, "traffic_raw_counters": raw, "traffic_over_alg_bytes": round(tr / alg_bytes_k, 2) if (tr and alg_bytes_k) else None}
         if swept:
             sweep_stream = 4 * (int(sweep.nentries) + int(sweep.nedges_long) + int(sweep.ngiant_edges) * 2) * (2 if int(sweep.val_bytes) else 1)
-            per_kernel = {"k_spmv_rowblock (rows of up to 64 edges)": kfrac(by_kernel[0], stats["rowblock_ms"], 4 * by_kernel[0] + 12 * n_short_rows,
-                                                                             ("k_spmv_rowblock", "k_spmv_rowwave"), 4 * by_kernel[0] + 8 * n_short_rows),
-                          "k_spmv_sell (rows of 65 .. giant-limit edges)": kfrac(by_kernel[1], stats["wave_ms"], 4 * by_kernel[1] + 8 * int(sweep.nrows), ("k_spmv_sell", "k_spmv_sell_sharded"), sweep_stream),
+            if streamed:
+                short_kernel = {"k_short_fold (rows of up to 64 edges, folded from the products stream the sweep wrote: 4 B product + 2 B place per edge, 12 B per row)":
+                                    kfrac(by_kernel[0], stats["rowblock_ms"], 6 * by_kernel[0] + 12 * n_short_rows, ("k_short_fold",), 6 * by_kernel[0] + 8 * n_short_rows),
+                                "k_spmv_sell_stream (rows of 65 .. giant-limit edges, and the gathers of the rows of up to 64 edges)":
+                                    kfrac(by_kernel[1] + by_kernel[0], stats["wave_ms"], 4 * by_kernel[1] + 8 * int(sweep.nrows) + 8 * by_kernel[0],
+                                          ("k_spmv_sell", "k_spmv_sell_sharded", "k_spmv_sell_stream"), sweep_stream)}
+            else:
+                short_kernel = {"k_spmv_rowblock (rows of up to 64 edges)": kfrac(by_kernel[0], stats["rowblock_ms"], 4 * by_kernel[0] + 12 * n_short_rows,
+                                                                                   ("k_spmv_rowblock", "k_spmv_rowwave"), 4 * by_kernel[0] + 8 * n_short_rows),
+                                "k_spmv_sell (rows of 65 .. giant-limit edges)": kfrac(by_kernel[1], stats["wave_ms"], 4 * by_kernel[1] + 8 * int(sweep.nrows), ("k_spmv_sell", "k_spmv_sell_sharded"), sweep_stream)}
+            per_kernel = {**short_kernel,
                           "k_giant_sums + k_giant_maps + k_giant_replay_maps: the giant rows' fold passes (auxiliary stream, next to the row-block kernel; their gathers are done by the sweep, "
                           "they read the products stream twice and the replayed sub-pieces once more)":
-                              kfrac(by_kernel[3], stats["giant_ms"], 8 * by_kernel[3] + 8 * n_giant_rows, ("k_giant_sums", "k_giant_maps", "k_giant_replay_maps"), 8 * by_kernel[3])}
+                              # (behind k_short_fold the passes are hidden: the timer only sees the wait that is left, not their duration -- no rate is quoted then)
+                              kfrac(by_kernel[3], 0.0 if streamed else stats["giant_ms"], 8 * by_kernel[3] + 8 * n_giant_rows, ("k_giant_sums", "k_giant_maps", "k_giant_replay_maps"), 8 * by_kernel[3])}
         else:
             per_kernel = {"k_spmv_rowblock": kfrac(by_kernel[0], stats["rowblock_ms"], 4 * by_kernel[0] + 12 * n_short_rows, ("k_spmv_rowblock", "k_spmv_rowwave"), 4 * by_kernel[0] + 8 * n_short_rows),
                           "k_spmv_wave16+k_spmv_wave": kfrac(by_kernel[1] + by_kernel[2], stats["wave_ms"], 4 * (by_kernel[1] + by_kernel[2]) + 12 * int(c_out.nmid),
@@ -947,7 +965,7 @@ def main():
                 "wave_avg_ms": round(stats["wave_ms"] / max(args.steps, 1), 4),
                 "aux_streams_avg_ms_overlapped": round(stats["giant_ms"] / max(args.steps, 1), 4),  # giant-row passes + long wave rows
                 "edges_rowblock_wave_giant": [e_short, e_mid, e_giant],
-                "edges_by_kernel": ({"k_spmv_rowblock": by_kernel[0], "k_spmv_sell": by_kernel[1], "k_giant_terms+k_spmv_giant": by_kernel[3]} if swept else
+                "edges_by_kernel": ({"k_spmv_sell_stream+k_short_fold" if streamed else "k_spmv_rowblock": by_kernel[0], "k_spmv_sell": by_kernel[1], "k_giant_terms+k_spmv_giant": by_kernel[3]} if swept else
                                     {"k_spmv_rowblock": by_kernel[0], "k_spmv_wave16": by_kernel[1], "k_spmv_wave": by_kernel[2],
                                      "k_giant_terms+k_spmv_giant": by_kernel[3]}),
                 "send_avg_ms": round(stats["send_ms"] / args.steps, 4),

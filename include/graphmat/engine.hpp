@@ -1483,9 +1483,10 @@ class Run {
       if (where == 2) short_rows();
       if (where == 4) {  // the short rows' fold from the products the sweep left (next to the giant rows' fold passes on the auxiliary stream)
         hipLaunchKernelGGL((dev::k_short_fold<P, U>), dim3((unsigned)sw.nbins), dim3(512), 0, s, pa, (const U*)sterms, sw.sinv, sw.schunk, sw.nslices, sw.bin_cap, sw.sbin_row,
-                           sw.soff, sw.srow, y, (acc & dev::ACC_STATIC_BITS) ? (uint32_t*)nullptr : ybits, getenv("GM_FOLD_ABL") ? atoi(getenv("GM_FOLD_ABL")) : 0);
+                           sw.soff, sw.srow, y, (acc & dev::ACC_STATIC_BITS) ? (uint32_t*)nullptr : ybits);
         st.spmv_launches++;
         short_folds++;
+        timer.mark(TAG_ROWBLOCK);  // (the short rows' share of the multiply that is not inside the sweep)
       }
       if (aux.pending && !defer_join) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
       aux.keep = aux.forked = aux.pending = false;

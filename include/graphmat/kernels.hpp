@@ -1780,7 +1780,7 @@ sell_body(const ProgArg<P>& pa, int set, int stage_words, int nslices, int nrows
                 if (!SPARSE && sterms != nullptr && (int32_t)cA[j] >= 0) {
                   U res;
                   p.P::process_message(as_t(mA[j]), as_e(eA[j]), no_vp, res);
-                  sterms[(size_t)srow * 64 + lane] = res;
+                  __builtin_nontemporal_store(raw_u(res), reinterpret_cast<uint32_t*>(sterms) + ((size_t)srow * 64 + lane));  // (streamed: the slice's part of x stays in L2)
                 }
                 srow++;
               } else if (SPARSE ? ((pA >> j) & 1u) != 0u : (int32_t)cA[j] >= 0) {
@@ -1905,10 +1905,10 @@ k_spmv_sell_stream(ProgArg<P> pa, int set, int stage_words, int nslices, int nro
 // in ascending native column order: the first message assigns (spmspv.h:73-77), like every other kernel of the path.  ybits = nullptr: the
 // presence bits are the graph's static ones.
 template <class P, class U>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512, 6)
 k_short_fold(ProgArg<P> pa, const U* __restrict__ sterms, const uint16_t* __restrict__ sinv, const uint32_t* __restrict__ schunk, int nslices, int cap,
              const uint32_t* __restrict__ sbin_row, const uint32_t* __restrict__ soff, const int32_t* __restrict__ srow_id, U* __restrict__ y,
-             uint32_t* __restrict__ ybits, int abl = 0) {
+             uint32_t* __restrict__ ybits) {
   static_assert(sizeof(U) == 4, "4-byte reductions");
   __shared__ uint32_t s_prod[GM_STREAM_BIN + 64];
   __shared__ uint32_t s_cpos[GM_MAX_SLICES], s_cpre[GM_MAX_SLICES + 1];
@@ -1931,9 +1931,8 @@ k_short_fold(ProgArg<P> pa, const U* __restrict__ sterms, const uint16_t* __rest
     s_cpre[threadIdx.x] = pn.y;
   }
   __syncthreads();
-  // wave w takes the chunks w, w + 8, ...: six chunks' first 256 products are requested before any of them is awaited
-  constexpr int CB = 6, CK = 4;
-  if (!(abl & 1))
+  // wave w takes the chunks w, w + 8, ...: four chunks' first 256 products are requested before any of them is awaited
+  constexpr int CB = 4, CK = 4;
   for (int c0 = wv; c0 < nslices; c0 += 8 * CB) {
     uint32_t vv[CB][CK];
     uint16_t qq[CB][CK];
@@ -1965,8 +1964,7 @@ k_short_fold(ProgArg<P> pa, const U* __restrict__ sterms, const uint16_t* __rest
   }
   __syncthreads();
   auto as_u = [](uint32_t r) { U u; __builtin_memcpy(&u, &r, 4); return u; };
-  if (abl & 4) return;
-  for (uint32_t ii = i0 + (uint32_t)(wv * 64), jj = 0; ii < ((abl & 2) ? i0 : i1); ii += 512u, jj++) {
+  for (uint32_t ii = i0 + (uint32_t)(wv * 64), jj = 0; ii < i1; ii += 512u, jj++) {
     const uint32_t i = ii + (uint32_t)lane;
     const bool valid = i < i1;
     int row = 0;

@@ -37,7 +37,7 @@ def main(path):
     tot = sum(r[2] for r in rows) or 1
     print("| kernel | calls | total ms | avg us | min us | max us | % |")
     print("|---|---:|---:|---:|---:|---:|---:|")
-    for name, n, t, mn, mx in rows[:25]:
+    for name, n, t, mn, mx in rows[:int(__import__("os").environ.get("PROF_ROWS", "25"))]:
         print("| `%s` | %d | %.3f | %.1f | %.1f | %.1f | %.1f |" % (short(name), n, t / 1e6, t / n / 1e3, mn / 1e3, mx / 1e3, 100.0 * t / tot))
     pe = table(db, "rocpd_pmc_event")
     pi = table(db, "rocpd_info_pmc")
