@@ -2,7 +2,7 @@
 # Round-6 summary profiles for the exact bench commands (run through gpurun): kernel-trace stats and timeline, PMC passes (each in its own
 # rocprofv3 run, kernel-trace only) for memory-side traffic, the calibration of those counters on known access patterns
 # (tools/pmc_calibrate.hip), the BFS timeline, one shard of 8 (kernel stats), and the unchanged reference apps.
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp PROF_ROWS=40
 R=$GRAFT_REPO_ROOT; cd $R; tag=r06
 export LD_LIBRARY_PATH=$R/graphmat_amd
 mkdir -p build
@@ -11,11 +11,11 @@ for sc in 26 22; do
   out=$R/gpurun_out/final_$sc; mkdir -p $out
   timeout 900 rocprofv3 --kernel-trace --stats -d $out -o kt -- python bench.py --scale $sc --steps 20 --warmup 3 --cpu-scale 0 --no-extra > $out/${tag}_scale${sc}_bench.json 2> $out/kt.err
   python tools/prof_summary.py $out/kt_results.db > $out/${tag}_scale${sc}_kernel_stats.md
-  [ $sc = 26 ] && python tools/prof_timeline.py $out/kt_results.db --match "k_spmv|k_giant|k_apply|k_send" --last 18 > $out/${tag}_iteration_timeline_scale26.md 2>/dev/null
+  [ $sc = 26 ] && python tools/prof_timeline.py $out/kt_results.db --match "k_spmv|k_short|k_giant|k_apply|k_send" --last 18 > $out/${tag}_iteration_timeline_scale26.md 2>/dev/null
   for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
     n=$(echo $set | cut -d' ' -f1)
     timeout 900 rocprofv3 --kernel-trace --pmc $set -d $out -o pmc_$n -- python bench.py --scale $sc --steps 5 --warmup 1 --cpu-scale 0 --no-timing --no-extra > /dev/null 2> $out/pmc_$n.err
-    python tools/prof_summary.py $out/pmc_${n}_results.db | grep -E "counter|k_spmv|k_giant|k_send|k_apply" | grep -v Degree > $out/${tag}_scale${sc}_pmc_$n.md
+    python tools/prof_summary.py $out/pmc_${n}_results.db | grep -E "counter|k_spmv|k_short|k_giant|k_send|k_apply" | grep -v Degree > $out/${tag}_scale${sc}_pmc_$n.md
   done
   rm -f $out/*.db
 done
@@ -28,8 +28,8 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_MISS_sum TCC_REQ_sum"; do
 done
 # one shard of 8 (shard 0: it owns the hub row), compute only
 timeout 900 rocprofv3 --kernel-trace --stats -d $out -o kt_shard -- python tools/shard_emulation.py --nshards 8 --shards 0 --iters 20 > $out/kt_shard.log 2> $out/kt_shard.err
-python tools/prof_summary.py $out/kt_shard_results.db | grep -E "kernel|---|k_spmv|k_giant|k_apply|k_send" | grep -v Degree > $out/${tag}_shard0_of_8_kernel_stats.md
-python tools/prof_timeline.py $out/kt_shard_results.db --match "k_spmv|k_giant|k_apply|k_send" --last 16 > $out/${tag}_shard0_of_8_iteration_timeline.md 2>/dev/null
+python tools/prof_summary.py $out/kt_shard_results.db | grep -E "kernel|---|k_spmv|k_short|k_giant|k_apply|k_send" | grep -v Degree > $out/${tag}_shard0_of_8_kernel_stats.md
+python tools/prof_timeline.py $out/kt_shard_results.db --match "k_spmv|k_short|k_giant|k_apply|k_send" --last 16 > $out/${tag}_shard0_of_8_iteration_timeline.md 2>/dev/null
 rm -f $out/kt_shard_results.db
 # BFS RMAT-26, level by level
 timeout 900 rocprofv3 --kernel-trace -d $out -o bfs -- python tools/bfs_bench.py --scale 26 > $out/bfs.log 2> $out/bfs.err
