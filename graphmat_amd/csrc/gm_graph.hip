@@ -1192,7 +1192,7 @@ k_stream_fill(uint32_t ngroups, const uint32_t* __restrict__ gbase, const uint32
     const uint32_t slice = b % (uint32_t)nslices;
     const uint32_t e_lo = first[b] + j * (GM_STREAM_WIDTH * 64u), e_end = first[b + 1];
     const uint32_t drow = row_base[b] + j * GM_STREAM_WIDTH;
-    const uint32_t pad = GM_SWEEP_PAD | ((uint32_t)sl.b[slice] << 2);
+    const uint32_t pad = sl.nsub > 1 ? (GM_SWEEP_PAD | GM_SWEEP_HOT) : (GM_SWEEP_PAD | ((uint32_t)sl.b[slice] << 2));
     for (uint32_t t = threadIdx.x; t < n; t += kT) {
       uint32_t c = pad, v = 0u, sp_ = 0xffffffffu;
       if (t < 64) {
@@ -1566,7 +1566,7 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
     // ---- the short rows (1 .. short_row edges) as STREAM groups behind the medium groups of the first launch's blocks (gm_sweep_t.nstream):
     // listed in device order, cut into bins of ~GM_STREAM_BIN edges, bin b -> workgroup b % 256; their edges sorted (workgroup, slice, bin, row,
     // column) -- stable, so a row's edges keep their ascending native column order inside every (bin, slice) chunk
-    if (g_sweep_stream != 0 && nsub == 1) {
+    if (g_sweep_stream != 0) {  // (shards too: the entries carry the build-time hot-set decision like every other entry of a sharded structure)
       const int nsblk = 256 * TS;
       DevBuf sflag, siota, scnt, slen, kin, vin, srows_;
       DevBuf& sgroups = st_sgroups;

@@ -747,7 +747,7 @@ static const EngineKey kEngineKeys[] = {
   {"ablate_cold_short", 14, 0, 0, 0x7fffffff},
   {"two_stage_head_permille", 15, 900, 100, 990},
   {"giant_stream", 16, 1, 0, 2},
-  {"sweep_form", 17, 0, 0, 255},
+  {"sweep_form", 17, 0, 0, 511},
   {"blocked_form", 18, 2, 0, 31},
   {"guided_pull", 19, 1, 0, 2},
 };

@@ -1371,11 +1371,14 @@ class Run {
       }
       // The short rows through the sweep (gm_sweep_t.nstream; round 6, last session): their edges sit in STREAM groups of the first launch's
       // blocks, the sweep gathers for them -- from ~1.3 MB of x at a time and its LDS hot sets, where the row-block kernel gathers from the
-      // whole message vector -- and leaves the products in a stream that k_short_fold folds bin by bin behind the sweep.  Dense x, 16 waves,
-      // single-shard structures; sweep_form bit 7 keeps the row-block kernel (every other form walks wrow, which leaves the groups out).
+      // whole message vector -- and leaves the products in a stream that k_short_fold folds bin by bin behind the sweep.  Dense x, 16 waves
+      // (a shard's structure too); sweep_form bit 7 keeps the row-block kernel (every other form walks wrow, which leaves the groups out).
+      // From 2^26 short-row edges on (bit 8: on any structure -- tests): below, the blocks' few stream rows cost the sweep more than the row-block
+      // kernel saves -- RMAT-23 (27 M) 0.596 -> 0.604 ms, RMAT-24 (53 M) 1.042 -> 1.036, a shard of 8 of RMAT-26 (20 M) 0.82 -> 0.90, of 4 (40 M) 1.28 -> 1.31;
+      // RMAT-25 (107 M) 2.08 -> 1.89, a shard of 2 (81 M) 2.25 -> 2.06, RMAT-26 3.78 -> 3.53, RMAT-27 9.35 -> 7.63.
       U* sterms = nullptr;
-      if (sw.nstream > 0 && sw.sinv != nullptr && sw.wrow_stream != nullptr && sw.nsub <= 1 && xb == nullptr && !w12 && !shorts_blocked && !(opt.sweep_form & 128) &&
-          sw.bin_cap == GM_STREAM_BIN) {
+      if (sw.nstream > 0 && sw.sinv != nullptr && sw.wrow_stream != nullptr && xb == nullptr && !w12 && !shorts_blocked && !(opt.sweep_form & 128) &&
+          sw.bin_cap == GM_STREAM_BIN && (sw.nstream >= (1ll << 26) || (opt.sweep_form & 256))) {
         void* p16 = nullptr;
         if (gm_graph_workspace(g, 16, (size_t)sw.nstream_slots * sizeof(U) + 256, &p16) == GM_OK) sterms = (U*)p16;
       }
@@ -1400,19 +1403,22 @@ class Run {
       for (int set = 0; set < sw.nsets; set++) {
         U* gt = (set == 0 && !gather_apart) ? gterms : (U*)nullptr;  // (the first launch gathers for the giant rows)
         bool with_vals = false;
+        // (the launch that holds the short rows' stream groups walks the wave ranges that include them and stores their products)
+        const uint32_t* st_rows = (sterms != nullptr && set == 0) ? sw.wrow_stream : sw.wrow;
+        U* st_terms = (sterms != nullptr && set == 0) ? sterms : (U*)nullptr;
         if (sw.nsub > 1) {  // a shard's rows: the message vector is made of nsub owners' ranges (kernels.hpp: k_spmv_sell_sharded)
           if constexpr (sizeof(E) == 4 && std::is_trivially_copyable<E>::value) {
             if (Aout.vals != nullptr) {
               hipLaunchKernelGGL((dev::k_spmv_sell_sharded<P, T, U, V, E, true>), dim3(256), dim3(1024), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base,
-                                 sw.scol, sw.sval, sw.wrow, sw.row_of_slot, sw.lcol, sw.lval, sw.lps, sw.lrow_of_slot, sw.gcol, sw.gval, sw.gdst, sw.gslice, gt, xq, y,
-                                 sw.nsub, sw.stride, sw.hot_words);
+                                 sw.scol, sw.sval, st_rows, sw.row_of_slot, sw.lcol, sw.lval, sw.lps, sw.lrow_of_slot, sw.gcol, sw.gval, sw.gdst, sw.gslice, gt, xq, y,
+                                 sw.nsub, sw.stride, sw.hot_words, st_terms);
               with_vals = true;
             }
           }
           if (!with_vals)
             hipLaunchKernelGGL((dev::k_spmv_sell_sharded<P, T, U, V, E, false>), dim3(256), dim3(1024), 0, s, pa, set, stage, sw.nslices, sw.nrows_long, sw.slice_base,
-                               sw.scol, (const uint32_t*)nullptr, sw.wrow, sw.row_of_slot, sw.lcol, (const uint32_t*)nullptr, sw.lps, sw.lrow_of_slot, sw.gcol,
-                               (const uint32_t*)nullptr, sw.gdst, sw.gslice, gt, xq, y, sw.nsub, sw.stride, sw.hot_words);
+                               sw.scol, (const uint32_t*)nullptr, st_rows, sw.row_of_slot, sw.lcol, (const uint32_t*)nullptr, sw.lps, sw.lrow_of_slot, sw.gcol,
+                               (const uint32_t*)nullptr, sw.gdst, sw.gslice, gt, xq, y, sw.nsub, sw.stride, sw.hot_words, st_terms);
           continue;
         }
         if (xb != nullptr) {  // a sparse message vector: presence tests per entry, y's presence bits OR-ed in (kernels.hpp: k_spmv_sell_sparse)

@@ -2047,9 +2047,9 @@ k_spmv_sell_sharded(ProgArg<P> pa, int set, int stage_words, int nslices, int nr
                     const uint32_t* __restrict__ sval, const uint32_t* __restrict__ wrow, const int32_t* __restrict__ row_of_slot, const uint32_t* __restrict__ lcol,
                     const uint32_t* __restrict__ lval, const uint32_t* __restrict__ lps, const int32_t* __restrict__ lrow_of_slot,
                     const uint32_t* __restrict__ gcol, const uint32_t* __restrict__ gval, const uint32_t* __restrict__ gdst, const uint32_t* __restrict__ gslice,
-                    U* __restrict__ gterms, const T* __restrict__ x, U* __restrict__ y, int nsub, int stride, int hot_words) {
+                    U* __restrict__ gterms, const T* __restrict__ x, U* __restrict__ y, int nsub, int stride, int hot_words, U* __restrict__ sterms) {
   sell_body<P, T, U, V, E, HAS_VALS, 0, 7, 2, GM_SWEEP_POOL, true>(pa, set, stage_words, nslices, nrows_long, slice_base, scol, sval, wrow, row_of_slot, lcol, lval, lps,
-                                                                    lrow_of_slot, gcol, gval, gdst, gslice, gterms, x, y, nsub, stride, hot_words);
+                                                                    lrow_of_slot, gcol, gval, gdst, gslice, gterms, x, y, nsub, stride, hot_words, nullptr, nullptr, sterms);
 }
 
 // ------------------------------------------------------------------------------------

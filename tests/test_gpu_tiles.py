@@ -471,6 +471,7 @@ def test_short_rows_ride_the_sweep(env, scale, tiles, threads, keep):
     try:
         api._lib.check(L.gm_reset_options())
         api._lib.check(L.gm_set_option(b"sweep_long_row", 256))
+        api._lib.check(L.gm_set_option(b"sweep_form", 256))  # (the path is taken from 2^26 short-row edges on; bit 8 lifts the limit)
         g = api.Graph(nv, s, d, v if keep else None, ref_threads=threads, keep_values=keep, col_tiles=tiles)
         sw = _lib.Sweep()
         assert L.gm_graph_sweep(g.h, C.byref(sw)) == 0 and sw.nrows > 0
@@ -518,7 +519,10 @@ def test_short_rows_ride_the_sweep(env, scale, tiles, threads, keep):
         api._lib.check(L.gm_set_option(b"sweep_form", 128))  # the row-block kernel for the short rows
         pr2, _, _ = g.pagerank(7)
         assert (f32bits(pr2) == f32bits(opr)).all() and L.gm_graph_note_get(g.h, 4, C.byref(n4)) == 0 and n4.value == 0
-        api._lib.check(L.gm_set_option(b"sweep_form", 0))
+        api._lib.check(L.gm_set_option(b"sweep_form", 0))  # (a small graph without bit 8: the row-block kernel too)
+        pr2, _, _ = g.pagerank(7)
+        assert (f32bits(pr2) == f32bits(opr)).all() and L.gm_graph_note_get(g.h, 4, C.byref(n4)) == 0 and n4.value == 0
+        api._lib.check(L.gm_set_option(b"sweep_form", 256))
         pru, itu, _ = og.pagerank(-1)
         pr3, _, it3 = g.pagerank(-1)  # (until convergence: ACTIVE_ONLY-free program, but the iteration count must agree too)
         assert it3 == itu and (f32bits(pr3) == f32bits(pru)).all()

@@ -66,7 +66,7 @@ def main():
     seen_sets = 1
     for form, keep, own, accl, longl, local in cases:
         _lib.check(L.gm_reset_options())
-        for k_, v_ in ((b"sweep_form", form), (b"sweep_long_row", own), (b"sweep_acc_rows", accl), (b"sweep_long_slots", longl)):
+        for k_, v_ in ((b"sweep_form", form | 256), (b"sweep_long_row", own), (b"sweep_acc_rows", accl), (b"sweep_long_slots", longl)):
             _lib.check(L.gm_set_option(k_, v_))
         if local:
             cuts = [len(s) * r // world + (13 if 0 < r < world else 0) for r in range(world + 1)]
@@ -133,6 +133,21 @@ def main():
             fail("PageRank through the sharded sweep differs from the oracle (%s): %d of %d values" % (tag, int((pr.view(np.uint32) != opr.view(np.uint32)).sum()), nv))
         if st["spmv_launches"] < 6 * sw.nsets:
             fail("fewer multiply launches than the sweep needs (%s)" % tag)
+        # the shard's short rows ride its sweep too (gm_sweep_t.nstream): the path must have been taken, and refusing it (sweep_form bit 7:
+        # the row-block kernel) must give the same bits
+        # (the groups sit behind a block's MEDIUM groups: a structure without medium rows -- sweep_long_row 65 on a small shard -- has none;
+        #  small structures only take the path when sweep_form bit 8 asks for it: the cases set it)
+        n4 = C.c_int64(-1)
+        if sw.nstream <= 0:
+            if sw.nedges > 0:
+                fail("no stream groups although the shard has medium rows (%s)" % tag)
+        elif not sw.wrow_stream or L.gm_graph_note_get(g.h, 4, C.byref(n4)) != 0 or n4.value != 6:
+            fail("the shard's short rows did not go through the sweep (%s): nstream %d, note 4 = %d" % (tag, sw.nstream, n4.value))
+        _lib.check(L.gm_set_option(b"sweep_form", form | 128))
+        pr_r, _, _ = g.pagerank(6)
+        _lib.check(L.gm_set_option(b"sweep_form", form | 256))
+        if L.gm_graph_note_get(g.h, 4, C.byref(n4)) != 0 or n4.value != 0 or not (pr_r.view(np.uint32) == opr.view(np.uint32)).all():
+            fail("the row-block kernel for the shard's short rows differs or was not taken (%s)" % tag)
         # ... and the plain loop (all-gather between send and multiply) through the same sweep
         p1 = parts_of(g)
         _lib.check(L.gm_set_option(b"debug_flags", 128))
@@ -167,7 +182,7 @@ def main():
     _lib.check(L.gm_graph_sweep(g.h, C.byref(sw)))
     attach(g)
     pr3, _, _ = g.pagerank(6)
-    if sw.nrows != 0 or not (pr3.view(np.uint32) == opr.view(np.uint32)).all():
+    if sw.nrows != 0 or sw.nstream != 0 or not (pr3.view(np.uint32) == opr.view(np.uint32)).all():
         fail("the unswept sharded path differs (sweep rows %d)" % sw.nrows)
     g.close()
     _lib.check(L.gm_reset_options())
