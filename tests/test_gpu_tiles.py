@@ -454,8 +454,8 @@ def test_sweep_in_768_thread_workgroups_bit_exact(env, keep):
         api._lib.check(L.gm_reset_options())
 
 
-@pytest.mark.parametrize("scale,tiles,threads,keep", [(13, 2, 1, False), (15, 3, 2, True), (16, 4, 1, False), (16, 3, 2, True)])
-def test_short_rows_ride_the_sweep(env, scale, tiles, threads, keep):
+@pytest.mark.parametrize("scale,tiles,threads,keep,acc_rows", [(13, 2, 1, False, 0), (15, 3, 2, True, 0), (16, 4, 1, False, 0), (16, 3, 2, True, 0), (16, 3, 1, False, 2)])
+def test_short_rows_ride_the_sweep(env, scale, tiles, threads, keep, acc_rows):
     """The rows of 1 .. 64 edges as STREAM groups of the sweep (graphmat_hip.h: gm_sweep_t.nstream; kernels.hpp: k_spmv_sell_stream + k_short_fold):
     the structure lists every short row once, in device order, its bins cover the short rows' edges exactly, every (bin, slice) chunk lies inside
     the products stream, the stream groups are the only difference between wrow and wrow_stream, and sinv is a permutation inside every bin; PageRank through it -- with and without edge values -- has the oracle's bits,
@@ -472,9 +472,12 @@ def test_short_rows_ride_the_sweep(env, scale, tiles, threads, keep):
         api._lib.check(L.gm_reset_options())
         api._lib.check(L.gm_set_option(b"sweep_long_row", 256))
         api._lib.check(L.gm_set_option(b"sweep_form", 256))  # (the path is taken from 2^26 short-row edges on; bit 8 lifts the limit)
+        if acc_rows:  # several launches: the stream groups all sit in the first one's blocks
+            api._lib.check(L.gm_set_option(b"sweep_acc_rows", acc_rows))
+            api._lib.check(L.gm_set_option(b"sweep_long_slots", 1))
         g = api.Graph(nv, s, d, v if keep else None, ref_threads=threads, keep_values=keep, col_tiles=tiles)
         sw = _lib.Sweep()
-        assert L.gm_graph_sweep(g.h, C.byref(sw)) == 0 and sw.nrows > 0
+        assert L.gm_graph_sweep(g.h, C.byref(sw)) == 0 and sw.nrows > 0 and (sw.nsets > 1) == bool(acc_rows)
         assert sw.nstream > 0 and sw.nbins > 0 and sw.bin_cap == 12288 and sw.nstream_slots % 64 == 0 and sw.nstream_slots >= sw.nstream and sw.wrow_stream
         c = g.csr(api.GM_DIR_OUT)
         rp = np.zeros(c.nrows + 1, np.int64)
