@@ -1492,6 +1492,7 @@ class Run {
                            sw.soff, sw.srow, y, (acc & dev::ACC_STATIC_BITS) ? (uint32_t*)nullptr : ybits);
         st.spmv_launches++;
         short_folds++;
+        if (verbose && !said_short_fold) { printf("GraphMat(HIP):   the rows of up to %d edges ride the sweep (k_short_fold)\n", (int)sw.short_row); said_short_fold = true; }
         timer.mark(TAG_ROWBLOCK);  // (the short rows' share of the multiply that is not inside the sweep)
       }
       if (aux.pending && !defer_join) GM_HIP_OK(hipStreamWaitEvent(s, aux.join, 0));
@@ -1630,7 +1631,7 @@ class Run {
 
   // Can this run's pull multiply of the OUT adjacency take the column-blocked stream of the short rows (graphmat_hip.h: gm_blocked_t;
   // kernels.hpp: k_spmv_blocked)?  The conditions of the sweep; the structure exists only for graphs without skew (edge values: none, or 4 bytes in its entries).
-  bool said_blocked = false, said_sparse_sweep = false;
+  bool said_blocked = false, said_sparse_sweep = false, said_short_fold = false;
   int sparse_sweeps = 0;  // multiplies of this run that took a sparse x through the sweep (note 3 of the graph: tests read it)
   int short_folds = 0;    // multiplies of this run whose short rows were folded from the sweep's products stream (note 4)
   bool blocked_usable(int acc, gm_blocked_t* bl) {

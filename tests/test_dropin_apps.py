@@ -384,6 +384,10 @@ def test_edge_values_through_the_sweep():
     text = _run(_need(os.path.join(OWN_APPS, "swept_edge_values")))
     assert "SWEPTEDGES PASS" in text, text[-2000:]
     assert re.search(r"sweep: [1-9][0-9]* rows \([1-9][0-9]* long\), value bytes 4, [1-9][0-9]* giant-row edges gathered by the sweep", text), text[-2000:]
+    # ... and with the rows of at most 64 edges riding the sweep too (gm_sweep_t.nstream; sweep_form bit 8: on a graph of any size): their stream groups
+    # carry the edge values, the rewritten ones after gm_graph_sync_tile_vals, also on the relayouted graph
+    text = _run(_need(os.path.join(OWN_APPS, "swept_edge_values")), env={"GRAPHMAT_OPTIONS": "sweep_form=256", "GRAPHMAT_VERBOSE": "1"})
+    assert "SWEPTEDGES PASS" in text and "ride the sweep (k_short_fold)" in text, text[-2000:]
 
 
 @pytest.mark.gpu
