@@ -34,6 +34,11 @@ int g_long_mid = 0;  // > 0: experiment -- wave rows of more than this many edge
 int g_sweep_slices = 1;  // 1: cut the device order into ntiles * k <= 64 slices and build the row-stationary sweep of the medium rows (gm_graph_sweep)
 int g_sort_tile_lists = 1;  // column tiles: the wave-row lists by descending piece length (sort_rows_by_length)
 int g_sweep_border_factor = 4;  // the medium / long border is lowered while it exceeds this many times a wave's share of a block per slice
+// cost of a stream row in the waves' shares of a block, percent of a medium row's.  A stream row is gathered like a medium row AND its products are stored, and a
+// slice ends at a workgroup barrier: with the rows counted alike (100) the waves that hold the stream groups -- the block's last -- were what every slice waited
+// for.  RMAT-26, ms per iteration at 100 / 150 / 200 / 250 / 300 / 350 / 400 / 500 / 700: 3.555 / 3.412 / 3.312 / 3.299 / 3.277 / 3.318 / 3.335 / 3.425 / 3.662;
+// RMAT-27 at 100 / 200 / 300 / 500: 7.63 / 7.38 / 7.34 / 7.87; RMAT-25 at 100 / 300 / 500: 1.89 / 1.76 / 1.89 (gm_set_option("sweep_stream_weight"))
+int g_sweep_stream_weight = 300;
 int g_sweep_stream = 1;  // the short rows ride the sweep as stream groups (gm_sweep_t.nstream; round 6, last session); 0: none built
 int g_sweep_waves = 16;  // waves per workgroup the sweep's blocks are dealt over (16; 12: a 768-thread sweep that leaves room on every CU for the short rows' kernel beside it -- experiment of round 6)
 int g_sweep_fold_share = 50;  // share (percent of an equal share) of a block's groups that the waves folding the long rows get
@@ -1219,15 +1224,20 @@ k_stream_fill(uint32_t ngroups, const uint32_t* __restrict__ gbase, const uint32
 __global__ void __launch_bounds__(64)
 k_sweep_wave_ranges(const uint32_t* __restrict__ grp_first, int nblk, const uint32_t* __restrict__ gbase, uint32_t* __restrict__ wfirst, uint32_t* __restrict__ wrow,
                     int fold_share, int fold_waves, int nwaves, const uint32_t* __restrict__ skip_groups /* per block: groups at its end to leave out, or null */,
-                    int nskip_blk) {
+                    int nskip_blk, const uint32_t* __restrict__ gblk = nullptr /* bit 31: a stream group */, int stream_weight = 100 /* percent of a medium row's cost */) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= nblk) return;
   constexpr int WS = 16;  // (entries per block in wfirst / wrow: WS + 1, whatever W)
   const int W = nwaves;
   const int FW = fold_waves;
   const uint32_t g0 = grp_first[b], g1 = grp_first[b + 1] - ((skip_groups != nullptr && b < nskip_blk) ? skip_groups[b] : 0u);
+  // (a stream row is gathered like a medium row and its products are stored as well: its cost in medium rows = stream_weight percent)
+  auto cost = [&](uint32_t g_) -> unsigned long long {
+    const unsigned long long rows = (gbase[g_ + 1] - gbase[g_]) / 64u + 1u;
+    return (gblk != nullptr && (gblk[g_] & 0x80000000u)) ? (rows * (unsigned)stream_weight + 99ull) / 100ull : rows;
+  };
   unsigned long long total = 0;
-  for (uint32_t g = g0; g < g1; g++) total += (gbase[g + 1] - gbase[g]) / 64u + 1u;
+  for (uint32_t g = g0; g < g1; g++) total += cost(g);
   const unsigned long long units = (unsigned long long)(W - FW) * 100ull + (unsigned long long)FW * (unsigned)fold_share;
   uint32_t g = g0;
   unsigned long long acc = 0, share = 0;
@@ -1236,7 +1246,7 @@ k_sweep_wave_ranges(const uint32_t* __restrict__ grp_first, int nblk, const uint
     wrow[(size_t)b * (WS + 1) + w] = gbase[g] >> 6;
     share += w >= W - FW ? (unsigned)fold_share : 100u;
     const unsigned long long want = total * share / units;
-    while (g < g1 && acc + ((gbase[g + 1] - gbase[g]) / 64u + 1u + 1u) / 2u <= want) { acc += (gbase[g + 1] - gbase[g]) / 64u + 1u; g++; }
+    while (g < g1 && acc + (cost(g) + 1u) / 2u <= want) { acc += cost(g); g++; }
   }
   for (int w = W; w <= WS; w++) {  // (entry W ends the block; the entries behind it repeat the end)
     wfirst[(size_t)b * (WS + 1) + w] = g1;
@@ -1655,7 +1665,7 @@ static int build_sweep(gm_graph* g, const CsrOwned* whole, hipStream_t s) {
       if ((rc = st_wrow.alloc(nblk * 17 * 4)) || (rc = st_wfirst.alloc(nblk * 17 * 4))) return rc;
       hipLaunchKernelGGL(k_sweep_wave_ranges, dim3((unsigned)((nblk + 63) / 64)), dim3(64), 0, s, (const uint32_t*)grp_first.as<uint32_t>(), (int)nblk,
                          (const uint32_t*)gbase.as<uint32_t>(), st_wfirst.as<uint32_t>(), st_wrow.as<uint32_t>(), nlong > 0 ? g_sweep_fold_share : 100,
-                         (int)std::min(8, (((per_wg_long + nsets - 1) / nsets) + 63) / 64), 16, (const uint32_t*)nullptr, 0);
+                         (int)std::min(8, (((per_wg_long + nsets - 1) / nsets) + 63) / 64), 16, (const uint32_t*)nullptr, 0, (const uint32_t*)gblk.as<uint32_t>(), g_sweep_stream_weight);
     }
     GM_TRY_HIP(hipGetLastError());
     GM_TRY_HIP(hipStreamSynchronize(s));

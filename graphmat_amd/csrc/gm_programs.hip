@@ -20,7 +20,7 @@
 
 namespace gm {
 
-extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance, g_own_wave_row, g_sort_tile_lists, g_sweep_slices, g_sweep_acc_limit, g_sweep_long_limit, g_sweep_long_row, g_sweep_fold_share, g_sweep_border_factor, g_blocked_rows, g_sweep_waves, g_sweep_stream;
+extern int g_short_row, g_giant_row, g_rank_by, g_rank_cap, g_col_tiles, g_tile_min_row, g_long_mid, g_tile_balance, g_own_wave_row, g_sort_tile_lists, g_sweep_slices, g_sweep_acc_limit, g_sweep_long_limit, g_sweep_long_row, g_sweep_fold_share, g_sweep_border_factor, g_blocked_rows, g_sweep_waves, g_sweep_stream, g_sweep_stream_weight;
 static int g_force_ordered = 0;
 
 // ---------------- PageRank (reference: src/PageRank.cpp:34-112) ----------------------------
@@ -842,6 +842,7 @@ int gm_reset_options(void) {
   gm::g_sweep_fold_share = 50;
   gm::g_sweep_waves = 16;
   gm::g_sweep_stream = 1;
+  gm::g_sweep_stream_weight = 300;
   gm::g_sweep_border_factor = 4;
   gm::g_col_tiles = 0;
   return GM_OK;
@@ -873,6 +874,7 @@ int gm_set_option(const char* key, int value) {
   if (key && !strcmp(key, "sweep_border_factor") && value >= 1 && value <= 64) { gm::g_sweep_border_factor = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_fold_share") && value >= 0 && value <= 100) { gm::g_sweep_fold_share = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_stream") && (value == 0 || value == 1)) { gm::g_sweep_stream = value; return GM_OK; }
+  if (key && !strcmp(key, "sweep_stream_weight") && value >= 50 && value <= 2000) { gm::g_sweep_stream_weight = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_waves") && (value == 16 || value == 12 || value == 8)) { gm::g_sweep_waves = value; return GM_OK; }
   if (key && !strcmp(key, "sweep_long_slots") && value >= 1 && value <= GM_SWEEP_LONG_SLOTS) { gm::g_sweep_long_limit = value; return GM_OK; }
   gm::set_error("gm_set_option: unknown option");

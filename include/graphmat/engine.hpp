@@ -1373,12 +1373,12 @@ class Run {
       // blocks, the sweep gathers for them -- from ~1.3 MB of x at a time and its LDS hot sets, where the row-block kernel gathers from the
       // whole message vector -- and leaves the products in a stream that k_short_fold folds bin by bin behind the sweep.  Dense x, 16 waves
       // (a shard's structure too); sweep_form bit 7 keeps the row-block kernel (every other form walks wrow, which leaves the groups out).
-      // From 2^26 short-row edges on (bit 8: on any structure -- tests): below, the blocks' few stream rows cost the sweep more than the row-block
-      // kernel saves -- RMAT-23 (27 M) 0.596 -> 0.604 ms, RMAT-24 (53 M) 1.042 -> 1.036, a shard of 8 of RMAT-26 (20 M) 0.82 -> 0.90, of 4 (40 M) 1.28 -> 1.31;
-      // RMAT-25 (107 M) 2.08 -> 1.89, a shard of 2 (81 M) 2.25 -> 2.06, RMAT-26 3.78 -> 3.53, RMAT-27 9.35 -> 7.63.
+      // From 2^25 short-row edges on (bit 8: on any structure -- tests): below, the blocks' few stream rows cost the sweep more than the row-block
+      // kernel saves -- RMAT-23 (27 M) 0.595 -> 0.610 ms, a shard of 8 of RMAT-26 (20 M) 0.82 -> 0.89; RMAT-24 (53 M) 1.049 -> 0.946, a shard of 4 (40 M) 1.28 -> 1.25,
+      // of 2 (81 M) 2.25 -> 1.92, RMAT-25 (107 M) 2.08 -> 1.76, RMAT-26 3.78 -> 3.28, RMAT-27 9.35 -> 7.34 (with the stream rows weighted 3 : 1 in the waves' shares).
       U* sterms = nullptr;
       if (sw.nstream > 0 && sw.sinv != nullptr && sw.wrow_stream != nullptr && xb == nullptr && !w12 && !shorts_blocked && !(opt.sweep_form & 128) &&
-          sw.bin_cap == GM_STREAM_BIN && (sw.nstream >= (1ll << 26) || (opt.sweep_form & 256))) {
+          sw.bin_cap == GM_STREAM_BIN && (sw.nstream >= (1ll << 25) || (opt.sweep_form & 256))) {
         void* p16 = nullptr;
         if (gm_graph_workspace(g, 16, (size_t)sw.nstream_slots * sizeof(U) + 256, &p16) == GM_OK) sterms = (U*)p16;
       }

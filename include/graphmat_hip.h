@@ -628,7 +628,7 @@ typedef struct {
                                      2 on the main stream behind the sweep; bit 2 = the long rows staged in rounds of 1024 entries (tests); bit 3 = the
                                      giant rows gather for themselves on the auxiliary stream (k_giant_terms) instead of the sweep gathering for them; bit 4 = the giant rows' gathers in a
                                      kernel of their own behind the sweep (k_giant_gather_sliced: their entries in slice order, on the auxiliary stream next to the short rows); bit 5 = a SPARSE
-                                     message vector (ACTIVE_ONLY programs) does not take the sweep (k_spmv_sell_sparse); bit 6 = it does on graphs of any size (default: from 2e8 edges on); bit 7 = the short rows keep the row-block kernel (gm_sweep_t.nstream is not used); bit 8 = they ride the sweep whatever their number (default: from 2^26 short-row edges on) */
+                                     message vector (ACTIVE_ONLY programs) does not take the sweep (k_spmv_sell_sparse); bit 6 = it does on graphs of any size (default: from 2e8 edges on); bit 7 = the short rows keep the row-block kernel (gm_sweep_t.nstream is not used); bit 8 = they ride the sweep whatever their number (default: from 2^25 short-row edges on) */
   int32_t blocked_form;           /* the column-blocked stream of the short rows (engine.hpp: multiply_out_blocked): bits 0-3 = window -- a workgroup starts a
                                      slice when all workgroups of its XCD have finished the one `window` slices back (default 2; 0 = workgroups not
                                      kept in step); bit 4 = batches of 4 x 64 entries instead of 2 x 64 */
