@@ -1910,7 +1910,10 @@ k_short_fold(ProgArg<P> pa, const U* __restrict__ sterms, const uint16_t* __rest
              const uint32_t* __restrict__ sbin_row, const uint32_t* __restrict__ soff, const int32_t* __restrict__ srow_id, U* __restrict__ y,
              uint32_t* __restrict__ ybits) {
   static_assert(sizeof(U) == 4, "4-byte reductions");
-  __shared__ uint32_t s_prod[GM_STREAM_BIN + 64];
+  // (a bin's rows are degree-ranked: neighbouring threads fold rows of the SAME length L, i.e. read LDS L words apart -- one pad word per 32 keeps
+  // L = 16 / 32 / 64 off a single bank)
+  __shared__ uint32_t s_prod[(GM_STREAM_BIN + 64) + (GM_STREAM_BIN + 64) / 32 + 1];
+  auto at = [](uint32_t q) { return q + (q >> 5); };
   __shared__ uint32_t s_cpos[GM_MAX_SLICES], s_cpre[GM_MAX_SLICES + 1];
   const P& p = *reinterpret_cast<const P*>(pa.b);
   const int b = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1958,8 +1961,8 @@ k_short_fold(ProgArg<P> pa, const U* __restrict__ sterms, const uint16_t* __rest
     for (int c = 0; c < CB; c++) {
 #pragma unroll
       for (int k = 0; k < CK; k++)
-        if ((uint32_t)(k * 64 + lane) < cn[c]) s_prod[qq[c][k]] = vv[c][k];
-      for (uint32_t i = (uint32_t)(CK * 64 + lane); i < cn[c]; i += 64u) s_prod[sinv[cp[c] + i]] = raw[cp[c] + i];  // (a chunk of more than 256 products)
+        if ((uint32_t)(k * 64 + lane) < cn[c]) s_prod[at(qq[c][k])] = vv[c][k];
+      for (uint32_t i = (uint32_t)(CK * 64 + lane); i < cn[c]; i += 64u) s_prod[at(sinv[cp[c] + i])] = raw[cp[c] + i];  // (a chunk of more than 256 products)
     }
   }
   __syncthreads();
@@ -1976,8 +1979,8 @@ k_short_fold(ProgArg<P> pa, const U* __restrict__ sterms, const uint16_t* __rest
         for (int j = 1; j < RK; j++) if ((int)jj == j) { o0 = ro0[j]; o1 = ro1[j]; row = rid[j]; }
       } else { o0 = soff[i]; o1 = soff[i + 1]; row = srow_id[i]; }
       o0 -= base; o1 -= base;
-      U acc = as_u(s_prod[o0]);
-      for (uint32_t k = o0 + 1; k < o1; k++) p.P::reduce_function(acc, as_u(s_prod[k]));
+      U acc = as_u(s_prod[at(o0)]);
+      for (uint32_t k = o0 + 1; k < o1; k++) p.P::reduce_function(acc, as_u(s_prod[at(k)]));
       y[row] = acc;
     }
     if (ybits != nullptr) {  // (rows of a run are consecutive device ids: three words per wave instead of 64 atomics)
